@@ -1,0 +1,483 @@
+"""TEST INFRASTRUCTURE -- functional CPU restatement of CFUN's volumetric hot path.
+
+Every function restates (does not import) the reference algorithm and cites the
+reference file:line it follows (paths relative to /root/reference).  Arithmetic
+is plain fp32 torch-CPU / numpy: those are the reference's own arithmetic
+libraries, so equality with the reference is exact up
+to op ordering.  Pinned by tests/test_oracle_golden.py against
+tests/golden/*.npz (generated from the reference import by
+tests/golden/gen_golden.py).
+
+All functions take a flat ``sd`` = {state-dict key: tensor} in the reference's
+checkpoint naming plus a key prefix, NCDHW fp32 activations.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------------------
+# backbone.py
+# --------------------------------------------------------------------------------------
+
+
+def _conv(x, sd, key, stride=1, padding=0):
+    return F.conv3d(x, sd[key + ".weight"], sd.get(key + ".bias"), stride=stride, padding=padding)
+
+
+def _bn_eval(x, sd, key, eps=1e-5):
+    """BatchNorm3d frozen in eval mode (model.py:1397-1406): constant affine."""
+    shp = (1, -1, 1, 1, 1)
+    rstd = torch.rsqrt(sd[key + ".running_var"] + eps)
+    return (x - sd[key + ".running_mean"].view(shp)) * (rstd * sd[key + ".weight"]).view(shp) \
+        + sd[key + ".bias"].view(shp)
+
+
+def bottleneck(x, sd, p, block_idx, expand, stride):
+    """backbone.py:26-114.  ST pattern cycles A,B,C with (block_idx-1)%3 (backbone.py:41)."""
+    st = "ABC"[(block_idx - 1) % 3]
+    out = F.relu(_bn_eval(_conv(x, sd, p + "conv1", stride=stride), sd, p + "bn1"))
+
+    def s(v):  # conv_S 1x3x3, backbone.py:14-17,42
+        return F.relu(_bn_eval(_conv(v, sd, p + "conv2", padding=(0, 1, 1)), sd, p + "bn2"))
+
+    def t(v):  # conv_T 3x1x1, backbone.py:20-23,44
+        return F.relu(_bn_eval(_conv(v, sd, p + "conv3", padding=(1, 0, 0)), sd, p + "bn3"))
+
+    if st == "A":      # backbone.py:58-67
+        out = t(s(out))
+    elif st == "B":    # backbone.py:69-78
+        out = t(out) + s(out)
+    else:              # backbone.py:80-89
+        y = s(out)
+        out = y + t(y)
+    out = _bn_eval(_conv(out, sd, p + "conv4"), sd, p + "bn4")
+    res = x
+    if expand:         # backbone.py:49-52,107-108
+        res = _bn_eval(_conv(x, sd, p + "downsample.0", stride=2), sd, p + "downsample.1")
+    return F.relu(out + res)
+
+
+def p3d_stages(x, sd, prefix="", layers=(2, 3), stem_pad=(1, 3, 3)):
+    """backbone.py:117-158: C1 (conv k(3,7,7) s2 + BN + ReLU + MaxPool 2/2), C2, C3."""
+    c1 = F.relu(_bn_eval(_conv(x, sd, prefix + "C1.0", stride=2, padding=stem_pad), sd, prefix + "C1.1"))
+    c1 = F.max_pool3d(c1, kernel_size=2, stride=2)
+    feats = [c1]
+    h = c1
+    for si, nblk in enumerate(layers):
+        name = "C%d." % (si + 2)
+        for b in range(nblk):
+            h = bottleneck(h, sd, prefix + name + "%d." % b, b + 1, expand=(b == 0), stride=2 if b == 0 else 1)
+        feats.append(h)
+    return feats
+
+
+def fpn(x, sd, prefix="fpn.", layers=(2, 3), stem_pad=(1, 3, 3)):
+    """model.py:124-148."""
+    _, c2, c3 = p3d_stages(x, sd, prefix, layers, stem_pad)
+    p3 = _conv(c3, sd, prefix + "P3_conv1")
+    p2 = _conv(c2, sd, prefix + "P2_conv1") + F.interpolate(p3, scale_factor=2)  # nearest
+    p3 = _conv(p3, sd, prefix + "P3_conv2", padding=1)
+    p2 = _conv(p2, sd, prefix + "P2_conv2", padding=1)
+    return p2, p3
+
+
+def rpn(p, sd, prefix="rpn."):
+    """model.py:700-743 -> logits [1,A,2], probs [1,A,2], bbox [1,A,6]; flatten order (z,y,x)."""
+    h = F.relu(_conv(p, sd, prefix + "conv_shared", padding=1))
+    logits = _conv(h, sd, prefix + "conv_class").permute(0, 2, 3, 4, 1).contiguous().view(p.shape[0], -1, 2)
+    probs = F.softmax(logits, dim=2)
+    bbox = _conv(h, sd, prefix + "conv_bbox").permute(0, 2, 3, 4, 1).contiguous().view(p.shape[0], -1, 6)
+    return logits, probs, bbox
+
+
+# --------------------------------------------------------------------------------------
+# utils.py: anchors, NMS
+# --------------------------------------------------------------------------------------
+
+
+def generate_pyramid_anchors(scales, feature_shapes, feature_strides, anchor_stride=1):
+    """utils.py:467-528 with one ratio ([1]).  np.meshgrid default 'xy' indexing makes the
+    enumeration y-slowest, then z, then x."""
+    out = []
+    for scale, (d, h, w), fs in zip(scales, feature_shapes, feature_strides):
+        z = np.arange(0, d, anchor_stride) * fs
+        y = np.arange(0, h, anchor_stride) * fs
+        x = np.arange(0, w, anchor_stride) * fs
+        # flat index = iy*(nz*nx) + iz*nx + ix
+        yy, zz, xx = np.meshgrid(y, z, x, indexing="ij")
+        c = np.stack([zz.reshape(-1), yy.reshape(-1), xx.reshape(-1)], axis=1).astype(np.float64)
+        half = 0.5 * float(scale)
+        out.append(np.concatenate([c - half, c + half], axis=1))
+    return np.concatenate(out, axis=0)
+
+
+def nms(boxes, scores, threshold, max_num):
+    """utils.py:122-157 + compute_iou utils.py:50-70, float32 numpy, same op order.
+    Written as an O(N*K) mask loop instead of np.delete; identical pick list."""
+    boxes = np.asarray(boxes, dtype=np.float32)
+    scores = np.asarray(scores, dtype=np.float32)
+    n = boxes.shape[0]
+    z1, y1, x1, z2, y2, x2 = [boxes[:, i] for i in range(6)]
+    volume = (z2 - z1) * (y2 - y1) * (x2 - x1)
+    order = scores.argsort()[::-1]
+    alive = np.ones(n, dtype=bool)
+    pick = []
+    for pos in range(n):
+        i = order[pos]
+        if not alive[i]:
+            continue
+        pick.append(i)
+        if len(pick) >= max_num:
+            break
+        rest = order[pos + 1:]
+        iz1 = np.maximum(z1[i], z1[rest]); iz2 = np.minimum(z2[i], z2[rest])
+        iy1 = np.maximum(y1[i], y1[rest]); iy2 = np.minimum(y2[i], y2[rest])
+        ix1 = np.maximum(x1[i], x1[rest]); ix2 = np.minimum(x2[i], x2[rest])
+        inter = np.maximum(ix2 - ix1, 0) * np.maximum(iy2 - iy1, 0) * np.maximum(iz2 - iz1, 0)
+        union = volume[i] + volume[rest] - inter
+        iou = inter / (union + np.float32(1e-6))
+        alive[rest[iou > np.float32(threshold)]] = False
+    return np.array(pick, dtype=np.int32)
+
+
+# --------------------------------------------------------------------------------------
+# model.py: proposals, RoIAlign
+# --------------------------------------------------------------------------------------
+
+
+def apply_box_deltas(boxes, deltas):
+    """model.py:155-182."""
+    d = boxes[:, 3] - boxes[:, 0]
+    h = boxes[:, 4] - boxes[:, 1]
+    w = boxes[:, 5] - boxes[:, 2]
+    cz = boxes[:, 0] + 0.5 * d
+    cy = boxes[:, 1] + 0.5 * h
+    cx = boxes[:, 2] + 0.5 * w
+    cz = cz + deltas[:, 0] * d
+    cy = cy + deltas[:, 1] * h
+    cx = cx + deltas[:, 2] * w
+    d = d * torch.exp(deltas[:, 3])
+    h = h * torch.exp(deltas[:, 4])
+    w = w * torch.exp(deltas[:, 5])
+    z1 = cz - 0.5 * d
+    y1 = cy - 0.5 * h
+    x1 = cx - 0.5 * w
+    return torch.stack([z1, y1, x1, z1 + d, y1 + h, x1 + w], dim=1)
+
+
+def clip_boxes(boxes, window):
+    """model.py:185-196."""
+    lo = torch.tensor([window[0], window[1], window[2]] * 2, dtype=boxes.dtype)
+    hi = torch.tensor([window[3], window[4], window[5]] * 2, dtype=boxes.dtype)
+    return torch.max(torch.min(boxes, hi), lo)
+
+
+def proposal_layer(rpn_probs, rpn_bbox, anchors, proposal_count, nms_threshold, image_dhw,
+                   pre_nms_limit=1000, std_dev=(0.1, 0.1, 0.1, 0.2, 0.2, 0.2)):
+    """model.py:199-258.  rpn_probs [A,2], rpn_bbox [A,6], anchors [A,6] -> normalised [K,6]."""
+    scores = rpn_probs[:, 1]
+    deltas = rpn_bbox * torch.tensor(std_dev, dtype=torch.float32).view(1, 6)
+    limit = min(pre_nms_limit, anchors.shape[0])
+    scores, order = scores.sort(descending=True)
+    order = order[:limit]
+    scores = scores[:limit]
+    boxes = apply_box_deltas(anchors[order], deltas[order])
+    depth, height, width = [float(v) for v in image_dhw]
+    boxes = clip_boxes(boxes, (0.0, 0.0, 0.0, depth, height, width))
+    keep = nms(boxes.detach().numpy(), scores.detach().numpy(), nms_threshold, proposal_count)
+    boxes = boxes[torch.from_numpy(keep).long()]
+    norm = torch.tensor([depth, height, width, depth, height, width], dtype=torch.float32)
+    return boxes / norm, keep, order
+
+
+def roi_bounds(boxes, dhw):
+    """model.py:271-278 / utils.py:160-174: fp32 product, floor lo / ceil hi, int64."""
+    scale = torch.tensor([dhw[0], dhw[1], dhw[2]] * 2, dtype=torch.float32)
+    b = torch.mul(boxes.float(), scale)
+    lo = b[:, :3].floor()
+    hi = b[:, 3:].ceil()
+    return torch.cat([lo, hi], dim=1).long()
+
+
+def roi_align(feature_map, pool_size, boxes):
+    """model.py:265-289: crop [lo:hi] (python slicing semantics: negative indices wrap,
+    upper bounds clamp) + trilinear align_corners=True resize; any failure -> zeros."""
+    c, d, h, w = feature_map.shape
+    ib = roi_bounds(boxes, (d, h, w))
+    out = torch.zeros((boxes.shape[0], c, pool_size[0], pool_size[1], pool_size[2]), dtype=feature_map.dtype)
+    for i in range(boxes.shape[0]):
+        z1, y1, x1, z2, y2, x2 = [int(v) for v in ib[i]]
+        crop = feature_map[:, z1:z2, y1:y2, x1:x2]
+        if crop.numel() == 0:
+            continue  # F.interpolate raises on an empty crop -> caught -> zeros (model.py:281-287)
+        out[i] = F.interpolate(crop.unsqueeze(0), size=tuple(pool_size), mode="trilinear", align_corners=True)[0]
+    return out
+
+
+def roi_levels(boxes):
+    """model.py:322-332: level = clamp(round(4 + log2(h*w*d)/3), 2, 3), fp32, half-to-even."""
+    d = boxes[:, 3] - boxes[:, 0]
+    h = boxes[:, 4] - boxes[:, 1]
+    w = boxes[:, 5] - boxes[:, 2]
+    ln2 = torch.log(torch.tensor([2.0], dtype=torch.float32))
+    lvl = 4 + (1.0 / 3.0) * (torch.log(h * w * d) / ln2)
+    return lvl.round().int().clamp(2, 3)
+
+
+def pyramid_roi_align(boxes, feature_maps, pool_size):
+    """model.py:292-370.  boxes [N,6] normalised; feature_maps = [level2, level3], each [C,D,H,W]."""
+    lv = roi_levels(boxes)
+    pooled, idx = [], []
+    for i, level in enumerate((2, 3)):
+        ix = torch.nonzero(lv == level)[:, 0]
+        if ix.numel() == 0:
+            continue
+        idx.append(ix)
+        pooled.append(roi_align(feature_maps[i], pool_size, boxes[ix].detach()))
+    pooled = torch.cat(pooled, dim=0)
+    _, back = torch.sort(torch.cat(idx, dim=0))
+    return pooled[back]
+
+
+# --------------------------------------------------------------------------------------
+# mask_branch.py
+# --------------------------------------------------------------------------------------
+
+
+def _inorm(x):
+    return F.instance_norm(x, eps=1e-5)
+
+
+def _lrelu(x):
+    return F.leaky_relu(x, 0.01)
+
+
+def unet(x, sd, prefix="", stage="beginning", dropout_masks=None):
+    """mask_branch.py:124-220.  dropout_masks: None (eval) or list of 5 [N,C] multipliers
+    (Dropout3d keep/(1-p) per (n,c)) applied at the 5 call sites."""
+    def w(name):
+        return sd[prefix + name + ".weight"]
+
+    def c3(v, name, stride=1):
+        return F.conv3d(v, w(name), None, stride=stride, padding=1)
+
+    def c1(v, name):
+        return F.conv3d(v, w(name), None)
+
+    def drop(v, i):
+        if dropout_masks is None:
+            return v
+        m = dropout_masks[i]
+        return v * m.view(m.shape[0], m.shape[1], 1, 1, 1)
+
+    def up(v):
+        return F.interpolate(v, scale_factor=2, mode="nearest")
+
+    def nluc(v, name):  # norm_lrelu_upscale_conv_norm_lrelu, mask_branch.py:108-116
+        return _lrelu(_inorm(c3(up(_lrelu(_inorm(v))), name + ".3")))
+
+    # level 1 (mask_branch.py:126-136; note residual is pre-activation, context_1 is pre-norm)
+    out = c3(x, "conv3d_c1_1")
+    res = out
+    out = c3(_lrelu(out), "conv3d_c1_2")
+    out = drop(out, 0)
+    out = c3(_lrelu(out), "lrelu_conv_c1.1")
+    out = out + res
+    ctx1 = _lrelu(out)
+    out = _lrelu(_inorm(out))
+    ctx = [ctx1]
+    # levels 2..5 (mask_branch.py:138-177); the norm_lrelu_conv weight is applied twice
+    for lvl in (2, 3, 4, 5):
+        out = c3(out, "conv3d_c%d" % lvl, stride=2)
+        res = out
+        name = "norm_lrelu_conv_c%d.2" % lvl
+        out = c3(_lrelu(_inorm(out)), name)
+        out = drop(out, lvl - 1)
+        out = c3(_lrelu(_inorm(out)), name)
+        out = out + res
+        if lvl < 5:
+            out = _lrelu(_inorm(out))
+            ctx.append(out)
+    out = nluc(out, "norm_lrelu_upscale_conv_norm_lrelu_l0")
+    out = _lrelu(_inorm(c1(out, "conv3d_l0")))
+    # localisation path (mask_branch.py:183-207)
+    out = torch.cat([out, ctx[3]], dim=1)
+    out = _lrelu(_inorm(c3(out, "conv_norm_lrelu_l1.0")))
+    out = c1(out, "conv3d_l1")
+    out = nluc(out, "norm_lrelu_upscale_conv_norm_lrelu_l1")
+    out = torch.cat([out, ctx[2]], dim=1)
+    out = _lrelu(_inorm(c3(out, "conv_norm_lrelu_l2.0")))
+    ds2 = out
+    out = c1(out, "conv3d_l2")
+    out = nluc(out, "norm_lrelu_upscale_conv_norm_lrelu_l2")
+    out = torch.cat([out, ctx[1]], dim=1)
+    out = _lrelu(_inorm(c3(out, "conv_norm_lrelu_l3.0")))
+    ds3 = out
+    out = c1(out, "conv3d_l3")
+    out = nluc(out, "norm_lrelu_upscale_conv_norm_lrelu_l3")
+    out = torch.cat([out, ctx[0]], dim=1)
+    out = _lrelu(_inorm(c3(out, "conv_norm_lrelu_l4.0")))
+    out_pred = c1(out, "conv3d_l4")
+    # deep supervision (mask_branch.py:209-215)
+    s = up(c1(ds2, "ds2_1x1_conv3d")) + c1(ds3, "ds3_1x1_conv3d")
+    out = out_pred + up(s)
+    if stage == "finetune":  # mask_branch.py:216-218
+        out = up(out) + F.conv3d(up(out), w("out_upscale_conv.1"), None, padding=2)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# model.py heads + losses
+# --------------------------------------------------------------------------------------
+
+
+def classifier(feature_maps, rois, sd, pool_size, prefix="classifier."):
+    """model.py:750-784 (BN eps 1e-3, eval).  feature_maps [p2,p3] each [C,D,H,W]; rois [N,6]."""
+    x = pyramid_roi_align(rois, feature_maps, pool_size)
+    x = F.relu(_bn_eval(_conv(x, sd, prefix + "conv1"), sd, prefix + "bn1", eps=1e-3))
+    x = F.relu(_bn_eval(_conv(x, sd, prefix + "conv2"), sd, prefix + "bn2", eps=1e-3))
+    x = x.view(x.shape[0], -1)
+    logits = F.linear(x, sd[prefix + "linear_class.weight"], sd[prefix + "linear_class.bias"])
+    probs = F.softmax(logits, dim=1)
+    bbox = F.linear(x, sd[prefix + "linear_bbox.weight"], sd[prefix + "linear_bbox.bias"])
+    return logits, probs, bbox.view(bbox.shape[0], -1, 6)
+
+
+def mask_head(image, rois, sd, pool_size, stage, prefix="mask.modified_u_net.", dropout_masks=None):
+    """model.py:787-801: RoIAlign of the RAW image -> U-Net -> softmax(dim=1)."""
+    x = pyramid_roi_align(rois, [image, image], pool_size)
+    logits = unet(x, sd, prefix, stage, dropout_masks)
+    return logits, F.softmax(logits, dim=1)
+
+
+def mask_ce_loss(target_onehot, logits):
+    """model.py:909-935 for all-positive inputs: target = argmax over one-hot channels,
+    CrossEntropyLoss mean over n*voxels.  target_onehot [n,C,D,H,W], logits [n,C,D,H,W]."""
+    y = torch.argmax(target_onehot.long(), dim=1)
+    return F.cross_entropy(logits, y)
+
+
+def sobel_stack():
+    """model.py:947-952."""
+    kx = np.array([[[1, 2, 1], [0, 0, 0], [-1, -2, -1]],
+                   [[2, 4, 2], [0, 0, 0], [-2, -4, -2]],
+                   [[1, 2, 1], [0, 0, 0], [-1, -2, -1]]])
+    ky = kx.transpose((1, 0, 2))
+    kz = kx.transpose((0, 2, 1))
+    return torch.from_numpy(np.array([kx, ky, kz]).reshape((3, 1, 3, 3, 3))).float()
+
+
+def edge_loss(target_onehot, probs):
+    """model.py:938-981: per (roi, class 1..C-1) valid Sobel conv, magnitude sqrt(c0^2+c1^2+c0^2)
+    (channel 0 twice, channel 2 unused -- reproduced as is), MSE mean; sum / n_pos."""
+    k = sobel_stack()
+    n, c = probs.shape[:2]
+    loss = torch.zeros(1, dtype=torch.float32)
+    for i in range(n):
+        for j in range(1, c):
+            t = F.conv3d(target_onehot[i, j][None, None].float(), k)
+            p = F.conv3d(probs[i, j][None, None], k)
+            tm = torch.sqrt(t[:, 0] ** 2 + t[:, 1] ** 2 + t[:, 0] ** 2)
+            pm = torch.sqrt(p[:, 0] ** 2 + p[:, 1] ** 2 + p[:, 0] ** 2)
+            loss = loss + F.mse_loss(pm, tm)
+    return loss / n
+
+
+def rpn_class_loss(rpn_match, rpn_class_logits):
+    """model.py:808-832.  rpn_match [1,A,1] in {-1,0,1}."""
+    m = rpn_match.squeeze(2)
+    idx = torch.nonzero(m != 0)
+    return F.cross_entropy(rpn_class_logits[idx[:, 0], idx[:, 1], :], (m == 1).long()[idx[:, 0], idx[:, 1]])
+
+
+def rpn_bbox_loss(target_bbox, rpn_match, rpn_bbox):
+    """model.py:835-860."""
+    m = rpn_match.squeeze(2)
+    idx = torch.nonzero(m == 1)
+    pred = rpn_bbox[idx[:, 0], idx[:, 1]]
+    return F.smooth_l1_loss(pred, target_bbox[0, :pred.shape[0], :])
+
+
+def mrcnn_class_loss(target_class_ids, logits):
+    """model.py:863-878 with the binarised ids of model.py:989."""
+    return F.cross_entropy(logits, (target_class_ids > 0).long())
+
+
+def mrcnn_bbox_loss(target_deltas, target_class_ids, pred_bbox):
+    """model.py:881-906 with the binarised ids of model.py:991-992 (class column = 1)."""
+    pos = torch.nonzero(target_class_ids > 0)[:, 0]
+    return F.smooth_l1_loss(pred_bbox[pos, 1, :], target_deltas[pos, :])
+
+
+def box_refinement(box, gt_box):
+    """utils.py:92-119."""
+    d = box[:, 3] - box[:, 0]; h = box[:, 4] - box[:, 1]; w = box[:, 5] - box[:, 2]
+    cz = box[:, 0] + 0.5 * d; cy = box[:, 1] + 0.5 * h; cx = box[:, 2] + 0.5 * w
+    gd = gt_box[:, 3] - gt_box[:, 0]; gh = gt_box[:, 4] - gt_box[:, 1]; gw = gt_box[:, 5] - gt_box[:, 2]
+    gz = gt_box[:, 0] + 0.5 * gd; gy = gt_box[:, 1] + 0.5 * gh; gx = gt_box[:, 2] + 0.5 * gw
+    return torch.stack([(gz - cz) / d, (gy - cy) / h, (gx - cx) / w,
+                        torch.log(gd / d), torch.log(gh / h), torch.log(gw / w)], dim=1)
+
+
+def nearest_resize(vol, out_shape):
+    """Restatement of skimage.transform.resize(order=0) as used at model.py:490 via
+    utils.py:318-339 (flagged restatement): output index o maps to input
+    index floor((o + 0.5) * in / out).  vol [..., d, h, w] -> [..., D, H, W]."""
+    idx = []
+    for ax, o in zip((-3, -2, -1), out_shape):
+        n = vol.shape[ax]
+        i = torch.floor((torch.arange(o, dtype=torch.float64) + 0.5) * (n / o)).long().clamp(0, n - 1)
+        idx.append(i)
+    return vol[..., idx[0][:, None, None], idx[1][None, :, None], idx[2][None, None, :]]
+
+
+def mask_targets(p_rois, gt_masks, mask_shape):
+    """model.py:481-493: crop with int() truncation of shape*coord, nearest resize.
+    gt_masks [C,D,H,W] one-hot; p_rois [n,6] normalised.  Returns [n,C,*mask_shape]."""
+    out = []
+    _, D, H, W = gt_masks.shape
+    for i in range(p_rois.shape[0]):
+        z1 = int(D * p_rois[i, 0]); z2 = int(D * p_rois[i, 3])
+        y1 = int(H * p_rois[i, 1]); y2 = int(H * p_rois[i, 4])
+        x1 = int(W * p_rois[i, 2]); x2 = int(W * p_rois[i, 5])
+        out.append(nearest_resize(gt_masks[:, z1:z2, y1:y2, x1:x2], mask_shape))
+    return torch.stack(out, dim=0)
+
+
+# --------------------------------------------------------------------------------------
+# one training step with injected RoI sets; the P row of 8(a)
+# --------------------------------------------------------------------------------------
+
+LOSS_WEIGHTS = (100.0, 50.0, 1.0, 20.0, 1.0, 1.0)  # heart_main.py:161-168
+
+
+def training_step(sd, image, anchors, rpn_match, rpn_bbox_t, p_rois, n_rois, target_class_ids,
+                  target_deltas, target_mask, stage, pool_size, mask_pool_size, dropout_masks=None,
+                  proposal_count=500, nms_threshold=0.7, pre_nms_limit=1000):
+    """predict('training') dataflow (model.py:1391-1514) + compute_losses (984-1000) with the
+    head RoIs injected (p_rois positives first, then n_rois).  image [1,1,D,H,W].
+    Returns dict of outputs and the 6 losses."""
+    p2, p3 = fpn(image, sd)
+    l2, pr2, b2 = rpn(p2, sd)
+    l3, pr3, b3 = rpn(p3, sd)
+    rpn_logits = torch.cat([l2, l3], dim=1)
+    rpn_probs = torch.cat([pr2, pr3], dim=1)
+    rpn_box = torch.cat([b2, b3], dim=1)
+    D, H, W = image.shape[2:]
+    rpn_rois, keep, order = proposal_layer(rpn_probs[0], rpn_box[0], anchors, proposal_count, nms_threshold,
+                                           (D, H, W), pre_nms_limit)
+    rois = torch.cat([p_rois, n_rois], dim=0)
+    cls_logits, cls_probs, cls_bbox = classifier([p2[0], p3[0]], rois, sd, pool_size)
+    m_logits, m_probs = mask_head(image[0], p_rois, sd, mask_pool_size, stage, dropout_masks=dropout_masks)
+    losses = [rpn_class_loss(rpn_match, rpn_logits),
+              rpn_bbox_loss(rpn_bbox_t, rpn_match, rpn_box),
+              mrcnn_class_loss(target_class_ids, cls_logits),
+              mrcnn_bbox_loss(target_deltas, target_class_ids, cls_bbox),
+              mask_ce_loss(target_mask, m_logits),
+              edge_loss(target_mask, m_probs)[0] if stage == "finetune" else torch.zeros(())]
+    total = sum(wt * l for wt, l in zip(LOSS_WEIGHTS, losses))
+    return dict(p2=p2, p3=p3, rpn_logits=rpn_logits, rpn_probs=rpn_probs, rpn_bbox=rpn_box, rpn_rois=rpn_rois,
+                nms_keep=keep, cls_logits=cls_logits, cls_bbox=cls_bbox, mask_logits=m_logits, mask_probs=m_probs,
+                losses=losses, total=total)

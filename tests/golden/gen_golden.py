@@ -1,0 +1,445 @@
+#!/usr/bin/env python3
+"""Golden-vector generator.  RUNS ONLY IN THE BUILD CONTAINER (needs /root/reference).
+
+Imports the reference's own Python (read-only, PYTHONDONTWRITEBYTECODE=1) with the three
+shims of SURVEY.md section 8(c) -- stub nibabel/skimage, identity .cuda(), GPU_COUNT=0 -- runs
+its functions/modules on closed-form inputs (oracle/formula.py) and stores inputs + outputs as
+small .npz fixtures next to this script.  Only DATA is stored; no reference source travels.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py [case ...]
+"""
+import os
+import sys
+import types
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import formula  # noqa: E402
+from oracle import cfun_oracle as orc  # noqa: E402  (only nearest_resize, for the skimage stub)
+
+REF = "/root/reference"
+
+
+def install_shims():
+    for name in ("nibabel", "skimage", "skimage.transform"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["skimage"].__version__ = "0.19.0"
+    sys.modules["skimage"].transform = sys.modules["skimage.transform"]
+
+    def resize(image, output_shape, order=1, mode="constant", preserve_range=True, **kw):
+        assert order == 0, "only the order=0 path is on the hot path (model.py:490)"
+        t = torch.from_numpy(np.asarray(image))
+        lead = t.shape[:-3]
+        assert tuple(output_shape[:len(lead)]) == tuple(lead)
+        return orc.nearest_resize(t, tuple(output_shape[-3:])).numpy()
+
+    sys.modules["skimage.transform"].resize = resize
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    nn.Module.cuda = lambda self, *a, **k: self
+    sys.path.insert(0, REF)
+
+
+install_shims()
+import backbone as ref_backbone  # noqa: E402
+import mask_branch as ref_mask_branch  # noqa: E402
+import model as ref_model  # noqa: E402
+import utils as ref_utils  # noqa: E402
+import heart_main as ref_heart  # noqa: E402
+
+
+def make_cfg(stage, max_dim, min_dim, **over):
+    ns = dict(GPU_COUNT=0, IMAGE_MAX_DIM=max_dim, IMAGE_MIN_DIM=min_dim)
+    ns.update(over)
+    return type("Cfg", (ref_heart.HeartConfig,), ns)(stage)
+
+
+def load_formula(module, gain=1.0):
+    shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+    arrs = formula.fill_state_dict(shapes, gain)
+    module.load_state_dict({k: torch.from_numpy(v) for k, v in arrs.items()}, strict=True)
+    return shapes
+
+
+def shapes_to_npz(shapes):
+    keys = sorted(shapes)
+    return dict(sd_keys=np.array(keys), sd_shapes=np.array([",".join(map(str, shapes[k])) for k in keys]))
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024.0))
+
+
+# ------------------------------------------------------------------------------------------
+
+
+def case_nms():
+    out = {}
+    rng = np.random.default_rng(1)
+
+    def boxes(n, dhw=(128, 256, 256), smin=8, smax=96):
+        c = rng.uniform(0, 1, (n, 3)) * np.array(dhw)
+        s = rng.uniform(smin, smax, (n, 3))
+        lo = np.clip(c - s / 2, 0, dhw)
+        hi = np.clip(c + s / 2, 0, dhw)
+        return np.concatenate([lo, hi], 1).astype(np.float32)
+
+    def scores(n):
+        s = rng.permutation(n).astype(np.float32) / n  # tie-free
+        return (s * 0.98 + 0.01).astype(np.float32)
+
+    cases = [("a", boxes(1000), scores(1000), 0.7, 500),
+             ("b", boxes(64, smin=40, smax=120), scores(64), 0.3, 32),
+             ("c", boxes(300, smin=60, smax=160), scores(300), 0.7, 5),       # max_num early break
+             ("d", boxes(1), scores(1), 0.7, 500),
+             ("e", np.zeros((0, 6), np.float32), np.zeros((0,), np.float32), 0.7, 500),
+             ("f", boxes(1000, smin=90, smax=200), scores(1000), 0.5, 500)]    # heavy suppression
+    tie = np.array([[0, 0, 0, 10, 10, 10], [0, 0, 0, 10, 10, 10], [20, 20, 20, 30, 30, 30]], np.float32)
+    cases.append(("tie", tie, np.array([0.5, 0.5, 0.4], np.float32), 0.7, 500))
+    for tag, b, s, thr, mx in cases:
+        keep = ref_utils.non_max_suppression(b.copy(), s.copy(), thr, mx)
+        out["%s_boxes" % tag] = b
+        out["%s_scores" % tag] = s
+        out["%s_cfg" % tag] = np.array([thr, mx], np.float64)
+        out["%s_keep" % tag] = keep
+        print("nms", tag, b.shape[0], "->", keep.shape[0])
+    save("nms", **out)
+
+
+def case_anchors():
+    out = {}
+    for tag, (h, w, d) in (("cfg0", (64, 64, 32)), ("odd", (96, 64, 48))):
+        cfg = make_cfg("beginning", 64, 32)
+        shapes = ref_model.compute_backbone_shapes(cfg, np.array([h, w, d, 1]))
+        a = ref_utils.generate_pyramid_anchors(cfg.RPN_ANCHOR_SCALES, cfg.RPN_ANCHOR_RATIOS, shapes,
+                                               cfg.BACKBONE_STRIDES, cfg.RPN_ANCHOR_STRIDE)
+        out[tag + "_hwd"] = np.array([h, w, d])
+        out[tag + "_shapes"] = shapes
+        out[tag + "_anchors"] = a
+    save("anchors", **out)
+
+
+def case_roi_align():
+    fm = torch.from_numpy(formula.uniform("roi.fm", (3, 6, 10, 12), -1, 1))
+    boxes = torch.tensor([
+        [0.10, 0.10, 0.10, 0.70, 0.80, 0.90],
+        [0.00, 0.00, 0.00, 1.00, 1.00, 1.00],     # whole map
+        [0.50, 0.50, 0.50, 0.50, 0.50, 0.50],     # z: floor(3.0)=3, ceil(3.0)=3 -> empty -> zeros
+        [0.34, 0.21, 0.26, 0.49, 0.29, 0.33],     # single-element crops on some axes (in==1)
+        [0.90, 0.90, 0.90, 1.20, 1.30, 1.10],     # upper bounds beyond the map (clamped by slicing)
+        [0.60, 0.20, 0.10, 0.40, 0.90, 0.80],     # inverted in z -> empty -> zeros
+        [0.17, 0.33, 0.41, 0.83, 0.67, 0.59],
+        [0.00, 0.95, 0.00, 0.20, 1.00, 0.10],
+    ], dtype=torch.float32)
+    pool = [4, 5, 3]
+    fm_g = fm.clone().requires_grad_(True)
+    out = ref_model.RoI_Align(fm_g, pool, boxes.clone())
+    gy = torch.from_numpy(formula.uniform("roi.gy", tuple(out.shape), -1, 1))
+    (out * gy).sum().backward()
+    # pyramid: two maps, boxes straddling the level threshold
+    p2 = torch.from_numpy(formula.uniform("roi.p2", (2, 8, 8, 8), -1, 1))
+    p3 = torch.from_numpy(formula.uniform("roi.p3", (2, 4, 4, 4), -1, 1))
+    pb = torch.tensor([
+        [0.10, 0.10, 0.10, 0.40, 0.40, 0.40],     # vol .027 -> level 2
+        [0.00, 0.00, 0.00, 0.90, 0.90, 0.90],     # level 3
+        [0.20, 0.20, 0.20, 0.55, 0.56, 0.57],     # ~0.045 near threshold
+        [0.20, 0.20, 0.20, 0.55, 0.55, 0.55],     # 0.0429
+        [0.50, 0.10, 0.30, 0.95, 0.60, 0.70],
+        [0.05, 0.05, 0.05, 0.30, 0.30, 0.30],
+    ], dtype=torch.float32)
+    lv = (4 + (1. / 3.) * ref_model.log2((pb[:, 4] - pb[:, 1]) * (pb[:, 5] - pb[:, 2]) * (pb[:, 3] - pb[:, 0])))
+    lv = lv.round().int().clamp(2, 3)
+    pooled = ref_model.pyramid_roi_align([pb.clone().unsqueeze(0).squeeze(0), p2.unsqueeze(0), p3.unsqueeze(0)],
+                                         [3, 3, 3])
+    save("roi_align", fm=fm.numpy(), boxes=boxes.numpy(), pool=np.array(pool), out=out.detach().numpy(),
+         gy=gy.numpy(), fm_grad=fm_g.grad.numpy(), p2=p2.numpy(), p3=p3.numpy(), pboxes=pb.numpy(),
+         plevels=lv.numpy(), ppool=np.array([3, 3, 3]), pooled=pooled.detach().numpy())
+
+
+def case_fpn_rpn():
+    cfg = make_cfg("beginning", 32, 16)
+    p3d = ref_backbone.P3D19(config=cfg)
+    c1, c2, c3 = p3d.stages()
+    fpn = ref_model.FPN(c1, c2, c3, out_channels=cfg.TOP_DOWN_PYRAMID_SIZE, config=cfg)
+    rpn = ref_model.RPN(len(cfg.RPN_ANCHOR_RATIOS), cfg.RPN_ANCHOR_STRIDE, cfg.TOP_DOWN_PYRAMID_SIZE,
+                        cfg.RPN_CONV_CHANNELS)
+    holder = nn.Module()
+    holder.fpn = fpn
+    holder.rpn = rpn
+    shapes = load_formula(holder)
+    holder.eval()
+    x = torch.from_numpy(formula.uniform("fpn.x", (1, 1, 16, 32, 32), -2, 2)).requires_grad_(True)
+    feats = {}
+    h = fpn.C1(x); feats["c1"] = h
+    h = fpn.C2(h); feats["c2"] = h
+    h = fpn.C3(h); feats["c3"] = h
+    p2, p3 = fpn(x)
+    outs = dict(p2=p2, p3=p3)
+    for tag, p in (("l2", p2), ("l3", p3)):
+        lg, pr, bb = rpn(p)
+        outs["rpn_logits_" + tag] = lg
+        outs["rpn_probs_" + tag] = pr
+        outs["rpn_bbox_" + tag] = bb
+    loss = 0
+    for k in ("p2", "p3", "rpn_logits_l2", "rpn_bbox_l2", "rpn_logits_l3", "rpn_bbox_l3"):
+        g = torch.from_numpy(formula.uniform("fpn.g." + k, tuple(outs[k].shape), -1, 1))
+        loss = loss + (outs[k] * g).sum()
+    loss.backward()
+    grads = {}
+    for k in ("fpn.C1.0.weight", "fpn.C1.0.bias", "fpn.C2.0.conv1.weight", "fpn.C2.0.conv2.weight",
+              "fpn.C2.1.conv3.weight", "fpn.C2.0.downsample.0.weight", "fpn.C3.2.conv3.weight",
+              "fpn.C3.1.conv4.bias", "fpn.P2_conv2.weight", "fpn.P3_conv1.weight", "fpn.P2_conv1.bias",
+              "rpn.conv_shared.weight", "rpn.conv_class.weight", "rpn.conv_bbox.bias"):
+        g = dict(holder.named_parameters())[k].grad.numpy()
+        if g.size > 100000:  # big tensors: keep every 4th output and input channel
+            grads["grad4:" + k] = g[::4, ::4].copy()
+        else:
+            grads["grad:" + k] = g
+    arrs = dict(x=x.detach().numpy(), x_grad=x.grad.numpy(), **shapes_to_npz(shapes))
+    arrs.update({k: v.detach().numpy() for k, v in feats.items()})
+    arrs.update({k: v.detach().numpy() for k, v in outs.items()})
+    arrs.update(grads)
+    save("fpn_rpn", **arrs)
+
+
+class DropRecorder:
+    """Records Dropout3d channel multipliers (out/in per (n,c)) -- SURVEY.md App. A-4."""
+
+    def __init__(self):
+        self.masks = []
+        self._orig = nn.Dropout3d.forward
+
+    def __enter__(self):
+        rec = self
+
+        def fwd(mod, inp):
+            out = rec._orig(mod, inp)
+            if mod.training:
+                n, c = inp.shape[:2]
+                m = torch.where(out.reshape(n, c, -1).abs().amax(-1) > 0,
+                                torch.full((n, c), 1.0 / (1.0 - mod.p)), torch.zeros(n, c))
+                rec.masks.append(m)
+            return out
+
+        nn.Dropout3d.forward = fwd
+        return self
+
+    def __exit__(self, *a):
+        nn.Dropout3d.forward = self._orig
+
+
+def case_unet():
+    for tag, stage, b, n, size, ncls, train in (("unet_beginning_eval", "beginning", 4, 2, 32, 8, False),
+                                                ("unet_beginning_train", "beginning", 4, 2, 32, 8, True),
+                                                ("unet_finetune_train", "finetune", 2, 1, 32, 8, True),
+                                                ("unet_lits_eval", "beginning", 4, 1, 32, 3, False)):
+        net = ref_mask_branch.Modified3DUNet(1, ncls, stage, b)
+        shapes = load_formula(net, gain=1.0)
+        net.train(train)
+        torch.manual_seed(7)
+        x = torch.from_numpy(formula.uniform(tag + ".x", (n, 1, size, size, size), -2, 2)).requires_grad_(True)
+        with DropRecorder() as rec:
+            y = net(x)
+        arrs = dict(x=x.detach().numpy(), stage=np.array(stage), b=np.array(b), ncls=np.array(ncls),
+                    **shapes_to_npz(shapes))
+        if train:
+            assert len(rec.masks) == 5
+            for i, m in enumerate(rec.masks):
+                arrs["drop%d" % i] = m.numpy()
+            gy = torch.from_numpy(formula.uniform(tag + ".gy", tuple(y.shape), -1, 1))
+            (y * gy).sum().backward()
+            arrs["x_grad"] = x.grad.numpy()
+            params = dict(net.named_parameters())
+            for k in ("conv3d_c1_1.weight", "conv3d_c1_2.weight", "lrelu_conv_c1.1.weight", "conv3d_c2.weight",
+                      "norm_lrelu_conv_c3.2.weight", "norm_lrelu_conv_c5.2.weight",
+                      "norm_lrelu_upscale_conv_norm_lrelu_l0.3.weight", "conv3d_l0.weight",
+                      "conv_norm_lrelu_l2.0.weight", "conv3d_l3.weight",
+                      "norm_lrelu_upscale_conv_norm_lrelu_l3.3.weight", "conv_norm_lrelu_l4.0.weight",
+                      "conv3d_l4.weight", "ds2_1x1_conv3d.weight", "ds3_1x1_conv3d.weight",
+                      "out_upscale_conv.1.weight"):
+                if params[k].grad is not None:
+                    arrs["grad:" + k] = params[k].grad.numpy()
+        yn = y.detach().numpy()
+        if yn.size > 600000:  # 'finetune' 8x64^3: keep a strided subsample + fp64 checksums
+            arrs["y_sub"] = yn[:, :, ::2, ::2, ::2].copy()
+            arrs["y_sum"] = np.array([yn.astype(np.float64).sum(), np.abs(yn).astype(np.float64).sum()])
+        else:
+            arrs["y"] = yn
+        save(tag, **arrs)
+
+
+def case_losses():
+    n, c, s = 2, 8, 12
+    logits = torch.from_numpy(formula.uniform("loss.logits", (n, c, s, s, s), -3, 3)).requires_grad_(True)
+    lab = (formula.uniform("loss.lab", (n, s, s, s), 0, 1) * c).astype(np.int64).clip(0, c - 1)
+    # blocky labels so that Sobel responses of the target are non-trivial
+    lab = np.repeat(np.repeat(np.repeat(lab[:, ::3, ::3, ::3], 3, 1), 3, 2), 3, 3)
+    onehot = np.zeros((n, c, s, s, s), np.float64)
+    for k in range(c):
+        onehot[:, k] = (lab == k)
+    target = torch.from_numpy(onehot)  # DoubleTensor like model.py:493
+    ids = torch.tensor([3, 5])
+    ce = ref_model.compute_mrcnn_mask_loss(target, ids, logits)
+    ce.backward()
+    g_ce = logits.grad.clone(); logits.grad = None
+    probs = torch.softmax(logits, dim=1)
+    el = ref_model.compute_mrcnn_mask_edge_loss(target, ids, probs)
+    el.backward()
+    g_edge = logits.grad.clone()
+    probs_leaf = probs.detach().clone().requires_grad_(True)
+    el2 = ref_model.compute_mrcnn_mask_edge_loss(target, ids, probs_leaf)
+    el2.backward()
+    save("losses", logits=logits.detach().numpy(), labels=lab.astype(np.uint8), ce=ce.detach().numpy(),
+         ce_grad=g_ce.numpy(), edge=el.detach().numpy(), edge_grad_logits=g_edge.numpy(),
+         edge_grad_probs=probs_leaf.grad.numpy())
+
+
+def case_proposal():
+    cfg = make_cfg("beginning", 64, 32)
+    shapes = ref_model.compute_backbone_shapes(cfg, cfg.IMAGE_SHAPE)
+    anchors = ref_utils.generate_pyramid_anchors(cfg.RPN_ANCHOR_SCALES, cfg.RPN_ANCHOR_RATIOS, shapes,
+                                                 cfg.BACKBONE_STRIDES, cfg.RPN_ANCHOR_STRIDE).astype(np.float32)
+    a = anchors.shape[0]
+    logits = formula.uniform("prop.logits", (1, a, 2), -3, 3)
+    probs = torch.softmax(torch.from_numpy(logits), dim=2)
+    bbox = torch.from_numpy(formula.uniform("prop.bbox", (1, a, 6), -2, 2))
+    out = {}
+    for tag, cnt in (("train", cfg.POST_NMS_ROIS_TRAINING), ("infer", 16)):
+        rois = ref_model.proposal_layer([probs.clone(), bbox.clone()], proposal_count=cnt,
+                                        nms_threshold=cfg.RPN_NMS_THRESHOLD, anchors=torch.from_numpy(anchors),
+                                        config=cfg)
+        out["rois_" + tag] = rois.numpy()
+        out["count_" + tag] = np.array(cnt)
+    save("proposal", anchors=anchors, probs=probs.numpy(), bbox=bbox.numpy(),
+         image_dhw=np.array([cfg.IMAGE_SHAPE[2], cfg.IMAGE_SHAPE[0], cfg.IMAGE_SHAPE[1]]), **out)
+
+
+def case_classifier():
+    ch, pool, fc = 8, [4, 4, 4], 16
+    net = ref_model.Classifier(ch, pool, None, 2, fc, test_flag=False)
+    shapes = load_formula(net)
+    net.eval()
+    p2 = torch.from_numpy(formula.uniform("cls.p2", (1, ch, 8, 16, 16), -1, 1)).requires_grad_(True)
+    p3 = torch.from_numpy(formula.uniform("cls.p3", (1, ch, 4, 8, 8), -1, 1)).requires_grad_(True)
+    rois = torch.tensor([[0.1, 0.1, 0.1, 0.4, 0.4, 0.4], [0.0, 0.0, 0.0, 1.0, 1.0, 1.0],
+                         [0.3, 0.2, 0.1, 0.9, 0.8, 0.7], [0.5, 0.5, 0.5, 0.7, 0.75, 0.8],
+                         [0.2, 0.6, 0.1, 0.5, 0.9, 0.3]], dtype=torch.float32)
+    lg, pr, bb = net([p2, p3], rois.clone())
+    g1 = torch.from_numpy(formula.uniform("cls.g1", tuple(lg.shape), -1, 1))
+    g2 = torch.from_numpy(formula.uniform("cls.g2", tuple(bb.shape), -1, 1))
+    ((lg * g1).sum() + (bb * g2).sum()).backward()
+    params = dict(net.named_parameters())
+    save("classifier", p2=p2.detach().numpy(), p3=p3.detach().numpy(), rois=rois.numpy(), pool=np.array(pool),
+         logits=lg.detach().numpy(), probs=pr.detach().numpy(), bbox=bb.detach().numpy(),
+         p2_grad=p2.grad.numpy(), p3_grad=p3.grad.numpy(),
+         **{"grad:conv1.weight": params["conv1.weight"].grad.numpy(),
+            "grad:linear_bbox.weight": params["linear_bbox.weight"].grad.numpy()},
+         **shapes_to_npz(shapes))
+
+
+def case_predict():
+    """Full, un-injected reference dataflow at cfg0 (64x64x32, 'beginning'), SURVEY.md 8(d)."""
+    stage = "beginning"
+    cfg = make_cfg(stage, 64, 32)
+    net = ref_model.MaskRCNN(cfg, "/tmp/cfun_logs", test_flag=False)
+    shapes = load_formula(net)
+    H, W, D = cfg.IMAGE_SHAPE[:3]
+    lab = np.zeros((D, H, W), np.int64)
+    for k in range(1, 8):  # 7 slabs along x inside the whole-volume GT box
+        lab[:, :, (k - 1) * W // 7:k * W // 7] = k
+    lab[:2] = 0
+    hu = np.where(lab == 0, -1000.0, (lab - 1) * 50.0) + formula.uniform("pred.noise", (D, H, W), -50, 50)
+    img = ((hu - hu.mean()) / hu.std()).astype(np.float32)
+    image = torch.from_numpy(img)[None, None]
+    gt_masks = np.zeros((1, 8, D, H, W), np.float32)
+    for k in range(8):
+        gt_masks[0, k] = (lab == k)
+    gt_boxes = np.tile(np.array([0, 0, 0, D, H, W], np.float32), (7, 1))[None]
+    gt_class_ids = np.arange(1, 8, dtype=np.int32)[None]
+    anchors = net.anchors.numpy()
+    # rpn targets: mark anchors by IoU with the GT box (host-side bookkeeping, inputs to the path)
+    ov = ref_utils.compute_overlaps(anchors.astype(np.float64), gt_boxes[0, :1].astype(np.float64))[:, 0]
+    rpn_match = np.zeros((1, anchors.shape[0], 1), np.int32)
+    rpn_match[0, ov < 0.1, 0] = -1
+    pos = np.argsort(-ov)[:6]
+    rpn_match[0, pos, 0] = 1
+    rpn_bbox_t = np.zeros((1, cfg.RPN_TRAIN_ANCHORS_PER_IMAGE, 6), np.float32)
+    rb = ref_utils.box_refinement(torch.from_numpy(anchors[np.sort(pos)]).float(),
+                                  torch.from_numpy(np.tile(gt_boxes[0, :1], (6, 1))).float()).numpy()
+    rpn_bbox_t[0, :6] = rb / cfg.RPN_BBOX_STD_DEV
+    perms = []
+    orig_randperm = torch.randperm
+
+    def rec_randperm(n, *a, **k):
+        g = torch.Generator().manual_seed(100 + len(perms))
+        p = orig_randperm(n, generator=g)
+        perms.append(p.numpy())
+        return p
+
+    torch.randperm = rec_randperm
+    torch.manual_seed(3)
+    try:
+        with DropRecorder() as rec:
+            outs = net.predict([image, None, torch.from_numpy(gt_class_ids), torch.from_numpy(gt_boxes),
+                                torch.from_numpy(gt_masks)], "training")
+    finally:
+        torch.randperm = orig_randperm
+    (rpn_class_logits, rpn_pred_bbox, target_class_ids, mrcnn_class_logits, target_deltas, mrcnn_bbox,
+     target_mask, mrcnn_mask, mrcnn_mask_logits) = outs
+    assert mrcnn_mask_logits.numel() > 0, "heads were skipped -- golden would be void"
+    losses = ref_model.compute_losses(torch.from_numpy(rpn_match), torch.from_numpy(rpn_bbox_t), rpn_class_logits,
+                                      rpn_pred_bbox, target_class_ids, mrcnn_class_logits, target_deltas,
+                                      mrcnn_bbox, target_mask, mrcnn_mask, mrcnn_mask_logits, stage)
+    w = cfg.LOSS_WEIGHTS
+    total = (w["rpn_class_loss"] * losses[0] + w["rpn_bbox_loss"] * losses[1] + w["mrcnn_class_loss"] * losses[2]
+             + w["mrcnn_bbox_loss"] * losses[3] + w["mrcnn_mask_loss"] * losses[4]
+             + w["mrcnn_mask_edge_loss"] * losses[5])
+    total.backward()
+    params = dict(net.named_parameters())
+    n_pos = int((target_class_ids > 0).sum())
+    n_all = int(target_class_ids.shape[0])
+    print("predict: n_pos", n_pos, "n_rois", n_all, "losses", [float(l) for l in losses])
+    ml = mrcnn_mask_logits.detach().numpy()
+    tm = target_mask.numpy()
+    arrs = dict(image=img, gt_masks_labels=lab.astype(np.uint8), gt_boxes=gt_boxes, gt_class_ids=gt_class_ids,
+                anchors=anchors, rpn_match=rpn_match, rpn_bbox_t=rpn_bbox_t,
+                randperm0=perms[0], randperm1=perms[1],
+                rpn_class_logits=rpn_class_logits.detach().numpy(), rpn_pred_bbox=rpn_pred_bbox.detach().numpy(),
+                target_class_ids=target_class_ids.numpy(), mrcnn_class_logits=mrcnn_class_logits.detach().numpy(),
+                target_deltas=target_deltas.numpy(), mrcnn_bbox=mrcnn_bbox.detach().numpy(),
+                target_mask_labels=tm.argmax(1).astype(np.uint8),
+                target_mask_is_onehot=np.array(bool(np.all(tm.sum(1) == 1))),
+                mask_logits_sub=ml[:, :, ::4, ::4, ::4].copy(),
+                mask_logits_sum=np.array([ml.astype(np.float64).sum(), np.abs(ml).astype(np.float64).sum()]),
+                losses=np.array([float(l) for l in losses]), total=np.array(float(total)),
+                n_pos=np.array(n_pos), n_rois=np.array(n_all), stage=np.array(stage), **shapes_to_npz(shapes))
+    for i, m in enumerate(rec.masks):
+        arrs["drop%d" % i] = m.numpy()
+    for k in ("fpn.C1.0.weight", "fpn.C3.2.conv3.weight", "fpn.P2_conv2.bias", "rpn.conv_class.weight",
+              "classifier.linear_class.weight", "classifier.conv2.weight",
+              "mask.modified_u_net.conv3d_c1_1.weight", "mask.modified_u_net.norm_lrelu_conv_c3.2.weight",
+              "mask.modified_u_net.conv3d_l4.weight"):
+        arrs["grad:" + k] = params[k].grad.numpy()
+    # the sampled RoI sets themselves (outputs of detection_target_layer) are recoverable from the
+    # recorded randperm draws; store them too so the restatement can be checked stage by stage
+    save("predict_cfg0", **arrs)
+
+
+CASES = dict(nms=case_nms, anchors=case_anchors, roi_align=case_roi_align, fpn_rpn=case_fpn_rpn, unet=case_unet,
+             losses=case_losses, proposal=case_proposal, classifier=case_classifier, predict=case_predict)
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or [k for k in CASES if k != "predict"]
+    for k in which:
+        print("== case", k)
+        CASES[k]()

@@ -1,0 +1,157 @@
+"""CPU: the oracle restatement (oracle/cfun_oracle.py) against the golden vectors generated from
+the reference import (tests/golden/gen_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_state_dict, load_golden
+from oracle import cfun_oracle as orc
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f", "tie"])
+def test_nms_bit_exact(tag):
+    g = load_golden("nms")
+    thr, mx = g[tag + "_cfg"]
+    keep = orc.nms(g[tag + "_boxes"], g[tag + "_scores"], float(thr), int(mx))
+    assert keep.dtype == np.int32
+    np.testing.assert_array_equal(keep, g[tag + "_keep"])
+
+
+@pytest.mark.parametrize("tag", ["cfg0", "odd"])
+def test_anchors_exact(tag):
+    g = load_golden("anchors")
+    a = orc.generate_pyramid_anchors((64, 128), g[tag + "_shapes"], (8, 16), 1)
+    np.testing.assert_array_equal(a, g[tag + "_anchors"])
+
+
+def test_roi_align_forward_and_grad():
+    g = load_golden("roi_align")
+    fm = t(g["fm"]).requires_grad_(True)
+    out = orc.roi_align(fm, [int(v) for v in g["pool"]], t(g["boxes"]))
+    np.testing.assert_allclose(out.detach().numpy(), g["out"], rtol=0, atol=1e-6)
+    assert np.all(g["out"][2] == 0) and np.all(g["out"][5] == 0)  # degenerate boxes -> zeros
+    (out * t(g["gy"])).sum().backward()
+    np.testing.assert_allclose(fm.grad.numpy(), g["fm_grad"], rtol=0, atol=1e-5)
+
+
+def test_pyramid_roi_align_levels_and_order():
+    g = load_golden("roi_align")
+    lv = orc.roi_levels(t(g["pboxes"]))
+    np.testing.assert_array_equal(lv.numpy(), g["plevels"])
+    assert set(g["plevels"].tolist()) == {2, 3}
+    pooled = orc.pyramid_roi_align(t(g["pboxes"]), [t(g["p2"]), t(g["p3"])], [3, 3, 3])
+    np.testing.assert_allclose(pooled.numpy(), g["pooled"], rtol=0, atol=1e-6)
+
+
+def test_fpn_rpn_forward_and_grads():
+    g = load_golden("fpn_rpn")
+    sd = golden_state_dict(g)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype == torch.float32}
+    sd_live = dict(sd)
+    sd_live.update(params)
+    x = t(g["x"]).requires_grad_(True)
+    c1, c2, c3 = orc.p3d_stages(x, sd_live, "fpn.")
+    for k, v in (("c1", c1), ("c2", c2), ("c3", c3)):
+        np.testing.assert_allclose(v.detach().numpy(), g[k], rtol=1e-5, atol=1e-6)
+    p2, p3 = orc.fpn(x, sd_live)
+    outs = dict(p2=p2, p3=p3)
+    for tag, p in (("l2", p2), ("l3", p3)):
+        lg, pr, bb = orc.rpn(p, sd_live)
+        outs["rpn_logits_" + tag], outs["rpn_probs_" + tag], outs["rpn_bbox_" + tag] = lg, pr, bb
+    for k, v in outs.items():
+        np.testing.assert_allclose(v.detach().numpy(), g[k], rtol=1e-5, atol=2e-6, err_msg=k)
+    from oracle import formula
+    loss = 0
+    for k in ("p2", "p3", "rpn_logits_l2", "rpn_bbox_l2", "rpn_logits_l3", "rpn_bbox_l3"):
+        loss = loss + (outs[k] * t(formula.uniform("fpn.g." + k, tuple(outs[k].shape), -1, 1))).sum()
+    loss.backward()
+    np.testing.assert_allclose(x.grad.numpy(), g["x_grad"], rtol=1e-4, atol=1e-5)
+    n = 0
+    for k in g:
+        if k.startswith("grad:"):
+            got = params[k[5:]].grad.numpy()
+        elif k.startswith("grad4:"):
+            got = params[k[6:]].grad.numpy()[::4, ::4]
+        else:
+            continue
+        n += 1
+        scale = np.abs(g[k]).max()
+        np.testing.assert_allclose(got, g[k], rtol=1e-4, atol=1e-5 * max(scale, 1.0), err_msg=k)
+    assert n >= 10
+
+
+@pytest.mark.parametrize("name", ["unet_beginning_eval", "unet_beginning_train", "unet_finetune_train",
+                                  "unet_lits_eval"])
+def test_unet(name):
+    g = load_golden(name)
+    sd = golden_state_dict(g)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    x = t(g["x"]).requires_grad_(True)
+    masks = [t(g["drop%d" % i]) for i in range(5)] if "drop0" in g else None
+    y = orc.unet(x, params, "", str(g["stage"]), masks)
+    yn = y.detach().numpy()
+    if "y" in g:
+        np.testing.assert_allclose(yn, g["y"], rtol=1e-4, atol=1e-4)
+    else:
+        np.testing.assert_allclose(yn[:, :, ::2, ::2, ::2], g["y_sub"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(np.abs(yn).astype(np.float64).sum(), g["y_sum"][1], rtol=1e-5)
+    if masks is not None:
+        from oracle import formula
+        (y * t(formula.uniform(name + ".gy", tuple(y.shape), -1, 1))).sum().backward()
+        np.testing.assert_allclose(x.grad.numpy(), g["x_grad"], rtol=1e-3, atol=1e-3 * np.abs(g["x_grad"]).max())
+        n = 0
+        for k in g:
+            if k.startswith("grad:"):
+                n += 1
+                ref = g[k]
+                np.testing.assert_allclose(params[k[5:]].grad.numpy(), ref, rtol=1e-3,
+                                           atol=1e-3 * np.abs(ref).max(), err_msg=k)
+        assert n >= 10
+
+
+def test_mask_losses():
+    g = load_golden("losses")
+    lab = g["labels"].astype(np.int64)
+    c = g["logits"].shape[1]
+    onehot = torch.stack([t(lab == k) for k in range(c)], dim=1).double()
+    logits = t(g["logits"]).requires_grad_(True)
+    ce = orc.mask_ce_loss(onehot, logits)
+    np.testing.assert_allclose(ce.item(), g["ce"], rtol=1e-6)
+    ce.backward()
+    np.testing.assert_allclose(logits.grad.numpy(), g["ce_grad"], rtol=1e-5, atol=1e-9)
+    logits.grad = None
+    el = orc.edge_loss(onehot, torch.softmax(logits, dim=1))
+    np.testing.assert_allclose(el.item(), g["edge"].item(), rtol=1e-6)
+    el.backward()
+    np.testing.assert_allclose(logits.grad.numpy(), g["edge_grad_logits"], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("tag", ["train", "infer"])
+def test_proposal_layer(tag):
+    g = load_golden("proposal")
+    rois, keep, order = orc.proposal_layer(t(g["probs"][0]), t(g["bbox"][0]), t(g["anchors"]),
+                                           int(g["count_" + tag]), 0.7, [int(v) for v in g["image_dhw"]])
+    np.testing.assert_array_equal(rois.numpy(), g["rois_" + tag][0])
+
+
+def test_classifier():
+    g = load_golden("classifier")
+    sd = golden_state_dict(g)
+    params = {k: v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v
+              for k, v in sd.items()}
+    p2 = t(g["p2"]).requires_grad_(True)
+    p3 = t(g["p3"]).requires_grad_(True)
+    lg, pr, bb = orc.classifier([p2[0], p3[0]], t(g["rois"]), params, [int(v) for v in g["pool"]], prefix="")
+    np.testing.assert_allclose(lg.detach().numpy(), g["logits"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(pr.detach().numpy(), g["probs"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(bb.detach().numpy(), g["bbox"], rtol=1e-5, atol=1e-6)
+    from oracle import formula
+    ((lg * t(formula.uniform("cls.g1", tuple(lg.shape), -1, 1))).sum()
+     + (bb * t(formula.uniform("cls.g2", tuple(bb.shape), -1, 1))).sum()).backward()
+    np.testing.assert_allclose(p2.grad.numpy(), g["p2_grad"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(p3.grad.numpy(), g["p3_grad"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(params["conv1.weight"].grad.numpy(), g["grad:conv1.weight"], rtol=1e-4, atol=1e-6)
