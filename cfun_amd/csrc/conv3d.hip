@@ -1,0 +1,185 @@
+// C ABI of the convolution family: algorithm selection between the MFMA implicit-GEMM kernels
+// (conv3d_mfma.h) and the generic direct kernels (conv3d_direct.hip).
+#include "conv3d_mfma.h"
+
+// conv3d_direct.hip
+int cfun_conv_fwd_direct(const float*, const float*, const float*, const float*, const float*, float*,
+                         const CfunConv3dParams*, hipStream_t);
+int cfun_conv_bwd_data_direct(const float*, const float*, float*, const CfunConv3dParams*, hipStream_t);
+int cfun_conv_bwd_weight_direct(const float*, const float*, float*, const CfunConv3dParams*, void*, size_t, hipStream_t);
+size_t cfun_direct_wgrad_ws(const CfunConv3dParams*);
+int cfun_reduce_partials(const float*, float*, int64_t, int, hipStream_t);
+
+namespace {
+
+typedef int (*FwdFn)(int, const float*, const float*, const float*, const float*, const float*, float*,
+                     const CfunConv3dParams&, int, hipStream_t);
+typedef void (*PlanFn)(const CfunConv3dParams&, int, cfun_mfma::WgPlan*);
+typedef int (*WgFn)(const float*, const float*, float*, const CfunConv3dParams&, const cfun_mfma::WgPlan&, hipStream_t);
+
+struct Shape {
+  int kd, kh, kw, s;
+  FwdFn fwd;
+  PlanFn plan;
+  WgFn wgrad;
+  int max_nsub;
+};
+
+#define SHAPE(NAME, KD, KH, KW, S, MAXN) \
+  { KD, KH, KW, S, cfun_mfma_fwd_##NAME, cfun_mfma_wgrad_plan_##NAME, cfun_mfma_wgrad_##NAME, MAXN }
+const Shape kShapes[] = {
+    SHAPE(k333s1, 3, 3, 3, 1, 5), SHAPE(k333s2, 3, 3, 3, 2, 5), SHAPE(k111s1, 1, 1, 1, 1, 5),
+    SHAPE(k111s2, 1, 1, 1, 2, 5), SHAPE(k133s1, 1, 3, 3, 1, 5), SHAPE(k311s1, 3, 1, 1, 1, 5),
+    SHAPE(k555s1, 5, 5, 5, 1, 1),
+};
+
+const Shape* find_shape(int kd, int kh, int kw, int s) {
+  for (const Shape& sh : kShapes)
+    if (sh.kd == kd && sh.kh == kh && sh.kw == kw && sh.s == s) return &sh;
+  return nullptr;
+}
+
+// number of 16-channel subtiles per block: minimise padded channels, prefer wide tiles on ties
+int pick_nsub(int co, int max_nsub) {
+  int best = 1, best_pad = 1 << 30;
+  for (int n = 1; n <= max_nsub; ++n) {
+    const int nt = 16 * n;
+    const int pad = (co + nt - 1) / nt * nt;
+    if (pad <= best_pad) { best_pad = pad; best = n; }
+  }
+  return best;
+}
+
+bool valid_params(const CfunConv3dParams* p) {
+  if (!p) return false;
+  if (p->N < 0 || p->Ci <= 0 || p->Co <= 0 || p->kd <= 0 || p->kh <= 0 || p->kw <= 0) return false;
+  if (p->stride != 1 && p->stride != 2) return false;
+  if (p->CoP < p->Co || (p->CoP & 15) || p->CiP < p->Ci || (p->CiP & 15)) return false;
+  const int sh = p->up2 ? 1 : 0;
+  // output size must match the conv arithmetic
+  if ((((p->Di << sh) + 2 * p->pd - p->kd) / p->stride + 1) != p->Do) return false;
+  if ((((p->Hi << sh) + 2 * p->ph - p->kh) / p->stride + 1) != p->Ho) return false;
+  if ((((p->Wi << sh) + 2 * p->pw - p->kw) / p->stride + 1) != p->Wo) return false;
+  if (p->res_mode && p->res_up2 && ((p->Do | p->Ho | p->Wo) & 1)) return false;
+  return true;
+}
+
+const Shape* mfma_shape(const CfunConv3dParams* p) {
+  if ((p->Ci & 3) || (p->Co & 3)) return nullptr;
+  const Shape* s = find_shape(p->kd, p->kh, p->kw, p->stride);
+  if (!s) return nullptr;
+  if (p->Co > 16 * s->max_nsub && s->max_nsub == 1) return nullptr;
+  return s;
+}
+
+// the data gradient of a stride-1 conv is a stride-1 conv of g with flipped, transposed weights
+bool make_dgrad_params(const CfunConv3dParams* p, CfunConv3dParams* q) {
+  if (p->stride != 1) return false;
+  const int sh = p->up2 ? 1 : 0;
+  *q = *p;
+  q->Di = p->Do; q->Hi = p->Ho; q->Wi = p->Wo; q->Ci = p->Co;
+  q->Do = p->Di << sh; q->Ho = p->Hi << sh; q->Wo = p->Wi << sh; q->Co = p->Ci;
+  q->CoP = p->CiP; q->CiP = p->CoP;
+  q->pd = p->kd - 1 - p->pd; q->ph = p->kh - 1 - p->ph; q->pw = p->kw - 1 - p->pw;
+  if (q->pd < 0 || q->ph < 0 || q->pw < 0) return false;
+  q->up2 = 0; q->act = CFUN_ACT_NONE; q->scale_mode = 0; q->has_shift = 0; q->res_mode = 0; q->res_up2 = 0;
+  return true;
+}
+
+bool use_mfma_dgrad(const CfunConv3dParams* p, CfunConv3dParams* q, const Shape** s) {
+  if (p->algo == CFUN_ALGO_DIRECT) return false;
+  if (!make_dgrad_params(p, q)) return false;
+  *s = mfma_shape(q);
+  return *s != nullptr;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cfun_version(void) { return CFUN_VERSION; }
+
+const char* cfun_error_string(int code) {
+  switch (code) {
+    case CFUN_OK: return "ok";
+    case CFUN_EINVAL: return "cfun: invalid argument or unsupported shape";
+    case CFUN_EWORKSPACE: return "cfun: workspace too small";
+    case CFUN_EALIGN: return "cfun: pointer not 16-byte aligned";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "cfun: unknown error";
+  }
+}
+
+int cfun_conv3d_fwd(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
+                    float* y, const CfunConv3dParams* p, cfun_stream_t stream) {
+  if (!valid_params(p)) return CFUN_EINVAL;
+  if ((p->scale_mode && !scale) || (p->has_shift && !shift) || (p->res_mode && !res)) return CFUN_EINVAL;
+  if (p->scale_mode < 0 || p->scale_mode > 2 || p->res_mode < 0 || p->res_mode > 1) return CFUN_EINVAL;
+  const Shape* s = p->algo == CFUN_ALGO_DIRECT ? nullptr : mfma_shape(p);
+  if (s) {
+    if (!cfun_aligned16(x) || !cfun_aligned16(wp) || !cfun_aligned16(y) || (scale && !cfun_aligned16(scale)) ||
+        (shift && !cfun_aligned16(shift)) || (res && !cfun_aligned16(res)))
+      return CFUN_EALIGN;
+    return s->fwd(pick_nsub(p->Co, s->max_nsub), x, wp, scale, shift, res, y, *p, 0, cfun_st(stream));
+  }
+  if (p->algo == CFUN_ALGO_MFMA) return CFUN_EINVAL;
+  return cfun_conv_fwd_direct(x, wp, scale, shift, res, y, p, cfun_st(stream));
+}
+
+size_t cfun_conv3d_bwd_data_workspace_bytes(const CfunConv3dParams* p) {
+  if (!valid_params(p)) return 0;
+  CfunConv3dParams q;
+  const Shape* s;
+  if (use_mfma_dgrad(p, &q, &s) && p->up2)
+    return cfun_align_up((size_t)q.N * q.Do * q.Ho * q.Wo * q.Co * sizeof(float), 256);
+  return 256;
+}
+
+int cfun_conv3d_bwd_data(const float* g, const float* wpT, float* dx, const CfunConv3dParams* p, void* ws,
+                         size_t ws_bytes, cfun_stream_t stream) {
+  if (!valid_params(p)) return CFUN_EINVAL;
+  CfunConv3dParams q;
+  const Shape* s;
+  if (use_mfma_dgrad(p, &q, &s)) {
+    if (!cfun_aligned16(g) || !cfun_aligned16(wpT) || !cfun_aligned16(dx)) return CFUN_EALIGN;
+    const int nsub = pick_nsub(q.Co, s->max_nsub);
+    if (!p->up2) return s->fwd(nsub, g, wpT, nullptr, nullptr, nullptr, dx, q, 1, cfun_st(stream));
+    if (ws_bytes < cfun_conv3d_bwd_data_workspace_bytes(p) || !cfun_aligned16(ws)) return CFUN_EWORKSPACE;
+    const int rc = s->fwd(nsub, g, wpT, nullptr, nullptr, nullptr, (float*)ws, q, 1, cfun_st(stream));
+    if (rc) return rc;
+    return cfun_upsample2_bwd((const float*)ws, dx, p->N, p->Di, p->Hi, p->Wi, p->Ci, stream);
+  }
+  // stride-2 data gradients have no MFMA kernel yet: CFUN_ALGO_MFMA means "MFMA where one exists"
+  return cfun_conv_bwd_data_direct(g, wpT, dx, p, cfun_st(stream));
+}
+
+size_t cfun_conv3d_bwd_weight_workspace_bytes(const CfunConv3dParams* p) {
+  if (!valid_params(p)) return 0;
+  const Shape* s = p->algo == CFUN_ALGO_DIRECT ? nullptr : mfma_shape(p);
+  if (s) {
+    cfun_mfma::WgPlan w;
+    s->plan(*p, pick_nsub(p->CoP, s->max_nsub), &w);
+    return cfun_align_up((size_t)w.nchunks * w.kslots * p->kd * p->kh * p->kw * p->Ci * p->CoP * sizeof(float), 256);
+  }
+  return cfun_align_up(cfun_direct_wgrad_ws(p), 256);
+}
+
+int cfun_conv3d_bwd_weight(const float* x, const float* g, float* dwp, const CfunConv3dParams* p, void* ws,
+                           size_t ws_bytes, cfun_stream_t stream) {
+  if (!valid_params(p)) return CFUN_EINVAL;
+  const Shape* s = p->algo == CFUN_ALGO_DIRECT ? nullptr : mfma_shape(p);
+  if (s) {
+    if (!cfun_aligned16(x) || !cfun_aligned16(g)) return CFUN_EALIGN;
+    if (ws_bytes < cfun_conv3d_bwd_weight_workspace_bytes(p)) return CFUN_EWORKSPACE;
+    const int64_t nout = (int64_t)p->kd * p->kh * p->kw * p->Ci * p->CoP;
+    cfun_mfma::WgPlan w;
+    s->plan(*p, pick_nsub(p->CoP, s->max_nsub), &w);
+    if (w.ntiles == 0) return (int)hipMemsetAsync(dwp, 0, nout * sizeof(float), cfun_st(stream));
+    const int rc = s->wgrad(x, g, (float*)ws, *p, w, cfun_st(stream));
+    if (rc) return rc;
+    return cfun_reduce_partials((const float*)ws, dwp, nout, w.nchunks * w.kslots, cfun_st(stream));
+  }
+  if (p->algo == CFUN_ALGO_MFMA) return CFUN_EINVAL;
+  return cfun_conv_bwd_weight_direct(x, g, dwp, p, ws, ws_bytes, cfun_st(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,485 @@
+// LDS-tiled, im2col-free implicit-GEMM 3-D convolution on the fp32 matrix cores
+// (v_mfma_f32_16x16x4_f32: exact fp32, same rate as the fp32 vector peak but one VGPR per operand).
+//
+//   forward / data-gradient kernel (k_conv_mfma):
+//     block  = 256 threads (4 waves) -> 4(z) x 4(y) x 16(x) output voxels x (16*NSUB) output channels
+//     wave w = z-plane w of the tile; 4 m-subtiles (rows y) of 16 voxels along x
+//     K loop = input channels in chunks of 4 (one MFMA k-step) x all taps, operands from LDS:
+//       X tile   [4 ch][IZ*IY*IX voxels incl. halo]   (channel planes padded so that a wave's 4x16
+//                                                       fragment read is bank-conflict free)
+//       W chunk  [tap][4 ch][16*NSUB (+16) co]
+//     A = W^T (rows = co), B = X (cols = voxels)  =>  D[co][voxel]: each lane owns 4 consecutive output
+//     channels of one voxel -> one float4 NDHWC store, fused epilogue (scale, shift, residual, activation).
+//     The next chunk's global loads are issued before the MFMA block of the current one (register prefetch).
+//
+//   weight-gradient kernel (k_wgrad_mfma):
+//     block  = 2(z) x 4(y) x 16(x) voxels per step, one 16-channel ci subtile x (16*NSUB) co, a range of
+//              spatial tiles; taps are split over the 4 waves (or the voxel groups, when taps < 4)
+//     A = X^T (rows = ci, k = 4 consecutive voxels), B = G (k = voxels, cols = co)  =>  D[ci][co] per tap,
+//     accumulated in registers over all tiles of the block, written as a partial; a second kernel sums the
+//     partials (deterministic, no atomics).
+#pragma once
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace cfun_mfma {
+
+constexpr int pad_plane(int v, int rs) { return rs == 1 ? v + ((16 - (v % 32)) + 32) % 32 : (v | 1); }
+constexpr int pad_row16(int v) { return (v % 32 == 16) ? v : v + 16; }  // v is a multiple of 16
+constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// bijective XCD-aware remap: consecutive logical ids stay on one XCD (blocks are dealt round-robin to the 8 XCDs)
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
+  const unsigned q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u, local = bid >> 3;
+  const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + local;
+}
+
+template <int KD, int KH, int KW, int S>
+struct FwdTile {
+  static constexpr int TD = 4, TH = 4, TW = 16;
+  static constexpr int TAPS = KD * KH * KW;
+  static constexpr bool COMPACT = TAPS == 1;     // 1x1x1: stage exactly the voxels that are read
+  static constexpr int RS = COMPACT ? 1 : S;     // x stride of a fragment read in LDS
+  static constexpr int IZ = COMPACT ? TD : (TD - 1) * S + KD;
+  static constexpr int IY = COMPACT ? TH : (TH - 1) * S + KH;
+  static constexpr int IX = COMPACT ? TW : (TW - 1) * S + KW;
+  static constexpr int IVOX = IZ * IY * IX;
+  static constexpr int PLANEP = pad_plane(IVOX, RS);
+  static constexpr int IN_LOADS = cdiv(IVOX, 256);
+};
+
+template <int KD, int KH, int KW, int S, int NSUB>
+__global__ void __launch_bounds__(256)
+k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale,
+            const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
+            CfunConv3dParams p, int flip, int ntz, int nty, int ntx, int ncot) {
+  using T = FwdTile<KD, KH, KW, S>;
+  constexpr int TAPS = T::TAPS, NT = 16 * NSUB, NTP = pad_row16(NT);
+  constexpr int W_ITEMS = TAPS * NT;  // float4 items per weight chunk: TAPS*4 rows x NT/4
+  constexpr int W_LOADS = cdiv(W_ITEMS, 256);
+  CFUN_DYN_LDS(float, smem);
+  float* Xl = smem;                      // [4][PLANEP]
+  float* Wl = smem + 4 * T::PLANEP;      // [TAPS*4][NTP]
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int cot = lid % ncot; lid /= ncot;
+  const int tx = lid % ntx; lid /= ntx;
+  const int ty = lid % nty; lid /= nty;
+  const int tz = lid % ntz;
+  const int n = lid / ntz;
+  const int z0 = tz * T::TD, y0 = ty * T::TH, x0 = tx * T::TW;
+  const int cobase = cot * NT;
+  const int sh = p.up2 ? 1 : 0;
+  const int Dv = p.Di << sh, Hv = p.Hi << sh, Wv = p.Wi << sh;
+
+  // ---- per-thread staging descriptors (independent of the channel chunk)
+  int64_t in_off[T::IN_LOADS];  // element offset of the voxel's channel 0, or -1 when padded / unused
+#pragma unroll
+  for (int i = 0; i < T::IN_LOADS; ++i) {
+    const int idx = tid + i * 256;
+    in_off[i] = -1;
+    if (idx < T::IVOX) {
+      const int ix = idx % T::IX, iy = (idx / T::IX) % T::IY, iz = idx / (T::IX * T::IY);
+      int vz, vy, vx;
+      if (T::COMPACT) { vz = (z0 + iz) * S - p.pd; vy = (y0 + iy) * S - p.ph; vx = (x0 + ix) * S - p.pw; }
+      else { vz = z0 * S - p.pd + iz; vy = y0 * S - p.ph + iy; vx = x0 * S - p.pw + ix; }
+      if (vz >= 0 && vz < Dv && vy >= 0 && vy < Hv && vx >= 0 && vx < Wv)
+        in_off[i] = ((((int64_t)n * p.Di + (vz >> sh)) * p.Hi + (vy >> sh)) * p.Wi + (vx >> sh)) * p.Ci;
+    }
+  }
+  float4 xin[T::IN_LOADS], win[W_LOADS];
+  auto prefetch = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < T::IN_LOADS; ++i)
+      xin[i] = in_off[i] >= 0 ? *reinterpret_cast<const float4*>(x + in_off[i] + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < W_LOADS; ++i) {
+      const int it = tid + i * 256;
+      win[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (it < W_ITEMS) {
+        const int row = it / (NT / 4), col = (it % (NT / 4)) * 4;
+        const int tap = row >> 2, cc = row & 3;
+        const int tapw = flip ? TAPS - 1 - tap : tap;
+        if (cobase + col < p.CoP)
+          win[i] = *reinterpret_cast<const float4*>(wp + ((int64_t)tapw * p.Ci + c0 + cc) * p.CoP + cobase + col);
+      }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < T::IN_LOADS; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < T::IVOX) {
+        Xl[idx] = xin[i].x; Xl[T::PLANEP + idx] = xin[i].y;
+        Xl[2 * T::PLANEP + idx] = xin[i].z; Xl[3 * T::PLANEP + idx] = xin[i].w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < W_LOADS; ++i) {
+      const int it = tid + i * 256;
+      if (it < W_ITEMS) {
+        const int row = it / (NT / 4), col = (it % (NT / 4)) * 4;
+        *reinterpret_cast<float4*>(Wl + row * NTP + col) = win[i];
+      }
+    }
+  };
+
+  f32x4 acc[4][NSUB];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int nn = 0; nn < NSUB; ++nn) acc[m][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const float* Xw = Xl + (lane >> 4) * T::PLANEP + (wv * T::RS * T::IY) * T::IX + (lane & 15) * T::RS;
+  const float* Ww = Wl + (lane >> 4) * NTP + (lane & 15);
+
+  const int nchunks = p.Ci >> 2;
+  prefetch(0);
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();           // every wave is done reading the previous chunk
+    commit();
+    __syncthreads();
+    if (c + 1 < nchunks) prefetch((c + 1) * 4);
+#pragma unroll
+    for (int dz = 0; dz < KD; ++dz)
+#pragma unroll
+      for (int dy = 0; dy < KH; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < KW; ++dx) {
+          const int tap = (dz * KH + dy) * KW + dx;
+          float a[NSUB];
+#pragma unroll
+          for (int nn = 0; nn < NSUB; ++nn) a[nn] = Ww[tap * 4 * NTP + nn * 16];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const float b = Xw[(dz * T::IY + (m * T::RS + dy)) * T::IX + dx];
+#pragma unroll
+            for (int nn = 0; nn < NSUB; ++nn)
+              acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nn], b, acc[m][nn], 0, 0, 0);
+          }
+        }
+  }
+
+  // ---- epilogue: lane owns voxel (z0+wv, y0+m, x0+(lane&15)), channels cobase + nn*16 + (lane>>4)*4 .. +3
+  const int oz = z0 + wv, ox = x0 + (lane & 15);
+  if (oz >= p.Do || ox >= p.Wo) return;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int oy = y0 + m;
+    if (oy >= p.Ho) continue;
+    const int64_t v = (((int64_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox;
+    int64_t rv = v;
+    if (p.res_mode && p.res_up2)
+      rv = (((int64_t)n * (p.Do >> 1) + (oz >> 1)) * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
+#pragma unroll
+    for (int nn = 0; nn < NSUB; ++nn) {
+      const int co = cobase + nn * 16 + (lane >> 4) * 4;
+      if (co >= p.Co) continue;
+      float4 r = make_float4(acc[m][nn][0], acc[m][nn][1], acc[m][nn][2], acc[m][nn][3]);
+      if (p.scale_mode) {
+        const float4 s = *reinterpret_cast<const float4*>(scale + (p.scale_mode == 2 ? n * p.Co : 0) + co);
+        r.x *= s.x; r.y *= s.y; r.z *= s.z; r.w *= s.w;
+      }
+      if (p.has_shift) {
+        const float4 t = *reinterpret_cast<const float4*>(shift + co);
+        r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+      }
+      if (p.res_mode) {
+        const float4 t = *reinterpret_cast<const float4*>(res + rv * p.Co + co);
+        r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+      }
+      r.x = cfun_apply_act(r.x, p.act, p.slope); r.y = cfun_apply_act(r.y, p.act, p.slope);
+      r.z = cfun_apply_act(r.z, p.act, p.slope); r.w = cfun_apply_act(r.w, p.act, p.slope);
+      *reinterpret_cast<float4*>(y + v * p.Co + co) = r;
+    }
+  }
+}
+
+template <int KD, int KH, int KW, int S, int NSUB>
+int launch_conv_mfma(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
+                     float* y, const CfunConv3dParams& p, int flip, hipStream_t st) {
+  using T = FwdTile<KD, KH, KW, S>;
+  constexpr int NT = 16 * NSUB, NTP = pad_row16(NT);
+  const int ntz = cdiv(p.Do, T::TD), nty = cdiv(p.Ho, T::TH), ntx = cdiv(p.Wo, T::TW), ncot = cdiv(p.Co, NT);
+  const int64_t nblk = (int64_t)p.N * ntz * nty * ntx * ncot;
+  if (nblk == 0) return CFUN_OK;
+  if (nblk > 0x7fffffffLL) return CFUN_EINVAL;
+  const size_t lds = (size_t)(4 * T::PLANEP + T::TAPS * 4 * NTP) * sizeof(float);
+  auto kern = k_conv_mfma<KD, KH, KW, S, NSUB>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, x, wp, scale, shift, res, y, p, flip, ntz, nty, ntx, ncot);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+template <int KD, int KH, int KW, int S>
+constexpr int max_nsub() { return KD * KH * KW > 27 ? 1 : 5; }   // 5x5x5: LDS / accumulator budget allows 16 channels
+
+template <int KD, int KH, int KW, int S>
+int dispatch_nsub(int nsub, const float* x, const float* wp, const float* scale, const float* shift, const float* res,
+                  float* y, const CfunConv3dParams& p, int flip, hipStream_t st) {
+  if constexpr (max_nsub<KD, KH, KW, S>() == 1) {
+    if (nsub != 1) return CFUN_EINVAL;
+    return launch_conv_mfma<KD, KH, KW, S, 1>(x, wp, scale, shift, res, y, p, flip, st);
+  } else {
+    switch (nsub) {
+      case 1: return launch_conv_mfma<KD, KH, KW, S, 1>(x, wp, scale, shift, res, y, p, flip, st);
+      case 2: return launch_conv_mfma<KD, KH, KW, S, 2>(x, wp, scale, shift, res, y, p, flip, st);
+      case 3: return launch_conv_mfma<KD, KH, KW, S, 3>(x, wp, scale, shift, res, y, p, flip, st);
+      case 4: return launch_conv_mfma<KD, KH, KW, S, 4>(x, wp, scale, shift, res, y, p, flip, st);
+      default: return launch_conv_mfma<KD, KH, KW, S, 5>(x, wp, scale, shift, res, y, p, flip, st);
+    }
+  }
+}
+
+// ============================================================================================ weight gradient
+template <int KD, int KH, int KW, int S>
+struct WgTile {
+  static constexpr int TD = (S == 1) ? 2 : 1, TH = 4, TW = 16;   // stride 2: smaller tile, the halo tile is 4x larger
+  static constexpr int TVOX = TD * TH * TW;  // 128 (64 for stride 2)
+  static constexpr int TAPS = KD * KH * KW;
+  static constexpr bool COMPACT = TAPS == 1;
+  static constexpr int RS = COMPACT ? 1 : S;
+  static constexpr int IZ = COMPACT ? TD : (TD - 1) * S + KD;
+  static constexpr int IY = COMPACT ? TH : (TH - 1) * S + KH;
+  static constexpr int IX = COMPACT ? TW : (TW - 1) * S + KW;
+  static constexpr int IVOX = IZ * IY * IX;
+  static constexpr int XS = 16;                         // floats per staged voxel (one ci subtile)
+  static constexpr int X_LOADS = cdiv(IVOX * 4, 256);   // float4 items
+  static constexpr int TSPLIT = TAPS >= 4 ? 4 : 1;      // taps over waves, else voxel groups over waves
+  static constexpr int KSPLIT = 4 / TSPLIT;
+  static constexpr int TPW = cdiv(TAPS, TSPLIT);        // taps per wave
+};
+
+template <int KD, int KH, int KW, int S, int NSUB>
+__global__ void __launch_bounds__(256)
+k_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ partial,
+             CfunConv3dParams p, int ntz, int nty, int ntx, int ncisub, int ncot, int tiles_per_chunk, int ntiles) {
+  using T = WgTile<KD, KH, KW, S>;
+  constexpr int TAPS = T::TAPS, NT = 16 * NSUB, GS = pad_row16(NT);
+  constexpr int G_ITEMS = T::TVOX * (NT / 4);
+  constexpr int G_LOADS = cdiv(G_ITEMS, 256);
+  CFUN_DYN_LDS(float, smem);
+  float* Xl = smem;                       // [IVOX][16]
+  float* Gl = smem + T::IVOX * T::XS;     // [TVOX][GS]
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int cot = lid % ncot; lid /= ncot;
+  const int cis = lid % ncisub;
+  const int chunk = lid / ncisub;
+  const int ci0 = cis * 16, cobase = cot * NT;
+  const int sh = p.up2 ? 1 : 0;
+  const int Dv = p.Di << sh, Hv = p.Hi << sh, Wv = p.Wi << sh;
+  const int tslot = wv % T::TSPLIT, kslot = wv / T::TSPLIT;
+
+  f32x4 acc[T::TPW][NSUB];
+#pragma unroll
+  for (int t = 0; t < T::TPW; ++t)
+#pragma unroll
+    for (int nn = 0; nn < NSUB; ++nn) acc[t][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float4 xin[T::X_LOADS], gin[G_LOADS];
+  auto prefetch = [&](int tile) {
+    int t = tile;
+    const int tx = t % ntx; t /= ntx;
+    const int ty = t % nty; t /= nty;
+    const int tz = t % ntz;
+    const int n = t / ntz;
+    const int z0 = tz * T::TD, y0 = ty * T::TH, x0 = tx * T::TW;
+#pragma unroll
+    for (int i = 0; i < T::X_LOADS; ++i) {
+      const int it = tid + i * 256;
+      xin[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (it < T::IVOX * 4) {
+        const int idx = it >> 2, c = ci0 + (it & 3) * 4;
+        const int ix = idx % T::IX, iy = (idx / T::IX) % T::IY, iz = idx / (T::IX * T::IY);
+        int vz, vy, vx;
+        if (T::COMPACT) { vz = (z0 + iz) * S - p.pd; vy = (y0 + iy) * S - p.ph; vx = (x0 + ix) * S - p.pw; }
+        else { vz = z0 * S - p.pd + iz; vy = y0 * S - p.ph + iy; vx = x0 * S - p.pw + ix; }
+        if (c < p.Ci && vz >= 0 && vz < Dv && vy >= 0 && vy < Hv && vx >= 0 && vx < Wv)
+          xin[i] = *reinterpret_cast<const float4*>(
+              x + ((((int64_t)n * p.Di + (vz >> sh)) * p.Hi + (vy >> sh)) * p.Wi + (vx >> sh)) * p.Ci + c);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < G_LOADS; ++i) {
+      const int it = tid + i * 256;
+      gin[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (it < G_ITEMS) {
+        const int vox = it / (NT / 4), col = (it % (NT / 4)) * 4;
+        const int lx = vox % T::TW, ly = (vox / T::TW) % T::TH, lz = vox / (T::TW * T::TH);
+        const int oz = z0 + lz, oy = y0 + ly, ox = x0 + lx;
+        if (cobase + col < p.Co && oz < p.Do && oy < p.Ho && ox < p.Wo)
+          gin[i] = *reinterpret_cast<const float4*>(
+              g + ((((int64_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * p.Co + cobase + col);
+      }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < T::X_LOADS; ++i) {
+      const int it = tid + i * 256;
+      if (it < T::IVOX * 4) *reinterpret_cast<float4*>(Xl + (it >> 2) * T::XS + (it & 3) * 4) = xin[i];
+    }
+#pragma unroll
+    for (int i = 0; i < G_LOADS; ++i) {
+      const int it = tid + i * 256;
+      if (it < G_ITEMS) *reinterpret_cast<float4*>(Gl + (it / (NT / 4)) * GS + (it % (NT / 4)) * 4) = gin[i];
+    }
+  };
+
+  const int t_begin = chunk * tiles_per_chunk;
+  const int t_end = (t_begin + tiles_per_chunk < ntiles) ? t_begin + tiles_per_chunk : ntiles;
+  // A fragment: lane -> ci = lane&15, voxel k = lane>>4 ; B fragment: lane -> co = lane&15, voxel k = lane>>4
+  const float* Xw = Xl + (lane >> 4) * T::RS * T::XS + (lane & 15);
+  const float* Gw = Gl + (lane >> 4) * GS + (lane & 15);
+
+  int toff[T::TPW];  // LDS offset of each of this wave's taps (wave-uniform)
+#pragma unroll
+  for (int t = 0; t < T::TPW; ++t) {
+    const int tap = t * T::TSPLIT + tslot;
+    const int dz = tap / (KH * KW), dy = (tap / KW) % KH, dx = tap % KW;
+    toff[t] = tap < TAPS ? ((dz * T::IY + dy) * T::IX + dx) * T::XS : -1;
+  }
+
+  if (t_begin < t_end) prefetch(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (tile + 1 < t_end) prefetch(tile + 1);
+    // voxel groups: (lz, ly, xq) with 4 consecutive x per group
+    for (int grp = kslot; grp < T::TVOX / 4; grp += T::KSPLIT) {
+      const int xq = grp & 3, ly = (grp >> 2) & 3, lz = grp >> 4;
+      float b[NSUB];
+#pragma unroll
+      for (int nn = 0; nn < NSUB; ++nn) b[nn] = Gw[(grp * 4) * GS + nn * 16];
+      const float* Xg = Xw + ((lz * T::RS * T::IY + ly * T::RS) * T::IX + xq * 4 * T::RS) * T::XS;
+#pragma unroll
+      for (int t = 0; t < T::TPW; ++t) {
+        if (toff[t] >= 0) {
+          const float a = Xg[toff[t]];
+#pragma unroll
+          for (int nn = 0; nn < NSUB; ++nn)
+            acc[t][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[nn], acc[t][nn], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // partial[(chunk*KSPLIT + kslot)][tap][ci][CoP]; D[i=ci][j=co]: lane -> co = lane&15, ci = (lane>>4)*4 + r
+  float* out = partial + (int64_t)(chunk * T::KSPLIT + kslot) * TAPS * p.Ci * p.CoP;
+#pragma unroll
+  for (int t = 0; t < T::TPW; ++t) {
+    const int tap = t * T::TSPLIT + tslot;
+    if (tap >= TAPS) continue;
+#pragma unroll
+    for (int nn = 0; nn < NSUB; ++nn) {
+      const int co = cobase + nn * 16 + (lane & 15);
+      if (co >= p.CoP) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ci = ci0 + (lane >> 4) * 4 + r;
+        if (ci < p.Ci) out[((int64_t)tap * p.Ci + ci) * p.CoP + co] = acc[t][nn][r];
+      }
+    }
+  }
+}
+
+struct WgPlan {
+  int ntz, nty, ntx, ntiles, ncisub, ncot, nchunks, tiles_per_chunk, nsub, kslots;
+};
+
+template <int KD, int KH, int KW, int S>
+WgPlan wgrad_plan(const CfunConv3dParams& p, int nsub) {
+  using T = WgTile<KD, KH, KW, S>;
+  WgPlan w;
+  w.nsub = nsub;
+  w.ntz = cdiv(p.Do, T::TD); w.nty = cdiv(p.Ho, T::TH); w.ntx = cdiv(p.Wo, T::TW);
+  w.ntiles = p.N * w.ntz * w.nty * w.ntx;
+  w.ncisub = cdiv(p.Ci, 16);
+  w.ncot = cdiv(p.CoP, 16 * nsub);
+  int want = 1024 / (w.ncisub * w.ncot);
+  if (want < 1) want = 1;
+  if (want > w.ntiles) want = w.ntiles;
+  if (want < 1) want = 1;
+  w.tiles_per_chunk = cdiv(w.ntiles, want);
+  if (w.tiles_per_chunk < 1) w.tiles_per_chunk = 1;
+  w.nchunks = cdiv(w.ntiles, w.tiles_per_chunk);
+  if (w.nchunks < 1) w.nchunks = 1;
+  w.kslots = T::KSPLIT;
+  return w;
+}
+
+template <int KD, int KH, int KW, int S, int NSUB>
+int launch_wgrad_mfma(const float* x, const float* g, float* partial, const CfunConv3dParams& p, const WgPlan& w,
+                      hipStream_t st) {
+  using T = WgTile<KD, KH, KW, S>;
+  constexpr int NT = 16 * NSUB, GS = pad_row16(NT);
+  const size_t lds = (size_t)(T::IVOX * T::XS + T::TVOX * GS) * sizeof(float);
+  auto kern = k_wgrad_mfma<KD, KH, KW, S, NSUB>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  const int64_t nblk = (int64_t)w.nchunks * w.ncisub * w.ncot;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, x, g, partial, p, w.ntz, w.nty, w.ntx, w.ncisub,
+                     w.ncot, w.tiles_per_chunk, w.ntiles);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+template <int KD, int KH, int KW, int S>
+int dispatch_wgrad(const float* x, const float* g, float* partial, const CfunConv3dParams& p, const WgPlan& w,
+                   hipStream_t st) {
+  if constexpr (max_nsub<KD, KH, KW, S>() == 1) {
+    if (w.nsub != 1) return CFUN_EINVAL;
+    return launch_wgrad_mfma<KD, KH, KW, S, 1>(x, g, partial, p, w, st);
+  } else {
+    switch (w.nsub) {
+      case 1: return launch_wgrad_mfma<KD, KH, KW, S, 1>(x, g, partial, p, w, st);
+      case 2: return launch_wgrad_mfma<KD, KH, KW, S, 2>(x, g, partial, p, w, st);
+      case 3: return launch_wgrad_mfma<KD, KH, KW, S, 3>(x, g, partial, p, w, st);
+      case 4: return launch_wgrad_mfma<KD, KH, KW, S, 4>(x, g, partial, p, w, st);
+      default: return launch_wgrad_mfma<KD, KH, KW, S, 5>(x, g, partial, p, w, st);
+    }
+  }
+}
+
+}  // namespace cfun_mfma
+
+// per-shape translation units (conv3d_mfma_*.hip) export these C++ entry points
+#define CFUN_MFMA_DECL(NAME)                                                                                        \
+  int cfun_mfma_fwd_##NAME(int nsub, const float* x, const float* wp, const float* scale, const float* shift,       \
+                           const float* res, float* y, const CfunConv3dParams& p, int flip, hipStream_t st);        \
+  void cfun_mfma_wgrad_plan_##NAME(const CfunConv3dParams& p, int nsub, cfun_mfma::WgPlan* w);                      \
+  int cfun_mfma_wgrad_##NAME(const float* x, const float* g, float* partial, const CfunConv3dParams& p,             \
+                             const cfun_mfma::WgPlan& w, hipStream_t st);
+
+#define CFUN_MFMA_DEFINE(NAME, KD, KH, KW, S)                                                                       \
+  int cfun_mfma_fwd_##NAME(int nsub, const float* x, const float* wp, const float* scale, const float* shift,       \
+                           const float* res, float* y, const CfunConv3dParams& p, int flip, hipStream_t st) {       \
+    return cfun_mfma::dispatch_nsub<KD, KH, KW, S>(nsub, x, wp, scale, shift, res, y, p, flip, st);                 \
+  }                                                                                                                 \
+  void cfun_mfma_wgrad_plan_##NAME(const CfunConv3dParams& p, int nsub, cfun_mfma::WgPlan* w) {                     \
+    *w = cfun_mfma::wgrad_plan<KD, KH, KW, S>(p, nsub);                                                             \
+  }                                                                                                                 \
+  int cfun_mfma_wgrad_##NAME(const float* x, const float* g, float* partial, const CfunConv3dParams& p,             \
+                             const cfun_mfma::WgPlan& w, hipStream_t st) {                                          \
+    return cfun_mfma::dispatch_wgrad<KD, KH, KW, S>(x, g, partial, p, w, st);                                       \
+  }
+
+CFUN_MFMA_DECL(k333s1)
+CFUN_MFMA_DECL(k333s2)
+CFUN_MFMA_DECL(k111s1)
+CFUN_MFMA_DECL(k111s2)
+CFUN_MFMA_DECL(k133s1)
+CFUN_MFMA_DECL(k311s1)
+CFUN_MFMA_DECL(k555s1)

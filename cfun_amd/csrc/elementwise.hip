@@ -1,0 +1,485 @@
+// HBM-bound passes of the hot path: activation derivatives, InstanceNorm3d(+LeakyReLU) forward/backward,
+// per-channel reductions, nearest-x2 upsample backward, MaxPool3d(2,2), halo pack/unpack.
+// All NDHWC fp32, float4 (16 B/lane) accesses along the channel axis, grid-stride loops.
+#include "common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+inline unsigned ew_grid(int64_t work_items) {
+  int64_t b = (work_items + kBlock - 1) / kBlock;
+  if (b > 256 * 8) b = 256 * 8;  // 8 blocks per CU, grid-stride the rest
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+// ------------------------------------------------------------------ simple elementwise
+__global__ void __launch_bounds__(kBlock) k_lrelu_fwd(const float4* x, float4* y, int64_t n4, float slope) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+    float4 v = x[i];
+    v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+    v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+    y[i] = v;
+  }
+}
+__global__ void k_lrelu_fwd_tail(const float* x, float* y, int64_t from, int64_t n, float slope) {
+  int64_t i = from + threadIdx.x;
+  if (i < n) y[i] = x[i] > 0.f ? x[i] : x[i] * slope;
+}
+__global__ void __launch_bounds__(kBlock)
+k_lrelu_bwd(const float4* x, const float4* dy, float4* dx, int64_t n4, float slope) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+    const float4 v = x[i];
+    float4 g = dy[i];
+    g.x = v.x > 0.f ? g.x : g.x * slope; g.y = v.y > 0.f ? g.y : g.y * slope;
+    g.z = v.z > 0.f ? g.z : g.z * slope; g.w = v.w > 0.f ? g.w : g.w * slope;
+    dx[i] = g;
+  }
+}
+__global__ void k_lrelu_bwd_tail(const float* x, const float* dy, float* dx, int64_t from, int64_t n, float slope) {
+  int64_t i = from + threadIdx.x;
+  if (i < n) dx[i] = x[i] > 0.f ? dy[i] : dy[i] * slope;
+}
+__global__ void __launch_bounds__(kBlock) k_add(const float4* a, const float4* b, float4* o, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+    const float4 u = a[i], v = b[i];
+    o[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+  }
+}
+__global__ void k_add_tail(const float* a, const float* b, float* o, int64_t from, int64_t n) {
+  int64_t i = from + threadIdx.x;
+  if (i < n) o[i] = a[i] + b[i];
+}
+
+// g = dy * act'(y) * scale ; one thread per element (C may be any size)
+__global__ void __launch_bounds__(kBlock)
+k_act_bwd(const float* __restrict__ y, const float* __restrict__ dy, const float* __restrict__ scale,
+          float* __restrict__ g, int64_t total, int C, int64_t vox_per_n, int act, float slope, int scale_mode) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    float d = dy[i];
+    if (act != CFUN_ACT_NONE) {
+      const float yy = y[i];
+      if (!(yy > 0.f)) d = (act == CFUN_ACT_RELU) ? 0.f : d * slope;
+    }
+    if (scale_mode) {
+      const int64_t v = i / C;
+      const int c = (int)(i - v * C);
+      d *= (scale_mode == 1) ? scale[c] : scale[(v / vox_per_n) * C + c];
+    }
+    g[i] = d;
+  }
+}
+
+// ------------------------------------------------------------------ per-(n,c) reductions over voxels
+// Thread = (voxel lane, 4-channel group).  Accumulates NQ quantities in fp64, reduces the voxel lanes through
+// LDS and writes partial[n][block][q][c] (deterministic two-stage reduction; no atomics).
+struct StatSumSq {  // sum x, sum x^2
+  static constexpr int NQ = 2;
+  const float* x;
+  __device__ void operator()(int64_t e4, int, int, double (&acc)[2][4]) const {
+    const float4 v = reinterpret_cast<const float4*>(x)[e4];
+    const float a[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc[0][j] += a[j]; acc[1][j] += (double)a[j] * a[j]; }
+  }
+};
+struct StatSum {  // sum g
+  static constexpr int NQ = 1;
+  const float* x;
+  __device__ void operator()(int64_t e4, int, int, double (&acc)[1][4]) const {
+    const float4 v = reinterpret_cast<const float4*>(x)[e4];
+    acc[0][0] += v.x; acc[0][1] += v.y; acc[0][2] += v.z; acc[0][3] += v.w;
+  }
+};
+struct StatNormBwd {  // sum gn, sum gn*xhat with gn = dy*lrelu'(xhat)
+  static constexpr int NQ = 2;
+  const float* x;
+  const float* dy;
+  const float* stats;  // [N,C,2]
+  int C;
+  float slope;
+  __device__ void operator()(int64_t e4, int n, int c0, double (&acc)[2][4]) const {
+    const float4 v = reinterpret_cast<const float4*>(x)[e4];
+    const float4 d = reinterpret_cast<const float4*>(dy)[e4];
+    const float a[4] = {v.x, v.y, v.z, v.w}, b[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float mean = stats[((int64_t)n * C + c0 + j) * 2], rstd = stats[((int64_t)n * C + c0 + j) * 2 + 1];
+      const float xh = (a[j] - mean) * rstd;
+      const float gn = xh > 0.f ? b[j] : b[j] * slope;
+      acc[0][j] += gn;
+      acc[1][j] += (double)gn * xh;
+    }
+  }
+};
+
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+k_channel_reduce(F f, double* __restrict__ partial, int64_t V, int C, int lanes) {
+  constexpr int NQ = F::NQ;
+  __shared__ double sm[kBlock * NQ * 4];
+  const int CG = C >> 2;
+  const int tid = threadIdx.x;
+  const int cg = tid % CG, vl = tid / CG;
+  const int n = blockIdx.y;
+  double acc[NQ][4];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[q][j] = 0.0;
+  if (vl < lanes) {
+    for (int64_t v = (int64_t)blockIdx.x * lanes + vl; v < V; v += (int64_t)gridDim.x * lanes)
+      f(((int64_t)n * V + v) * CG + cg, n, cg * 4, acc);
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sm[(tid * NQ + q) * 4 + j] = acc[q][j];
+  __syncthreads();
+  if (vl == 0) {
+    for (int l = 1; l < lanes; ++l) {
+      const int t2 = l * CG + cg;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[q][j] += sm[(t2 * NQ + q) * 4 + j];
+    }
+    double* out = partial + (((int64_t)n * gridDim.x + blockIdx.x) * NQ) * C;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) out[(int64_t)q * C + cg * 4 + j] = acc[q][j];
+  }
+}
+
+// mode 0: stats (mean, rstd) from (sum, sumsq); mode 1: plain sums (float) ; mode 2: means of the two sums
+__global__ void k_channel_finalize(const double* __restrict__ partial, float* __restrict__ out, int NC, int C,
+                                   int blocks, int NQ, int64_t V, float eps, int mode) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= NC) return;
+  const int n = i / C, c = i - n * C;
+  double s[2] = {0.0, 0.0};
+  for (int b = 0; b < blocks; ++b)
+    for (int q = 0; q < NQ; ++q) s[q] += partial[(((int64_t)n * blocks + b) * NQ + q) * C + c];
+  if (mode == 0) {
+    const double mean = s[0] / (double)V;
+    double var = s[1] / (double)V - mean * mean;
+    if (var < 0.0) var = 0.0;
+    out[(int64_t)i * 2] = (float)mean;
+    out[(int64_t)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  } else if (mode == 1) {
+    out[i] = (float)s[0];
+  } else {
+    out[(int64_t)i * 2] = (float)(s[0] / (double)V);
+    out[(int64_t)i * 2 + 1] = (float)(s[1] / (double)V);
+  }
+}
+
+struct ReducePlan {
+  int lanes, blocks;
+};
+inline ReducePlan reduce_plan(int N, int64_t V, int C) {
+  ReducePlan r;
+  const int CG = C >> 2;
+  r.lanes = kBlock / CG;
+  int64_t want = (2048 + N - 1) / N;                       // ~8 blocks per CU in total
+  int64_t maxb = (V + (int64_t)r.lanes * 16 - 1) / ((int64_t)r.lanes * 16);  // >= 16 voxels per thread
+  if (maxb < 1) maxb = 1;
+  r.blocks = (int)(want < maxb ? want : maxb);
+  return r;
+}
+inline size_t reduce_ws(int N, int64_t V, int C, int NQ) {
+  const ReducePlan r = reduce_plan(N, V, C);
+  return cfun_align_up((size_t)N * r.blocks * NQ * C * sizeof(double), 256);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_instnorm_lrelu_fwd(const float4* __restrict__ x, const float* __restrict__ stats, float4* __restrict__ y,
+                     int64_t total4, int64_t V, int C, float slope) {
+  const int CG = C >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total4; i += (int64_t)gridDim.x * kBlock) {
+    const int cg = (int)(i % CG);
+    const int64_t n = i / (V * CG);
+    const float* st = stats + ((int64_t)n * C + cg * 4) * 2;
+    const float4 v = x[i];
+    float a[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float xh = (a[j] - st[2 * j]) * st[2 * j + 1];
+      a[j] = xh > 0.f ? xh : xh * slope;
+    }
+    y[i] = make_float4(a[0], a[1], a[2], a[3]);
+  }
+}
+
+// dx = rstd * (gn - mean(gn) - xhat * mean(gn*xhat))
+__global__ void __launch_bounds__(kBlock)
+k_instnorm_lrelu_bwd(const float4* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ means,
+                     const float4* __restrict__ dy, float4* __restrict__ dx, int64_t total4, int64_t V, int C,
+                     float slope) {
+  const int CG = C >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total4; i += (int64_t)gridDim.x * kBlock) {
+    const int cg = (int)(i % CG);
+    const int64_t n = i / (V * CG);
+    const float* st = stats + ((int64_t)n * C + cg * 4) * 2;
+    const float* mm = means + ((int64_t)n * C + cg * 4) * 2;
+    const float4 v = x[i], d = dy[i];
+    const float a[4] = {v.x, v.y, v.z, v.w}, b[4] = {d.x, d.y, d.z, d.w};
+    float r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float rstd = st[2 * j + 1];
+      const float xh = (a[j] - st[2 * j]) * rstd;
+      const float gn = xh > 0.f ? b[j] : b[j] * slope;
+      r[j] = rstd * (gn - mm[2 * j] - xh * mm[2 * j + 1]);
+    }
+    dx[i] = make_float4(r[0], r[1], r[2], r[3]);
+  }
+}
+
+// ------------------------------------------------------------------ upsample backward, maxpool, halo
+__global__ void __launch_bounds__(kBlock)
+k_upsample2_bwd(const float4* __restrict__ hi, float4* __restrict__ lo, int64_t total4, int D, int H, int W, int CG) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total4; i += (int64_t)gridDim.x * kBlock) {
+    int64_t t = i;
+    const int cg = (int)(t % CG); t /= CG;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H); t /= H;
+    const int z = (int)(t % D);
+    const int64_t n = t / D;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int zz = 2 * z + (k >> 2), yy = 2 * y + ((k >> 1) & 1), xx = 2 * x + (k & 1);
+      const float4 v = hi[((((int64_t)n * 2 * D + zz) * 2 * H + yy) * 2 * W + xx) * CG + cg];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    lo[i] = s;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_maxpool2_fwd(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ idx, int64_t total, int Do,
+               int Ho, int Wo, int C) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    int64_t t = i;
+    const int c = (int)(t % C); t /= C;
+    const int xo = (int)(t % Wo); t /= Wo;
+    const int yo = (int)(t % Ho); t /= Ho;
+    const int zo = (int)(t % Do);
+    const int64_t n = t / Do;
+    float best = -INFINITY;
+    int bi = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {  // scan order (d,h,w), first maximum wins (torch max_pool3d)
+      const int zz = 2 * zo + (k >> 2), yy = 2 * yo + ((k >> 1) & 1), xx = 2 * xo + (k & 1);
+      const float v = x[((((int64_t)n * 2 * Do + zz) * 2 * Ho + yy) * 2 * Wo + xx) * C + c];
+      if (v > best || v != v) { best = v; bi = k; }
+    }
+    y[i] = best;
+    idx[i] = (uint8_t)bi;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_maxpool2_bwd(const float* __restrict__ dy, const uint8_t* __restrict__ idx, float* __restrict__ dx, int64_t total,
+               int Do, int Ho, int Wo, int C) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    int64_t t = i;
+    const int c = (int)(t % C); t /= C;
+    const int xo = (int)(t % Wo); t /= Wo;
+    const int yo = (int)(t % Ho); t /= Ho;
+    const int zo = (int)(t % Do);
+    const int64_t n = t / Do;
+    const int bi = idx[i];
+    const float g = dy[i];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int zz = 2 * zo + (k >> 2), yy = 2 * yo + ((k >> 1) & 1), xx = 2 * xo + (k & 1);
+      dx[((((int64_t)n * 2 * Do + zz) * 2 * Ho + yy) * 2 * Wo + xx) * C + c] = (k == bi) ? g : 0.f;
+    }
+  }
+}
+
+// copy `planes` z-planes starting at z0 between a [N,D,H,W,C] tensor and a dense [N,planes,H,W,C] buffer
+__global__ void __launch_bounds__(kBlock)
+k_halo_copy(const float* __restrict__ src, float* __restrict__ dst, int64_t per_n, int64_t plane_elems, int D, int z0,
+            int64_t total, int to_buf) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t n = i / per_n, r = i - n * per_n;
+    const int64_t t = (n * D + z0) * plane_elems + r;
+    if (to_buf) dst[i] = src[t]; else dst[t] = src[i];
+  }
+}
+
+}  // namespace
+
+// ====================================================================== C ABI
+extern "C" {
+
+int cfun_lrelu_fwd(const float* x, float* y, int64_t n, float slope, cfun_stream_t stream) {
+  if (n <= 0) return CFUN_OK;
+  const int64_t n4 = (cfun_aligned16(x) && cfun_aligned16(y)) ? n / 4 : 0;
+  if (n4) hipLaunchKernelGGL(k_lrelu_fwd, dim3(ew_grid(n4)), dim3(kBlock), 0, cfun_st(stream), (const float4*)x, (float4*)y, n4, slope);
+  for (int64_t from = n4 * 4; from < n; from += 1024)
+    hipLaunchKernelGGL(k_lrelu_fwd_tail, dim3(1), dim3(1024), 0, cfun_st(stream), x, y, from, n, slope);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+int cfun_lrelu_bwd(const float* x, const float* dy, float* dx, int64_t n, float slope, cfun_stream_t stream) {
+  if (n <= 0) return CFUN_OK;
+  const int64_t n4 = (cfun_aligned16(x) && cfun_aligned16(dy) && cfun_aligned16(dx)) ? n / 4 : 0;
+  if (n4) hipLaunchKernelGGL(k_lrelu_bwd, dim3(ew_grid(n4)), dim3(kBlock), 0, cfun_st(stream), (const float4*)x, (const float4*)dy, (float4*)dx, n4, slope);
+  for (int64_t from = n4 * 4; from < n; from += 1024)
+    hipLaunchKernelGGL(k_lrelu_bwd_tail, dim3(1), dim3(1024), 0, cfun_st(stream), x, dy, dx, from, n, slope);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+int cfun_add(const float* a, const float* b, float* out, int64_t n, cfun_stream_t stream) {
+  if (n <= 0) return CFUN_OK;
+  const int64_t n4 = (cfun_aligned16(a) && cfun_aligned16(b) && cfun_aligned16(out)) ? n / 4 : 0;
+  if (n4) hipLaunchKernelGGL(k_add, dim3(ew_grid(n4)), dim3(kBlock), 0, cfun_st(stream), (const float4*)a, (const float4*)b, (float4*)out, n4);
+  for (int64_t from = n4 * 4; from < n; from += 1024)
+    hipLaunchKernelGGL(k_add_tail, dim3(1), dim3(1024), 0, cfun_st(stream), a, b, out, from, n);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+int cfun_act_bwd(const float* y, const float* dy, const float* scale, float* g, int64_t nvox, int32_t C,
+                 int64_t vox_per_n, int32_t act, float slope, int32_t scale_mode, cfun_stream_t stream) {
+  const int64_t total = nvox * C;
+  if (total <= 0) return CFUN_OK;
+  if (scale_mode && !scale) return CFUN_EINVAL;
+  hipLaunchKernelGGL(k_act_bwd, dim3(ew_grid(total)), dim3(kBlock), 0, cfun_st(stream), y, dy, scale, g, total, C,
+                     vox_per_n > 0 ? vox_per_n : 1, act, slope, scale_mode);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+size_t cfun_channel_sum_workspace_bytes(int64_t nvox, int32_t C) {
+  if (C <= 0 || (C & 3) || C > 1024) return 0;
+  return reduce_ws(1, nvox, C, 1);
+}
+
+int cfun_channel_sum(const float* g, float* out, int64_t nvox, int32_t C, void* ws, size_t ws_bytes,
+                     cfun_stream_t stream) {
+  if (C <= 0 || (C & 3) || C > 1024) return CFUN_EINVAL;
+  if (nvox <= 0) return (int)hipMemsetAsync(out, 0, C * sizeof(float), cfun_st(stream));
+  if (!cfun_aligned16(g)) return CFUN_EALIGN;
+  if (ws_bytes < reduce_ws(1, nvox, C, 1)) return CFUN_EWORKSPACE;
+  const ReducePlan r = reduce_plan(1, nvox, C);
+  StatSum f{g};
+  hipLaunchKernelGGL(k_channel_reduce<StatSum>, dim3(r.blocks, 1), dim3(kBlock), 0, cfun_st(stream), f, (double*)ws, nvox, C, r.lanes);
+  hipLaunchKernelGGL(k_channel_finalize, dim3((C + kBlock - 1) / kBlock), dim3(kBlock), 0, cfun_st(stream),
+                     (const double*)ws, out, C, C, r.blocks, 1, nvox, 0.f, 1);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+size_t cfun_instnorm_workspace_bytes(int32_t N, int64_t V, int32_t C) {
+  if (C <= 0 || (C & 3) || C > 1024 || N <= 0 || V <= 0) return 0;
+  // forward: partial sums; backward: partial sums + the [N,C,2] means
+  return reduce_ws(N, V, C, 2) + cfun_align_up((size_t)N * C * 2 * sizeof(float), 256);
+}
+
+int cfun_instnorm_stats(const float* x, float* stats, int32_t N, int64_t V, int32_t C, float eps, void* ws,
+                        size_t ws_bytes, cfun_stream_t stream) {
+  if (N <= 0 || V <= 0) return CFUN_OK;
+  if (C <= 0 || (C & 3) || C > 1024) return CFUN_EINVAL;
+  if (!cfun_aligned16(x)) return CFUN_EALIGN;
+  if (ws_bytes < reduce_ws(N, V, C, 2)) return CFUN_EWORKSPACE;
+  const ReducePlan r = reduce_plan(N, V, C);
+  StatSumSq f{x};
+  hipLaunchKernelGGL(k_channel_reduce<StatSumSq>, dim3(r.blocks, N), dim3(kBlock), 0, cfun_st(stream), f, (double*)ws, V, C, r.lanes);
+  hipLaunchKernelGGL(k_channel_finalize, dim3((N * C + kBlock - 1) / kBlock), dim3(kBlock), 0, cfun_st(stream),
+                     (const double*)ws, stats, N * C, C, r.blocks, 2, V, eps, 0);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+int cfun_instnorm_lrelu_fwd(const float* x, const float* stats, float* y, int32_t N, int64_t V, int32_t C,
+                            float slope, cfun_stream_t stream) {
+  if (N <= 0 || V <= 0) return CFUN_OK;
+  if (C <= 0 || (C & 3)) return CFUN_EINVAL;
+  if (!cfun_aligned16(x) || !cfun_aligned16(y)) return CFUN_EALIGN;
+  const int64_t total4 = (int64_t)N * V * (C >> 2);
+  hipLaunchKernelGGL(k_instnorm_lrelu_fwd, dim3(ew_grid(total4)), dim3(kBlock), 0, cfun_st(stream), (const float4*)x,
+                     stats, (float4*)y, total4, V, C, slope);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+int cfun_instnorm_lrelu_bwd(const float* x, const float* stats, const float* dy, float* dx, int32_t N, int64_t V,
+                            int32_t C, float slope, void* ws, size_t ws_bytes, cfun_stream_t stream) {
+  if (N <= 0 || V <= 0) return CFUN_OK;
+  if (C <= 0 || (C & 3) || C > 1024) return CFUN_EINVAL;
+  if (!cfun_aligned16(x) || !cfun_aligned16(dy) || !cfun_aligned16(dx)) return CFUN_EALIGN;
+  if (ws_bytes < cfun_instnorm_workspace_bytes(N, V, C)) return CFUN_EWORKSPACE;
+  const ReducePlan r = reduce_plan(N, V, C);
+  double* partial = (double*)ws;
+  float* means = (float*)((char*)ws + reduce_ws(N, V, C, 2));
+  StatNormBwd f{x, dy, stats, C, slope};
+  hipLaunchKernelGGL(k_channel_reduce<StatNormBwd>, dim3(r.blocks, N), dim3(kBlock), 0, cfun_st(stream), f, partial, V, C, r.lanes);
+  hipLaunchKernelGGL(k_channel_finalize, dim3((N * C + kBlock - 1) / kBlock), dim3(kBlock), 0, cfun_st(stream),
+                     (const double*)partial, means, N * C, C, r.blocks, 2, V, 0.f, 2);
+  const int64_t total4 = (int64_t)N * V * (C >> 2);
+  hipLaunchKernelGGL(k_instnorm_lrelu_bwd, dim3(ew_grid(total4)), dim3(kBlock), 0, cfun_st(stream), (const float4*)x,
+                     stats, (const float*)means, (const float4*)dy, (float4*)dx, total4, V, C, slope);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+int cfun_upsample2_bwd(const float* hi, float* lo, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C,
+                       cfun_stream_t stream) {
+  if (C <= 0 || (C & 3)) return CFUN_EINVAL;
+  if (!cfun_aligned16(hi) || !cfun_aligned16(lo)) return CFUN_EALIGN;
+  const int64_t total4 = (int64_t)N * D * H * W * (C >> 2);
+  if (total4 <= 0) return CFUN_OK;
+  hipLaunchKernelGGL(k_upsample2_bwd, dim3(ew_grid(total4)), dim3(kBlock), 0, cfun_st(stream), (const float4*)hi,
+                     (float4*)lo, total4, D, H, W, C >> 2);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+int cfun_maxpool2_fwd(const float* x, float* y, uint8_t* idx, int32_t N, int32_t Do, int32_t Ho, int32_t Wo,
+                      int32_t C, cfun_stream_t stream) {
+  const int64_t total = (int64_t)N * Do * Ho * Wo * C;
+  if (total <= 0) return CFUN_OK;
+  hipLaunchKernelGGL(k_maxpool2_fwd, dim3(ew_grid(total)), dim3(kBlock), 0, cfun_st(stream), x, y, idx, total, Do, Ho, Wo, C);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+int cfun_maxpool2_bwd(const float* dy, const uint8_t* idx, float* dx, int32_t N, int32_t Do, int32_t Ho, int32_t Wo,
+                      int32_t C, cfun_stream_t stream) {
+  const int64_t total = (int64_t)N * Do * Ho * Wo * C;
+  if (total <= 0) return CFUN_OK;
+  hipLaunchKernelGGL(k_maxpool2_bwd, dim3(ew_grid(total)), dim3(kBlock), 0, cfun_st(stream), dy, idx, dx, total, Do, Ho, Wo, C);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+int cfun_halo_pack(const float* x, float* buf, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C, int32_t z0,
+                   int32_t planes, cfun_stream_t stream) {
+  if (z0 < 0 || planes < 0 || z0 + planes > D) return CFUN_EINVAL;
+  const int64_t plane = (int64_t)H * W * C, per_n = plane * planes, total = per_n * N;
+  if (total <= 0) return CFUN_OK;
+  hipLaunchKernelGGL(k_halo_copy, dim3(ew_grid(total)), dim3(kBlock), 0, cfun_st(stream), x, buf, per_n, plane, D, z0, total, 1);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+int cfun_halo_unpack(const float* buf, float* x, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C, int32_t z0,
+                     int32_t planes, cfun_stream_t stream) {
+  if (z0 < 0 || planes < 0 || z0 + planes > D) return CFUN_EINVAL;
+  const int64_t plane = (int64_t)H * W * C, per_n = plane * planes, total = per_n * N;
+  if (total <= 0) return CFUN_OK;
+  hipLaunchKernelGGL(k_halo_copy, dim3(ew_grid(total)), dim3(kBlock), 0, cfun_st(stream), buf, x, per_n, plane, D, z0, total, 0);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,286 @@
+// 3-D RoIAlign (crop + trilinear align_corners resize) and greedy 3-D NMS.
+// Compiled with -ffp-contract=off: the integer crop bounds and the NMS keep list are bit-exact contracts
+// (SURVEY.md App. A-9/A-10), so the fp32 operation order of torch/numpy is reproduced without FMA contraction.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ RoIAlign
+// python slice semantics of fm[:, lo:hi] on an axis of size S (model.py:282)
+__device__ __forceinline__ void py_slice(int lo, int hi, int S, int* olo, int* ohi) {
+  if (lo < 0) { lo += S; if (lo < 0) lo = 0; }
+  if (lo > S) lo = S;
+  if (hi < 0) { hi += S; if (hi < 0) hi = 0; }
+  if (hi > S) hi = S;
+  if (hi < lo) hi = lo;
+  *olo = lo;
+  *ohi = hi;
+}
+
+__global__ void k_roi_bounds(const float* __restrict__ boxes, int32_t* __restrict__ bounds, int R, int D, int H, int W) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const float sc[3] = {(float)D, (float)H, (float)W};
+  const int S[3] = {D, H, W};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    // utils.py:172-173 torch.mul in fp32; model.py:272-278 floor / ceil / .long()
+    const float lo = floorf(__fmul_rn(boxes[r * 6 + a], sc[a]));
+    const float hi = ceilf(__fmul_rn(boxes[r * 6 + 3 + a], sc[a]));
+    int l, h;
+    py_slice((int)lo, (int)hi, S[a], &l, &h);
+    bounds[r * 6 + a] = l;
+    bounds[r * 6 + 3 + a] = h;
+  }
+}
+
+struct Lerp {
+  int i0, i1;
+  float w0, w1;
+};
+// torch area_pixel_compute_source_index, align_corners=True
+__device__ __forceinline__ Lerp make_lerp(int o, int in_size, int out_size) {
+  Lerp l;
+  const float scale = out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+  const float src = scale * (float)o;
+  l.i0 = (int)src;
+  if (l.i0 > in_size - 1) l.i0 = in_size - 1;
+  l.i1 = l.i0 + (l.i0 < in_size - 1 ? 1 : 0);
+  l.w1 = src - (float)l.i0;
+  l.w0 = 1.f - l.w1;
+  return l;
+}
+
+__global__ void __launch_bounds__(256)
+k_roi_align_fwd(const float* __restrict__ fm, const int32_t* __restrict__ bounds, float* __restrict__ out,
+                int64_t total, int D, int H, int W, int C, int pd, int ph, int pw) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t t = i;
+    const int c = (int)(t % C); t /= C;
+    const int ox = (int)(t % pw); t /= pw;
+    const int oy = (int)(t % ph); t /= ph;
+    const int oz = (int)(t % pd);
+    const int r = (int)(t / pd);
+    const int32_t* b = bounds + r * 6;
+    const int nz = b[3] - b[0], ny = b[4] - b[1], nx = b[5] - b[2];
+    if (nz <= 0 || ny <= 0 || nx <= 0) { out[i] = 0.f; continue; }  // failed crop -> zeros (model.py:284-287)
+    const Lerp lz = make_lerp(oz, nz, pd), ly = make_lerp(oy, ny, ph), lx = make_lerp(ox, nx, pw);
+    const int64_t z0 = (int64_t)(b[0] + lz.i0) * H, z1 = (int64_t)(b[0] + lz.i1) * H;
+    const int64_t y0 = b[1] + ly.i0, y1 = b[1] + ly.i1;
+    const int64_t x0 = b[2] + lx.i0, x1 = b[2] + lx.i1;
+    const float v000 = fm[((z0 + y0) * W + x0) * C + c], v001 = fm[((z0 + y0) * W + x1) * C + c];
+    const float v010 = fm[((z0 + y1) * W + x0) * C + c], v011 = fm[((z0 + y1) * W + x1) * C + c];
+    const float v100 = fm[((z1 + y0) * W + x0) * C + c], v101 = fm[((z1 + y0) * W + x1) * C + c];
+    const float v110 = fm[((z1 + y1) * W + x0) * C + c], v111 = fm[((z1 + y1) * W + x1) * C + c];
+    out[i] = lz.w0 * (ly.w0 * (lx.w0 * v000 + lx.w1 * v001) + ly.w1 * (lx.w0 * v010 + lx.w1 * v011)) +
+             lz.w1 * (ly.w0 * (lx.w0 * v100 + lx.w1 * v101) + ly.w1 * (lx.w0 * v110 + lx.w1 * v111));
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_roi_align_bwd(const float* __restrict__ dout, const int32_t* __restrict__ bounds, float* __restrict__ dfm,
+                int64_t total, int D, int H, int W, int C, int pd, int ph, int pw) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t t = i;
+    const int c = (int)(t % C); t /= C;
+    const int ox = (int)(t % pw); t /= pw;
+    const int oy = (int)(t % ph); t /= ph;
+    const int oz = (int)(t % pd);
+    const int r = (int)(t / pd);
+    const int32_t* b = bounds + r * 6;
+    const int nz = b[3] - b[0], ny = b[4] - b[1], nx = b[5] - b[2];
+    if (nz <= 0 || ny <= 0 || nx <= 0) continue;
+    const Lerp lz = make_lerp(oz, nz, pd), ly = make_lerp(oy, ny, ph), lx = make_lerp(ox, nx, pw);
+    const float g = dout[i];
+    const int zi[2] = {b[0] + lz.i0, b[0] + lz.i1}, yi[2] = {b[1] + ly.i0, b[1] + ly.i1}, xi[2] = {b[2] + lx.i0, b[2] + lx.i1};
+    const float wz[2] = {lz.w0, lz.w1}, wy[2] = {ly.w0, ly.w1}, wx[2] = {lx.w0, lx.w1};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int a = k >> 2, bb = (k >> 1) & 1, cc = k & 1;
+      atomicAdd(&dfm[(((int64_t)zi[a] * H + yi[bb]) * W + xi[cc]) * C + c], g * wz[a] * wy[bb] * wx[cc]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ NMS
+struct Box6 {
+  float z1, y1, x1, z2, y2, x2;
+};
+__device__ __forceinline__ Box6 load_box(const float* b) { return Box6{b[0], b[1], b[2], b[3], b[4], b[5]}; }
+__device__ __forceinline__ float box_volume(const Box6& b) {  // utils.py:136 (z2-z1)*(y2-y1)*(x2-x1)
+  return __fmul_rn(__fmul_rn(__fsub_rn(b.z2, b.z1), __fsub_rn(b.y2, b.y1)), __fsub_rn(b.x2, b.x1));
+}
+// utils.py:60-69: inter = max(x2-x1,0)*max(y2-y1,0)*max(z2-z1,0); iou = inter / (vol_a + vol_b - inter + 1e-6)
+__device__ __forceinline__ float box_iou(const Box6& a, float va, const Box6& b, float vb) {
+  const float z1 = fmaxf(a.z1, b.z1), z2 = fminf(a.z2, b.z2);
+  const float y1 = fmaxf(a.y1, b.y1), y2 = fminf(a.y2, b.y2);
+  const float x1 = fmaxf(a.x1, b.x1), x2 = fminf(a.x2, b.x2);
+  const float inter = __fmul_rn(__fmul_rn(fmaxf(__fsub_rn(x2, x1), 0.f), fmaxf(__fsub_rn(y2, y1), 0.f)),
+                                fmaxf(__fsub_rn(z2, z1), 0.f));
+  const float uni = __fsub_rn(__fadd_rn(va, vb), inter);
+  return __fdiv_rn(inter, __fadd_rn(uni, 1e-6f));
+}
+
+// "a sorts before b": higher score first; equal scores: higher original index first (App. A-8)
+__device__ __forceinline__ bool before(float sa, int ia, float sb, int ib) {
+  return sa > sb || (sa == sb && ia > ib);
+}
+
+// one workgroup: bitonic sort of (score, index) in LDS; writes order[n] and the gathered boxes/volumes
+__global__ void __launch_bounds__(1024)
+k_nms_sort(const float* __restrict__ boxes, const float* __restrict__ scores, int n, int npow2,
+           int32_t* __restrict__ order, float* __restrict__ sboxes, float* __restrict__ svol) {
+  CFUN_DYN_LDS(char, smem);
+  float* ks = reinterpret_cast<float*>(smem);
+  int* ki = reinterpret_cast<int*>(smem + (size_t)npow2 * sizeof(float));
+  for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+    ks[i] = i < n ? scores[i] : -INFINITY;
+    ki[i] = i < n ? i : -1;
+  }
+  __syncthreads();
+  for (int k = 2; k <= npow2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+        const int l = i ^ j;
+        if (l > i) {
+          const bool up = (i & k) == 0;  // ascending position = "before" order
+          const float sa = ks[i], sb = ks[l];
+          const int ia = ki[i], ib = ki[l];
+          const bool swap = up ? before(sb, ib, sa, ia) : before(sa, ia, sb, ib);
+          if (swap) { ks[i] = sb; ks[l] = sa; ki[i] = ib; ki[l] = ia; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int src = ki[i];
+    order[i] = src;
+    const Box6 b = load_box(boxes + (int64_t)src * 6);
+    float* d = sboxes + (int64_t)i * 6;
+    d[0] = b.z1; d[1] = b.y1; d[2] = b.x1; d[3] = b.z2; d[4] = b.y2; d[5] = b.x2;
+    svol[i] = box_volume(b);
+  }
+}
+
+// mask[i][w] bit j: sorted box 64w+j (> i) is suppressed by sorted box i
+__global__ void __launch_bounds__(256)
+k_nms_mask(const float* __restrict__ sboxes, const float* __restrict__ svol, int n, int W64, float thr,
+           unsigned long long* __restrict__ mask) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n * W64) return;
+  const int i = t / W64, w = t - i * W64;
+  unsigned long long bits = 0ull;
+  if (w * 64 + 63 > i) {
+    const Box6 a = load_box(sboxes + (int64_t)i * 6);
+    const float va = svol[i];
+    for (int j = 0; j < 64; ++j) {
+      const int k = w * 64 + j;
+      if (k > i && k < n) {
+        const Box6 b = load_box(sboxes + (int64_t)k * 6);
+        if (box_iou(a, va, b, svol[k]) > thr) bits |= (1ull << j);
+      }
+    }
+  }
+  mask[t] = bits;
+}
+
+// single wave: lane w holds word w of the "removed" bitset; rows are prefetched 16 at a time
+__global__ void __launch_bounds__(64)
+k_nms_scan(const unsigned long long* __restrict__ mask, const int32_t* __restrict__ order, int n, int W64,
+           int max_num, int32_t* __restrict__ keep, int32_t* __restrict__ count) {
+  const int lane = threadIdx.x;
+  unsigned long long removed = 0ull;
+  int cnt = 0;
+  constexpr int CH = 16;
+  unsigned long long cur[CH], nxt[CH];
+#pragma unroll
+  for (int r = 0; r < CH; ++r) cur[r] = (r < n && lane < W64) ? mask[(int64_t)r * W64 + lane] : 0ull;
+  bool done = (max_num <= 0);
+  for (int base = 0; base < n && !done; base += CH) {
+#pragma unroll
+    for (int r = 0; r < CH; ++r) {
+      const int row = base + CH + r;
+      nxt[r] = (row < n && lane < W64) ? mask[(int64_t)row * W64 + lane] : 0ull;
+    }
+#pragma unroll
+    for (int r = 0; r < CH; ++r) {
+      const int i = base + r;
+      if (i < n && !done) {
+        const unsigned long long word = __shfl(removed, i >> 6, 64);
+        if (!((word >> (i & 63)) & 1ull)) {
+          if (lane == 0) keep[cnt] = order[i];
+          ++cnt;
+          if (cnt >= max_num) done = true;   // utils.py:147-148: break right after the append
+          removed |= cur[r];
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < CH; ++r) cur[r] = nxt[r];
+  }
+  if (lane == 0) count[0] = cnt;
+}
+
+inline int next_pow2(int n) {
+  int p = 1;
+  while (p < n) p <<= 1;
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cfun_roi_align3d_fwd(const float* fm, const float* boxes, float* out, int32_t* bounds, int32_t R, int32_t D,
+                         int32_t H, int32_t W, int32_t C, int32_t pd, int32_t ph, int32_t pw, cfun_stream_t stream) {
+  if (R <= 0) return CFUN_OK;
+  if (D <= 0 || H <= 0 || W <= 0 || C <= 0 || pd <= 0 || ph <= 0 || pw <= 0) return CFUN_EINVAL;
+  hipLaunchKernelGGL(k_roi_bounds, dim3((R + 63) / 64), dim3(64), 0, cfun_st(stream), boxes, bounds, R, D, H, W);
+  const int64_t total = (int64_t)R * pd * ph * pw * C;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(k_roi_align_fwd, dim3((unsigned)blocks), dim3(256), 0, cfun_st(stream), fm, bounds, out, total, D, H, W, C, pd, ph, pw);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+int cfun_roi_align3d_bwd(const float* dout, const int32_t* bounds, float* dfm, int32_t R, int32_t D, int32_t H,
+                         int32_t W, int32_t C, int32_t pd, int32_t ph, int32_t pw, cfun_stream_t stream) {
+  if (R <= 0) return CFUN_OK;
+  const int64_t total = (int64_t)R * pd * ph * pw * C;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(k_roi_align_bwd, dim3((unsigned)blocks), dim3(256), 0, cfun_st(stream), dout, bounds, dfm, total, D, H, W, C, pd, ph, pw);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+// workspace: order[n] i32 | sboxes[n*6] f32 | svol[n] f32 | mask[n*W64] u64
+size_t cfun_nms3d_workspace_bytes(int32_t n) {
+  if (n <= 0) return 256;
+  const size_t W64 = (n + 63) / 64;
+  return cfun_align_up((size_t)n * 4, 256) + cfun_align_up((size_t)n * 24, 256) + cfun_align_up((size_t)n * 4, 256) +
+         cfun_align_up((size_t)n * W64 * 8, 256);
+}
+
+int cfun_nms3d(const float* boxes, const float* scores, int32_t n, float threshold, int32_t max_num, int32_t* keep,
+               int32_t* count, void* ws, size_t ws_bytes, cfun_stream_t stream) {
+  if (n < 0 || n > 4096) return CFUN_EINVAL;
+  if (n == 0) return (int)hipMemsetAsync(count, 0, sizeof(int32_t), cfun_st(stream));
+  if (ws_bytes < cfun_nms3d_workspace_bytes(n)) return CFUN_EWORKSPACE;
+  const int W64 = (n + 63) / 64;
+  char* p = (char*)ws;
+  int32_t* order = (int32_t*)p; p += cfun_align_up((size_t)n * 4, 256);
+  float* sboxes = (float*)p; p += cfun_align_up((size_t)n * 24, 256);
+  float* svol = (float*)p; p += cfun_align_up((size_t)n * 4, 256);
+  unsigned long long* mask = (unsigned long long*)p;
+  const int np2 = next_pow2(n);
+  hipLaunchKernelGGL(k_nms_sort, dim3(1), dim3(1024), (size_t)np2 * 8, cfun_st(stream), boxes, scores, n, np2, order, sboxes, svol);
+  hipLaunchKernelGGL(k_nms_mask, dim3((n * W64 + 255) / 256), dim3(256), 0, cfun_st(stream), sboxes, svol, n, W64, threshold, mask);
+  hipLaunchKernelGGL(k_nms_scan, dim3(1), dim3(64), 0, cfun_st(stream), mask, order, n, W64, max_num, keep, count);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+}  // extern "C"

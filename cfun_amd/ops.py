@@ -1,0 +1,455 @@
+"""torch.autograd bindings of the HIP kernels (libcfun_hip.so).
+
+All activations are fp32 tensors shaped [N, D, H, W, C] and contiguous (NDHWC).  Weight packing
+(OIDHW -> [tap][ci][CoP]) is done with differentiable torch ops, so parameter gradients arrive in the
+reference's OIDHW layout and shared weights (mask_branch.py:141/143 ...) are summed by autograd.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ALGO_AUTO, ConvParams, check, ptr, stream, workspace
+
+LRELU_SLOPE = 0.01  # nn.LeakyReLU() default, mask_branch.py:18
+
+
+def _round16(v):
+    return (v + 15) // 16 * 16
+
+
+def pack_weight(w):
+    """OIDHW [Co,Ci,kd,kh,kw] -> wp [taps, Ci, CoP] (differentiable)."""
+    co, ci, kd, kh, kw = w.shape
+    wp = w.permute(2, 3, 4, 1, 0).reshape(kd * kh * kw, ci, co)
+    cop = _round16(co)
+    if cop != co:
+        wp = torch.nn.functional.pad(wp, (0, cop - co))
+    return wp.contiguous()
+
+
+def _transpose_pack(wp, co):
+    """wp [T,Ci,CoP] -> wpT [T,Co,CiP] (no grad; used by bwd_data)."""
+    t, ci, _ = wp.shape
+    cip = _round16(ci)
+    out = torch.zeros((t, co, cip), dtype=wp.dtype, device=wp.device)
+    out[:, :, :ci] = wp[:, :, :co].transpose(1, 2)
+    return out
+
+
+@dataclass(frozen=True)
+class ConvSpec:
+    k: tuple            # (kd, kh, kw)
+    co: int
+    stride: int = 1
+    pad: tuple = (0, 0, 0)
+    up2: bool = False   # conv input = nearest x2 upsample of x
+    act: int = ACT_NONE
+    res_up2: bool = False
+    scale_per_n: bool = False   # scale is [N, Co] (Dropout3d mask) instead of [Co]
+    algo: int = ALGO_AUTO
+
+
+def _out_dim(i, k, s, p):
+    return (i + 2 * p - k) // s + 1
+
+
+def _params(spec, x_shape, has_scale, has_shift, has_res):
+    n, d, h, w, ci = x_shape
+    sh = 1 if spec.up2 else 0
+    p = ConvParams()
+    p.N, p.Di, p.Hi, p.Wi, p.Ci = n, d, h, w, ci
+    p.kd, p.kh, p.kw = spec.k
+    p.stride = spec.stride
+    p.pd, p.ph, p.pw = spec.pad
+    p.Do = _out_dim(d << sh, p.kd, p.stride, p.pd)
+    p.Ho = _out_dim(h << sh, p.kh, p.stride, p.ph)
+    p.Wo = _out_dim(w << sh, p.kw, p.stride, p.pw)
+    p.Co = spec.co
+    p.CoP, p.CiP = _round16(spec.co), _round16(ci)
+    p.up2 = int(spec.up2)
+    p.act = spec.act
+    p.slope = LRELU_SLOPE
+    p.scale_mode = 0 if not has_scale else (2 if spec.scale_per_n else 1)
+    p.has_shift = int(has_shift)
+    p.res_mode = int(has_res)
+    p.res_up2 = int(spec.res_up2 and has_res)
+    p.algo = spec.algo
+    return p
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class _Conv3d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, wp, scale, shift, res, spec):
+        lib = _lib.load()
+        x = _c(x)
+        wp = _c(wp)
+        scale = None if scale is None else _c(scale)
+        shift = None if shift is None else _c(shift)
+        res = None if res is None else _c(res)
+        p = _params(spec, x.shape, scale is not None, shift is not None, res is not None)
+        if wp.shape != (p.kd * p.kh * p.kw, p.Ci, p.CoP):
+            raise RuntimeError("packed weight %s does not match conv %s" % (tuple(wp.shape), spec))
+        y = torch.empty((p.N, p.Do, p.Ho, p.Wo, p.Co), dtype=torch.float32, device=x.device)
+        check(lib.cfun_conv3d_fwd(ptr(x), ptr(wp), ptr(scale), ptr(shift), ptr(res), ptr(y), C.byref(p), stream(x)),
+              "conv3d_fwd")
+        ctx.spec = spec
+        ctx.p = p
+        ctx.res_shape = None if res is None else res.shape
+        ctx.save_for_backward(x, wp, scale, y if spec.act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, wp, scale, y = ctx.saved_tensors
+        spec, p = ctx.spec, ctx.p
+        need_x, need_w, need_scale, need_shift, need_res = ctx.needs_input_grad[:5]
+        if need_scale:
+            raise RuntimeError("cfun_amd conv3d: gradient w.r.t. the epilogue scale is not implemented "
+                               "(BatchNorm is frozen on this path, model.py:1297-1304)")
+        dy = _c(dy)
+        st = stream(dy)
+        nvox = p.N * p.Do * p.Ho * p.Wo
+        # gp = dL/d(pre-activation); g = gp * scale = dL/d(conv sum)
+        gp = dy
+        if spec.act != ACT_NONE:
+            gp = torch.empty_like(dy)
+            check(lib.cfun_act_bwd(ptr(y), ptr(dy), None, ptr(gp), nvox, p.Co, p.Do * p.Ho * p.Wo, spec.act,
+                                   LRELU_SLOPE, 0, st), "act_bwd")
+        g = gp
+        if scale is not None:
+            g = torch.empty_like(dy)
+            check(lib.cfun_act_bwd(None, ptr(gp), ptr(scale), ptr(g), nvox, p.Co, p.Do * p.Ho * p.Wo, ACT_NONE,
+                                   LRELU_SLOPE, p.scale_mode, st), "act_bwd(scale)")
+        dx = dwp = dshift = dres = None
+        if need_x:
+            wpT = _transpose_pack(wp, p.Co)
+            dx = torch.empty_like(x)
+            nb = lib.cfun_conv3d_bwd_data_workspace_bytes(C.byref(p))
+            ws = workspace(nb, x)
+            check(lib.cfun_conv3d_bwd_data(ptr(g), ptr(wpT), ptr(dx), C.byref(p), ptr(ws), ws.numel(), st),
+                  "conv3d_bwd_data")
+        if need_w:
+            dwp = torch.empty_like(wp)
+            nb = lib.cfun_conv3d_bwd_weight_workspace_bytes(C.byref(p))
+            ws = workspace(nb, x)
+            check(lib.cfun_conv3d_bwd_weight(ptr(x), ptr(g), ptr(dwp), C.byref(p), ptr(ws), ws.numel(), st),
+                  "conv3d_bwd_weight")
+        if need_shift:
+            dshift = channel_sum(gp.view(-1, p.Co))
+        if need_res:
+            if p.res_up2:
+                dres = torch.empty(ctx.res_shape, dtype=torch.float32, device=dy.device)
+                check(lib.cfun_upsample2_bwd(ptr(gp), ptr(dres), p.N, p.Do // 2, p.Ho // 2, p.Wo // 2, p.Co, st),
+                      "upsample2_bwd")
+            else:
+                dres = gp
+        return dx, dwp, None, dshift, dres, None
+
+
+def conv3d(x, wp, spec, scale=None, shift=None, res=None):
+    """y = act(scale * conv(x) + shift + res); see include/cfun_hip.h (cfun_conv3d_fwd)."""
+    return _Conv3d.apply(x, wp, scale, shift, res, spec)
+
+
+def channel_sum(g2d):
+    """[V, C] -> [C] sum over rows (bias gradients)."""
+    lib = _lib.load()
+    g2d = _c(g2d)
+    v, c = g2d.shape
+    if c % 4 != 0:
+        return g2d.sum(0)  # never on the hot path (all biased convs there have C % 4 == 0)
+    out = torch.empty((c,), dtype=torch.float32, device=g2d.device)
+    ws = workspace(lib.cfun_channel_sum_workspace_bytes(v, c), g2d)
+    check(lib.cfun_channel_sum(ptr(g2d), ptr(out), v, c, ptr(ws), ws.numel(), stream(g2d)), "channel_sum")
+    return out
+
+
+class _InstNormLReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        lib = _lib.load()
+        x = _c(x)
+        n, c = x.shape[0], x.shape[-1]
+        v = x.numel() // (n * c)
+        if v <= 1:
+            raise ValueError("Expected more than 1 spatial element when training, got input size %s"
+                             % (tuple(x.shape),))  # InstanceNorm3d behaviour, SURVEY.md App. A-3
+        stats = torch.empty((n, c, 2), dtype=torch.float32, device=x.device)
+        ws = workspace(lib.cfun_instnorm_workspace_bytes(n, v, c), x)
+        st = stream(x)
+        check(lib.cfun_instnorm_stats(ptr(x), ptr(stats), n, v, c, eps, ptr(ws), ws.numel(), st), "instnorm_stats")
+        y = torch.empty_like(x)
+        check(lib.cfun_instnorm_lrelu_fwd(ptr(x), ptr(stats), ptr(y), n, v, c, LRELU_SLOPE, st), "instnorm_lrelu_fwd")
+        ctx.save_for_backward(x, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, stats = ctx.saved_tensors
+        dy = _c(dy)
+        n, c = x.shape[0], x.shape[-1]
+        v = x.numel() // (n * c)
+        dx = torch.empty_like(x)
+        ws = workspace(lib.cfun_instnorm_workspace_bytes(n, v, c), x)
+        check(lib.cfun_instnorm_lrelu_bwd(ptr(x), ptr(stats), ptr(dy), ptr(dx), n, v, c, LRELU_SLOPE, ptr(ws),
+                                          ws.numel(), stream(x)), "instnorm_lrelu_bwd")
+        return dx, None
+
+
+def instnorm_lrelu(x, eps=1e-5):
+    """LeakyReLU(InstanceNorm3d(x)) (affine=False, biased variance), mask_branch.py:28-116."""
+    return _InstNormLReLU.apply(x, eps)
+
+
+class _LReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = _c(x)
+        y = torch.empty_like(x)
+        check(lib.cfun_lrelu_fwd(ptr(x), ptr(y), x.numel(), LRELU_SLOPE, stream(x)), "lrelu_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (x,) = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        check(lib.cfun_lrelu_bwd(ptr(x), ptr(dy), ptr(dx), x.numel(), LRELU_SLOPE, stream(x)), "lrelu_bwd")
+        return dx
+
+
+def lrelu(x):
+    return _LReLU.apply(x)
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        lib = _lib.load()
+        a, b = _c(a), _c(b)
+        out = torch.empty_like(a)
+        check(lib.cfun_add(ptr(a), ptr(b), ptr(out), a.numel(), stream(a)), "add")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    if a.shape != b.shape:
+        raise RuntimeError("add: shape mismatch %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+    return _Add.apply(a, b)
+
+
+class _MaxPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = _c(x)
+        n, d, h, w, c = x.shape
+        do, ho, wo = d // 2, h // 2, w // 2
+        if (d | h | w) & 1:
+            raise RuntimeError("maxpool2: odd input size %s" % (tuple(x.shape),))
+        y = torch.empty((n, do, ho, wo, c), dtype=torch.float32, device=x.device)
+        idx = torch.empty((n, do, ho, wo, c), dtype=torch.uint8, device=x.device)
+        check(lib.cfun_maxpool2_fwd(ptr(x), ptr(y), ptr(idx), n, do, ho, wo, c, stream(x)), "maxpool2_fwd")
+        ctx.save_for_backward(idx)
+        ctx.mark_non_differentiable(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (idx,) = ctx.saved_tensors
+        dy = _c(dy)
+        n, do, ho, wo, c = dy.shape
+        dx = torch.empty((n, 2 * do, 2 * ho, 2 * wo, c), dtype=torch.float32, device=dy.device)
+        check(lib.cfun_maxpool2_bwd(ptr(dy), ptr(idx), ptr(dx), n, do, ho, wo, c, stream(dy)), "maxpool2_bwd")
+        return dx
+
+
+def maxpool2(x):
+    """MaxPool3d(kernel_size=2, stride=2), backbone.py:127."""
+    return _MaxPool2.apply(x)
+
+
+class _RoIAlign(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fm, boxes, pool):
+        lib = _lib.load()
+        fm = _c(fm)
+        boxes = _c(boxes.detach().float())
+        d, h, w, c = fm.shape
+        r = boxes.shape[0]
+        pd, ph, pw = [int(v) for v in pool]
+        out = torch.empty((r, pd, ph, pw, c), dtype=torch.float32, device=fm.device)
+        bounds = torch.empty((max(r, 1), 6), dtype=torch.int32, device=fm.device)
+        check(lib.cfun_roi_align3d_fwd(ptr(fm), ptr(boxes), ptr(out), ptr(bounds), r, d, h, w, c, pd, ph, pw,
+                                       stream(fm)), "roi_align3d_fwd")
+        ctx.save_for_backward(bounds)
+        ctx.dims = (r, d, h, w, c, pd, ph, pw)
+        ctx.mark_non_differentiable(bounds)
+        return out, bounds
+
+    @staticmethod
+    def backward(ctx, dout, _dbounds):
+        lib = _lib.load()
+        (bounds,) = ctx.saved_tensors
+        r, d, h, w, c, pd, ph, pw = ctx.dims
+        dout = _c(dout)
+        dfm = torch.zeros((d, h, w, c), dtype=torch.float32, device=dout.device)
+        check(lib.cfun_roi_align3d_bwd(ptr(dout), ptr(bounds), ptr(dfm), r, d, h, w, c, pd, ph, pw, stream(dout)),
+              "roi_align3d_bwd")
+        return dfm, None, None
+
+
+def roi_align(fm, boxes, pool):
+    """fm [D,H,W,C], boxes [R,6] normalised -> ([R,pd,ph,pw,C], int32 crop bounds [R,6])."""
+    return _RoIAlign.apply(fm, boxes, tuple(pool))
+
+
+def nms3d(boxes, scores, threshold, max_num):
+    """Greedy 3-D NMS on device; returns (keep int32 [n], count int32 [1]) -- keep[:count] is the pick order."""
+    lib = _lib.load()
+    boxes = _c(boxes.detach().float())
+    scores = _c(scores.detach().float())
+    n = boxes.shape[0]
+    keep = torch.empty((max(n, 1),), dtype=torch.int32, device=boxes.device)
+    count = torch.zeros((1,), dtype=torch.int32, device=boxes.device)
+    ws = workspace(lib.cfun_nms3d_workspace_bytes(n), boxes)
+    check(lib.cfun_nms3d(ptr(boxes), ptr(scores), n, float(threshold), int(max_num), ptr(keep), ptr(count), ptr(ws),
+                         ws.numel(), stream(boxes)), "nms3d")
+    return keep, count
+
+
+class _Softmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits):
+        lib = _lib.load()
+        logits = _c(logits)
+        c = logits.shape[-1]
+        probs = torch.empty_like(logits)
+        check(lib.cfun_softmax_fwd(ptr(logits), ptr(probs), logits.numel() // c, c, stream(logits)), "softmax_fwd")
+        ctx.save_for_backward(probs)
+        return probs
+
+    @staticmethod
+    def backward(ctx, dp):
+        lib = _lib.load()
+        (probs,) = ctx.saved_tensors
+        dp = _c(dp)
+        c = probs.shape[-1]
+        dl = torch.empty_like(probs)
+        check(lib.cfun_softmax_bwd(ptr(probs), ptr(dp), ptr(dl), probs.numel() // c, c, stream(probs)), "softmax_bwd")
+        return dl
+
+
+def softmax_channels(logits):
+    """softmax over the last (channel) axis of an NDHWC tensor (model.py:799)."""
+    return _Softmax.apply(logits)
+
+
+class _MaskCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        lib = _lib.load()
+        logits = _c(logits)
+        labels = _c(labels)
+        c = logits.shape[-1]
+        nvox = logits.numel() // c
+        if labels.dtype != torch.uint8 or labels.numel() != nvox:
+            raise RuntimeError("mask_cross_entropy: labels must be uint8 [n,D,H,W]")
+        loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
+        ws = workspace(lib.cfun_loss_workspace_bytes(nvox), logits)
+        check(lib.cfun_softmax_ce_fwd(ptr(logits), ptr(labels), ptr(loss), nvox, c, ptr(ws), ws.numel(),
+                                      stream(logits)), "softmax_ce_fwd")
+        ctx.save_for_backward(logits, labels)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        logits, labels = ctx.saved_tensors
+        c = logits.shape[-1]
+        gs = _c(g.reshape(1).float())
+        dl = torch.empty_like(logits)
+        check(lib.cfun_softmax_ce_bwd(ptr(logits), ptr(labels), ptr(gs), ptr(dl), logits.numel() // c, c,
+                                      stream(logits)), "softmax_ce_bwd")
+        return dl, None
+
+
+def mask_cross_entropy(logits, labels):
+    """CrossEntropyLoss(logits [n,D,H,W,C], labels uint8 [n,D,H,W]) -- model.py:909-935."""
+    return _MaskCE.apply(logits, labels)
+
+
+class _EdgeLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, probs, labels):
+        lib = _lib.load()
+        probs = _c(probs)
+        labels = _c(labels)
+        n, d, h, w, c = probs.shape
+        loss = torch.empty((1,), dtype=torch.float32, device=probs.device)
+        ws = workspace(lib.cfun_loss_workspace_bytes(n * d * h * w), probs)
+        check(lib.cfun_edge_loss_fwd(ptr(probs), ptr(labels), ptr(loss), n, d, h, w, c, ptr(ws), ws.numel(),
+                                     stream(probs)), "edge_loss_fwd")
+        ctx.save_for_backward(probs, labels)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        probs, labels = ctx.saved_tensors
+        n, d, h, w, c = probs.shape
+        gs = _c(g.reshape(1).float())
+        dp = torch.empty_like(probs)
+        ws = workspace(lib.cfun_edge_loss_bwd_workspace_bytes(n, d, h, w, c), probs)
+        check(lib.cfun_edge_loss_bwd(ptr(probs), ptr(labels), ptr(gs), ptr(dp), n, d, h, w, c, ptr(ws), ws.numel(),
+                                     stream(probs)), "edge_loss_bwd")
+        return dp, None
+
+
+def edge_loss(probs, labels):
+    """3-D Sobel edge-agreement loss (model.py:938-981) on NDHWC probabilities and uint8 labels."""
+    return _EdgeLoss.apply(probs, labels)
+
+
+def halo_pack(x, z0, planes):
+    lib = _lib.load()
+    x = _c(x)
+    n, d, h, w, c = x.shape
+    buf = torch.empty((n, planes, h, w, c), dtype=torch.float32, device=x.device)
+    check(lib.cfun_halo_pack(ptr(x), ptr(buf), n, d, h, w, c, z0, planes, stream(x)), "halo_pack")
+    return buf
+
+
+def halo_unpack(buf, x, z0):
+    lib = _lib.load()
+    n, d, h, w, c = x.shape
+    planes = buf.shape[1]
+    check(lib.cfun_halo_unpack(ptr(_c(buf)), ptr(x), n, d, h, w, c, z0, planes, stream(x)), "halo_unpack")
+    return x
+
+
+# ---- layout helpers (module boundary only; NCDHW <-> NDHWC) -------------------------------------------
+def to_ndhwc(x):
+    """[N,C,D,H,W] (any memory format) -> contiguous [N,D,H,W,C]; free for channels_last_3d / C == 1."""
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def to_ncdhw(y):
+    """[N,D,H,W,C] -> [N,C,D,H,W] view (channels_last_3d memory format, no copy)."""
+    return y.permute(0, 4, 1, 2, 3)

@@ -1,0 +1,187 @@
+/*
+ * cfun_hip.h -- C ABI of libcfun_hip.so: MI355X (gfx950) kernels for CFUN's volumetric hot path.
+ *
+ * The reference (Wuziyi616/CFUN) has no native code and no FFI: every entry point below replaces a
+ * stock torch / numpy call made by the reference's Python on the hot path (file:line cited per
+ * function, paths relative to the reference root).  INTEGRATION.md shows the ctypes stub a
+ * maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, POD structs of int32/int64/float; no torch / HIP types
+ *     (`cfun_stream_t` is a hipStream_t passed as void*; NULL = the null stream);
+ *   - every pointer is DEVICE memory owned by the caller (incl. workspaces); the library never
+ *     allocates, frees or keeps a pointer after return;
+ *   - activations are fp32, NDHWC ("channels last 3d"), dense; weights are the packed layouts
+ *     described at cfun_conv3d_fwd;
+ *   - every call only enqueues on `stream` and returns; no hidden synchronisation;
+ *   - return 0 on success, a hipError_t (>0) or CFUN_E* (<0) otherwise; never throws;
+ *   - semantic "errors" follow the reference: a degenerate RoI gives zeros (model.py:281-287),
+ *     empty inputs give empty outputs.
+ */
+#ifndef CFUN_HIP_H
+#define CFUN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* cfun_stream_t;
+
+#define CFUN_VERSION 100          /* 0.1.0 */
+#define CFUN_OK 0
+#define CFUN_EINVAL (-1)          /* bad argument / unsupported shape */
+#define CFUN_EWORKSPACE (-2)      /* workspace too small */
+#define CFUN_EALIGN (-3)          /* pointer not 16-byte aligned where required */
+
+#define CFUN_ACT_NONE 0
+#define CFUN_ACT_RELU 1
+#define CFUN_ACT_LRELU 2
+
+#define CFUN_ALGO_AUTO 0
+#define CFUN_ALGO_DIRECT 1        /* generic VALU direct convolution (any shape) */
+#define CFUN_ALGO_MFMA 2          /* LDS-tiled implicit GEMM on v_mfma_f32_16x16x4_f32 (Ci%4==0, Co%4==0) */
+
+int cfun_version(void);
+const char* cfun_error_string(int code);
+
+/* ------------------------------------------------------------------------------------------------
+ * Direct 3-D convolution, NDHWC fp32, im2col-free, fused epilogue.
+ * Replaces nn.Conv3d (+ BatchNorm3d(eval) + ReLU / residual add) of backbone.py:14-23,38-54,123-128,
+ * model.py:131-134,713-717 and every bias-free Conv3d of mask_branch.py:23-88,91-122, plus the
+ * nn.Upsample(scale_factor=2) that feeds a conv (mask_branch.py:112,120) and F.upsample at
+ * model.py:144 (as the x2-nearest residual).
+ *
+ *   y[n,zo,yo,xo,co] = act( s * sum_{tap,ci} X[n, zo*stride+dz-pd, ..., ci] * W[tap][ci][co] + t + r )
+ *     X      = x, or nearest-x2 upsample of x when up2 (x is stored at Di,Hi,Wi; X has 2*Di,...)
+ *     s      = scale[co] (scale_mode 1) | scale[n*Co+co] (scale_mode 2: Dropout3d channel mask) | 1
+ *     t      = shift[co] (bias and/or folded BatchNorm) | 0
+ *     r      = res[...] (res_mode 1) read at (zo>>1,yo>>1,xo>>1) when res_up2 | 0
+ *
+ * Packed weights: wp[tap][ci][CoP] fp32, tap = (dz*kh+dy)*kw+dx, CoP = Co rounded up to 16, pad = 0.
+ * bwd_data takes the transposed pack wpT[tap][co][CiP] (same tap order, CiP = Ci rounded up to 16).
+ * bwd_weight writes dwp in the wp layout (pad columns are written as zeros).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct CfunConv3dParams {
+  int32_t N;
+  int32_t Di, Hi, Wi, Ci;       /* stored input */
+  int32_t Do, Ho, Wo, Co;       /* output */
+  int32_t CoP, CiP;             /* padded row lengths of wp / wpT */
+  int32_t kd, kh, kw;
+  int32_t stride;               /* same on the three axes (1 or 2) */
+  int32_t pd, ph, pw;
+  int32_t up2;
+  int32_t act;
+  float slope;                  /* LeakyReLU negative slope */
+  int32_t scale_mode;
+  int32_t has_shift;
+  int32_t res_mode;             /* 0 none, 1 add before the activation */
+  int32_t res_up2;
+  int32_t algo;                 /* CFUN_ALGO_* */
+} CfunConv3dParams;
+
+int cfun_conv3d_fwd(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
+                    float* y, const CfunConv3dParams* p, cfun_stream_t stream);
+/* dx[n,zi,yi,xi,ci] (stored-input resolution) = sum over outputs/taps that read it of g * W. g = dL/d(conv sum). */
+size_t cfun_conv3d_bwd_data_workspace_bytes(const CfunConv3dParams* p);
+int cfun_conv3d_bwd_data(const float* g, const float* wpT, float* dx, const CfunConv3dParams* p, void* ws,
+                         size_t ws_bytes, cfun_stream_t stream);
+size_t cfun_conv3d_bwd_weight_workspace_bytes(const CfunConv3dParams* p);
+int cfun_conv3d_bwd_weight(const float* x, const float* g, float* dwp, const CfunConv3dParams* p, void* ws,
+                           size_t ws_bytes, cfun_stream_t stream);
+
+/* g = dy * act'(y) * s  -- the epilogue's derivative (y is the saved conv output); also the gradient of `res`.
+ * `vox_per_n` = Do*Ho*Wo (only used by scale_mode 2). */
+int cfun_act_bwd(const float* y, const float* dy, const float* scale, float* g, int64_t nvox, int32_t C,
+                 int64_t vox_per_n, int32_t act, float slope, int32_t scale_mode, cfun_stream_t stream);
+/* out[c] = sum over voxels of g[v,c]  (bias gradients).  ws: cfun_channel_sum_workspace_bytes. */
+size_t cfun_channel_sum_workspace_bytes(int64_t nvox, int32_t C);
+int cfun_channel_sum(const float* g, float* out, int64_t nvox, int32_t C, void* ws, size_t ws_bytes,
+                     cfun_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Elementwise / normalisation (mask_branch.py:18,28,34,40,46,57,94,99,110,115; backbone.py:56,78,89).
+ * ---------------------------------------------------------------------------------------------- */
+int cfun_lrelu_fwd(const float* x, float* y, int64_t n, float slope, cfun_stream_t stream);
+int cfun_lrelu_bwd(const float* x, const float* dy, float* dx, int64_t n, float slope, cfun_stream_t stream);
+int cfun_add(const float* a, const float* b, float* out, int64_t n, cfun_stream_t stream);
+/* lo[n,z,y,x,c] = sum of the 8 children of hi (backward of nearest x2 upsampling). lo dims D,H,W. */
+int cfun_upsample2_bwd(const float* hi, float* lo, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C,
+                       cfun_stream_t stream);
+
+/* InstanceNorm3d(affine=False, eps, biased variance) fused with LeakyReLU.
+ * stats[n,c] = {mean, rstd}.  x is [N, V voxels, C].  Two-stage deterministic fp64 reduction. */
+size_t cfun_instnorm_workspace_bytes(int32_t N, int64_t V, int32_t C);
+int cfun_instnorm_stats(const float* x, float* stats, int32_t N, int64_t V, int32_t C, float eps, void* ws,
+                        size_t ws_bytes, cfun_stream_t stream);
+int cfun_instnorm_lrelu_fwd(const float* x, const float* stats, float* y, int32_t N, int64_t V, int32_t C,
+                            float slope, cfun_stream_t stream);
+int cfun_instnorm_lrelu_bwd(const float* x, const float* stats, const float* dy, float* dx, int32_t N, int64_t V,
+                            int32_t C, float slope, void* ws, size_t ws_bytes, cfun_stream_t stream);
+
+/* MaxPool3d(kernel 2, stride 2) (backbone.py:127).  idx[v,c] = argmax child 0..7 (uint8). */
+int cfun_maxpool2_fwd(const float* x, float* y, uint8_t* idx, int32_t N, int32_t Do, int32_t Ho, int32_t Wo,
+                      int32_t C, cfun_stream_t stream);
+int cfun_maxpool2_bwd(const float* dy, const uint8_t* idx, float* dx, int32_t N, int32_t Do, int32_t Ho, int32_t Wo,
+                      int32_t C, cfun_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * 3-D RoIAlign = crop + trilinear(align_corners=True) resize (model.py:265-289, utils.py:160-174).
+ * fm [D,H,W,C]; boxes [R,6] normalised (z1,y1,x1,z2,y2,x2); out [R,pd,ph,pw,C];
+ * bounds [R,6] int32 receives the integer crop (floor lo / ceil hi, python-slice clamped) -- the
+ * bit-exact part of the contract.  Empty crop => zeros.
+ * ---------------------------------------------------------------------------------------------- */
+int cfun_roi_align3d_fwd(const float* fm, const float* boxes, float* out, int32_t* bounds, int32_t R, int32_t D,
+                         int32_t H, int32_t W, int32_t C, int32_t pd, int32_t ph, int32_t pw, cfun_stream_t stream);
+/* dfm must be zero-initialised by the caller; gradients are accumulated with fp32 atomics. */
+int cfun_roi_align3d_bwd(const float* dout, const int32_t* bounds, float* dfm, int32_t R, int32_t D, int32_t H,
+                         int32_t W, int32_t C, int32_t pd, int32_t ph, int32_t pw, cfun_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Greedy 3-D NMS (utils.py:122-157 + compute_iou utils.py:50-70): fp32 IoU in numpy's operation
+ * order (no FMA contraction), iou > threshold suppresses, stops after max_num picks.
+ * boxes [n,6], scores [n], n <= 4096.  keep [max(n,1)] int32 (pick order), count [1] int32.
+ * Ties in score are ordered higher-original-index first.
+ * ---------------------------------------------------------------------------------------------- */
+size_t cfun_nms3d_workspace_bytes(int32_t n);
+int cfun_nms3d(const float* boxes, const float* scores, int32_t n, float threshold, int32_t max_num, int32_t* keep,
+               int32_t* count, void* ws, size_t ws_bytes, cfun_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Mask-head losses on NDHWC logits [n,V,C] with uint8 class labels [n,V].
+ *   softmax            model.py:794,799
+ *   cross-entropy      model.py:909-935 (target = argmax of the one-hot GT, mean over n*V)
+ *   Sobel edge loss    model.py:938-981 (valid 3x3x3, channels 0,1,0 magnitude, MSE, sum over classes 1..C-1, / n)
+ * ---------------------------------------------------------------------------------------------- */
+int cfun_softmax_fwd(const float* logits, float* probs, int64_t nvox, int32_t C, cfun_stream_t stream);
+int cfun_softmax_bwd(const float* probs, const float* dprobs, float* dlogits, int64_t nvox, int32_t C,
+                     cfun_stream_t stream);
+size_t cfun_loss_workspace_bytes(int64_t nvox);
+/* loss[0] = mean over voxels of -log softmax(logits)[label] */
+int cfun_softmax_ce_fwd(const float* logits, const uint8_t* labels, float* loss, int64_t nvox, int32_t C, void* ws,
+                        size_t ws_bytes, cfun_stream_t stream);
+/* dlogits = gscale[0] * (softmax(logits) - onehot(label)) / nvox */
+int cfun_softmax_ce_bwd(const float* logits, const uint8_t* labels, const float* gscale, float* dlogits,
+                        int64_t nvox, int32_t C, cfun_stream_t stream);
+/* probs [n,D,H,W,C], labels [n,D,H,W]; loss[0] = (1/n) sum_{i,j>=1} mean_{valid voxels} (|grad p| - |grad t|)^2 */
+int cfun_edge_loss_fwd(const float* probs, const uint8_t* labels, float* loss, int32_t n, int32_t D, int32_t H,
+                       int32_t W, int32_t C, void* ws, size_t ws_bytes, cfun_stream_t stream);
+size_t cfun_edge_loss_bwd_workspace_bytes(int32_t n, int32_t D, int32_t H, int32_t W, int32_t C);
+int cfun_edge_loss_bwd(const float* probs, const uint8_t* labels, const float* gscale, float* dprobs, int32_t n,
+                       int32_t D, int32_t H, int32_t W, int32_t C, void* ws, size_t ws_bytes, cfun_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Depth-sharding helpers: copy `planes` depth planes at z0 of a [N,D,H,W,C]
+ * tensor into a dense send buffer / write a received buffer into a padded tensor.
+ * ---------------------------------------------------------------------------------------------- */
+int cfun_halo_pack(const float* x, float* buf, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C, int32_t z0,
+                   int32_t planes, cfun_stream_t stream);
+int cfun_halo_unpack(const float* buf, float* x, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C, int32_t z0,
+                     int32_t planes, cfun_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CFUN_HIP_H */
