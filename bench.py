@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the CFUN hot path on MI355X (BASELINE.json: volumes/sec, forward+backward).
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+A "step" = one synthetic 256x256x128 8-class CT volume through FPN -> RPN -> proposals/NMS -> classifier head
+(12 RoIs) -> U-Net mask head (4 positive RoIs, 96^3 in, 192^3 out, stage 'finetune') -> 6 losses incl. the
+3-D Sobel edge loss -> backward (cfun_amd.step.training_step); inputs are resident in HBM before the timed
+region, no optimizer step, no host sync inside a step except the NMS count read the reference also has.
+N > 1: one process per GPU, every rank trains its own volume (whole volumes are independent units) and the
+replicated weights' gradients are all-reduced over RCCL at the end of each step -- weak scaling.
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel, timed live with HIP
+events on the launch stream) and, at N = 1, `cpu_baseline` (the oracle on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak (= fp32 vector peak)
+
+WORKLOADS = {
+    # name: (stage, H, W, D)
+    "cfg2": ("finetune", 256, 256, 128),   # the configuration BASELINE.json's metric is quoted on
+    "cfg1": ("beginning", 128, 128, 64),
+    "cfg0": ("beginning", 64, 64, 32),
+}
+
+
+def dominant_kernel_match(cfg):
+    """conv_norm_lrelu_l4.0: 3x3x3, 2b -> 2b channels on the full-resolution crops -- the single largest
+    launch of the step (76.4 GFLOP per RoI)."""
+    b = cfg.UNET_MASK_BRANCH_CHANNEL
+    side = cfg.MASK_POOL_SIZE
+
+    def match(p):
+        return (p.kd, p.kh, p.kw, p.stride, p.up2) == (3, 3, 3, 1, 0) and p.Ci == 2 * b and p.Co == 2 * b \
+            and (p.Do, p.Ho, p.Wo) == tuple(side)
+    return match
+
+
+def cpu_baseline(cfg, threads):
+    """The oracle (plain fp32 torch-CPU restatement of the reference path) on the host cores: bounded sample =
+    FPN+RPN forward+backward on the full volume + U-Net mask head forward+backward on ONE 96^3 RoI;
+    a step is estimated as fpn_rpn + n_pos * unet (>= 96 % of the step's FLOPs)."""
+    from oracle import cfun_oracle as orc
+    from cfun_amd import step
+    torch.set_num_threads(threads)
+    net = step.CFUNHotPath(cfg)
+    sd = {k: v.detach().clone().requires_grad_(v.dtype == torch.float32 and "running" not in k)
+          for k, v in net.state_dict().items()}
+    d, h, w = cfg.image_dhw
+    g = torch.Generator().manual_seed(0)
+    image = torch.randn(1, 1, d, h, w, generator=g)
+    t0 = time.time()
+    p2, p3 = orc.fpn(image, sd)
+    outs = [orc.rpn(p, sd) for p in (p2, p3)]
+    sum(o[0].sum() + o[2].sum() for o in outs).backward()
+    t_fpn = time.time() - t0
+    x = torch.randn(1, 1, *cfg.MASK_POOL_SIZE, generator=g)
+    b = cfg.UNET_MASK_BRANCH_CHANNEL
+    masks = [torch.ones(1, c) for c in (b, 2 * b, 4 * b, 8 * b, 16 * b)]
+    t0 = time.time()
+    y = orc.unet(x, sd, "mask.modified_u_net.", cfg.STAGE, masks)
+    torch.softmax(y, dim=1).sum().backward()
+    t_unet = time.time() - t0
+    est = t_fpn + 4 * t_unet
+    return dict(value=1.0 / est, unit="volumes/s", cores=threads, kind="port",
+                sample="oracle (torch-CPU fp32): FPN+RPN fwd+bwd on the %dx%dx%d volume (%.2fs) + U-Net '%s' fwd+bwd on "
+                       "1 of 4 RoIs at 96^3 (%.2fs); step estimated as fpn_rpn + 4*unet, losses/classifier excluded"
+                       % (h, w, d, t_fpn, cfg.STAGE, t_unet))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+
+    from cfun_amd import config, ops, step
+    stage, h, w, d = WORKLOADS[args.workload]
+    cfg = config.heart_config(stage, h, w, d)
+    torch.manual_seed(0)                       # identical replicated weights on every rank
+    net = step.CFUNHotPath(cfg).to(dev)
+    sample = step.synthetic_inputs(cfg, dev, seed=rank)
+    assert sample["p_rois"].shape[0] == 4 and sample["n_rois"].shape[0] == 8   # heads must not be skipped
+    params = [p for p in net.parameters() if p.requires_grad]
+    timer = ops.LaunchTimer(dominant_kernel_match(cfg))
+
+    def one_step():
+        net.zero_grad(set_to_none=True)
+        out, losses, total = step.training_step(net, sample)
+        if world > 1:   # data-parallel replicas: one flat gradient all-reduce per step
+            flat = torch.cat([p.grad.reshape(-1) for p in params if p.grad is not None])
+            dist.all_reduce(flat)
+            flat.div_(world)
+        return losses
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        losses = one_step()
+    fence()
+    ops.set_launch_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = one_step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ops.set_launch_timer(None)
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    lv = [float(l) for l in losses]
+    assert all(v == v and abs(v) != float("inf") for v in lv), "non-finite loss: %s" % lv
+
+    if rank == 0:
+        b = cfg.UNET_MASK_BRANCH_CHANNEL
+        side = cfg.MASK_POOL_SIZE
+        flops = 2.0 * (2 * b) * (2 * b) * 27 * side[0] * side[1] * side[2] * 4      # per launch (4 RoIs)
+        durs = timer.durations_ms()
+        t_k = sum(durs) / max(len(durs), 1) * 1e-3
+        achieved = flops / t_k / 1e12 if t_k > 0 else 0.0
+        result = {
+            "metric": "volumes/sec fwd+bwd, 256x256x128 8-class CT" if args.workload == "cfg2"
+                      else "volumes/sec fwd+bwd (%s)" % args.workload,
+            "value": world * args.steps / elapsed, "unit": "volumes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %dx%dx%d CT, stage '%s', 4 positive + 8 negative RoIs, U-Net b=%d, "
+                                   "96^3 -> %d^3 masks, 6 losses incl. 3-D Sobel edge loss, fwd+bwd"
+                                   % (args.workload, h, w, d, stage, b, cfg.MASK_SHAPE[0]),
+                       "parallelism": "1 volume per GPU x %d, gradient all-reduce (RCCL)" % world if world > 1
+                                      else "single GPU"},
+            "losses": lv,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "k_conv_mfma<3,3,3,1,3> (conv_norm_lrelu_l4.0: 3x3x3 %d->%d @ %dx%d^3)"
+                                   % (2 * b, 2 * b, 4, side[0]),
+                         "flops_per_launch": flops, "avg_launch_ms": t_k * 1e3, "launches_timed": len(durs)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(cfg, threads=os.cpu_count() or 1)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -71,27 +71,49 @@ k_act_bwd(const float* __restrict__ y, const float* __restrict__ dy, const float
   }
 }
 
+// VEC = 4: float4 accesses (C % 4 == 0, 16-byte aligned); VEC = 1: scalar path for odd channel counts
+// (e.g. the 3-class LiTS heads) -- same kernels, one channel per "group".
+template <int VEC> struct Vec;
+template <> struct Vec<4> {
+  static __device__ __forceinline__ void load(const float* p, int64_t e, float (&a)[4]) {
+    const float4 v = reinterpret_cast<const float4*>(p)[e];
+    a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+  }
+  static __device__ __forceinline__ void store(float* p, int64_t e, const float (&a)[4]) {
+    reinterpret_cast<float4*>(p)[e] = make_float4(a[0], a[1], a[2], a[3]);
+  }
+};
+template <> struct Vec<1> {
+  static __device__ __forceinline__ void load(const float* p, int64_t e, float (&a)[1]) { a[0] = p[e]; }
+  static __device__ __forceinline__ void store(float* p, int64_t e, const float (&a)[1]) { p[e] = a[0]; }
+};
+
 // ------------------------------------------------------------------ per-(n,c) reductions over voxels
 // Thread = (voxel lane, 4-channel group).  Accumulates NQ quantities in fp64, reduces the voxel lanes through
 // LDS and writes partial[n][block][q][c] (deterministic two-stage reduction; no atomics).
+template <int VEC>
 struct StatSumSq {  // sum x, sum x^2
   static constexpr int NQ = 2;
   const float* x;
-  __device__ void operator()(int64_t e4, int, int, double (&acc)[2][4]) const {
-    const float4 v = reinterpret_cast<const float4*>(x)[e4];
-    const float a[4] = {v.x, v.y, v.z, v.w};
+  __device__ void operator()(int64_t e, int, int, double (&acc)[2][VEC]) const {
+    float a[VEC];
+    Vec<VEC>::load(x, e, a);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { acc[0][j] += a[j]; acc[1][j] += (double)a[j] * a[j]; }
+    for (int j = 0; j < VEC; ++j) { acc[0][j] += a[j]; acc[1][j] += (double)a[j] * a[j]; }
   }
 };
+template <int VEC>
 struct StatSum {  // sum g
   static constexpr int NQ = 1;
   const float* x;
-  __device__ void operator()(int64_t e4, int, int, double (&acc)[1][4]) const {
-    const float4 v = reinterpret_cast<const float4*>(x)[e4];
-    acc[0][0] += v.x; acc[0][1] += v.y; acc[0][2] += v.z; acc[0][3] += v.w;
+  __device__ void operator()(int64_t e, int, int, double (&acc)[1][VEC]) const {
+    float a[VEC];
+    Vec<VEC>::load(x, e, a);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[0][j] += a[j];
   }
 };
+template <int VEC>
 struct StatNormBwd {  // sum gn, sum gn*xhat with gn = dy*lrelu'(xhat)
   static constexpr int NQ = 2;
   const float* x;
@@ -99,12 +121,12 @@ struct StatNormBwd {  // sum gn, sum gn*xhat with gn = dy*lrelu'(xhat)
   const float* stats;  // [N,C,2]
   int C;
   float slope;
-  __device__ void operator()(int64_t e4, int n, int c0, double (&acc)[2][4]) const {
-    const float4 v = reinterpret_cast<const float4*>(x)[e4];
-    const float4 d = reinterpret_cast<const float4*>(dy)[e4];
-    const float a[4] = {v.x, v.y, v.z, v.w}, b[4] = {d.x, d.y, d.z, d.w};
+  __device__ void operator()(int64_t e, int n, int c0, double (&acc)[2][VEC]) const {
+    float a[VEC], b[VEC];
+    Vec<VEC>::load(x, e, a);
+    Vec<VEC>::load(dy, e, b);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < VEC; ++j) {
       const float mean = stats[((int64_t)n * C + c0 + j) * 2], rstd = stats[((int64_t)n * C + c0 + j) * 2 + 1];
       const float xh = (a[j] - mean) * rstd;
       const float gn = xh > 0.f ? b[j] : b[j] * slope;
@@ -114,28 +136,28 @@ struct StatNormBwd {  // sum gn, sum gn*xhat with gn = dy*lrelu'(xhat)
   }
 };
 
-template <class F>
+template <class F, int VEC>
 __global__ void __launch_bounds__(kBlock)
 k_channel_reduce(F f, double* __restrict__ partial, int64_t V, int C, int lanes) {
   constexpr int NQ = F::NQ;
-  __shared__ double sm[kBlock * NQ * 4];
-  const int CG = C >> 2;
+  __shared__ double sm[kBlock * NQ * VEC];
+  const int CG = C / VEC;
   const int tid = threadIdx.x;
   const int cg = tid % CG, vl = tid / CG;
   const int n = blockIdx.y;
-  double acc[NQ][4];
+  double acc[NQ][VEC];
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[q][j] = 0.0;
+    for (int j = 0; j < VEC; ++j) acc[q][j] = 0.0;
   if (vl < lanes) {
     for (int64_t v = (int64_t)blockIdx.x * lanes + vl; v < V; v += (int64_t)gridDim.x * lanes)
-      f(((int64_t)n * V + v) * CG + cg, n, cg * 4, acc);
+      f(((int64_t)n * V + v) * CG + cg, n, cg * VEC, acc);
   }
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sm[(tid * NQ + q) * 4 + j] = acc[q][j];
+    for (int j = 0; j < VEC; ++j) sm[(tid * NQ + q) * VEC + j] = acc[q][j];
   __syncthreads();
   if (vl == 0) {
     for (int l = 1; l < lanes; ++l) {
@@ -143,13 +165,13 @@ k_channel_reduce(F f, double* __restrict__ partial, int64_t V, int C, int lanes)
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[q][j] += sm[(t2 * NQ + q) * 4 + j];
+        for (int j = 0; j < VEC; ++j) acc[q][j] += sm[(t2 * NQ + q) * VEC + j];
     }
     double* out = partial + (((int64_t)n * gridDim.x + blockIdx.x) * NQ) * C;
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) out[(int64_t)q * C + cg * 4 + j] = acc[q][j];
+      for (int j = 0; j < VEC; ++j) out[(int64_t)q * C + cg * VEC + j] = acc[q][j];
   }
 }
 
@@ -179,9 +201,10 @@ __global__ void k_channel_finalize(const double* __restrict__ partial, float* __
 struct ReducePlan {
   int lanes, blocks;
 };
+inline int vec_of(int C) { return (C & 3) ? 1 : 4; }
 inline ReducePlan reduce_plan(int N, int64_t V, int C) {
   ReducePlan r;
-  const int CG = C >> 2;
+  const int CG = C / vec_of(C);
   r.lanes = kBlock / CG;
   int64_t want = (2048 + N - 1) / N;                       // ~8 blocks per CU in total
   int64_t maxb = (V + (int64_t)r.lanes * 16 - 1) / ((int64_t)r.lanes * 16);  // >= 16 voxels per thread
@@ -194,68 +217,75 @@ inline size_t reduce_ws(int N, int64_t V, int C, int NQ) {
   return cfun_align_up((size_t)N * r.blocks * NQ * C * sizeof(double), 256);
 }
 
+template <int VEC>
 __global__ void __launch_bounds__(kBlock)
-k_instnorm_lrelu_fwd(const float4* __restrict__ x, const float* __restrict__ stats, float4* __restrict__ y,
-                     int64_t total4, int64_t V, int C, float slope) {
-  const int CG = C >> 2;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total4; i += (int64_t)gridDim.x * kBlock) {
+k_instnorm_lrelu_fwd(const float* __restrict__ x, const float* __restrict__ stats, float* __restrict__ y,
+                     int64_t total, int64_t V, int C, float slope) {
+  const int CG = C / VEC;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
     const int cg = (int)(i % CG);
     const int64_t n = i / (V * CG);
-    const float* st = stats + ((int64_t)n * C + cg * 4) * 2;
-    const float4 v = x[i];
-    float a[4] = {v.x, v.y, v.z, v.w};
+    const float* st = stats + ((int64_t)n * C + cg * VEC) * 2;
+    float a[VEC];
+    Vec<VEC>::load(x, i, a);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < VEC; ++j) {
       const float xh = (a[j] - st[2 * j]) * st[2 * j + 1];
       a[j] = xh > 0.f ? xh : xh * slope;
     }
-    y[i] = make_float4(a[0], a[1], a[2], a[3]);
+    Vec<VEC>::store(y, i, a);
   }
 }
 
 // dx = rstd * (gn - mean(gn) - xhat * mean(gn*xhat))
+template <int VEC>
 __global__ void __launch_bounds__(kBlock)
-k_instnorm_lrelu_bwd(const float4* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ means,
-                     const float4* __restrict__ dy, float4* __restrict__ dx, int64_t total4, int64_t V, int C,
+k_instnorm_lrelu_bwd(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ means,
+                     const float* __restrict__ dy, float* __restrict__ dx, int64_t total, int64_t V, int C,
                      float slope) {
-  const int CG = C >> 2;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total4; i += (int64_t)gridDim.x * kBlock) {
+  const int CG = C / VEC;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
     const int cg = (int)(i % CG);
     const int64_t n = i / (V * CG);
-    const float* st = stats + ((int64_t)n * C + cg * 4) * 2;
-    const float* mm = means + ((int64_t)n * C + cg * 4) * 2;
-    const float4 v = x[i], d = dy[i];
-    const float a[4] = {v.x, v.y, v.z, v.w}, b[4] = {d.x, d.y, d.z, d.w};
-    float r[4];
+    const float* st = stats + ((int64_t)n * C + cg * VEC) * 2;
+    const float* mm = means + ((int64_t)n * C + cg * VEC) * 2;
+    float a[VEC], b[VEC], r[VEC];
+    Vec<VEC>::load(x, i, a);
+    Vec<VEC>::load(dy, i, b);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < VEC; ++j) {
       const float rstd = st[2 * j + 1];
       const float xh = (a[j] - st[2 * j]) * rstd;
       const float gn = xh > 0.f ? b[j] : b[j] * slope;
       r[j] = rstd * (gn - mm[2 * j] - xh * mm[2 * j + 1]);
     }
-    dx[i] = make_float4(r[0], r[1], r[2], r[3]);
+    Vec<VEC>::store(dx, i, r);
   }
 }
 
 // ------------------------------------------------------------------ upsample backward, maxpool, halo
+template <int VEC>
 __global__ void __launch_bounds__(kBlock)
-k_upsample2_bwd(const float4* __restrict__ hi, float4* __restrict__ lo, int64_t total4, int D, int H, int W, int CG) {
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total4; i += (int64_t)gridDim.x * kBlock) {
+k_upsample2_bwd(const float* __restrict__ hi, float* __restrict__ lo, int64_t total, int D, int H, int W, int CG) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
     int64_t t = i;
     const int cg = (int)(t % CG); t /= CG;
     const int x = (int)(t % W); t /= W;
     const int y = (int)(t % H); t /= H;
     const int z = (int)(t % D);
     const int64_t n = t / D;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    float sacc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) sacc[j] = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int zz = 2 * z + (k >> 2), yy = 2 * y + ((k >> 1) & 1), xx = 2 * x + (k & 1);
-      const float4 v = hi[((((int64_t)n * 2 * D + zz) * 2 * H + yy) * 2 * W + xx) * CG + cg];
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      float v[VEC];
+      Vec<VEC>::load(hi, ((((int64_t)n * 2 * D + zz) * 2 * H + yy) * 2 * W + xx) * CG + cg, v);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) sacc[j] += v[j];
     }
-    lo[i] = s;
+    Vec<VEC>::store(lo, i, sacc);
   }
 }
 
@@ -360,19 +390,24 @@ int cfun_act_bwd(const float* y, const float* dy, const float* scale, float* g, 
 }
 
 size_t cfun_channel_sum_workspace_bytes(int64_t nvox, int32_t C) {
-  if (C <= 0 || (C & 3) || C > 1024) return 0;
+  if (C <= 0 || C / vec_of(C) > kBlock) return 0;
   return reduce_ws(1, nvox, C, 1);
 }
 
 int cfun_channel_sum(const float* g, float* out, int64_t nvox, int32_t C, void* ws, size_t ws_bytes,
                      cfun_stream_t stream) {
-  if (C <= 0 || (C & 3) || C > 1024) return CFUN_EINVAL;
+  if (C <= 0 || C / vec_of(C) > kBlock) return CFUN_EINVAL;
   if (nvox <= 0) return (int)hipMemsetAsync(out, 0, C * sizeof(float), cfun_st(stream));
-  if (!cfun_aligned16(g)) return CFUN_EALIGN;
+  if (vec_of(C) == 4 && !cfun_aligned16(g)) return CFUN_EALIGN;
   if (ws_bytes < reduce_ws(1, nvox, C, 1)) return CFUN_EWORKSPACE;
   const ReducePlan r = reduce_plan(1, nvox, C);
-  StatSum f{g};
-  hipLaunchKernelGGL(k_channel_reduce<StatSum>, dim3(r.blocks, 1), dim3(kBlock), 0, cfun_st(stream), f, (double*)ws, nvox, C, r.lanes);
+  if (vec_of(C) == 4) {
+    auto kern = k_channel_reduce<StatSum<4>, 4>;
+    hipLaunchKernelGGL(kern, dim3(r.blocks, 1), dim3(kBlock), 0, cfun_st(stream), StatSum<4>{g}, (double*)ws, nvox, C, r.lanes);
+  } else {
+    auto kern = k_channel_reduce<StatSum<1>, 1>;
+    hipLaunchKernelGGL(kern, dim3(r.blocks, 1), dim3(kBlock), 0, cfun_st(stream), StatSum<1>{g}, (double*)ws, nvox, C, r.lanes);
+  }
   hipLaunchKernelGGL(k_channel_finalize, dim3((C + kBlock - 1) / kBlock), dim3(kBlock), 0, cfun_st(stream),
                      (const double*)ws, out, C, C, r.blocks, 1, nvox, 0.f, 1);
   CFUN_LAUNCH_CHECK();
@@ -380,7 +415,7 @@ int cfun_channel_sum(const float* g, float* out, int64_t nvox, int32_t C, void* 
 }
 
 size_t cfun_instnorm_workspace_bytes(int32_t N, int64_t V, int32_t C) {
-  if (C <= 0 || (C & 3) || C > 1024 || N <= 0 || V <= 0) return 0;
+  if (C <= 0 || C / vec_of(C) > kBlock || N <= 0 || V <= 0) return 0;
   // forward: partial sums; backward: partial sums + the [N,C,2] means
   return reduce_ws(N, V, C, 2) + cfun_align_up((size_t)N * C * 2 * sizeof(float), 256);
 }
@@ -388,12 +423,17 @@ size_t cfun_instnorm_workspace_bytes(int32_t N, int64_t V, int32_t C) {
 int cfun_instnorm_stats(const float* x, float* stats, int32_t N, int64_t V, int32_t C, float eps, void* ws,
                         size_t ws_bytes, cfun_stream_t stream) {
   if (N <= 0 || V <= 0) return CFUN_OK;
-  if (C <= 0 || (C & 3) || C > 1024) return CFUN_EINVAL;
-  if (!cfun_aligned16(x)) return CFUN_EALIGN;
+  if (C <= 0 || C / vec_of(C) > kBlock) return CFUN_EINVAL;
+  if (vec_of(C) == 4 && !cfun_aligned16(x)) return CFUN_EALIGN;
   if (ws_bytes < reduce_ws(N, V, C, 2)) return CFUN_EWORKSPACE;
   const ReducePlan r = reduce_plan(N, V, C);
-  StatSumSq f{x};
-  hipLaunchKernelGGL(k_channel_reduce<StatSumSq>, dim3(r.blocks, N), dim3(kBlock), 0, cfun_st(stream), f, (double*)ws, V, C, r.lanes);
+  if (vec_of(C) == 4) {
+    auto kern = k_channel_reduce<StatSumSq<4>, 4>;
+    hipLaunchKernelGGL(kern, dim3(r.blocks, N), dim3(kBlock), 0, cfun_st(stream), StatSumSq<4>{x}, (double*)ws, V, C, r.lanes);
+  } else {
+    auto kern = k_channel_reduce<StatSumSq<1>, 1>;
+    hipLaunchKernelGGL(kern, dim3(r.blocks, N), dim3(kBlock), 0, cfun_st(stream), StatSumSq<1>{x}, (double*)ws, V, C, r.lanes);
+  }
   hipLaunchKernelGGL(k_channel_finalize, dim3((N * C + kBlock - 1) / kBlock), dim3(kBlock), 0, cfun_st(stream),
                      (const double*)ws, stats, N * C, C, r.blocks, 2, V, eps, 0);
   CFUN_LAUNCH_CHECK();
@@ -403,11 +443,12 @@ int cfun_instnorm_stats(const float* x, float* stats, int32_t N, int64_t V, int3
 int cfun_instnorm_lrelu_fwd(const float* x, const float* stats, float* y, int32_t N, int64_t V, int32_t C,
                             float slope, cfun_stream_t stream) {
   if (N <= 0 || V <= 0) return CFUN_OK;
-  if (C <= 0 || (C & 3)) return CFUN_EINVAL;
-  if (!cfun_aligned16(x) || !cfun_aligned16(y)) return CFUN_EALIGN;
-  const int64_t total4 = (int64_t)N * V * (C >> 2);
-  hipLaunchKernelGGL(k_instnorm_lrelu_fwd, dim3(ew_grid(total4)), dim3(kBlock), 0, cfun_st(stream), (const float4*)x,
-                     stats, (float4*)y, total4, V, C, slope);
+  if (C <= 0) return CFUN_EINVAL;
+  const int vec = vec_of(C);
+  if (vec == 4 && (!cfun_aligned16(x) || !cfun_aligned16(y))) return CFUN_EALIGN;
+  const int64_t total = (int64_t)N * V * (C / vec);
+  if (vec == 4) hipLaunchKernelGGL(k_instnorm_lrelu_fwd<4>, dim3(ew_grid(total)), dim3(kBlock), 0, cfun_st(stream), x, stats, y, total, V, C, slope);
+  else hipLaunchKernelGGL(k_instnorm_lrelu_fwd<1>, dim3(ew_grid(total)), dim3(kBlock), 0, cfun_st(stream), x, stats, y, total, V, C, slope);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }
@@ -415,31 +456,38 @@ int cfun_instnorm_lrelu_fwd(const float* x, const float* stats, float* y, int32_
 int cfun_instnorm_lrelu_bwd(const float* x, const float* stats, const float* dy, float* dx, int32_t N, int64_t V,
                             int32_t C, float slope, void* ws, size_t ws_bytes, cfun_stream_t stream) {
   if (N <= 0 || V <= 0) return CFUN_OK;
-  if (C <= 0 || (C & 3) || C > 1024) return CFUN_EINVAL;
-  if (!cfun_aligned16(x) || !cfun_aligned16(dy) || !cfun_aligned16(dx)) return CFUN_EALIGN;
+  if (C <= 0 || C / vec_of(C) > kBlock) return CFUN_EINVAL;
+  const int vec = vec_of(C);
+  if (vec == 4 && (!cfun_aligned16(x) || !cfun_aligned16(dy) || !cfun_aligned16(dx))) return CFUN_EALIGN;
   if (ws_bytes < cfun_instnorm_workspace_bytes(N, V, C)) return CFUN_EWORKSPACE;
   const ReducePlan r = reduce_plan(N, V, C);
   double* partial = (double*)ws;
   float* means = (float*)((char*)ws + reduce_ws(N, V, C, 2));
-  StatNormBwd f{x, dy, stats, C, slope};
-  hipLaunchKernelGGL(k_channel_reduce<StatNormBwd>, dim3(r.blocks, N), dim3(kBlock), 0, cfun_st(stream), f, partial, V, C, r.lanes);
+  if (vec == 4) {
+    auto kern = k_channel_reduce<StatNormBwd<4>, 4>;
+    hipLaunchKernelGGL(kern, dim3(r.blocks, N), dim3(kBlock), 0, cfun_st(stream), StatNormBwd<4>{x, dy, stats, C, slope}, partial, V, C, r.lanes);
+  } else {
+    auto kern = k_channel_reduce<StatNormBwd<1>, 1>;
+    hipLaunchKernelGGL(kern, dim3(r.blocks, N), dim3(kBlock), 0, cfun_st(stream), StatNormBwd<1>{x, dy, stats, C, slope}, partial, V, C, r.lanes);
+  }
   hipLaunchKernelGGL(k_channel_finalize, dim3((N * C + kBlock - 1) / kBlock), dim3(kBlock), 0, cfun_st(stream),
                      (const double*)partial, means, N * C, C, r.blocks, 2, V, 0.f, 2);
-  const int64_t total4 = (int64_t)N * V * (C >> 2);
-  hipLaunchKernelGGL(k_instnorm_lrelu_bwd, dim3(ew_grid(total4)), dim3(kBlock), 0, cfun_st(stream), (const float4*)x,
-                     stats, (const float*)means, (const float4*)dy, (float4*)dx, total4, V, C, slope);
+  const int64_t total = (int64_t)N * V * (C / vec);
+  if (vec == 4) hipLaunchKernelGGL(k_instnorm_lrelu_bwd<4>, dim3(ew_grid(total)), dim3(kBlock), 0, cfun_st(stream), x, stats, (const float*)means, dy, dx, total, V, C, slope);
+  else hipLaunchKernelGGL(k_instnorm_lrelu_bwd<1>, dim3(ew_grid(total)), dim3(kBlock), 0, cfun_st(stream), x, stats, (const float*)means, dy, dx, total, V, C, slope);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }
 
 int cfun_upsample2_bwd(const float* hi, float* lo, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C,
                        cfun_stream_t stream) {
-  if (C <= 0 || (C & 3)) return CFUN_EINVAL;
-  if (!cfun_aligned16(hi) || !cfun_aligned16(lo)) return CFUN_EALIGN;
-  const int64_t total4 = (int64_t)N * D * H * W * (C >> 2);
-  if (total4 <= 0) return CFUN_OK;
-  hipLaunchKernelGGL(k_upsample2_bwd, dim3(ew_grid(total4)), dim3(kBlock), 0, cfun_st(stream), (const float4*)hi,
-                     (float4*)lo, total4, D, H, W, C >> 2);
+  if (C <= 0) return CFUN_EINVAL;
+  const int vec = vec_of(C);
+  if (vec == 4 && (!cfun_aligned16(hi) || !cfun_aligned16(lo))) return CFUN_EALIGN;
+  const int64_t total = (int64_t)N * D * H * W * (C / vec);
+  if (total <= 0) return CFUN_OK;
+  if (vec == 4) hipLaunchKernelGGL(k_upsample2_bwd<4>, dim3(ew_grid(total)), dim3(kBlock), 0, cfun_st(stream), hi, lo, total, D, H, W, C / vec);
+  else hipLaunchKernelGGL(k_upsample2_bwd<1>, dim3(ew_grid(total)), dim3(kBlock), 0, cfun_st(stream), hi, lo, total, D, H, W, C / vec);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }

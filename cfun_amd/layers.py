@@ -1,0 +1,68 @@
+"""Parameter holders shared by the drop-in modules.
+
+The state-dict contract is the reference's: every conv keeps ``weight`` in OIDHW (and
+``bias``), BatchNorm3d keeps its five entries.  These holders never call torch convolutions; the forward
+passes in backbone.py / mask_branch.py / model.py feed them to the HIP kernels through cfun_amd.ops.
+"""
+import math
+import os
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA
+
+
+def default_algo():
+    """CFUN_CONV_ALGO=auto|direct|mfma selects the HIP conv kernel family (tests; default auto)."""
+    return {"auto": ALGO_AUTO, "direct": ALGO_DIRECT, "mfma": ALGO_MFMA}[os.environ.get("CFUN_CONV_ALGO", "auto")]
+
+
+class Conv3dParams(nn.Module):
+    """weight [Co,Ci,kd,kh,kw] (+ bias [Co]) with nn.Conv3d's default initialisation."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__()
+        k = (kernel_size,) * 3 if isinstance(kernel_size, int) else tuple(kernel_size)
+        p = (padding,) * 3 if isinstance(padding, int) else tuple(padding)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = k, int(stride), p
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, *k))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if bias:
+            bound = 1.0 / math.sqrt(in_channels * k[0] * k[1] * k[2])
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def spec(self, act=ops.ACT_NONE, up2=False, res_up2=False, scale_per_n=False):
+        return ops.ConvSpec(k=self.kernel_size, co=self.out_channels, stride=self.stride, pad=self.padding, up2=up2,
+                            act=act, res_up2=res_up2, scale_per_n=scale_per_n, algo=default_algo())
+
+    def packed(self):
+        return ops.pack_weight(self.weight)
+
+    def forward(self, x, act=ops.ACT_NONE, bn=None, bn_eps=None, res=None, up2=False, res_up2=False, scale=None):
+        """NDHWC in / out.  bn: a frozen nn.BatchNorm3d folded into the epilogue;
+        scale: per-(n, channel) multiplier (Dropout3d mask) -- mutually exclusive with bn."""
+        shift = self.bias
+        per_n = False
+        if bn is not None:
+            eps = bn.eps if bn_eps is None else bn_eps
+            s = bn.weight * torch.rsqrt(bn.running_var + eps)
+            b = self.bias if self.bias is not None else 0.0
+            shift = (b - bn.running_mean) * s + bn.bias
+            scale = s.detach()
+        elif scale is not None:
+            per_n = True
+        return ops.conv3d(x, self.packed(), self.spec(act, up2, res_up2, per_n), scale=scale, shift=shift, res=res)
+
+    def extra_repr(self):
+        return "%d, %d, kernel_size=%s, stride=%d, padding=%s, bias=%s" % (
+            self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding, self.bias is not None)
+
+
+def frozen_bn(channels, eps=1e-5, momentum=0.1):
+    """BatchNorm3d used as a parameter/buffer holder only: always evaluated in eval mode as a constant
+    per-channel affine folded into the preceding conv (model.py:1397-1406)."""
+    return nn.BatchNorm3d(channels, eps=eps, momentum=momentum)

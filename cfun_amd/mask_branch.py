@@ -1,0 +1,116 @@
+"""3-D U-Net mask head on HIP kernels -- drop-in for the reference's ``mask_branch`` module.
+
+``Modified3DUNet(in_channels, n_classes, stage, base_n_filter)`` keeps the constructor, the attribute /
+state-dict names (27 bias-free convs) and the forward semantics of
+mask_branch.py:11-220, but runs as NDHWC HIP kernels:
+
+  * every conv is one launch of the MFMA implicit-GEMM kernel (direct VALU kernel for the C_in = 1 stem);
+  * nearest x2 up-sampling is never materialised (the consumer conv reads (z>>1, y>>1, x>>1));
+  * residual / deep-supervision adds, the Dropout3d channel mask and the 'finetune' skip are conv epilogues;
+  * InstanceNorm3d + LeakyReLU is one fused statistics pass + one apply pass.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .layers import Conv3dParams
+
+
+def _holder(index, length, conv):
+    """nn.Sequential whose child ``index`` is the conv: reproduces names such as 'norm_lrelu_conv_c2.2.weight'."""
+    mods = [nn.Identity() for _ in range(length)]
+    mods[index] = conv
+    return nn.Sequential(*mods)
+
+
+class Modified3DUNet(nn.Module):
+    def __init__(self, in_channels, n_classes, stage, base_n_filter=32, dropout_p=0.6):
+        super().__init__()
+        self.in_channels, self.n_classes, self.stage = in_channels, n_classes, stage
+        self.base_n_filter = b = base_n_filter
+        self.dropout_p = dropout_p
+        self.dropout_masks = None        # tests: list of 5 [N,C] multipliers injected instead of torch's RNG
+
+        def c3(ci, co, stride=1):
+            return Conv3dParams(ci, co, 3, stride=stride, padding=1, bias=False)
+
+        def c1(ci, co):
+            return Conv3dParams(ci, co, 1, bias=False)
+
+        # context pathway (mask_branch.py:22-50)
+        self.conv3d_c1_1 = c3(in_channels, b)
+        self.conv3d_c1_2 = c3(b, b)
+        self.lrelu_conv_c1 = _holder(1, 2, c3(b, b))
+        for lvl, (ci, co) in enumerate(((b, 2 * b), (2 * b, 4 * b), (4 * b, 8 * b), (8 * b, 16 * b)), start=2):
+            setattr(self, "conv3d_c%d" % lvl, c3(ci, co, stride=2))
+            setattr(self, "norm_lrelu_conv_c%d" % lvl, _holder(2, 3, c3(co, co)))
+        # localisation pathway (mask_branch.py:51-88)
+        self.norm_lrelu_upscale_conv_norm_lrelu_l0 = _holder(3, 6, c3(16 * b, 8 * b))
+        self.conv3d_l0 = c1(8 * b, 8 * b)
+        self.conv_norm_lrelu_l1 = _holder(0, 3, c3(16 * b, 16 * b))
+        self.conv3d_l1 = c1(16 * b, 8 * b)
+        self.norm_lrelu_upscale_conv_norm_lrelu_l1 = _holder(3, 6, c3(8 * b, 4 * b))
+        self.conv_norm_lrelu_l2 = _holder(0, 3, c3(8 * b, 8 * b))
+        self.conv3d_l2 = c1(8 * b, 4 * b)
+        self.norm_lrelu_upscale_conv_norm_lrelu_l2 = _holder(3, 6, c3(4 * b, 2 * b))
+        self.conv_norm_lrelu_l3 = _holder(0, 3, c3(4 * b, 4 * b))
+        self.conv3d_l3 = c1(4 * b, 2 * b)
+        self.norm_lrelu_upscale_conv_norm_lrelu_l3 = _holder(3, 6, c3(2 * b, b))
+        self.conv_norm_lrelu_l4 = _holder(0, 3, c3(2 * b, 2 * b))
+        self.conv3d_l4 = c1(2 * b, n_classes)
+        self.ds2_1x1_conv3d = c1(8 * b, n_classes)
+        self.ds3_1x1_conv3d = c1(4 * b, n_classes)
+        self.out_upscale_conv = _holder(1, 2, Conv3dParams(n_classes, n_classes, 5, padding=2, bias=False))
+
+    # ------------------------------------------------------------------------------------------
+    def _drop_masks(self, n, device):
+        """Five Dropout3d(p) channel masks (keep / (1-p)); None in eval mode (mask_branch.py:19,130-175)."""
+        if not self.training or self.dropout_p <= 0:
+            return [None] * 5
+        if self.dropout_masks is not None:
+            return [m.to(device=device, dtype=torch.float32).contiguous() for m in self.dropout_masks]
+        b, keep = self.base_n_filter, 1.0 - self.dropout_p
+        return [torch.empty((n, c), device=device).bernoulli_(keep).div_(keep) for c in (b, 2 * b, 4 * b, 8 * b, 16 * b)]
+
+    def forward_ndhwc(self, x):
+        nl = ops.instnorm_lrelu
+        drop = self._drop_masks(x.shape[0], x.device)
+
+        def nluc(h, holder):   # norm -> lrelu -> (up x2 folded into the conv) -> conv -> norm -> lrelu
+            return nl(holder[3](nl(h), up2=True))
+
+        # level 1: residual is the pre-activation stem output, context_1 is taken before the norm
+        res = self.conv3d_c1_1(x)
+        h = self.conv3d_c1_2(ops.lrelu(res), scale=drop[0])
+        out = self.lrelu_conv_c1[1](ops.lrelu(h), res=res)
+        ctx = [ops.lrelu(out)]
+        h = nl(out)
+        # levels 2..5: stride-2 conv, then the SAME norm_lrelu_conv weights twice around the dropout
+        for lvl in (2, 3, 4, 5):
+            res = getattr(self, "conv3d_c%d" % lvl)(h)
+            conv = getattr(self, "norm_lrelu_conv_c%d" % lvl)[2]
+            t = conv(nl(res), scale=drop[lvl - 1])
+            out = conv(nl(t), res=res)
+            if lvl < 5:
+                h = nl(out)
+                ctx.append(h)
+        h = nluc(out, self.norm_lrelu_upscale_conv_norm_lrelu_l0)
+        h = nl(self.conv3d_l0(h))
+        h = nl(self.conv_norm_lrelu_l1[0](torch.cat([h, ctx[3]], dim=-1)))
+        h = nluc(self.conv3d_l1(h), self.norm_lrelu_upscale_conv_norm_lrelu_l1)
+        ds2 = nl(self.conv_norm_lrelu_l2[0](torch.cat([h, ctx[2]], dim=-1)))
+        h = nluc(self.conv3d_l2(ds2), self.norm_lrelu_upscale_conv_norm_lrelu_l2)
+        ds3 = nl(self.conv_norm_lrelu_l3[0](torch.cat([h, ctx[1]], dim=-1)))
+        h = nluc(self.conv3d_l3(ds3), self.norm_lrelu_upscale_conv_norm_lrelu_l3)
+        h = nl(self.conv_norm_lrelu_l4[0](torch.cat([h, ctx[0]], dim=-1)))
+        # deep supervision: up(up(ds2_1x1) + ds3_1x1) + out_pred, each add is a conv epilogue
+        s = self.ds3_1x1_conv3d(ds3, res=self.ds2_1x1_conv3d(ds2), res_up2=True)
+        out = self.conv3d_l4(h, res=s, res_up2=True)
+        if self.stage == "finetune":   # up(out) + conv5(up(out))
+            out = self.out_upscale_conv[1](out, up2=True, res=out, res_up2=True)
+        return out
+
+    def forward(self, x):
+        """x [N,in,D,H,W] -> logits [N,n_classes,D,H,W] (x2 spatial in stage 'finetune'); the result is a
+        channels_last_3d view of the NDHWC buffer."""
+        return ops.to_ncdhw(self.forward_ndhwc(ops.to_ndhwc(x)))

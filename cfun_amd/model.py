@@ -1,0 +1,267 @@
+"""Detection glue of the hot path on HIP kernels -- the ★ symbols of the reference's ``model.py``:
+FPN (124-148), RPN (700-743), proposal_layer (199-258), RoI_Align (265-289), pyramid_roi_align (292-370),
+Classifier (750-784), Mask (787-801) and the two mask losses (909-981).  Constructors, call signatures,
+return shapes and state-dict keys follow the reference; tensors at the surface are NCDHW-shaped views of
+NDHWC buffers (channels_last_3d), internally everything stays NDHWC.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import mask_branch, ops, utils
+from .layers import Conv3dParams, default_algo, frozen_bn
+from .ops import ACT_NONE, ACT_RELU
+
+
+def _stage_ndhwc(stage, x):
+    if hasattr(stage, "forward_ndhwc"):
+        return stage.forward_ndhwc(x)
+    return ops.to_ndhwc(stage(ops.to_ncdhw(x)))   # foreign (e.g. reference) stage modules
+
+
+class FPN(nn.Module):
+    def __init__(self, C1, C2, C3, out_channels, config):
+        super().__init__()
+        self.out_channels = out_channels
+        self.C1, self.C2, self.C3 = C1, C2, C3
+        self.P3_conv1 = Conv3dParams(config.BACKBONE_CHANNELS[1] * 4, out_channels, 1)
+        self.P3_conv2 = Conv3dParams(out_channels, out_channels, 3, padding=1)
+        self.P2_conv1 = Conv3dParams(config.BACKBONE_CHANNELS[0] * 4, out_channels, 1)
+        self.P2_conv2 = Conv3dParams(out_channels, out_channels, 3, padding=1)
+
+    def forward_ndhwc(self, x):
+        c2 = _stage_ndhwc(self.C2, _stage_ndhwc(self.C1, x))
+        c3 = _stage_ndhwc(self.C3, c2)
+        p3 = self.P3_conv1(c3)
+        p2 = self.P2_conv1(c2, res=p3, res_up2=True)        # P2_conv1(c2) + nearest_up2(p3), model.py:144
+        return self.P2_conv2(p2), self.P3_conv2(p3)
+
+    def forward(self, x):
+        p2, p3 = self.forward_ndhwc(ops.to_ndhwc(x))
+        return [ops.to_ncdhw(p2), ops.to_ncdhw(p3)]
+
+
+class RPN(nn.Module):
+    def __init__(self, anchors_per_location, anchor_stride, channel, conv_channel):
+        super().__init__()
+        self.anchors_per_location = anchors_per_location
+        self.conv_shared = Conv3dParams(channel, conv_channel, 3, stride=anchor_stride, padding=1)
+        self.conv_class = Conv3dParams(conv_channel, 2 * anchors_per_location, 1)
+        self.conv_bbox = Conv3dParams(conv_channel, 6 * anchors_per_location, 1)
+
+    def forward_ndhwc(self, p):
+        """p [N,D,H,W,C] -> [logits [N,A,2], probs [N,A,2], bbox [N,A,6]], anchors flattened (z,y,x)."""
+        n = p.shape[0]
+        h = self.conv_shared(p, ACT_RELU)
+        # the class (2a) and bbox (6a) 1x1x1 heads run as ONE 8a-channel MFMA GEMM over the shared features
+        w = torch.cat([self.conv_class.weight, self.conv_bbox.weight], dim=0)
+        b = torch.cat([self.conv_class.bias, self.conv_bbox.bias], dim=0)
+        spec = ops.ConvSpec(k=(1, 1, 1), co=w.shape[0], algo=default_algo())
+        out = ops.conv3d(h, ops.pack_weight(w), spec, shift=b)
+        a2 = 2 * self.anchors_per_location
+        logits = out[..., :a2].reshape(n, -1, 2)
+        bbox = out[..., a2:].reshape(n, -1, 6)
+        probs = ops.softmax_channels(logits)
+        return [logits, probs, bbox]
+
+    def forward(self, x):
+        return self.forward_ndhwc(ops.to_ndhwc(x))
+
+
+# ------------------------------------------------------------------------------------------ proposals
+def apply_box_deltas(boxes, deltas):
+    """model.py:155-182."""
+    size = boxes[:, 3:] - boxes[:, :3]
+    center = boxes[:, :3] + 0.5 * size
+    center = center + deltas[:, :3] * size
+    size = size * torch.exp(deltas[:, 3:])
+    lo = center - 0.5 * size
+    return torch.cat([lo, lo + size], dim=1)
+
+
+def clip_boxes(boxes, window):
+    """model.py:185-196; window = (z1,y1,x1,z2,y2,x2)."""
+    lo = torch.tensor([window[0], window[1], window[2]] * 2, dtype=boxes.dtype, device=boxes.device)
+    hi = torch.tensor([window[3], window[4], window[5]] * 2, dtype=boxes.dtype, device=boxes.device)
+    return torch.max(torch.min(boxes, hi), lo)
+
+
+def proposal_layer(inputs, proposal_count, nms_threshold, anchors, config=None):
+    """model.py:199-258 with the NMS on device (no boxes.cpu().numpy() round trip): scores sorted
+    descending, top PRE_NMS_LIMIT, decode, clip, HIP NMS, normalise.  Returns [1, K, 6]."""
+    probs, bbox = inputs[0].squeeze(0), inputs[1].squeeze(0)
+    scores = probs[:, 1]
+    std = torch.tensor(np.reshape(config.RPN_BBOX_STD_DEV, [1, 6]), dtype=torch.float32, device=bbox.device)
+    deltas = bbox * std
+    limit = min(config.PRE_NMS_LIMIT, anchors.shape[0])
+    scores, order = scores.sort(descending=True)
+    order, scores = order[:limit], scores[:limit]
+    boxes = apply_box_deltas(anchors[order.detach()], deltas[order.detach()])
+    height, width, depth = [float(v) for v in config.IMAGE_SHAPE[:3]]
+    boxes = clip_boxes(boxes, (0.0, 0.0, 0.0, depth, height, width))
+    keep = utils.nms_device(boxes, scores, nms_threshold, proposal_count)
+    norm = torch.tensor([depth, height, width, depth, height, width], dtype=torch.float32, device=boxes.device)
+    return (boxes[keep] / norm).unsqueeze(0)
+
+
+# ------------------------------------------------------------------------------------------ RoIAlign
+def roi_levels(boxes):
+    """model.py:322-332: clamp(round(4 + log2(h*w*d)/3), 2, 3) on normalised boxes (fp32, half-to-even)."""
+    d = boxes[:, 3] - boxes[:, 0]
+    h = boxes[:, 4] - boxes[:, 1]
+    w = boxes[:, 5] - boxes[:, 2]
+    ln2 = torch.log(torch.tensor([2.0], dtype=torch.float32, device=boxes.device))
+    return (4 + (1.0 / 3.0) * (torch.log(h * w * d) / ln2)).round().int().clamp(2, 3)
+
+
+def pyramid_roi_align_ndhwc(boxes, feature_maps, pool_size):
+    """boxes [R,6] normalised; feature_maps = two [D,H,W,C] maps (levels 2, 3) -> [R,pd,ph,pw,C]."""
+    if feature_maps[0] is feature_maps[1]:      # mask head: both "levels" are the raw image (model.py:1413)
+        return ops.roi_align(feature_maps[0], boxes.detach(), pool_size)[0]
+    lv = roi_levels(boxes)
+    pooled, index = [], []
+    for i, level in enumerate((2, 3)):
+        ix = torch.nonzero(lv == level)[:, 0]
+        if ix.numel() == 0:
+            continue
+        index.append(ix)
+        pooled.append(ops.roi_align(feature_maps[i], boxes[ix].detach(), pool_size)[0])
+    pooled = torch.cat(pooled, dim=0)
+    _, back = torch.sort(torch.cat(index, dim=0))
+    return pooled[back]
+
+
+def RoI_Align(feature_map, pool_size, boxes):
+    """model.py:265-289 drop-in: feature_map [C,D,H,W], boxes [R,6] normalised -> [R,C,pd,ph,pw]."""
+    fm = feature_map.permute(1, 2, 3, 0).contiguous()
+    return ops.roi_align(fm, boxes, pool_size)[0].permute(0, 4, 1, 2, 3)
+
+
+def pyramid_roi_align(inputs, pool_size, test_flag=False):
+    """model.py:292-370 drop-in: inputs = [boxes, fm_level2, fm_level3] (batch dim 1) -> [R,C,pd,ph,pw]."""
+    boxes = inputs[0].squeeze(0) if inputs[0].dim() == 3 else inputs[0]
+    fms = [f.squeeze(0) if f.dim() == 5 else f for f in inputs[1:]]
+    same = fms[0] is fms[1] or inputs[1] is inputs[2]
+    fms = [f.permute(1, 2, 3, 0).contiguous() for f in fms]
+    if same:
+        fms[1] = fms[0]
+    return pyramid_roi_align_ndhwc(boxes, fms, pool_size).permute(0, 4, 1, 2, 3)
+
+
+# ------------------------------------------------------------------------------------------ heads
+class Classifier(nn.Module):
+    """model.py:750-784.  RoIAlign runs on the HIP kernel; conv1 (kernel == pool size) is a plain
+    [R x C*pd*ph*pw] x [.. x fc] GEMM that streams a 113 MB weight once (HBM-bound), so it and the two tiny
+    linear layers go to the library GEMM (rocBLAS via torch) -- SURVEY.md section 8(a) row A15 "adjacent"."""
+
+    def __init__(self, channel, pool_size, image_shape, num_classes, fc_size, test_flag=False):
+        super().__init__()
+        self.pool_size, self.image_shape, self.fc_size, self.test_flag = pool_size, image_shape, fc_size, test_flag
+        self.conv1 = Conv3dParams(channel, fc_size, tuple(pool_size))
+        self.bn1 = frozen_bn(fc_size, eps=0.001, momentum=0.01)
+        self.conv2 = Conv3dParams(fc_size, fc_size, 1)
+        self.bn2 = frozen_bn(fc_size, eps=0.001, momentum=0.01)
+        self.linear_class = nn.Linear(fc_size, num_classes)
+        self.linear_bbox = nn.Linear(fc_size, num_classes * 6)
+
+    @staticmethod
+    def _bn(x, bn):
+        s = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).detach()
+        return F.relu((x - bn.running_mean) * s + bn.bias)
+
+    def forward_ndhwc(self, feature_maps, rois):
+        x = pyramid_roi_align_ndhwc(rois, feature_maps, self.pool_size)            # [R,pd,ph,pw,C]
+        x = x.permute(0, 4, 1, 2, 3).reshape(x.shape[0], -1)                        # OIDHW flatten order
+        x = self._bn(F.linear(x, self.conv1.weight.reshape(self.fc_size, -1), self.conv1.bias), self.bn1)
+        x = self._bn(F.linear(x, self.conv2.weight.reshape(self.fc_size, -1), self.conv2.bias), self.bn2)
+        logits = self.linear_class(x)
+        bbox = self.linear_bbox(x)
+        return [logits, F.softmax(logits, dim=1), bbox.view(bbox.shape[0], -1, 6)]
+
+    def forward(self, x, rois):
+        rois = rois.squeeze(0) if rois.dim() == 3 else rois
+        fms = [(f.squeeze(0) if f.dim() == 5 else f).permute(1, 2, 3, 0).contiguous() for f in x]
+        return self.forward_ndhwc(fms, rois)
+
+
+class Mask(nn.Module):
+    """model.py:787-801: RoIAlign of the RAW image -> U-Net -> softmax over classes."""
+
+    def __init__(self, channel, pool_size, num_classes, conv_channel, stage, test_flag=False, dropout_p=0.6):
+        super().__init__()
+        self.pool_size, self.test_flag = pool_size, test_flag
+        self.modified_u_net = mask_branch.Modified3DUNet(channel, num_classes, stage, conv_channel, dropout_p)
+
+    def forward_ndhwc(self, image, rois):
+        """image [D,H,W,C]; rois [R,6] -> (logits, probs) both [R,d,h,w,classes]."""
+        x = ops.roi_align(image, rois.detach(), self.pool_size)[0]
+        logits = self.modified_u_net.forward_ndhwc(x)
+        return logits, ops.softmax_channels(logits)
+
+    def forward(self, x, rois):
+        rois = rois.squeeze(0) if rois.dim() == 3 else rois
+        img = x[0].squeeze(0) if x[0].dim() == 5 else x[0]
+        logits, probs = self.forward_ndhwc(img.permute(1, 2, 3, 0).contiguous(), rois)
+        return ops.to_ncdhw(logits), ops.to_ncdhw(probs)
+
+
+# ------------------------------------------------------------------------------------------ losses
+def _as_ndhwc(t):
+    """[n,C,D,H,W] (any memory format) -> contiguous [n,D,H,W,C]; free for the views our heads return."""
+    return t.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def mask_labels(target_masks):
+    """One-hot GT masks [n,C,D,H,W] (float/double, model.py:493) -> uint8 class labels [n,D,H,W]
+    (the argmax of model.py:925).  uint8 label tensors pass through."""
+    if target_masks.dtype == torch.uint8:
+        return target_masks
+    return torch.argmax(target_masks, dim=1).to(torch.uint8)
+
+
+def compute_mrcnn_mask_loss(target_masks, target_class_ids, pred_masks):
+    """model.py:909-935 for positive-first RoI sets: CrossEntropyLoss(logits, argmax(one-hot target))."""
+    n_pos = int((target_class_ids > 0).sum()) if target_class_ids.numel() else 0
+    if n_pos == 0:
+        return torch.zeros((), device=pred_masks.device)
+    labels = mask_labels(target_masks)[:n_pos].to(pred_masks.device)
+    return ops.mask_cross_entropy(_as_ndhwc(pred_masks[:n_pos]), labels.contiguous())
+
+
+def compute_mrcnn_mask_edge_loss(target_masks, target_class_ids, pred_masks):
+    """model.py:938-981 (Sobel channels 0,1,0 -- reproduced as is) on softmax probabilities."""
+    n_pos = int((target_class_ids > 0).sum()) if target_class_ids.numel() else 0
+    if n_pos == 0:
+        return torch.zeros((), device=pred_masks.device)
+    labels = mask_labels(target_masks)[:n_pos].to(pred_masks.device)
+    return ops.edge_loss(_as_ndhwc(pred_masks[:n_pos]), labels.contiguous())
+
+
+def compute_rpn_class_loss(rpn_match, rpn_class_logits):
+    """model.py:808-832 (<= a few hundred anchors: left to torch)."""
+    m = rpn_match.squeeze(2)
+    idx = torch.nonzero(m != 0)
+    return F.cross_entropy(rpn_class_logits[idx[:, 0], idx[:, 1], :], (m == 1).long()[idx[:, 0], idx[:, 1]])
+
+
+def compute_rpn_bbox_loss(target_bbox, rpn_match, rpn_bbox):
+    """model.py:835-860."""
+    idx = torch.nonzero(rpn_match.squeeze(2) == 1)
+    pred = rpn_bbox[idx[:, 0], idx[:, 1]]
+    return F.smooth_l1_loss(pred, target_bbox[0, :pred.shape[0], :])
+
+
+def compute_mrcnn_class_loss(target_class_ids, pred_class_logits):
+    """model.py:863-878 with the binarisation of model.py:989."""
+    if target_class_ids.numel() == 0:
+        return torch.zeros((), device=pred_class_logits.device)
+    return F.cross_entropy(pred_class_logits, (target_class_ids > 0).long())
+
+
+def compute_mrcnn_bbox_loss(target_bbox, target_class_ids, pred_bbox):
+    """model.py:881-906 with the binarised ids (class column 1)."""
+    pos = torch.nonzero(target_class_ids > 0)[:, 0]
+    if pos.numel() == 0:
+        return torch.zeros((), device=pred_bbox.device)
+    return F.smooth_l1_loss(pred_bbox[pos, 1, :], target_bbox[pos, :])

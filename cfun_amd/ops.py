@@ -83,6 +83,26 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+class LaunchTimer:
+    """Times forward conv launches with HIP events on the launch stream (bench.py roofline leg).
+    ``match(p)`` selects the launches; durations are read after a synchronise with ``durations_ms()``."""
+
+    def __init__(self, match):
+        self.match = match
+        self.events = []
+
+    def durations_ms(self):
+        return [a.elapsed_time(b) for a, b in self.events]
+
+
+_TIMER = None
+
+
+def set_launch_timer(timer):
+    global _TIMER
+    _TIMER = timer
+
+
 class _Conv3d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, wp, scale, shift, res, spec):
@@ -96,8 +116,15 @@ class _Conv3d(torch.autograd.Function):
         if wp.shape != (p.kd * p.kh * p.kw, p.Ci, p.CoP):
             raise RuntimeError("packed weight %s does not match conv %s" % (tuple(wp.shape), spec))
         y = torch.empty((p.N, p.Do, p.Ho, p.Wo, p.Co), dtype=torch.float32, device=x.device)
+        timed = _TIMER is not None and x.is_cuda and _TIMER.match(p)
+        if timed:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         check(lib.cfun_conv3d_fwd(ptr(x), ptr(wp), ptr(scale), ptr(shift), ptr(res), ptr(y), C.byref(p), stream(x)),
               "conv3d_fwd")
+        if timed:
+            ev1.record()
+            _TIMER.events.append((ev0, ev1))
         ctx.spec = spec
         ctx.p = p
         ctx.res_shape = None if res is None else res.shape
@@ -163,8 +190,6 @@ def channel_sum(g2d):
     lib = _lib.load()
     g2d = _c(g2d)
     v, c = g2d.shape
-    if c % 4 != 0:
-        return g2d.sum(0)  # never on the hot path (all biased convs there have C % 4 == 0)
     out = torch.empty((c,), dtype=torch.float32, device=g2d.device)
     ws = workspace(lib.cfun_channel_sum_workspace_bytes(v, c), g2d)
     check(lib.cfun_channel_sum(ptr(g2d), ptr(out), v, c, ptr(ws), ws.numel(), stream(g2d)), "channel_sum")

@@ -1,0 +1,177 @@
+"""The caller harness of the hot path: the dataflow of ``MaskRCNN.predict(mode='training')`` +
+``compute_losses`` (model.py:1391-1514, 984-1000) with the module tree -- and therefore the state-dict keys
+``fpn.* / rpn.* / classifier.* / mask.modified_u_net.*`` -- of the reference's ``MaskRCNN``
+(model.py:1259-1304), so a reference checkpoint loads with ``strict=True``.
+
+Out of scope here: sampling of detection targets.  The head RoI sets (positives
+first, then negatives), their class ids / box deltas and the uint8 mask labels are inputs.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import backbone, model, ops, utils
+
+
+class CFUNHotPath(nn.Module):
+    def __init__(self, config, test_flag=False):
+        super().__init__()
+        self.config = config
+        d, h, w = config.image_dhw
+        if any(v % 16 for v in (d, h, w)):
+            raise Exception("Image size must be dividable by 16. Use 256, 320, 512, ... etc.")  # model.py:1263-1265
+        layers = tuple(getattr(config, "BACKBONE_LAYERS", (2, 3)))
+        net = backbone.P3D(backbone.Bottleneck, list(layers), config=config,
+                           stem_kd=getattr(config, "BACKBONE_STEM_KD", 3))
+        c1, c2, c3 = net.stages()
+        self.fpn = model.FPN(c1, c2, c3, out_channels=config.TOP_DOWN_PYRAMID_SIZE, config=config)
+        anchors = utils.generate_pyramid_anchors(config.RPN_ANCHOR_SCALES, config.RPN_ANCHOR_RATIOS,
+                                                 utils.compute_backbone_shapes(config, config.IMAGE_SHAPE),
+                                                 config.BACKBONE_STRIDES, config.RPN_ANCHOR_STRIDE)
+        self.anchors = torch.from_numpy(anchors).float()   # plain attribute, not in the state dict (model.py:1276)
+        self.rpn = model.RPN(len(config.RPN_ANCHOR_RATIOS), config.RPN_ANCHOR_STRIDE, config.TOP_DOWN_PYRAMID_SIZE,
+                             config.RPN_CONV_CHANNELS)
+        self.classifier = model.Classifier(config.TOP_DOWN_PYRAMID_SIZE, config.POOL_SIZE, config.IMAGE_SHAPE, 2,
+                                           config.FPN_CLASSIFY_FC_LAYERS_SIZE, test_flag)
+        self.mask = model.Mask(1, config.MASK_POOL_SIZE, config.NUM_CLASSES, config.UNET_MASK_BRANCH_CHANNEL,
+                               config.STAGE, test_flag, dropout_p=getattr(config, "UNET_DROPOUT", 0.6))
+        if not config.TRAIN_BN:                           # model.py:1297-1304
+            for m in self.modules():
+                if isinstance(m, nn.BatchNorm3d):
+                    for p in m.parameters():
+                        p.requires_grad = False
+        self.initialize_weights()
+
+    def initialize_weights(self):
+        """model.py:1306-1319: xavier-uniform convs, zero biases, BN 1/0, Linear N(0, 0.01)."""
+        from .layers import Conv3dParams
+        for m in self.modules():
+            if isinstance(m, Conv3dParams):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    m.bias.data.zero_()
+            elif isinstance(m, nn.BatchNorm3d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+            elif isinstance(m, nn.Linear):
+                m.weight.data.normal_(0, 0.01)
+                m.bias.data.zero_()
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self.anchors = fn(self.anchors)
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    def backbone_rpn(self, image):
+        """image [1,1,D,H,W] -> p2, p3 (NDHWC), rpn_class_logits [1,A,2], rpn_probs, rpn_bbox [1,A,6]."""
+        p2, p3 = self.fpn.forward_ndhwc(ops.to_ndhwc(image))
+        outs = [self.rpn.forward_ndhwc(p) for p in (p2, p3)]           # levels concatenated p2-then-p3
+        logits, probs, bbox = [torch.cat([o[i] for o in outs], dim=1) for i in range(3)]
+        return p2, p3, logits, probs, bbox
+
+    def proposals(self, rpn_probs, rpn_bbox, mode="training"):
+        cfg = self.config
+        count = cfg.POST_NMS_ROIS_TRAINING if mode == "training" else cfg.POST_NMS_ROIS_INFERENCE
+        return model.proposal_layer([rpn_probs, rpn_bbox], proposal_count=count, nms_threshold=cfg.RPN_NMS_THRESHOLD,
+                                    anchors=self.anchors, config=cfg)
+
+    def predict_training(self, image, p_rois, n_rois):
+        """BatchNorm stays in eval mode while the rest trains (model.py:1397-1406): folded BN needs no switch.
+        p_rois [n_pos,6] / n_rois [n_neg,6] normalised.  Returns a dict of the path's outputs."""
+        self.train()
+        p2, p3, rpn_logits, rpn_probs, rpn_bbox = self.backbone_rpn(image)
+        rpn_rois = self.proposals(rpn_probs, rpn_bbox, "training")
+        rois = torch.cat([p_rois, n_rois], dim=0)
+        cls_logits, cls_probs, cls_bbox = self.classifier.forward_ndhwc([p2[0], p3[0]], rois)
+        img = ops.to_ndhwc(image)[0]
+        mask_logits, mask_probs = self.mask.forward_ndhwc(img, p_rois)
+        return dict(rpn_class_logits=rpn_logits, rpn_probs=rpn_probs, rpn_bbox=rpn_bbox, rpn_rois=rpn_rois,
+                    mrcnn_class_logits=cls_logits, mrcnn_class=cls_probs, mrcnn_bbox=cls_bbox,
+                    mrcnn_mask_logits=mask_logits, mrcnn_mask=mask_probs, p2=p2, p3=p3)
+
+    def compute_losses(self, out, rpn_match, rpn_bbox_t, target_class_ids, target_deltas, mask_labels):
+        """The 6 losses of model.py:984-1000 (mask labels: uint8 [n_pos,d,h,w])."""
+        losses = [model.compute_rpn_class_loss(rpn_match, out["rpn_class_logits"]),
+                  model.compute_rpn_bbox_loss(rpn_bbox_t, rpn_match, out["rpn_bbox"]),
+                  model.compute_mrcnn_class_loss(target_class_ids, out["mrcnn_class_logits"]),
+                  model.compute_mrcnn_bbox_loss(target_deltas, target_class_ids, out["mrcnn_bbox"]),
+                  ops.mask_cross_entropy(out["mrcnn_mask_logits"], mask_labels)]
+        if self.config.STAGE == "finetune":
+            losses.append(ops.edge_loss(out["mrcnn_mask"], mask_labels))
+        else:
+            losses.append(torch.zeros((), device=mask_labels.device))
+        return losses
+
+    def total_loss(self, losses):
+        w = self.config.LOSS_WEIGHTS
+        keys = ("rpn_class_loss", "rpn_bbox_loss", "mrcnn_class_loss", "mrcnn_bbox_loss", "mrcnn_mask_loss",
+                "mrcnn_mask_edge_loss")
+        return sum(float(w[k]) * l for k, l in zip(keys, losses))
+
+
+# ---------------------------------------------------------------------------------------------- synthetic step
+def synthetic_inputs(config, device, seed=0):
+    """The synthetic training sample of SURVEY.md section 8(d): z-scored piecewise-constant 8-class CT,
+    GT box = the central half in (y, x), 4 positive RoIs (GT box shifted by (0,+-8,+-8) voxels, IoU 0.78)
+    and 8 negative 64^3-style corner boxes, their class ids / deltas, uint8 mask labels at MASK_SHAPE and
+    RPN targets.  Host-side bookkeeping (numpy), done once outside the timed region."""
+    rng = np.random.default_rng(seed)
+    d, h, w = config.image_dhw
+    ncls = config.NUM_CLASSES
+    y1, y2, x1, x2 = h // 4, 3 * h // 4, w // 4, 3 * w // 4
+    lab = np.zeros((d, h, w), np.uint8)
+    nfg = ncls - 1
+    for k in range(nfg):                                    # equal slabs along x inside the GT box
+        lab[:, y1:y2, x1 + (x2 - x1) * k // nfg: x1 + (x2 - x1) * (k + 1) // nfg] = k + 1
+    hu = np.where(lab == 0, -1000.0, (lab.astype(np.float32) - 1) * 50.0) + rng.normal(0, 30, lab.shape)
+    img = ((hu - hu.mean()) / hu.std()).astype(np.float32)
+    gt = np.array([0, y1, x1, d, y2, x2], np.float32)
+    norm = np.array([d, h, w, d, h, w], np.float32)
+    sh = 8.0 * min(1.0, h / 256.0)
+    p_rois = np.stack([gt + np.array([0, sy, sx, 0, sy, sx], np.float32) * sh
+                       for sy in (-1, 1) for sx in (-1, 1)]) / norm
+    cz, cy, cx = d // 2, h // 4, w // 4
+    n_rois = np.array([[z0, y0, x0, z0 + cz, y0 + cy, x0 + cx] for z0 in (0, d - cz) for y0 in (0, h - cy)
+                       for x0 in (0, w - cx)], np.float32) / norm
+    target_class_ids = np.array([1, 2, 3, 4] + [0] * 8, np.int64)
+    p_t, gt_t = torch.from_numpy(p_rois), torch.from_numpy(np.tile(gt / norm, (4, 1)))
+    deltas = utils.box_refinement(p_t, gt_t) / torch.from_numpy(config.BBOX_STD_DEV).float()
+    target_deltas = torch.cat([deltas, torch.zeros(8, 6)], dim=0)
+    # mask labels: crop with int() truncation, nearest resize to MASK_SHAPE (model.py:481-493)
+    ms = config.MASK_SHAPE
+    labels = np.zeros((4,) + tuple(ms), np.uint8)
+    for i in range(4):
+        b = p_rois[i]
+        z0, z1 = int(d * b[0]), int(d * b[3]); yy0, yy1 = int(h * b[1]), int(h * b[4]); xx0, xx1 = int(w * b[2]), int(w * b[5])
+        crop = lab[z0:z1, yy0:yy1, xx0:xx1]
+        idx = [np.clip(np.floor((np.arange(o) + 0.5) * (n / o)).astype(np.int64), 0, n - 1)
+               for o, n in zip(ms, crop.shape)]
+        labels[i] = crop[idx[0][:, None, None], idx[1][None, :, None], idx[2][None, None, :]]
+    # RPN targets: best anchors by IoU with the GT box positive, far anchors negative
+    anchors = utils.generate_pyramid_anchors(config.RPN_ANCHOR_SCALES, config.RPN_ANCHOR_RATIOS,
+                                             utils.compute_backbone_shapes(config, config.IMAGE_SHAPE),
+                                             config.BACKBONE_STRIDES, config.RPN_ANCHOR_STRIDE).astype(np.float32)
+    vol_a = np.prod(anchors[:, 3:] - anchors[:, :3], axis=1)
+    iou = utils.compute_iou(gt, anchors, np.prod(gt[3:] - gt[:3]), vol_a)
+    rpn_match = np.zeros((1, anchors.shape[0], 1), np.int32)
+    rpn_match[0, iou < 0.1, 0] = -1
+    pos = np.sort(np.argsort(-iou)[:8])
+    rpn_match[0, pos, 0] = 1
+    rpn_bbox_t = np.zeros((1, config.RPN_TRAIN_ANCHORS_PER_IMAGE, 6), np.float32)
+    rb = utils.box_refinement(torch.from_numpy(anchors[pos]), torch.from_numpy(np.tile(gt, (len(pos), 1))))
+    rpn_bbox_t[0, :len(pos)] = rb.numpy() / config.RPN_BBOX_STD_DEV
+    t = lambda a: torch.as_tensor(a).to(device)
+    return dict(image=t(img)[None, None], p_rois=t(p_rois), n_rois=t(n_rois), target_class_ids=t(target_class_ids),
+                target_deltas=target_deltas.to(device), mask_labels=t(labels), rpn_match=t(rpn_match),
+                rpn_bbox_t=t(rpn_bbox_t), labels_volume=lab)
+
+
+def training_step(net, s):
+    """One forward + 6 losses + backward of the hot path on the sample ``s`` (no optimizer step)."""
+    out = net.predict_training(s["image"], s["p_rois"], s["n_rois"])
+    losses = net.compute_losses(out, s["rpn_match"], s["rpn_bbox_t"], s["target_class_ids"], s["target_deltas"],
+                                s["mask_labels"])
+    total = net.total_loss(losses)
+    total.backward()
+    return out, losses, total

@@ -1,0 +1,274 @@
+"""Kernel-level parity cases shared by the CPU tier (HIP emulator, tests/test_kernels_emu.py) and the GPU
+tier (real libcfun_hip.so on cuda:0, tests/test_kernels_gpu.py).  Every case compares one HIP op
+(forward and gradients, called through the C ABI via cfun_amd.ops) with the plain-torch fp32 restatement
+used by the oracle, on seeded inputs.  Tolerances are relative to the reference tensor's max-abs."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from cfun_amd import ops
+from cfun_amd._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA
+from oracle import cfun_oracle as orc
+
+RTOL = 2e-5
+
+
+def rel_err(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def assert_close(a, b, what, tol=RTOL):
+    assert tuple(a.shape) == tuple(b.shape), "%s: shape %s vs %s" % (what, tuple(a.shape), tuple(b.shape))
+    e = rel_err(a, b)
+    assert e < tol, "%s: rel err %.3e >= %.1e" % (what, e, tol)
+
+
+def _gen(seed):
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return g
+
+
+def randn(gen, *shape):
+    return torch.randn(*shape, generator=gen)
+
+
+# ------------------------------------------------------------------------------------------ conv
+def ref_conv(x, w, spec, scale, shift, res):
+    xc = x.permute(0, 4, 1, 2, 3)
+    if spec.up2:
+        xc = F.interpolate(xc, scale_factor=2, mode="nearest")
+    y = F.conv3d(xc, w, None, stride=spec.stride, padding=spec.pad)
+    if scale is not None:
+        y = y * (scale.view(scale.shape[0], -1, 1, 1, 1) if spec.scale_per_n else scale.view(1, -1, 1, 1, 1))
+    if shift is not None:
+        y = y + shift.view(1, -1, 1, 1, 1)
+    if res is not None:
+        r = res.permute(0, 4, 1, 2, 3)
+        if spec.res_up2:
+            r = F.interpolate(r, scale_factor=2, mode="nearest")
+        y = y + r
+    if spec.act == ACT_RELU:
+        y = F.relu(y)
+    elif spec.act == ACT_LRELU:
+        y = F.leaky_relu(y, 0.01)
+    return y.permute(0, 2, 3, 4, 1)
+
+
+CONV_CASES = {
+    # name: (n, dhw, ci, co, k, kwargs)
+    "direct_stem_c1": (1, (5, 6, 7), 1, 20, (3, 3, 3), dict(algo=ALGO_DIRECT)),
+    "direct_p3d_stem": (1, (6, 10, 12), 1, 16, (3, 7, 7), dict(stride=2, pad=(1, 3, 3), act=ACT_RELU, scale=True, shift=True, algo=ALGO_DIRECT)),
+    "direct_lits_stem": (1, (6, 8, 8), 1, 24, (5, 7, 7), dict(stride=2, pad=(2, 3, 3), act=ACT_RELU, scale=True, shift=True, algo=ALGO_DIRECT)),
+    "direct_s2": (2, (6, 8, 8), 4, 8, (3, 3, 3), dict(stride=2, algo=ALGO_DIRECT)),
+    "direct_up2_res": (1, (3, 4, 4), 4, 8, (3, 3, 3), dict(up2=True, res=True, res_up2=True, act=ACT_LRELU, algo=ALGO_DIRECT)),
+    "direct_1x1_co3": (1, (4, 4, 5), 8, 3, (1, 1, 1), dict(algo=ALGO_DIRECT)),
+    "direct_1x1_32_8": (2, (4, 4, 4), 32, 8, (1, 1, 1), dict(algo=ALGO_DIRECT)),
+    "direct_dropout_scale": (2, (4, 4, 4), 4, 8, (3, 3, 3), dict(scale=True, per_n=True, algo=ALGO_DIRECT)),
+    "mfma_333_8_20": (1, (5, 6, 18), 8, 20, (3, 3, 3), dict(algo=ALGO_MFMA)),
+    "mfma_333_epilogue": (2, (4, 5, 7), 8, 40, (3, 3, 3), dict(act=ACT_LRELU, scale=True, per_n=True, res=True, algo=ALGO_MFMA)),
+    "mfma_333_s2": (1, (8, 8, 10), 4, 40, (3, 3, 3), dict(stride=2, algo=ALGO_MFMA)),
+    "mfma_111_res_up2": (1, (4, 6, 18), 12, 8, (1, 1, 1), dict(shift=True, res=True, res_up2=True, algo=ALGO_MFMA)),
+    "mfma_111_32_8": (2, (4, 4, 4), 32, 8, (1, 1, 1), dict(algo=ALGO_MFMA)),
+    "mfma_111_s2_bn_relu": (1, (8, 8, 8), 16, 64, (1, 1, 1), dict(stride=2, pad=(0, 0, 0), scale=True, shift=True, act=ACT_RELU, algo=ALGO_MFMA)),
+    "mfma_133_bn_relu": (1, (5, 6, 7), 16, 16, (1, 3, 3), dict(scale=True, shift=True, act=ACT_RELU, algo=ALGO_MFMA)),
+    "mfma_311_bn_relu": (1, (5, 6, 7), 16, 16, (3, 1, 1), dict(scale=True, shift=True, act=ACT_RELU, algo=ALGO_MFMA)),
+    "mfma_333_up2": (1, (3, 3, 5), 8, 20, (3, 3, 3), dict(up2=True, algo=ALGO_MFMA)),
+    "mfma_555_up2_res": (1, (3, 3, 4), 8, 8, (5, 5, 5), dict(up2=True, res=True, res_up2=True, algo=ALGO_MFMA)),
+    "mfma_333_two_cotiles": (1, (3, 4, 5), 4, 96, (3, 3, 3), dict(algo=ALGO_MFMA)),
+    "mfma_333_ci20_co20": (1, (4, 4, 16), 20, 20, (3, 3, 3), dict(algo=ALGO_MFMA)),
+}
+# bigger shapes: many workgroups, several chunks per wgrad block, channel counts of the real nets (GPU tier)
+CONV_CASES_LARGE = {
+    "mfma_333_40_40_32cube": (2, (32, 32, 32), 40, 40, (3, 3, 3), dict(algo=ALGO_MFMA, act=ACT_LRELU, res=True)),
+    "mfma_333_128_256_fpn": (1, (8, 16, 16), 128, 256, (3, 3, 3), dict(algo=ALGO_MFMA, shift=True, act=ACT_RELU)),
+    "mfma_333_320_160_up2": (2, (6, 6, 6), 320, 160, (3, 3, 3), dict(algo=ALGO_MFMA, up2=True)),
+    "mfma_333_s2_80_160": (2, (24, 24, 24), 80, 160, (3, 3, 3), dict(algo=ALGO_MFMA, stride=2)),
+    "mfma_111_160_80": (2, (24, 24, 24), 160, 80, (1, 1, 1), dict(algo=ALGO_MFMA)),
+    "mfma_555_8_8_up2": (1, (24, 24, 24), 8, 8, (5, 5, 5), dict(algo=ALGO_MFMA, up2=True, res=True, res_up2=True)),
+    "direct_stem_96": (2, (48, 48, 48), 1, 20, (3, 3, 3), dict(algo=ALGO_DIRECT)),
+    "auto_333_20_20_48cube": (2, (48, 48, 48), 20, 20, (3, 3, 3), dict(algo=ALGO_AUTO, scale=True, per_n=True)),
+}
+
+
+def check_conv(device, n, dhw, ci, co, k, stride=1, pad=None, up2=False, act=ACT_NONE, scale=False, shift=False,
+               res=False, res_up2=False, per_n=False, algo=ALGO_AUTO, seed=0, tol=RTOL):
+    gen = _gen(seed)
+    pad = pad if pad is not None else tuple(kk // 2 for kk in k)
+    spec = ops.ConvSpec(k=tuple(k), co=co, stride=stride, pad=tuple(pad), up2=up2, act=act, res_up2=res_up2,
+                        scale_per_n=per_n, algo=algo)
+    x = randn(gen, n, *dhw, ci)
+    w = randn(gen, co, ci, *k) / float(ci * k[0] * k[1] * k[2]) ** 0.5
+    sc = ((torch.rand(n, co, generator=gen) + 0.5) if per_n else (torch.rand(co, generator=gen) + 0.5)) if scale else None
+    sf = randn(gen, co) if shift else None
+    out_shape = ref_conv(x, w, spec, sc, sf, None).shape
+    rs = None
+    if res:
+        shp = list(out_shape)
+        if res_up2:
+            shp = [shp[0], shp[1] // 2, shp[2] // 2, shp[3] // 2, shp[4]]
+        rs = randn(gen, *shp)
+    gy = randn(gen, *out_shape)
+
+    def leafs(dev):
+        return [None if t is None else t.to(dev).requires_grad_(True) for t in (x, w, sf, rs)]
+
+    xr, wr, sfr, rsr = leafs("cpu")
+    yr = ref_conv(xr, wr, spec, sc, sfr, rsr)
+    yr.backward(gy)
+    xd, wd, sfd, rsd = leafs(device)
+    y = ops.conv3d(xd, ops.pack_weight(wd), spec, None if sc is None else sc.to(device), sfd, rsd)
+    y.backward(gy.to(device))
+    assert_close(y, yr, "y", tol)
+    assert_close(xd.grad, xr.grad, "dx", tol)
+    assert_close(wd.grad, wr.grad, "dw", tol)
+    if shift:
+        assert_close(sfd.grad, sfr.grad, "dshift", tol)
+    if res:
+        assert_close(rsd.grad, rsr.grad, "dres", tol)
+
+
+# ------------------------------------------------------------------------------------------ norm / act / pool
+NORM_CASES = {"c3_v60": (2, (3, 4, 5), 3), "c2_v512": (1, (8, 8, 8), 2), "c20_v343": (2, (7, 7, 7), 20), "c32_v512": (2, (8, 8, 8), 32), "c16_v4096": (2, (16, 16, 16), 16),
+              "c320_v8": (1, (2, 2, 2), 320), "c4_v30": (3, (2, 3, 5), 4), "c160_v216": (4, (6, 6, 6), 160)}
+
+
+def check_instnorm_lrelu(device, n, dhw, c, seed=1):
+    gen = _gen(seed)
+    x = randn(gen, n, *dhw, c) * 2.0 + randn(gen, 1, 1, 1, 1, c)
+    gy = randn(gen, n, *dhw, c)
+    xr = x.clone().requires_grad_(True)
+    yr = F.leaky_relu(F.instance_norm(xr.permute(0, 4, 1, 2, 3), eps=1e-5), 0.01).permute(0, 2, 3, 4, 1)
+    yr.backward(gy)
+    xd = x.to(device).requires_grad_(True)
+    y = ops.instnorm_lrelu(xd)
+    y.backward(gy.to(device))
+    assert_close(y, yr, "y")
+    assert_close(xd.grad, xr.grad, "dx", 1e-4)
+
+
+def check_elementwise(device, seed=2):
+    gen = _gen(seed)
+    for shape in ((2, 3, 4, 5, 8), (1, 3, 3, 3, 3), (1, 2, 2, 2, 1)):
+        x, gy = randn(gen, *shape), randn(gen, *shape)
+        xr = x.clone().requires_grad_(True)
+        F.leaky_relu(xr, 0.01).backward(gy)
+        xd = x.to(device).requires_grad_(True)
+        y = ops.lrelu(xd)
+        y.backward(gy.to(device))
+        assert_close(y, F.leaky_relu(x, 0.01), "lrelu")
+        assert_close(xd.grad, xr.grad, "lrelu dx")
+        b = randn(gen, *shape)
+        assert_close(ops.add(x.to(device), b.to(device)), x + b, "add")
+    g2 = randn(gen, 1000, 16)
+    assert_close(ops.channel_sum(g2.to(device)), g2.sum(0), "channel_sum")
+
+
+def check_maxpool(device, seed=3):
+    gen = _gen(seed)
+    x = F.relu(randn(gen, 2, 4, 6, 8, 16))   # ReLU output: many exact ties at 0 like the real stem
+    gy = randn(gen, 2, 2, 3, 4, 16)
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool3d(xr.permute(0, 4, 1, 2, 3), 2, 2).permute(0, 2, 3, 4, 1)
+    yr.backward(gy)
+    xd = x.to(device).requires_grad_(True)
+    y = ops.maxpool2(xd)
+    y.backward(gy.to(device))
+    assert_close(y, yr, "y", 1e-7)
+    # gradients routed to tied zeros may pick a different zero; compare where the input is positive
+    m = (x > 0)
+    assert_close(xd.grad.cpu() * m, xr.grad * m, "dx", 1e-7)
+
+
+# ------------------------------------------------------------------------------------------ RoIAlign / NMS
+def py_bounds(boxes, dhw):
+    """oracle roi_bounds + python slice clamping (what fm[:, lo:hi] actually reads)."""
+    ib = orc.roi_bounds(boxes, dhw).numpy()
+    out = np.zeros_like(ib)
+    for r in range(ib.shape[0]):
+        for a in range(3):
+            lo, hi, _ = slice(int(ib[r, a]), int(ib[r, 3 + a])).indices(int(dhw[a]))
+            out[r, a], out[r, 3 + a] = lo, max(hi, lo)
+    return out
+
+
+def check_roi_align(device, fm, boxes, pool, gy=None, expect=None, expect_grad=None):
+    """fm [C,D,H,W] numpy, boxes [R,6]; compares against the oracle (and golden arrays when given)."""
+    fm_t = torch.from_numpy(fm)
+    bx = torch.from_numpy(boxes)
+    fr = fm_t.clone().requires_grad_(True)
+    ref = orc.roi_align(fr, pool, bx)
+    fd = fm_t.permute(1, 2, 3, 0).contiguous().to(device).requires_grad_(True)
+    out, bounds = ops.roi_align(fd, bx.to(device), pool)
+    np.testing.assert_array_equal(bounds.cpu().numpy()[:boxes.shape[0]], py_bounds(bx, fm.shape[1:]))  # bit-exact
+    got = out.permute(0, 4, 1, 2, 3)
+    assert float((got.detach().cpu() - ref.detach()).abs().max()) < 2e-6
+    if expect is not None:
+        assert float((got.detach().cpu() - torch.from_numpy(expect)).abs().max()) < 2e-6
+    if gy is not None:
+        g = torch.from_numpy(gy)
+        (ref * g).sum().backward()
+        (got * g.to(device)).sum().backward()
+        gd = fd.grad.permute(3, 0, 1, 2).cpu()
+        assert float((gd - fr.grad).abs().max()) < 1e-5
+        if expect_grad is not None:
+            assert float((gd - torch.from_numpy(expect_grad)).abs().max()) < 1e-5
+
+
+def check_nms(device, boxes, scores, thr, max_num, expect):
+    keep, count = ops.nms3d(torch.from_numpy(boxes).to(device), torch.from_numpy(scores).to(device), thr, max_num)
+    k = int(count.item())
+    got = keep[:k].cpu().numpy()
+    assert got.dtype == np.int32
+    np.testing.assert_array_equal(got, expect)   # bit-exact keep list, pick order
+
+
+# ------------------------------------------------------------------------------------------ losses
+def check_mask_losses(device, logits_ncdhw, labels, expect=None):
+    """logits [n,C,D,H,W] numpy, labels uint8 [n,D,H,W]."""
+    lg = torch.from_numpy(logits_ncdhw)
+    lab = torch.from_numpy(labels.astype(np.int64))
+    c = lg.shape[1]
+    onehot = torch.stack([(lab == k) for k in range(c)], dim=1).double()
+    lr = lg.clone().requires_grad_(True)
+    ce_r = orc.mask_ce_loss(onehot, lr)
+    ce_r.backward()
+    g_ce_r = lr.grad.clone()
+    lr.grad = None
+    el_r = orc.edge_loss(onehot, torch.softmax(lr, dim=1))[0]
+    el_r.backward()
+    g_el_r = lr.grad.clone()
+
+    ld = lg.permute(0, 2, 3, 4, 1).contiguous().to(device).requires_grad_(True)
+    labd = torch.from_numpy(labels).to(device)
+    ce = ops.mask_cross_entropy(ld, labd)
+    ce.backward()
+    g_ce = ld.grad.clone()
+    ld.grad = None
+    probs = ops.softmax_channels(ld)
+    assert_close(probs, torch.softmax(lg, dim=1).permute(0, 2, 3, 4, 1), "softmax", 1e-5)
+    el = ops.edge_loss(probs, labd)
+    el.backward()
+    g_el = ld.grad.clone()
+    assert abs(float(ce) - float(ce_r)) < 1e-5 * abs(float(ce_r))
+    assert abs(float(el) - float(el_r)) < 1e-4 * abs(float(el_r))
+    assert_close(g_ce.permute(0, 4, 1, 2, 3), g_ce_r, "dCE/dlogits", 1e-4)
+    assert_close(g_el.permute(0, 4, 1, 2, 3), g_el_r, "dEdge/dlogits", 1e-3)
+    if expect is not None:
+        assert abs(float(ce) - float(expect["ce"])) < 1e-5 * abs(float(expect["ce"]))
+        assert abs(float(el) - float(expect["edge"].reshape(-1)[0])) < 1e-4 * abs(float(expect["edge"].reshape(-1)[0]))
+        assert_close(g_ce.permute(0, 4, 1, 2, 3), torch.from_numpy(expect["ce_grad"]), "golden dCE", 1e-4)
+        assert_close(g_el.permute(0, 4, 1, 2, 3), torch.from_numpy(expect["edge_grad_logits"]), "golden dEdge", 1e-3)
+
+
+def check_halo(device, seed=5):
+    gen = _gen(seed)
+    x = randn(gen, 2, 6, 3, 4, 8)
+    xd = x.to(device)
+    buf = ops.halo_pack(xd, 4, 2)
+    assert_close(buf, x[:, 4:6], "halo_pack", 1e-9)
+    dst = torch.zeros(2, 8, 3, 4, 8, device=device)
+    ops.halo_unpack(buf, dst, 0)
+    assert_close(dst[:, 0:2], x[:, 4:6], "halo_unpack", 1e-9)
+    assert float(dst[:, 2:].abs().max()) == 0.0

@@ -1,0 +1,252 @@
+"""Module-level parity cases shared by the CPU (emulator) and GPU tiers: the drop-in modules of cfun_amd
+against the golden vectors generated from the reference import and against the oracle."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from conftest import golden_state_dict, load_golden
+from oracle import cfun_oracle as orc
+from oracle import formula
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def rel_max(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / (np.abs(b).max() + 1e-30))
+
+
+# Gradients that pass through InstanceNorm+LeakyReLU are only piecewise smooth: an fp32-rounding-level change
+# of a normalised value that sits at |x| < 1e-6 flips one LeakyReLU mask bit, which moves single gradient
+# entries by O(1) and parameter gradients by ~1e-2 (measured: the reference itself, fp32 vs fp64, flips one
+# mask in this very golden and moves conv_norm_lrelu_l4.0's gradient by 6e-3).  U-Net gradients are
+# therefore compared in relative L2 norm; forward values and every per-op gradient test stay tight.
+UNET_GRAD_L2_TOL = 6e-2
+
+
+def check_unet_golden(device, name, check_grads=True, logits_atol=1e-3):
+    from cfun_amd.mask_branch import Modified3DUNet
+    g = load_golden(name)
+    sd = golden_state_dict(g)
+    net = Modified3DUNet(1, int(g["ncls"]), str(g["stage"]), int(g["b"])).to(device)
+    net.load_state_dict(sd, strict=True)
+    train = "drop0" in g
+    net.train(train)
+    if train:
+        net.dropout_masks = [torch.from_numpy(g["drop%d" % i]) for i in range(5)]
+    x = torch.from_numpy(g["x"]).to(device).requires_grad_(True)
+    y = net(x)
+    yn = y.detach().cpu().numpy()
+    if "y" in g:
+        assert yn.shape == g["y"].shape
+        assert np.abs(yn - g["y"]).max() < logits_atol          # U-Net logits atol 1e-3
+    else:
+        assert np.abs(yn[:, :, ::2, ::2, ::2] - g["y_sub"]).max() < logits_atol
+        np.testing.assert_allclose(np.abs(yn).astype(np.float64).sum(), g["y_sum"][1], rtol=1e-5)
+    if train and check_grads:
+        gy = torch.from_numpy(formula.uniform(name + ".gy", tuple(y.shape), -1, 1)).to(device)
+        (y * gy).sum().backward()
+        assert rel_l2(x.grad.cpu().numpy(), g["x_grad"]) < UNET_GRAD_L2_TOL
+        params = dict(net.named_parameters())
+        n = 0
+        for k in g:
+            if k.startswith("grad:"):
+                n += 1
+                e = rel_l2(params[k[5:]].grad.cpu().numpy(), g[k])
+                assert e < UNET_GRAD_L2_TOL, "%s: rel L2 %.3e" % (k, e)
+        assert n >= 10
+        # downstream of the last norm nothing is discontinuous: tight
+        for k in ("conv3d_l4.weight", "ds2_1x1_conv3d.weight", "ds3_1x1_conv3d.weight"):
+            if "grad:" + k in g:
+                assert rel_max(params[k].grad.cpu().numpy(), g["grad:" + k]) < 1e-4, k
+
+
+def build_fpn_rpn(device):
+    from cfun_amd import backbone, config, model
+    g = load_golden("fpn_rpn")
+    cfg = config.heart_config("beginning", 32, 32, 16)
+    net = backbone.P3D19(config=cfg)
+    c1, c2, c3 = net.stages()
+    holder = nn.Module()
+    holder.fpn = model.FPN(c1, c2, c3, cfg.TOP_DOWN_PYRAMID_SIZE, cfg)
+    holder.rpn = model.RPN(1, 1, cfg.TOP_DOWN_PYRAMID_SIZE, cfg.RPN_CONV_CHANNELS)
+    holder.load_state_dict(golden_state_dict(g), strict=True)
+    return holder.to(device), g
+
+
+def check_fpn_rpn_golden(device, check_grads=True):
+    holder, g = build_fpn_rpn(device)
+    x = torch.from_numpy(g["x"]).to(device).requires_grad_(True)
+    h = x
+    for name in ("c1", "c2", "c3"):
+        h = getattr(holder.fpn, name.upper())(h)
+        np.testing.assert_allclose(h.detach().cpu().numpy(), g[name], rtol=1e-5, atol=1e-5, err_msg=name)
+    p2, p3 = holder.fpn(x)
+    outs = dict(p2=p2, p3=p3)
+    for tag, p in (("l2", p2), ("l3", p3)):
+        lg, pr, bb = holder.rpn(p)
+        outs["rpn_logits_" + tag], outs["rpn_probs_" + tag], outs["rpn_bbox_" + tag] = lg, pr, bb
+    for k, v in outs.items():   # backbone/FPN/RPN atol 1e-5 rtol 1e-5 (+ headroom 2x)
+        np.testing.assert_allclose(v.detach().cpu().numpy(), g[k], rtol=2e-5, atol=2e-5, err_msg=k)
+    if not check_grads:
+        return
+    loss = 0
+    for k in ("p2", "p3", "rpn_logits_l2", "rpn_bbox_l2", "rpn_logits_l3", "rpn_bbox_l3"):
+        gk = torch.from_numpy(formula.uniform("fpn.g." + k, tuple(outs[k].shape), -1, 1)).to(device)
+        loss = loss + (outs[k] * gk).sum()
+    loss.backward()
+    assert rel_max(x.grad.cpu().numpy(), g["x_grad"]) < 1e-4
+    params = dict(holder.named_parameters())
+    n = 0
+    for k in g:
+        if k.startswith("grad:"):
+            got = params[k[5:]].grad.cpu().numpy()
+        elif k.startswith("grad4:"):
+            got = params[k[6:]].grad.cpu().numpy()[::4, ::4]
+        else:
+            continue
+        n += 1
+        assert rel_max(got, g[k]) < 1e-4, k
+    assert n >= 10
+
+
+def check_proposal_layer_golden(device):
+    from cfun_amd import config, model
+    g = load_golden("proposal")
+    d, h, w = [int(v) for v in g["image_dhw"]]
+    cfg = config.heart_config("beginning", h, w, d)
+    for tag in ("train", "infer"):
+        rois = model.proposal_layer([torch.from_numpy(g["probs"]).to(device), torch.from_numpy(g["bbox"]).to(device)],
+                                    proposal_count=int(g["count_" + tag]), nms_threshold=0.7,
+                                    anchors=torch.from_numpy(g["anchors"]).to(device), config=cfg)
+        ref = g["rois_" + tag]
+        assert tuple(rois.shape) == ref.shape        # same number of proposals = same NMS decisions
+        np.testing.assert_allclose(rois.cpu().numpy(), ref, rtol=0, atol=2e-6)
+
+
+def check_anchors_golden():
+    from cfun_amd import utils
+    g = load_golden("anchors")
+    for tag in ("cfg0", "odd"):
+        a = utils.generate_pyramid_anchors((64, 128), [1], g[tag + "_shapes"], (8, 16), 1)
+        np.testing.assert_array_equal(a, g[tag + "_anchors"])
+
+
+def check_pyramid_roi_align_golden(device):
+    from cfun_amd import model
+    g = load_golden("roi_align")
+    lv = model.roi_levels(torch.from_numpy(g["pboxes"]).to(device))
+    np.testing.assert_array_equal(lv.cpu().numpy(), g["plevels"])
+    pooled = model.pyramid_roi_align([torch.from_numpy(g["pboxes"]).to(device)[None],
+                                      torch.from_numpy(g["p2"]).to(device)[None],
+                                      torch.from_numpy(g["p3"]).to(device)[None]], [3, 3, 3])
+    np.testing.assert_allclose(pooled.cpu().numpy(), g["pooled"], rtol=0, atol=2e-6)
+    out = model.RoI_Align(torch.from_numpy(g["fm"]).to(device), [int(v) for v in g["pool"]],
+                          torch.from_numpy(g["boxes"]).to(device))
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=0, atol=2e-6)
+
+
+def check_classifier_golden(device):
+    from cfun_amd import model
+    g = load_golden("classifier")
+    net = model.Classifier(8, [int(v) for v in g["pool"]], None, 2, 16).to(device)
+    net.load_state_dict(golden_state_dict(g), strict=True)
+    net.eval()
+    p2 = torch.from_numpy(g["p2"]).to(device).requires_grad_(True)
+    p3 = torch.from_numpy(g["p3"]).to(device).requires_grad_(True)
+    lg, pr, bb = net([p2, p3], torch.from_numpy(g["rois"]).to(device))
+    np.testing.assert_allclose(lg.detach().cpu().numpy(), g["logits"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(pr.detach().cpu().numpy(), g["probs"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(bb.detach().cpu().numpy(), g["bbox"], rtol=1e-4, atol=1e-5)
+    ((lg * torch.from_numpy(formula.uniform("cls.g1", tuple(lg.shape), -1, 1)).to(device)).sum()
+     + (bb * torch.from_numpy(formula.uniform("cls.g2", tuple(bb.shape), -1, 1)).to(device)).sum()).backward()
+    assert rel_max(p2.grad.cpu().numpy(), g["p2_grad"]) < 1e-4
+    assert rel_max(p3.grad.cpu().numpy(), g["p3_grad"]) < 1e-4
+    assert rel_max(net.conv1.weight.grad.cpu().numpy(), g["grad:conv1.weight"]) < 1e-4
+
+
+def check_nms_dropin(device):
+    from cfun_amd import utils
+    g = load_golden("nms")
+    for tag in ("a", "b", "e", "tie"):
+        thr, mx = g[tag + "_cfg"]
+        keep = utils.non_max_suppression(g[tag + "_boxes"], g[tag + "_scores"], float(thr), int(mx))
+        assert keep.dtype == np.int32
+        np.testing.assert_array_equal(keep, g[tag + "_keep"])
+
+
+def tiny_config(stage="finetune"):
+    """A shrunken HeartConfig for step-level tests: 32x32x16 volume, 32^3 mask crops, b = 4."""
+    from cfun_amd import config
+    cls = type("TinyHeart", (config.HeartConfig,), dict(
+        IMAGE_MAX_DIM=32, IMAGE_MIN_DIM=16, MASK_POOL_SIZE=[32, 32, 32], POOL_SIZE=[4, 4, 4],
+        UNET_MASK_BRANCH_CHANNEL=4, TOP_DOWN_PYRAMID_SIZE=16, RPN_CONV_CHANNELS=16, FPN_CLASSIFY_FC_LAYERS_SIZE=16,
+        RPN_ANCHOR_SCALES=(16, 32), PRE_NMS_LIMIT=64, POST_NMS_ROIS_TRAINING=16))
+    cfg = cls(stage)
+    side = 64 if stage == "finetune" else 32
+    cfg.MASK_SHAPE = cfg.MINI_MASK_SHAPE = (side, side, side)
+    return cfg
+
+
+def check_training_step_vs_oracle(device, cfg, seed=0, n_pos=None):
+    """One training step of cfun_amd.step (forward, 6 losses, backward) against oracle.training_step on the
+    same weights, inputs and dropout masks."""
+    from cfun_amd import step
+    torch.manual_seed(seed)
+    net = step.CFUNHotPath(cfg).to(device)
+    s = step.synthetic_inputs(cfg, device, seed)
+    if n_pos is not None:   # shrink the RoI sets (CPU tier)
+        s["p_rois"], s["mask_labels"] = s["p_rois"][:n_pos], s["mask_labels"][:n_pos]
+        s["n_rois"] = s["n_rois"][:2 * n_pos]
+        keep = list(range(n_pos)) + list(range(4, 4 + 2 * n_pos))
+        s["target_class_ids"], s["target_deltas"] = s["target_class_ids"][keep], s["target_deltas"][keep]
+    b = cfg.UNET_MASK_BRANCH_CHANNEL
+    gen = torch.Generator().manual_seed(seed + 1)
+    npos = s["p_rois"].shape[0]
+    masks = [torch.empty(npos, c).bernoulli_(0.4, generator=gen) / 0.4 for c in (b, 2 * b, 4 * b, 8 * b, 16 * b)]
+    net.mask.modified_u_net.dropout_masks = masks
+    out, losses, total = step.training_step(net, s)
+
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype == torch.float32 and "running" not in k)
+          for k, v in net.state_dict().items()}
+    cpu = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in s.items()}
+    ncls = cfg.NUM_CLASSES
+    onehot = torch.stack([(cpu["mask_labels"] == k) for k in range(ncls)], dim=1).double()
+    ref = orc.training_step(sd, cpu["image"], net.anchors.cpu(), cpu["rpn_match"], cpu["rpn_bbox_t"], cpu["p_rois"],
+                            cpu["n_rois"], cpu["target_class_ids"], cpu["target_deltas"], onehot, cfg.STAGE,
+                            cfg.POOL_SIZE, cfg.MASK_POOL_SIZE, dropout_masks=masks,
+                            proposal_count=cfg.POST_NMS_ROIS_TRAINING, nms_threshold=cfg.RPN_NMS_THRESHOLD,
+                            pre_nms_limit=cfg.PRE_NMS_LIMIT)
+    ref["total"].backward()
+    # forward parity
+    np.testing.assert_allclose(out["rpn_class_logits"].detach().cpu().numpy(), ref["rpn_logits"].detach().numpy(),
+                               rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(out["rpn_bbox"].detach().cpu().numpy(), ref["rpn_bbox"].detach().numpy(),
+                               rtol=1e-4, atol=2e-5)
+    assert out["rpn_rois"].shape[1] == ref["rpn_rois"].shape[0]         # identical NMS keep count
+    np.testing.assert_allclose(out["rpn_rois"][0].detach().cpu().numpy(), ref["rpn_rois"].detach().numpy(),
+                               rtol=0, atol=1e-5)
+    np.testing.assert_allclose(out["mrcnn_class_logits"].detach().cpu().numpy(), ref["cls_logits"].detach().numpy(),
+                               rtol=1e-3, atol=1e-5)
+    ml = out["mrcnn_mask_logits"].detach().cpu().permute(0, 4, 1, 2, 3).numpy()
+    assert np.abs(ml - ref["mask_logits"].detach().numpy()).max() < 1e-3
+    mp = out["mrcnn_mask"].detach().cpu().permute(0, 4, 1, 2, 3).numpy()
+    assert np.abs(mp - ref["mask_probs"].detach().numpy()).max() < 1e-4
+    assert float((mp.argmax(1) != ref["mask_probs"].detach().numpy().argmax(1)).mean()) <= 1e-4
+    for i, (a, r) in enumerate(zip(losses, ref["losses"])):
+        assert abs(float(a) - float(r)) <= 1e-4 * max(abs(float(r)), 1e-3), "loss %d: %g vs %g" % (i, float(a), float(r))
+    # gradient parity (relative L2 over each tensor; see UNET_GRAD_L2_TOL)
+    worst = 0.0
+    for k, p in net.named_parameters():
+        if not p.requires_grad:
+            continue
+        if p.grad is None:
+            assert sd[k].grad is None or float(sd[k].grad.abs().max()) == 0.0, k
+            continue
+        e = rel_l2(p.grad.cpu().numpy(), sd[k].grad.numpy())
+        worst = max(worst, e)
+        assert e < UNET_GRAD_L2_TOL, "%s: rel L2 %.3e" % (k, e)
+    return dict(losses=[float(l) for l in losses], worst_grad_l2=worst)

@@ -1,0 +1,74 @@
+"""CPU tier: the C-ABI library builds for gfx950, loads, and exports every symbol include/cfun_hip.h declares
+(no kernel is launched here); the C restatement of NMS agrees with the golden vectors."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "cfun_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(cfun_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_matches_binding():
+    from cfun_amd import _lib
+    assert header_symbols() == sorted(_lib.EXPORTS)
+
+
+def test_library_exports_every_symbol(monkeypatch):
+    monkeypatch.delenv("CFUN_LIB_PATH", raising=False)
+    from cfun_amd import _lib
+    if not os.path.exists(_lib.DEFAULT_LIB):
+        import __graft_entry__ as ge
+        ge.build()
+    lib = ctypes.CDLL(_lib.DEFAULT_LIB)
+    for name in header_symbols():
+        assert hasattr(lib, name), name
+    lib.cfun_version.restype = ctypes.c_int
+    assert lib.cfun_version() == 100
+    lib.cfun_error_string.restype = ctypes.c_char_p
+    assert b"workspace" in lib.cfun_error_string(-2)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from cfun_amd import _lib
+    monkeypatch.setenv("CFUN_LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_cpu_tensor_rejected_by_real_library(monkeypatch):
+    import torch
+    from cfun_amd import _lib, ops
+    monkeypatch.delenv("CFUN_LIB_PATH", raising=False)
+    if not os.path.exists(_lib.DEFAULT_LIB):
+        pytest.skip("library not built")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.lrelu(torch.zeros(4))
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "f", "tie"])
+def test_c_restatement_of_nms(tag):
+    so = os.path.join(ROOT, "oracle", "_build", "libnms_ref.so")
+    if not os.path.exists(so):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    lib = ctypes.CDLL(so)
+    g = load_golden("nms")
+    boxes = np.ascontiguousarray(g[tag + "_boxes"], np.float32)
+    scores = g[tag + "_scores"]
+    thr, mx = g[tag + "_cfg"]
+    n = boxes.shape[0]
+    order = np.lexsort((-np.arange(n), -scores)).astype(np.int32)   # score desc, ties: higher index first
+    keep = np.zeros(max(n, 1), np.int32)
+    fp, ip = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)
+    lib.cfun_ref_nms.restype = ctypes.c_int32
+    cnt = lib.cfun_ref_nms(boxes.ctypes.data_as(fp), order.ctypes.data_as(ip), n, ctypes.c_float(thr), int(mx),
+                           keep.ctypes.data_as(ip))
+    np.testing.assert_array_equal(keep[:cnt], g[tag + "_keep"])

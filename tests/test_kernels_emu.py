@@ -1,0 +1,56 @@
+"""CPU tier: every HIP kernel source, compiled for the host against tests/emu (fiber-based functional HIP
+emulator, incl. the v_mfma_f32_16x16x4_f32 lane layout), checked through the C ABI against plain torch /
+the oracle / the golden vectors at small sizes.  The GPU tier (test_kernels_gpu.py) runs the same cases on
+the real library."""
+import numpy as np
+import pytest
+
+import kernel_cases as kc
+from conftest import load_golden
+
+
+@pytest.mark.parametrize("name", sorted(kc.CONV_CASES))
+def test_conv(emu, name):
+    n, dhw, ci, co, k, kw = kc.CONV_CASES[name]
+    kc.check_conv(emu, n, dhw, ci, co, k, **kw)
+
+
+@pytest.mark.parametrize("name", sorted(kc.NORM_CASES))
+def test_instnorm_lrelu(emu, name):
+    kc.check_instnorm_lrelu(emu, *kc.NORM_CASES[name])
+
+
+def test_elementwise(emu):
+    kc.check_elementwise(emu)
+
+
+def test_maxpool(emu):
+    kc.check_maxpool(emu)
+
+
+def test_halo(emu):
+    kc.check_halo(emu)
+
+
+def test_roi_align_golden(emu):
+    g = load_golden("roi_align")
+    kc.check_roi_align(emu, g["fm"], g["boxes"], [int(v) for v in g["pool"]], g["gy"], g["out"], g["fm_grad"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f", "tie"])
+def test_nms_golden(emu, tag):
+    g = load_golden("nms")
+    thr, mx = g[tag + "_cfg"]
+    kc.check_nms(emu, g[tag + "_boxes"], g[tag + "_scores"], float(thr), int(mx), g[tag + "_keep"])
+
+
+def test_mask_losses_golden(emu):
+    g = load_golden("losses")
+    kc.check_mask_losses(emu, g["logits"], g["labels"], g)
+
+
+def test_mask_losses_3class(emu):
+    rng = np.random.default_rng(0)
+    logits = rng.normal(size=(1, 3, 6, 7, 8)).astype(np.float32)
+    labels = rng.integers(0, 3, size=(1, 6, 7, 8)).astype(np.uint8)
+    kc.check_mask_losses(emu, logits, labels)

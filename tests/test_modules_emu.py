@@ -1,0 +1,59 @@
+"""CPU tier: the drop-in modules (cfun_amd.backbone / mask_branch / model / utils / step) executed on the
+HIP emulator build of the kernel sources, against the golden vectors of the reference and the oracle."""
+import os
+
+import pytest
+
+import module_cases as mc
+
+
+@pytest.fixture()
+def emu_direct(emu, monkeypatch):
+    # the fiber emulator pays ~1 us per MFMA rendezvous per lane; module-sized graphs use the direct kernels
+    # (the MFMA kernels are covered case by case in test_kernels_emu.py and by test_fpn_rpn_golden below)
+    monkeypatch.setenv("CFUN_CONV_ALGO", "direct")
+    return emu
+
+
+@pytest.mark.parametrize("name", ["unet_beginning_eval", "unet_beginning_train", "unet_lits_eval"])
+def test_unet_golden(emu_direct, name):
+    mc.check_unet_golden(emu_direct, name)
+
+
+def test_unet_finetune_golden(emu_direct):
+    mc.check_unet_golden(emu_direct, "unet_finetune_train")
+
+
+def test_fpn_rpn_golden_mfma(emu):
+    """P3D19 + FPN + RPN forward on the MFMA kernels (algo auto) against the reference's outputs."""
+    mc.check_fpn_rpn_golden(emu, check_grads=False)
+
+
+def test_fpn_rpn_golden_grads(emu_direct):
+    mc.check_fpn_rpn_golden(emu_direct, check_grads=True)
+
+
+def test_proposal_layer_golden(emu):
+    mc.check_proposal_layer_golden(emu)
+
+
+def test_anchors_golden():
+    mc.check_anchors_golden()
+
+
+def test_pyramid_roi_align_golden(emu):
+    mc.check_pyramid_roi_align_golden(emu)
+
+
+def test_classifier_golden(emu):
+    mc.check_classifier_golden(emu)
+
+
+def test_nms_dropin(emu):
+    mc.check_nms_dropin(emu)
+
+
+@pytest.mark.parametrize("stage", ["beginning", "finetune"])
+def test_training_step_vs_oracle(emu_direct, stage):
+    r = mc.check_training_step_vs_oracle(emu_direct, mc.tiny_config(stage), n_pos=1)
+    assert all(l == l for l in r["losses"])   # finite
