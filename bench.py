@@ -139,7 +139,7 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    lv = [float(l) for l in losses]
+    lv = [float(l.detach()) for l in losses]
     assert all(v == v and abs(v) != float("inf") for v in lv), "non-finite loss: %s" % lv
 
     if rank == 0:
@@ -168,7 +168,7 @@ def main():
                          "flops_per_launch": flops, "avg_launch_ms": t_k * 1e3, "launches_timed": len(durs)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(cfg, threads=os.cpu_count() or 1)
+            result["cpu_baseline"] = cpu_baseline(cfg, threads=min(os.cpu_count() or 1, 32))
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()

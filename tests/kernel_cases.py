@@ -112,7 +112,7 @@ def check_conv(device, n, dhw, ci, co, k, stride=1, pad=None, up2=False, act=ACT
     gy = randn(gen, *out_shape)
 
     def leafs(dev):
-        return [None if t is None else t.to(dev).requires_grad_(True) for t in (x, w, sf, rs)]
+        return [None if t is None else t.detach().clone().to(dev).requires_grad_(True) for t in (x, w, sf, rs)]
 
     xr, wr, sfr, rsr = leafs("cpu")
     yr = ref_conv(xr, wr, spec, sc, sfr, rsr)
@@ -141,7 +141,7 @@ def check_instnorm_lrelu(device, n, dhw, c, seed=1):
     xr = x.clone().requires_grad_(True)
     yr = F.leaky_relu(F.instance_norm(xr.permute(0, 4, 1, 2, 3), eps=1e-5), 0.01).permute(0, 2, 3, 4, 1)
     yr.backward(gy)
-    xd = x.to(device).requires_grad_(True)
+    xd = x.clone().to(device).requires_grad_(True)
     y = ops.instnorm_lrelu(xd)
     y.backward(gy.to(device))
     assert_close(y, yr, "y")
@@ -154,7 +154,7 @@ def check_elementwise(device, seed=2):
         x, gy = randn(gen, *shape), randn(gen, *shape)
         xr = x.clone().requires_grad_(True)
         F.leaky_relu(xr, 0.01).backward(gy)
-        xd = x.to(device).requires_grad_(True)
+        xd = x.clone().to(device).requires_grad_(True)
         y = ops.lrelu(xd)
         y.backward(gy.to(device))
         assert_close(y, F.leaky_relu(x, 0.01), "lrelu")
@@ -172,7 +172,7 @@ def check_maxpool(device, seed=3):
     xr = x.clone().requires_grad_(True)
     yr = F.max_pool3d(xr.permute(0, 4, 1, 2, 3), 2, 2).permute(0, 2, 3, 4, 1)
     yr.backward(gy)
-    xd = x.to(device).requires_grad_(True)
+    xd = x.clone().to(device).requires_grad_(True)
     y = ops.maxpool2(xd)
     y.backward(gy.to(device))
     assert_close(y, yr, "y", 1e-7)
