@@ -9,6 +9,10 @@ int cfun_conv_bwd_data_direct(const float*, const float*, float*, const CfunConv
 int cfun_conv_bwd_weight_direct(const float*, const float*, float*, const CfunConv3dParams*, void*, size_t, hipStream_t);
 size_t cfun_direct_wgrad_ws(const CfunConv3dParams*);
 int cfun_reduce_partials(const float*, float*, int64_t, int, hipStream_t);
+// conv3d_wgrad_c1.hip
+int cfun_wgrad_c1_supported(const CfunConv3dParams*);
+size_t cfun_wgrad_c1_ws(const CfunConv3dParams*);
+int cfun_wgrad_c1(const float*, const float*, float*, const CfunConv3dParams*, void*, size_t, hipStream_t);
 
 namespace {
 
@@ -30,7 +34,7 @@ struct Shape {
 const Shape kShapes[] = {
     SHAPE(k333s1, 3, 3, 3, 1, 5), SHAPE(k333s2, 3, 3, 3, 2, 5), SHAPE(k111s1, 1, 1, 1, 1, 5),
     SHAPE(k111s2, 1, 1, 1, 2, 5), SHAPE(k133s1, 1, 3, 3, 1, 5), SHAPE(k311s1, 3, 1, 1, 1, 5),
-    SHAPE(k555s1, 5, 5, 5, 1, 1),
+    SHAPE(k555s1, 5, 5, 5, 1, 1), SHAPE(k222s1, 2, 2, 2, 1, 5),
 };
 
 const Shape* find_shape(int kd, int kh, int kw, int s) {
@@ -50,22 +54,31 @@ int pick_nsub(int co, int max_nsub) {
   return best;
 }
 
+bool standard_dims(const CfunConv3dParams* p) {
+  const int sh = p->up2 ? 1 : 0;
+  return (((p->Di << sh) + 2 * p->pd - p->kd) / p->stride + 1) == p->Do &&
+         (((p->Hi << sh) + 2 * p->ph - p->kh) / p->stride + 1) == p->Ho &&
+         (((p->Wi << sh) + 2 * p->pw - p->kw) / p->stride + 1) == p->Wo;
+}
+
 bool valid_params(const CfunConv3dParams* p) {
   if (!p) return false;
   if (p->N < 0 || p->Ci <= 0 || p->Co <= 0 || p->kd <= 0 || p->kh <= 0 || p->kw <= 0) return false;
   if (p->stride != 1 && p->stride != 2) return false;
   if (p->CoP < p->Co || (p->CoP & 15) || p->CiP < p->Ci || (p->CiP & 15)) return false;
-  const int sh = p->up2 ? 1 : 0;
   // output size must match the conv arithmetic
-  if ((((p->Di << sh) + 2 * p->pd - p->kd) / p->stride + 1) != p->Do) return false;
-  if ((((p->Hi << sh) + 2 * p->ph - p->kh) / p->stride + 1) != p->Ho) return false;
-  if ((((p->Wi << sh) + 2 * p->pw - p->kw) / p->stride + 1) != p->Wo) return false;
-  if (p->res_mode && p->res_up2 && ((p->Do | p->Ho | p->Wo) & 1)) return false;
+  if (!standard_dims(p)) return false;
+  if (p->d2s) {
+    if (p->Co & 7) return false;
+  } else if (p->res_mode && p->res_up2 && ((p->Do | p->Ho | p->Wo) & 1)) {
+    return false;
+  }
   return true;
 }
 
 const Shape* mfma_shape(const CfunConv3dParams* p) {
   if ((p->Ci & 3) || (p->Co & 3)) return nullptr;
+  if (p->d2s && ((p->Co >> 3) & 3)) return nullptr;   // a lane's float4 must stay inside one parity group
   const Shape* s = find_shape(p->kd, p->kh, p->kw, p->stride);
   if (!s) return nullptr;
   if (p->Co > 16 * s->max_nsub && s->max_nsub == 1) return nullptr;
@@ -74,7 +87,7 @@ const Shape* mfma_shape(const CfunConv3dParams* p) {
 
 // the data gradient of a stride-1 conv is a stride-1 conv of g with flipped, transposed weights
 bool make_dgrad_params(const CfunConv3dParams* p, CfunConv3dParams* q) {
-  if (p->stride != 1) return false;
+  if (p->stride != 1 || !standard_dims(p)) return false;
   const int sh = p->up2 ? 1 : 0;
   *q = *p;
   q->Di = p->Do; q->Hi = p->Ho; q->Wi = p->Wo; q->Ci = p->Co;
@@ -83,7 +96,51 @@ bool make_dgrad_params(const CfunConv3dParams* p, CfunConv3dParams* q) {
   q->pd = p->kd - 1 - p->pd; q->ph = p->kh - 1 - p->ph; q->pw = p->kw - 1 - p->pw;
   if (q->pd < 0 || q->ph < 0 || q->pw < 0) return false;
   q->up2 = 0; q->act = CFUN_ACT_NONE; q->scale_mode = 0; q->has_shift = 0; q->res_mode = 0; q->res_up2 = 0;
+  q->d2s = 0;
   return true;
+}
+
+// ---- data gradient of the stride-2 3x3x3 (pad 1) convs as ONE stride-1 2x2x2 conv over g with a
+// depth-to-space epilogue:  dx[2z+p] = sum_{a in {0,1}} g[z+a] * W[t(p,a)],  t(0,0)=1, t(1,0)=2, t(1,1)=0,
+// (0,1) -> no tap.  Folded weights wd[tap'=(a,b,c)][co][(pz,py,px)*Ci + ci] are built on device from wpT.
+bool use_folded_s2_dgrad(const CfunConv3dParams* p) {
+  return p->algo != CFUN_ALGO_DIRECT && p->stride == 2 && !p->up2 && p->kd == 3 && p->kh == 3 && p->kw == 3 &&
+         p->pd == 1 && p->ph == 1 && p->pw == 1 && !((p->Di | p->Hi | p->Wi) & 1) && !(p->Ci & 3) && !(p->Co & 3) &&
+         p->Di == 2 * p->Do && p->Hi == 2 * p->Ho && p->Wi == 2 * p->Wo;
+}
+
+__global__ void __launch_bounds__(256)
+k_fold_s2_dgrad_weights(const float* __restrict__ wpT, float* __restrict__ wd, int Ci, int Co, int CiP, int CoPd) {
+  // one thread per element of wd [8][Co][CoPd]
+  const int64_t total = (int64_t)8 * Co * CoPd;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int col = (int)(i % CoPd);
+  const int co = (int)((i / CoPd) % Co);
+  const int tap = (int)(i / ((int64_t)CoPd * Co));
+  float v = 0.f;
+  if (col < 8 * Ci) {
+    const int q = col / Ci, ci = col - q * Ci;
+    const int par[3] = {q >> 2, (q >> 1) & 1, q & 1}, off[3] = {tap >> 2, (tap >> 1) & 1, tap & 1};
+    int t[3];
+    bool ok = true;
+    for (int d = 0; d < 3; ++d) {
+      if (par[d] == 0) { t[d] = 1; ok = ok && off[d] == 0; }
+      else t[d] = off[d] == 0 ? 2 : 0;
+    }
+    if (ok) v = wpT[((int64_t)((t[0] * 3 + t[1]) * 3 + t[2]) * Co + co) * CiP + ci];
+  }
+  wd[i] = v;
+}
+
+CfunConv3dParams folded_s2_params(const CfunConv3dParams* p) {
+  CfunConv3dParams q = *p;
+  q.Di = p->Do; q.Hi = p->Ho; q.Wi = p->Wo; q.Ci = p->Co;
+  q.Do = p->Do; q.Ho = p->Ho; q.Wo = p->Wo; q.Co = 8 * p->Ci;
+  q.CoP = (8 * p->Ci + 15) / 16 * 16; q.CiP = p->CoP;
+  q.kd = q.kh = q.kw = 2; q.stride = 1; q.pd = q.ph = q.pw = 0;
+  q.up2 = 0; q.act = CFUN_ACT_NONE; q.scale_mode = 0; q.has_shift = 0; q.res_mode = 0; q.res_up2 = 0; q.d2s = 1;
+  return q;
 }
 
 bool use_mfma_dgrad(const CfunConv3dParams* p, CfunConv3dParams* q, const Shape** s) {
@@ -129,6 +186,7 @@ size_t cfun_conv3d_bwd_data_workspace_bytes(const CfunConv3dParams* p) {
   if (!valid_params(p)) return 0;
   CfunConv3dParams q;
   const Shape* s;
+  if (use_folded_s2_dgrad(p)) return cfun_align_up((size_t)8 * p->Co * ((8 * p->Ci + 15) / 16 * 16) * sizeof(float), 256);
   if (use_mfma_dgrad(p, &q, &s) && p->up2)
     return cfun_align_up((size_t)q.N * q.Do * q.Ho * q.Wo * q.Co * sizeof(float), 256);
   return 256;
@@ -139,6 +197,17 @@ int cfun_conv3d_bwd_data(const float* g, const float* wpT, float* dx, const Cfun
   if (!valid_params(p)) return CFUN_EINVAL;
   CfunConv3dParams q;
   const Shape* s;
+  if (use_folded_s2_dgrad(p)) {
+    if (!cfun_aligned16(g) || !cfun_aligned16(wpT) || !cfun_aligned16(dx) || !cfun_aligned16(ws)) return CFUN_EALIGN;
+    if (ws_bytes < cfun_conv3d_bwd_data_workspace_bytes(p)) return CFUN_EWORKSPACE;
+    q = folded_s2_params(p);
+    const int64_t nw = (int64_t)8 * p->Co * q.CoP;
+    hipLaunchKernelGGL(k_fold_s2_dgrad_weights, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, cfun_st(stream), wpT,
+                       (float*)ws, p->Ci, p->Co, p->CiP, q.CoP);
+    CFUN_LAUNCH_CHECK();
+    const Shape* s2 = find_shape(2, 2, 2, 1);
+    return s2->fwd(pick_nsub(q.Co, s2->max_nsub), g, (const float*)ws, nullptr, nullptr, nullptr, dx, q, 0, cfun_st(stream));
+  }
   if (use_mfma_dgrad(p, &q, &s)) {
     if (!cfun_aligned16(g) || !cfun_aligned16(wpT) || !cfun_aligned16(dx)) return CFUN_EALIGN;
     const int nsub = pick_nsub(q.Co, s->max_nsub);
@@ -154,6 +223,7 @@ int cfun_conv3d_bwd_data(const float* g, const float* wpT, float* dx, const Cfun
 
 size_t cfun_conv3d_bwd_weight_workspace_bytes(const CfunConv3dParams* p) {
   if (!valid_params(p)) return 0;
+  if (p->algo != CFUN_ALGO_DIRECT && cfun_wgrad_c1_supported(p)) return cfun_align_up(cfun_wgrad_c1_ws(p), 256);
   const Shape* s = p->algo == CFUN_ALGO_DIRECT ? nullptr : mfma_shape(p);
   if (s) {
     cfun_mfma::WgPlan w;
@@ -166,6 +236,10 @@ size_t cfun_conv3d_bwd_weight_workspace_bytes(const CfunConv3dParams* p) {
 int cfun_conv3d_bwd_weight(const float* x, const float* g, float* dwp, const CfunConv3dParams* p, void* ws,
                            size_t ws_bytes, cfun_stream_t stream) {
   if (!valid_params(p)) return CFUN_EINVAL;
+  if (p->algo != CFUN_ALGO_DIRECT && cfun_wgrad_c1_supported(p) && (int64_t)p->N * p->Do * p->Ho * p->Wo > 0) {
+    if (!cfun_aligned16(g) || !cfun_aligned16(ws)) return CFUN_EALIGN;
+    return cfun_wgrad_c1(x, g, dwp, p, ws, ws_bytes, cfun_st(stream));
+  }
   const Shape* s = p->algo == CFUN_ALGO_DIRECT ? nullptr : mfma_shape(p);
   if (s) {
     if (!cfun_aligned16(x) || !cfun_aligned16(g)) return CFUN_EALIGN;

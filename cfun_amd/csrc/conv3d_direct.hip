@@ -60,9 +60,11 @@ k_conv_fwd_direct(const float* __restrict__ x, const float* __restrict__ wp, con
   }
   int64_t ridx = 0;
   if (p.res_mode) {
-    ridx = p.res_up2 ? ((((int64_t)o.n * (p.Do >> 1) + (o.z >> 1)) * (p.Ho >> 1) + (o.y >> 1)) * (p.Wo >> 1) + (o.x >> 1))
-                     : v;
+    ridx = (p.res_up2 && !p.d2s)
+               ? ((((int64_t)o.n * (p.Do >> 1) + (o.z >> 1)) * (p.Ho >> 1) + (o.y >> 1)) * (p.Wo >> 1) + (o.x >> 1))
+               : v;
   }
+  const int Cq = p.Co >> 3;   // d2s only
 #pragma unroll
   for (int j = 0; j < COT; ++j) {
     const int co = co0 + j;
@@ -71,8 +73,16 @@ k_conv_fwd_direct(const float* __restrict__ x, const float* __restrict__ wp, con
       if (p.scale_mode == 1) r *= scale[co];
       else if (p.scale_mode == 2) r *= scale[o.n * p.Co + co];
       if (p.has_shift) r += shift[co];
-      if (p.res_mode) r += res[ridx * p.Co + co];
-      y[v * p.Co + co] = cfun_apply_act(r, p.act, p.slope);
+      if (p.d2s) {
+        const int q = co / Cq, oc = co - q * Cq;
+        if (p.res_mode) r += res[ridx * Cq + oc];
+        const int64_t hv = (((int64_t)o.n * 2 * p.Do + 2 * o.z + (q >> 2)) * 2 * p.Ho + 2 * o.y + ((q >> 1) & 1)) * 2 * p.Wo +
+                           2 * o.x + (q & 1);
+        y[hv * Cq + oc] = cfun_apply_act(r, p.act, p.slope);
+      } else {
+        if (p.res_mode) r += res[ridx * p.Co + co];
+        y[v * p.Co + co] = cfun_apply_act(r, p.act, p.slope);
+      }
     }
   }
 }

@@ -172,7 +172,7 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
     if (oy >= p.Ho) continue;
     const int64_t v = (((int64_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox;
     int64_t rv = v;
-    if (p.res_mode && p.res_up2)
+    if (p.res_mode && p.res_up2 && !p.d2s)
       rv = (((int64_t)n * (p.Do >> 1) + (oz >> 1)) * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
 #pragma unroll
     for (int nn = 0; nn < NSUB; ++nn) {
@@ -187,13 +187,21 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
         const float4 t = *reinterpret_cast<const float4*>(shift + co);
         r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
       }
+      const int Cq = p.Co >> 3;
+      const int q = p.d2s ? co / Cq : 0, oc = p.d2s ? co - q * Cq : co;
       if (p.res_mode) {
-        const float4 t = *reinterpret_cast<const float4*>(res + rv * p.Co + co);
+        const float4 t = *reinterpret_cast<const float4*>(res + rv * (p.d2s ? Cq : p.Co) + oc);
         r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
       }
       r.x = cfun_apply_act(r.x, p.act, p.slope); r.y = cfun_apply_act(r.y, p.act, p.slope);
       r.z = cfun_apply_act(r.z, p.act, p.slope); r.w = cfun_apply_act(r.w, p.act, p.slope);
-      *reinterpret_cast<float4*>(y + v * p.Co + co) = r;
+      if (p.d2s) {
+        const int64_t hv = (((int64_t)n * 2 * p.Do + 2 * oz + (q >> 2)) * 2 * p.Ho + 2 * oy + ((q >> 1) & 1)) * 2 * p.Wo +
+                           2 * ox + (q & 1);
+        *reinterpret_cast<float4*>(y + hv * Cq + oc) = r;
+      } else {
+        *reinterpret_cast<float4*>(y + v * p.Co + co) = r;
+      }
     }
   }
 }
@@ -406,7 +414,7 @@ WgPlan wgrad_plan(const CfunConv3dParams& p, int nsub) {
   w.ntiles = p.N * w.ntz * w.nty * w.ntx;
   w.ncisub = cdiv(p.Ci, 16);
   w.ncot = cdiv(p.CoP, 16 * nsub);
-  int want = 1024 / (w.ncisub * w.ncot);
+  int want = 512 / (w.ncisub * w.ncot);   // ~2 workgroups per CU in total; fewer partials to reduce
   if (want < 1) want = 1;
   if (want > w.ntiles) want = w.ntiles;
   if (want < 1) want = 1;
@@ -483,3 +491,4 @@ CFUN_MFMA_DECL(k111s2)
 CFUN_MFMA_DECL(k133s1)
 CFUN_MFMA_DECL(k311s1)
 CFUN_MFMA_DECL(k555s1)
+CFUN_MFMA_DECL(k222s1)

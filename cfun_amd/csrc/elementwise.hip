@@ -175,15 +175,21 @@ k_channel_reduce(F f, double* __restrict__ partial, int64_t V, int C, int lanes)
   }
 }
 
-// mode 0: stats (mean, rstd) from (sum, sumsq); mode 1: plain sums (float) ; mode 2: means of the two sums
-__global__ void k_channel_finalize(const double* __restrict__ partial, float* __restrict__ out, int NC, int C,
-                                   int blocks, int NQ, int64_t V, float eps, int mode) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
+// mode 0: stats (mean, rstd) from (sum, sumsq); mode 1: plain sums (float) ; mode 2: means of the two sums.
+// One wave per (n, c): lanes stride over the per-block partials, fp64 wave reduction (deterministic order).
+__global__ void __launch_bounds__(kBlock)
+k_channel_finalize(const double* __restrict__ partial, float* __restrict__ out, int NC, int C, int blocks, int NQ,
+                   int64_t V, float eps, int mode) {
+  const int i = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
   if (i >= NC) return;
   const int n = i / C, c = i - n * C;
   double s[2] = {0.0, 0.0};
-  for (int b = 0; b < blocks; ++b)
+  for (int b = lane; b < blocks; b += 64)
     for (int q = 0; q < NQ; ++q) s[q] += partial[(((int64_t)n * blocks + b) * NQ + q) * C + c];
+  s[0] = cfun_wave_sum_d(s[0]);
+  s[1] = cfun_wave_sum_d(s[1]);
+  if (lane != 0) return;
   if (mode == 0) {
     const double mean = s[0] / (double)V;
     double var = s[1] / (double)V - mean * mean;
@@ -206,7 +212,7 @@ inline ReducePlan reduce_plan(int N, int64_t V, int C) {
   ReducePlan r;
   const int CG = C / vec_of(C);
   r.lanes = kBlock / CG;
-  int64_t want = (2048 + N - 1) / N;                       // ~8 blocks per CU in total
+  int64_t want = (1024 + N - 1) / N;                       // ~4 blocks per CU in total
   int64_t maxb = (V + (int64_t)r.lanes * 16 - 1) / ((int64_t)r.lanes * 16);  // >= 16 voxels per thread
   if (maxb < 1) maxb = 1;
   r.blocks = (int)(want < maxb ? want : maxb);
@@ -408,7 +414,7 @@ int cfun_channel_sum(const float* g, float* out, int64_t nvox, int32_t C, void* 
     auto kern = k_channel_reduce<StatSum<1>, 1>;
     hipLaunchKernelGGL(kern, dim3(r.blocks, 1), dim3(kBlock), 0, cfun_st(stream), StatSum<1>{g}, (double*)ws, nvox, C, r.lanes);
   }
-  hipLaunchKernelGGL(k_channel_finalize, dim3((C + kBlock - 1) / kBlock), dim3(kBlock), 0, cfun_st(stream),
+  hipLaunchKernelGGL(k_channel_finalize, dim3((C * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, cfun_st(stream),
                      (const double*)ws, out, C, C, r.blocks, 1, nvox, 0.f, 1);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
@@ -434,7 +440,7 @@ int cfun_instnorm_stats(const float* x, float* stats, int32_t N, int64_t V, int3
     auto kern = k_channel_reduce<StatSumSq<1>, 1>;
     hipLaunchKernelGGL(kern, dim3(r.blocks, N), dim3(kBlock), 0, cfun_st(stream), StatSumSq<1>{x}, (double*)ws, V, C, r.lanes);
   }
-  hipLaunchKernelGGL(k_channel_finalize, dim3((N * C + kBlock - 1) / kBlock), dim3(kBlock), 0, cfun_st(stream),
+  hipLaunchKernelGGL(k_channel_finalize, dim3((N * C * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, cfun_st(stream),
                      (const double*)ws, stats, N * C, C, r.blocks, 2, V, eps, 0);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
@@ -470,7 +476,7 @@ int cfun_instnorm_lrelu_bwd(const float* x, const float* stats, const float* dy,
     auto kern = k_channel_reduce<StatNormBwd<1>, 1>;
     hipLaunchKernelGGL(kern, dim3(r.blocks, N), dim3(kBlock), 0, cfun_st(stream), StatNormBwd<1>{x, dy, stats, C, slope}, partial, V, C, r.lanes);
   }
-  hipLaunchKernelGGL(k_channel_finalize, dim3((N * C + kBlock - 1) / kBlock), dim3(kBlock), 0, cfun_st(stream),
+  hipLaunchKernelGGL(k_channel_finalize, dim3((N * C * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, cfun_st(stream),
                      (const double*)partial, means, N * C, C, r.blocks, 2, V, 0.f, 2);
   const int64_t total = (int64_t)N * V * (C / vec);
   if (vec == 4) hipLaunchKernelGGL(k_instnorm_lrelu_bwd<4>, dim3(ew_grid(total)), dim3(kBlock), 0, cfun_st(stream), x, stats, (const float*)means, dy, dx, total, V, C, slope);

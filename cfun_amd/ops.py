@@ -29,6 +29,23 @@ def pack_weight(w):
     return wp.contiguous()
 
 
+def fold_up2_weight(w):
+    """Fold "nearest x2 upsample -> conv k^3 (pad k//2)" into a 3x3x3 conv (pad 1) on the LOW-resolution input
+    that produces the 8 output parities as channels: [O,I,k,k,k] -> [8*O, I, 3,3,3], channel ((pz*2+py)*2+px)*O + o.
+    Hi-res tap t of output parity p reads low-res offset floor((p + t - k//2) / 2) in {-1,0,1}; taps that hit the
+    same low-res voxel are summed (differentiable, so the gradient reaches the original 5x5x5 weight).  The
+    hi-res zero padding of k//2 <= 2 maps exactly onto a low-res zero padding of 1."""
+    o, i, k = w.shape[0], w.shape[1], w.shape[-1]
+    if k not in (3, 5):
+        raise ValueError("fold_up2_weight: kernel size %d" % k)
+    f = torch.zeros(2, 3, k, dtype=w.dtype, device=w.device)
+    for p in range(2):
+        for t in range(k):
+            f[p, (p + t - k // 2) // 2 + 1, t] = 1.0
+    wf = torch.einsum("pat,qbu,rcv,oituv->pqroiabc", f, f, f, w)
+    return wf.reshape(8 * o, i, 3, 3, 3)
+
+
 def _transpose_pack(wp, co):
     """wp [T,Ci,CoP] -> wpT [T,Co,CiP] (no grad; used by bwd_data)."""
     t, ci, _ = wp.shape
@@ -48,6 +65,7 @@ class ConvSpec:
     act: int = ACT_NONE
     res_up2: bool = False
     scale_per_n: bool = False   # scale is [N, Co] (Dropout3d mask) instead of [Co]
+    d2s: bool = False           # depth-to-space x2 epilogue (co = 8*Cq), see include/cfun_hip.h
     algo: int = ALGO_AUTO
 
 
@@ -75,6 +93,7 @@ def _params(spec, x_shape, has_scale, has_shift, has_res):
     p.has_shift = int(has_shift)
     p.res_mode = int(has_res)
     p.res_up2 = int(spec.res_up2 and has_res)
+    p.d2s = int(spec.d2s)
     p.algo = spec.algo
     return p
 
@@ -115,7 +134,10 @@ class _Conv3d(torch.autograd.Function):
         p = _params(spec, x.shape, scale is not None, shift is not None, res is not None)
         if wp.shape != (p.kd * p.kh * p.kw, p.Ci, p.CoP):
             raise RuntimeError("packed weight %s does not match conv %s" % (tuple(wp.shape), spec))
-        y = torch.empty((p.N, p.Do, p.Ho, p.Wo, p.Co), dtype=torch.float32, device=x.device)
+        if spec.d2s:
+            y = torch.empty((p.N, 2 * p.Do, 2 * p.Ho, 2 * p.Wo, p.Co // 8), dtype=torch.float32, device=x.device)
+        else:
+            y = torch.empty((p.N, p.Do, p.Ho, p.Wo, p.Co), dtype=torch.float32, device=x.device)
         timed = _TIMER is not None and x.is_cuda and _TIMER.match(p)
         if timed:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -147,8 +169,13 @@ class _Conv3d(torch.autograd.Function):
         gp = dy
         if spec.act != ACT_NONE:
             gp = torch.empty_like(dy)
-            check(lib.cfun_act_bwd(ptr(y), ptr(dy), None, ptr(gp), nvox, p.Co, p.Do * p.Ho * p.Wo, spec.act,
-                                   LRELU_SLOPE, 0, st), "act_bwd")
+            check(lib.cfun_act_bwd(ptr(y), ptr(dy), None, ptr(gp), dy.numel() // dy.shape[-1], dy.shape[-1],
+                                   p.Do * p.Ho * p.Wo * (8 if spec.d2s else 1), spec.act, LRELU_SLOPE, 0, st), "act_bwd")
+        gp_out = gp     # in the layout of y (what the residual sees)
+        if spec.d2s:    # space-to-depth: [N,2D,2H,2W,Cq] -> [N,D,H,W,(pz,py,px,Cq)]
+            cq = p.Co // 8
+            gp = gp.view(p.N, p.Do, 2, p.Ho, 2, p.Wo, 2, cq).permute(0, 1, 3, 5, 2, 4, 6, 7).reshape(
+                p.N, p.Do, p.Ho, p.Wo, p.Co).contiguous()
         g = gp
         if scale is not None:
             g = torch.empty_like(dy)
@@ -171,7 +198,11 @@ class _Conv3d(torch.autograd.Function):
         if need_shift:
             dshift = channel_sum(gp.view(-1, p.Co))
         if need_res:
-            if p.res_up2:
+            if spec.d2s:
+                dres = torch.empty(ctx.res_shape, dtype=torch.float32, device=dy.device)
+                check(lib.cfun_upsample2_bwd(ptr(gp_out), ptr(dres), p.N, p.Do, p.Ho, p.Wo, p.Co // 8, st),
+                      "upsample2_bwd")
+            elif p.res_up2:
                 dres = torch.empty(ctx.res_shape, dtype=torch.float32, device=dy.device)
                 check(lib.cfun_upsample2_bwd(ptr(gp), ptr(dres), p.N, p.Do // 2, p.Ho // 2, p.Wo // 2, p.Co, st),
                       "upsample2_bwd")

@@ -59,6 +59,7 @@ const char* cfun_error_string(int code);
  *     s      = scale[co] (scale_mode 1) | scale[n*Co+co] (scale_mode 2: Dropout3d channel mask) | 1
  *     t      = shift[co] (bias and/or folded BatchNorm) | 0
  *     r      = res[...] (res_mode 1) read at (zo>>1,yo>>1,xo>>1) when res_up2 | 0
+ *   (bwd_data / bwd_weight always take g = dL/d(conv sum) as [N,Do,Ho,Wo,Co], also for d2s convs)
  *
  * Packed weights: wp[tap][ci][CoP] fp32, tap = (dz*kh+dy)*kw+dx, CoP = Co rounded up to 16, pad = 0.
  * bwd_data takes the transposed pack wpT[tap][co][CiP] (same tap order, CiP = Ci rounded up to 16).
@@ -79,6 +80,11 @@ typedef struct CfunConv3dParams {
   int32_t has_shift;
   int32_t res_mode;             /* 0 none, 1 add before the activation */
   int32_t res_up2;
+  int32_t d2s;                  /* 1: depth-to-space x2 epilogue: Co = 8*Cq, channel (pz,py,px,o) of low-res voxel
+                                   (z,y,x) is written to y[n, 2z+pz, 2y+py, 2x+px, o]; y is [N,2Do,2Ho,2Wo,Cq];
+                                   the residual (if any) is [N,Do,Ho,Wo,Cq] = nearest-x2 up-sampled into y.
+                                   Used to run "nearest x2 upsample -> 5x5x5 conv" (mask_branch.py:118-122) as a
+                                   3x3x3 conv with parity-folded weights: 27/125 of the FLOPs, same result. */
   int32_t algo;                 /* CFUN_ALGO_* */
 } CfunConv3dParams;
 

@@ -44,9 +44,12 @@ def ref_conv(x, w, spec, scale, shift, res):
         y = y * (scale.view(scale.shape[0], -1, 1, 1, 1) if spec.scale_per_n else scale.view(1, -1, 1, 1, 1))
     if shift is not None:
         y = y + shift.view(1, -1, 1, 1, 1)
+    if spec.d2s:   # depth-to-space x2: channel (pz,py,px,o) -> voxel (2z+pz, 2y+py, 2x+px), channel o
+        n, c8, d, h, w = y.shape
+        y = y.view(n, 2, 2, 2, c8 // 8, d, h, w).permute(0, 4, 5, 1, 6, 2, 7, 3).reshape(n, c8 // 8, 2 * d, 2 * h, 2 * w)
     if res is not None:
         r = res.permute(0, 4, 1, 2, 3)
-        if spec.res_up2:
+        if spec.res_up2 or spec.d2s:
             r = F.interpolate(r, scale_factor=2, mode="nearest")
         y = y + r
     if spec.act == ACT_RELU:
@@ -78,6 +81,11 @@ CONV_CASES = {
     "mfma_555_up2_res": (1, (3, 3, 4), 8, 8, (5, 5, 5), dict(up2=True, res=True, res_up2=True, algo=ALGO_MFMA)),
     "mfma_333_two_cotiles": (1, (3, 4, 5), 4, 96, (3, 3, 3), dict(algo=ALGO_MFMA)),
     "mfma_333_ci20_co20": (1, (4, 4, 16), 20, 20, (3, 3, 3), dict(algo=ALGO_MFMA)),
+    "auto_stem_c1_wgrad_mfma": (2, (5, 6, 18), 1, 20, (3, 3, 3), dict(algo=ALGO_AUTO)),
+    "auto_p3d_stem_wgrad_mfma": (1, (6, 10, 36), 1, 16, (3, 7, 7), dict(stride=2, pad=(1, 3, 3), act=ACT_RELU, scale=True, shift=True, algo=ALGO_AUTO)),
+    "auto_lits_stem_wgrad_mfma": (1, (6, 8, 8), 1, 24, (5, 7, 7), dict(stride=2, pad=(2, 3, 3), algo=ALGO_AUTO)),
+    "mfma_333_d2s_res": (2, (3, 4, 5), 8, 64, (3, 3, 3), dict(algo=ALGO_MFMA, d2s=True, res=True)),
+    "direct_333_d2s_res_cq3": (1, (3, 4, 5), 3, 24, (3, 3, 3), dict(algo=ALGO_DIRECT, d2s=True, res=True, act=ACT_LRELU)),
 }
 # bigger shapes: many workgroups, several chunks per wgrad block, channel counts of the real nets (GPU tier)
 CONV_CASES_LARGE = {
@@ -93,11 +101,11 @@ CONV_CASES_LARGE = {
 
 
 def check_conv(device, n, dhw, ci, co, k, stride=1, pad=None, up2=False, act=ACT_NONE, scale=False, shift=False,
-               res=False, res_up2=False, per_n=False, algo=ALGO_AUTO, seed=0, tol=RTOL):
+               res=False, res_up2=False, per_n=False, algo=ALGO_AUTO, seed=0, tol=RTOL, d2s=False):
     gen = _gen(seed)
     pad = pad if pad is not None else tuple(kk // 2 for kk in k)
     spec = ops.ConvSpec(k=tuple(k), co=co, stride=stride, pad=tuple(pad), up2=up2, act=act, res_up2=res_up2,
-                        scale_per_n=per_n, algo=algo)
+                        scale_per_n=per_n, algo=algo, d2s=d2s)
     x = randn(gen, n, *dhw, ci)
     w = randn(gen, co, ci, *k) / float(ci * k[0] * k[1] * k[2]) ** 0.5
     sc = ((torch.rand(n, co, generator=gen) + 0.5) if per_n else (torch.rand(co, generator=gen) + 0.5)) if scale else None
@@ -106,7 +114,7 @@ def check_conv(device, n, dhw, ci, co, k, stride=1, pad=None, up2=False, act=ACT
     rs = None
     if res:
         shp = list(out_shape)
-        if res_up2:
+        if res_up2 or d2s:
             shp = [shp[0], shp[1] // 2, shp[2] // 2, shp[3] // 2, shp[4]]
         rs = randn(gen, *shp)
     gy = randn(gen, *out_shape)
@@ -146,6 +154,25 @@ def check_instnorm_lrelu(device, n, dhw, c, seed=1):
     y.backward(gy.to(device))
     assert_close(y, yr, "y")
     assert_close(xd.grad, xr.grad, "dx", 1e-4)
+
+
+def check_fold_up2(device, seed=7):
+    """nearest x2 upsample -> 5x5x5 conv (+ up-sampled skip) == folded 3x3x3 conv with depth-to-space epilogue."""
+    gen = _gen(seed)
+    x = randn(gen, 2, 4, 5, 6, 8)
+    w = randn(gen, 8, 8, 5, 5, 5) / 30.0
+    gy = randn(gen, 2, 8, 10, 12, 8)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    up = F.interpolate(xr.permute(0, 4, 1, 2, 3), scale_factor=2, mode="nearest")
+    yr = (up + F.conv3d(up, wr, padding=2)).permute(0, 2, 3, 4, 1)
+    yr.backward(gy)
+    xd, wd = x.clone().to(device).requires_grad_(True), w.clone().to(device).requires_grad_(True)
+    spec = ops.ConvSpec(k=(3, 3, 3), co=64, pad=(1, 1, 1), d2s=True, res_up2=True)
+    y = ops.conv3d(xd, ops.pack_weight(ops.fold_up2_weight(wd)), spec, res=xd)
+    y.backward(gy.to(device))
+    assert_close(y, yr, "y")
+    assert_close(xd.grad, xr.grad, "dx")
+    assert_close(wd.grad, wr.grad, "dw")
 
 
 def check_elementwise(device, seed=2):

@@ -20,6 +20,10 @@ def test_instnorm_lrelu(emu, name):
     kc.check_instnorm_lrelu(emu, *kc.NORM_CASES[name])
 
 
+def test_fold_up2_conv5(emu):
+    kc.check_fold_up2(emu)
+
+
 def test_elementwise(emu):
     kc.check_elementwise(emu)
 

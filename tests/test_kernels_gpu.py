@@ -30,6 +30,10 @@ def test_instnorm_lrelu_large(gpu):
     kc.check_instnorm_lrelu(gpu, 4, (48, 48, 48), 40)
 
 
+def test_fold_up2_conv5(gpu):
+    kc.check_fold_up2(gpu)
+
+
 def test_elementwise(gpu):
     kc.check_elementwise(gpu)
 
