@@ -183,19 +183,34 @@ k_conv_bwd_weight_direct(const float* __restrict__ x, const float* __restrict__ 
 
 }  // namespace
 
-// sum partial[chunk][i] over chunks -> out[i]; shared with the MFMA wgrad through cfun_reduce_partials()
+// sum partial[chunk][i] over chunks -> out[i]; shared with the MFMA wgrads through cfun_reduce_partials().
+// block = 64 consecutive outputs x 4 chunk lanes (coalesced 256-byte rows, 4 loads in flight per thread),
+// fixed summation order => deterministic.
 static __global__ void __launch_bounds__(256)
 cfun_k_reduce_partials(const float* __restrict__ partial, float* __restrict__ out, int64_t n, int chunks) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int c = 0; c < chunks; ++c) s += partial[(int64_t)c * n + i];
-  out[i] = s;
+  __shared__ float sm[256];
+  const int tid = threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * 64 + (tid & 63);
+  const int cl = tid >> 6;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    int c = cl;
+    for (; c + 12 < chunks; c += 16) {
+      s0 += partial[(int64_t)c * n + i];
+      s1 += partial[(int64_t)(c + 4) * n + i];
+      s2 += partial[(int64_t)(c + 8) * n + i];
+      s3 += partial[(int64_t)(c + 12) * n + i];
+    }
+    for (; c < chunks; c += 4) s0 += partial[(int64_t)c * n + i];
+  }
+  sm[tid] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (cl == 0 && i < n) out[i] = (sm[tid] + sm[tid + 64]) + (sm[tid + 128] + sm[tid + 192]);
 }
 
 int cfun_reduce_partials(const float* partial, float* out, int64_t n, int chunks, hipStream_t st) {
   if (n <= 0) return CFUN_OK;
-  hipLaunchKernelGGL(cfun_k_reduce_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, out, n, chunks);
+  hipLaunchKernelGGL(cfun_k_reduce_partials, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, partial, out, n, chunks);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }

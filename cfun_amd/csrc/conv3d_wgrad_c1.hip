@@ -130,20 +130,27 @@ k_wgrad_c1_mfma(const float* __restrict__ x, const float* __restrict__ g, float*
       }
     }
   }
-  // partial[(chunk*4 + wave)][tap][0][CoP];  D[i = tap][j = co]: lane -> co = nn*16 + (lane&15), tap = m*16 + (lane>>4)*4 + r
-  float* out = partial + (int64_t)(chunk * 4 + wv) * T::TAPS * p.CoP;
+  // D[i = tap][j = co]: lane -> co = nn*16 + (lane&15), tap = m*16 + (lane>>4)*4 + r.  The 4 waves hold partial
+  // sums over disjoint voxel groups: combine them through LDS (wave order 0..3, deterministic), one partial per
+  // workgroup: partial[chunk][tap][0][CoP].
+  __syncthreads();                       // all waves are done with Xl / Gl
+  float* red = smem;                     // [4 waves][MSUB*16 taps][NT]   (<= 4*256*32 floats = 128 KB for 5x7x7)
+  constexpr int MROWS = T::MSUB * 16;
 #pragma unroll
   for (int m = 0; m < T::MSUB; ++m)
 #pragma unroll
-    for (int nn = 0; nn < NSUB; ++nn) {
-      const int co = nn * 16 + (lane & 15);
-      if (co >= p.CoP) continue;
+    for (int nn = 0; nn < NSUB; ++nn)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int tap = m * 16 + (lane >> 4) * 4 + r;
-        if (tap < T::TAPS) out[(int64_t)tap * p.CoP + co] = acc[m][nn][r];
-      }
-    }
+      for (int r = 0; r < 4; ++r)
+        red[((wv * MROWS) + m * 16 + (lane >> 4) * 4 + r) * NT + nn * 16 + (lane & 15)] = acc[m][nn][r];
+  __syncthreads();
+  float* out = partial + (int64_t)chunk * T::TAPS * p.CoP;
+  for (int e = tid; e < T::TAPS * NT; e += 256) {
+    const int tap = e / NT, co = e - tap * NT;
+    if (co < p.CoP)
+      out[(int64_t)tap * p.CoP + co] = (red[(0 * MROWS + tap) * NT + co] + red[(1 * MROWS + tap) * NT + co]) +
+                                       (red[(2 * MROWS + tap) * NT + co] + red[(3 * MROWS + tap) * NT + co]);
+  }
 }
 
 struct C1Plan {
@@ -156,7 +163,7 @@ C1Plan c1_plan(const CfunConv3dParams& p) {
   C1Plan w;
   w.ntz = cdiv(p.Do, T::TD); w.nty = cdiv(p.Ho, T::TH); w.ntx = cdiv(p.Wo, T::TW);
   w.ntiles = p.N * w.ntz * w.nty * w.ntx;
-  int want = w.ntiles < 1024 ? (w.ntiles > 0 ? w.ntiles : 1) : 1024;   // HBM-bound: ~4 workgroups per CU
+  int want = w.ntiles < 512 ? (w.ntiles > 0 ? w.ntiles : 1) : 512;   // HBM-bound: ~2 workgroups per CU
   w.tiles_per_chunk = cdiv(w.ntiles > 0 ? w.ntiles : 1, want);
   w.nchunks = cdiv(w.ntiles > 0 ? w.ntiles : 1, w.tiles_per_chunk);
   return w;
@@ -169,13 +176,19 @@ int launch_c1(const float* x, const float* g, float* dwp, const CfunConv3dParams
   constexpr int NT = 16 * NSUB, GS = pad_row16(NT);
   const C1Plan w = c1_plan<KD, KH, KW, S>(p);
   const int64_t nout = (int64_t)T::TAPS * p.CoP;
-  if ((size_t)w.nchunks * 4 * nout * sizeof(float) > ws_bytes) return CFUN_EWORKSPACE;
-  const size_t lds = (size_t)(((T::IVOX + 3) & ~3) + T::TVOX * GS) * sizeof(float);
+  if ((size_t)w.nchunks * nout * sizeof(float) > ws_bytes) return CFUN_EWORKSPACE;
+  size_t lds = (size_t)(((T::IVOX + 3) & ~3) + T::TVOX * GS) * sizeof(float);
+  const size_t lds_red = (size_t)4 * T::MSUB * 16 * NT * sizeof(float);
+  if (lds_red > lds) lds = lds_red;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_c1_mfma<KD, KH, KW, S, NSUB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
   auto kern = k_wgrad_c1_mfma<KD, KH, KW, S, NSUB>;
   hipLaunchKernelGGL(kern, dim3((unsigned)w.nchunks), dim3(256), lds, st, x, g, (float*)ws, p, w.ntz, w.nty, w.ntx,
                      w.tiles_per_chunk, w.ntiles);
   CFUN_LAUNCH_CHECK();
-  return cfun_reduce_partials((const float*)ws, dwp, nout, w.nchunks * 4, st);
+  return cfun_reduce_partials((const float*)ws, dwp, nout, w.nchunks, st);
 }
 
 template <int KD, int KH, int KW, int S>
@@ -205,7 +218,7 @@ size_t cfun_wgrad_c1_ws(const CfunConv3dParams* p) {
     case 3: w = c1_plan<5, 7, 7, 2>(*p); taps = 245; break;
     default: return 0;
   }
-  return (size_t)w.nchunks * 4 * taps * p->CoP * sizeof(float);
+  return (size_t)w.nchunks * taps * p->CoP * sizeof(float);
 }
 
 int cfun_wgrad_c1(const float* x, const float* g, float* dwp, const CfunConv3dParams* p, void* ws, size_t ws_bytes,

@@ -1,0 +1,175 @@
+"""Depth-wise (z) sharding of one CT volume across the GPUs of a node.
+
+One process per GPU (``torch.distributed``; backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the
+CPU test tier).  The volume is split into R contiguous depth slabs; the only ops on the backbone / FPN / RPN
+path that couple neighbouring slabs are the convolutions with a depth kernel of 3 (the stem, every conv_T,
+the FPN / RPN 3x3x3 convs).  Inside ``depth_sharded(group)`` every ``Conv3dParams`` with kD > 1 first
+exchanges its depth halo with the ring neighbours (point-to-point send/recv of packed planes -- xGMI is
+point-to-point, messages are 0.13-2.1 MB) and then runs as a depth-VALID convolution on the padded slab;
+all other ops are slab-local.  The halo exchange is an autograd Function: its backward returns the halo
+planes' gradients to their owners, so the same context also serves training.
+
+RPN outputs are flattened (z, y, x) (model.py:727-729), i.e. every rank owns a contiguous anchor range per
+pyramid level; ``gather_rpn_outputs`` is the single all-gather after which every rank runs the identical,
+deterministic proposal_layer / NMS -- no broadcast needed.
+"""
+import contextlib
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+_CTX = None
+
+
+class ShardContext:
+    def __init__(self, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    @property
+    def prev(self):
+        return self.rank - 1 if self.rank > 0 else None
+
+    @property
+    def next(self):
+        return self.rank + 1 if self.rank < self.world - 1 else None
+
+
+def current():
+    return _CTX
+
+
+@contextlib.contextmanager
+def depth_sharded(group=None):
+    """Activate depth sharding for the convolutions executed inside the block."""
+    global _CTX
+    old, _CTX = _CTX, ShardContext(group)
+    try:
+        yield _CTX
+    finally:
+        _CTX = old
+
+
+def _exchange(ctx, send_prev, send_next, recv_prev_shape, recv_next_shape, like):
+    """Ring-neighbour exchange of packed plane buffers.  Returns (from_prev, from_next); None at the volume
+    boundary.  Global ranks are resolved through the group so sub-groups work."""
+    reqs, from_prev, from_next = [], None, None
+
+    def peer(r):
+        return dist.get_global_rank(ctx.group, r) if ctx.group is not None else r
+
+    opsl = []
+    if ctx.prev is not None:
+        if recv_prev_shape is not None:
+            from_prev = torch.empty(recv_prev_shape, dtype=like.dtype, device=like.device)
+            opsl.append(dist.P2POp(dist.irecv, from_prev, peer(ctx.prev), ctx.group))
+        if send_prev is not None:
+            opsl.append(dist.P2POp(dist.isend, send_prev.contiguous(), peer(ctx.prev), ctx.group))
+    if ctx.next is not None:
+        if send_next is not None:
+            opsl.append(dist.P2POp(dist.isend, send_next.contiguous(), peer(ctx.next), ctx.group))
+        if recv_next_shape is not None:
+            from_next = torch.empty(recv_next_shape, dtype=like.dtype, device=like.device)
+            opsl.append(dist.P2POp(dist.irecv, from_next, peer(ctx.next), ctx.group))
+    if opsl:
+        reqs = dist.batch_isend_irecv(opsl)
+        for r in reqs:
+            r.wait()
+    return from_prev, from_next
+
+
+class _HaloExchange(torch.autograd.Function):
+    """x [N,Dl,H,W,C] -> [N,lo+Dl+hi,H,W,C]: ``lo`` planes from the previous rank's top, ``hi`` planes from the next
+    rank's bottom, zeros at the volume boundary (= the conv's zero padding)."""
+
+    @staticmethod
+    def forward(ctx, x, lo, hi, shard):
+        x = x.contiguous()
+        n, d, h, w, c = x.shape
+        send_next = ops.halo_pack(x, d - lo, lo) if lo > 0 else None      # my top planes are next's low halo
+        send_prev = ops.halo_pack(x, 0, hi) if hi > 0 else None           # my bottom planes are prev's high halo
+        from_prev, from_next = _exchange(shard, send_prev, send_next, (n, lo, h, w, c) if lo > 0 else None,
+                                         (n, hi, h, w, c) if hi > 0 else None, x)
+        out = torch.zeros((n, lo + d + hi, h, w, c), dtype=x.dtype, device=x.device)
+        ops.halo_unpack(x, out, lo)
+        if from_prev is not None:
+            ops.halo_unpack(from_prev, out, 0)
+        if from_next is not None:
+            ops.halo_unpack(from_next, out, lo + d)
+        ctx.shard, ctx.lo, ctx.hi, ctx.d = shard, lo, hi, d
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        lo, hi, d, shard = ctx.lo, ctx.hi, ctx.d, ctx.shard
+        n, _, h, w, c = g.shape
+        # gradients of the halo planes go back to the rank that owns them
+        send_prev = ops.halo_pack(g, 0, lo) if lo > 0 else None
+        send_next = ops.halo_pack(g, lo + d, hi) if hi > 0 else None
+        from_prev, from_next = _exchange(shard, send_prev, send_next, (n, hi, h, w, c) if hi > 0 else None,
+                                         (n, lo, h, w, c) if lo > 0 else None, g)
+        gx = ops.halo_pack(g, lo, d)
+        if from_prev is not None:      # prev used my bottom `hi` planes as its high halo
+            gx[:, :hi] += from_prev
+        if from_next is not None:      # next used my top `lo` planes as its low halo
+            gx[:, d - lo:] += from_next
+        return gx, None, None, None
+
+
+def halo_exchange(x, lo, hi, shard=None):
+    shard = shard or _CTX
+    if shard is None or shard.world == 1 or (lo == 0 and hi == 0):
+        return torch.nn.functional.pad(x, (0, 0, 0, 0, 0, 0, lo, hi)) if (lo or hi) else x
+    return _HaloExchange.apply(x, lo, hi, shard)
+
+
+def conv_depth_halo(kd, stride, pd):
+    """(lo, hi) halo planes a slab needs for a conv with depth kernel kd / stride / padding pd, for slabs whose
+    first plane is a multiple of the stride (the slabs of an evenly split, 16-divisible volume)."""
+    if kd == 1:
+        return 0, 0
+    lo = pd
+    hi = kd - 1 - pd - (stride - 1)
+    return lo, max(hi, 0)
+
+
+def slab(t, dim=2, shard=None):
+    """This rank's depth slab of a full tensor (NCDHW: dim 2; NDHWC: dim 1)."""
+    shard = shard or _CTX
+    d = t.shape[dim]
+    if d % shard.world:
+        raise ValueError("depth %d does not split evenly over %d ranks" % (d, shard.world))
+    s = d // shard.world
+    return t.narrow(dim, shard.rank * s, s)
+
+
+def gather_rpn_outputs(level_outputs, shard=None):
+    """level_outputs: per pyramid level [logits [1,Al,2], probs [1,Al,2], bbox [1,Al,6]] of THIS rank's slab.
+    One all-gather per tensor kind; returns the global tensors in the reference's order: all of level 2
+    (slabs in rank order = (z,y,x) order), then level 3 (model.py:1424-1426)."""
+    shard = shard or _CTX
+    outs = []
+    for kind in range(3):
+        per_level = []
+        for lv in level_outputs:
+            t = lv[kind].contiguous()
+            parts = [torch.empty_like(t) for _ in range(shard.world)]
+            dist.all_gather(parts, t, group=shard.group)
+            per_level.append(torch.cat(parts, dim=1))
+        outs.append(torch.cat(per_level, dim=1))
+    return outs
+
+
+def sharded_backbone_rpn(net, image_slab):
+    """Depth-sharded FPN -> RPN -> proposals of ``cfun_amd.step.CFUNHotPath`` on this rank's slab
+    [1,1,D/R,H,W].  Returns (p2_slab, p3_slab, rpn_logits, rpn_probs, rpn_bbox, rpn_rois) with the RPN tensors and
+    the proposals global and identical on every rank."""
+    p2, p3 = net.fpn.forward_ndhwc(ops.to_ndhwc(image_slab))
+    local = [net.rpn.forward_ndhwc(p) for p in (p2, p3)]
+    logits, probs, bbox = gather_rpn_outputs(local)
+    rois = net.proposals(probs, bbox, "inference" if not net.training else "training")
+    return p2, p3, logits, probs, bbox, rois

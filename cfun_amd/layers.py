@@ -10,7 +10,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import dist, ops
 from ._lib import ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA
 
 
@@ -35,9 +35,10 @@ class Conv3dParams(nn.Module):
             bound = 1.0 / math.sqrt(in_channels * k[0] * k[1] * k[2])
             nn.init.uniform_(self.bias, -bound, bound)
 
-    def spec(self, act=ops.ACT_NONE, up2=False, res_up2=False, scale_per_n=False):
-        return ops.ConvSpec(k=self.kernel_size, co=self.out_channels, stride=self.stride, pad=self.padding, up2=up2,
-                            act=act, res_up2=res_up2, scale_per_n=scale_per_n, algo=default_algo())
+    def spec(self, act=ops.ACT_NONE, up2=False, res_up2=False, scale_per_n=False, pad=None):
+        return ops.ConvSpec(k=self.kernel_size, co=self.out_channels, stride=self.stride,
+                            pad=self.padding if pad is None else pad, up2=up2, act=act, res_up2=res_up2,
+                            scale_per_n=scale_per_n, algo=default_algo())
 
     def packed(self):
         return ops.pack_weight(self.weight)
@@ -47,6 +48,15 @@ class Conv3dParams(nn.Module):
         scale: per-(n, channel) multiplier (Dropout3d mask) -- mutually exclusive with bn."""
         shift = self.bias
         per_n = False
+        pad = None
+        shard = dist.current()
+        if shard is not None and shard.world > 1 and self.kernel_size[0] > 1:
+            # depth-sharded volume: fetch the depth halo from the ring neighbours, then convolve depth-VALID
+            if up2:
+                raise NotImplementedError("depth sharding of up-sampling convs (U-Net) is not part of the path")
+            lo, hi = dist.conv_depth_halo(self.kernel_size[0], self.stride, self.padding[0])
+            x = dist.halo_exchange(x, lo, hi, shard)
+            pad = (0, self.padding[1], self.padding[2])
         if bn is not None:
             eps = bn.eps if bn_eps is None else bn_eps
             s = bn.weight * torch.rsqrt(bn.running_var + eps)
@@ -55,7 +65,7 @@ class Conv3dParams(nn.Module):
             scale = s.detach()
         elif scale is not None:
             per_n = True
-        return ops.conv3d(x, self.packed(), self.spec(act, up2, res_up2, per_n), scale=scale, shift=shift, res=res)
+        return ops.conv3d(x, self.packed(), self.spec(act, up2, res_up2, per_n, pad), scale=scale, shift=shift, res=res)
 
     def extra_repr(self):
         return "%d, %d, kernel_size=%s, stride=%d, padding=%s, bias=%s" % (

@@ -1,0 +1,82 @@
+"""Worker for the world_size-2 gloo tests (spawned by tests/test_dist_gloo.py).  Runs on CPU tensors through the
+HIP emulator build of the kernels (CFUN_LIB_PATH) -- the exchange logic is what is under test."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = port
+    os.environ["CFUN_CONV_ALGO"] = "direct"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cfun_amd import dist as cdist
+    from cfun_amd import ops, step
+    import module_cases as mc
+
+    res = {}
+    # 1) halo exchange forward + backward against plain padding of the full tensor
+    g = torch.Generator().manual_seed(0)
+    full = torch.randn(1, 8, 3, 4, 4, generator=g)
+    gy_full = torch.randn(1, 8 + 2 * world, 3, 4, 4, generator=g)     # per-rank padded slabs, concatenated
+    with cdist.depth_sharded() as sh:
+        x = cdist.slab(full, dim=1).clone().requires_grad_(True)
+        y = cdist.halo_exchange(x, 1, 1)
+        dl = full.shape[1] // world
+        gy = gy_full[:, rank * (dl + 2):(rank + 1) * (dl + 2)]
+        (y * gy).sum().backward()
+    res["halo_y"] = y.detach().numpy()
+    res["halo_gx"] = x.grad.numpy()
+
+    # 2) depth-sharded FPN -> RPN -> proposals == single-rank result
+    cfg = mc.tiny_config("beginning")
+    cfg.IMAGE_SHAPE = np.array([32, 32, 32, 1])           # D = 32: 16 planes per rank, 1 p3 plane per rank
+    torch.manual_seed(0)
+    net = step.CFUNHotPath(cfg).eval()
+    image = torch.randn(1, 1, 32, 32, 32, generator=g)
+    with torch.no_grad():
+        with cdist.depth_sharded():
+            p2, p3, logits, probs, bbox, rois = cdist.sharded_backbone_rpn(net, cdist.slab(image, dim=2))
+        if rank == 0:
+            rp2, rp3, rlogits, rprobs, rbbox = net.backbone_rpn(image)
+            rrois = net.proposals(rprobs, rbbox, "inference")
+            res.update(ref_p2=rp2.numpy(), ref_p3=rp3.numpy(), ref_logits=rlogits.numpy(), ref_bbox=rbbox.numpy(),
+                       ref_rois=rrois.numpy())
+    res.update(p2=p2.numpy(), p3=p3.numpy(), logits=logits.numpy(), bbox=bbox.numpy(), rois=rois.numpy())
+
+    # 3) a depth-coupled conv trains through the halo exchange: gradients equal the unsharded ones
+    from cfun_amd.layers import Conv3dParams
+    torch.manual_seed(1)
+    conv = Conv3dParams(4, 8, 3, padding=1)
+    xs = torch.randn(1, 8, 4, 4, 4, generator=g)
+    gys = torch.randn(1, 8, 4, 4, 8, generator=g)
+    with cdist.depth_sharded():
+        xl = cdist.slab(xs, dim=1).clone().requires_grad_(True)
+        yl = conv(xl)
+        (yl * cdist.slab(gys, dim=1)).sum().backward()
+        wg = conv.weight.grad.clone()
+        dist.all_reduce(wg)                                  # data-parallel style sum of the slabs' contributions
+    res["conv_y"] = yl.detach().numpy()
+    res["conv_gx"] = xl.grad.numpy()
+    res["conv_gw"] = wg.numpy()
+    if rank == 0:
+        conv.weight.grad = None
+        xr = xs.clone().requires_grad_(True)
+        yr = conv(xr)
+        (yr * gys).sum().backward()
+        res.update(ref_conv_y=yr.detach().numpy(), ref_conv_gx=xr.grad.numpy(), ref_conv_gw=conv.weight.grad.numpy())
+    np.savez(out % rank, **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,60 @@
+"""CPU tier: the multi-GPU path (cfun_amd.dist) with world_size 2 over gloo -- halo exchange (forward and
+backward), depth-sharded FPN -> RPN -> proposal all-gather vs the single-rank result, and a depth-coupled conv
+trained through the exchange.  The kernels run through the HIP emulator build (CPU tensors)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return str(p)
+
+
+def test_depth_sharding_world2(emu_lib, tmp_path):
+    port = _free_port()
+    out = str(tmp_path / "rank%d.npz")
+    env = dict(os.environ, CFUN_LIB_PATH=emu_lib, PYTHONPATH=ROOT)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(r), "2", port, out],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    logs = [p.communicate(timeout=900)[0].decode() for p in procs]
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log[-3000:]
+    r = [dict(np.load(out % k)) for k in range(2)]
+
+    # halo exchange: rank k's padded slab = planes [8k-1, 8k+5) of the zero-padded full tensor
+    import torch
+    g = torch.Generator().manual_seed(0)
+    full = torch.randn(1, 8, 3, 4, 4, generator=g)
+    gy_full = torch.randn(1, 12, 3, 4, 4, generator=g)
+    padded = torch.nn.functional.pad(full, (0, 0, 0, 0, 0, 0, 1, 1)).numpy()
+    gx_ref = np.zeros((1, 10, 3, 4, 4), np.float32)
+    for k in range(2):
+        np.testing.assert_array_equal(r[k]["halo_y"], padded[:, 4 * k:4 * k + 6])
+        gx_ref[:, 4 * k:4 * k + 6] += gy_full[:, 6 * k:6 * k + 6].numpy()
+    for k in range(2):
+        np.testing.assert_allclose(r[k]["halo_gx"], gx_ref[:, 1 + 4 * k:5 + 4 * k], rtol=0, atol=1e-6)
+
+    # sharded backbone / RPN / proposals
+    ref = r[0]
+    np.testing.assert_allclose(np.concatenate([r[0]["p2"], r[1]["p2"]], axis=1), ref["ref_p2"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(np.concatenate([r[0]["p3"], r[1]["p3"]], axis=1), ref["ref_p3"], rtol=1e-5, atol=1e-5)
+    for k in range(2):
+        np.testing.assert_allclose(r[k]["logits"], ref["ref_logits"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(r[k]["bbox"], ref["ref_bbox"], rtol=1e-5, atol=1e-5)
+        assert r[k]["rois"].shape == ref["ref_rois"].shape
+        np.testing.assert_allclose(r[k]["rois"], ref["ref_rois"], rtol=0, atol=1e-5)
+    np.testing.assert_array_equal(r[0]["rois"], r[1]["rois"])     # every rank holds the identical proposal set
+
+    # conv through the exchange
+    np.testing.assert_allclose(np.concatenate([r[0]["conv_y"], r[1]["conv_y"]], axis=1), ref["ref_conv_y"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(np.concatenate([r[0]["conv_gx"], r[1]["conv_gx"]], axis=1), ref["ref_conv_gx"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(r[0]["conv_gw"], ref["ref_conv_gw"], rtol=1e-4, atol=1e-5)
