@@ -21,7 +21,7 @@ class ConvParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("N", "Di", "Hi", "Wi", "Ci", "Do", "Ho", "Wo", "Co", "CoP", "CiP",
                                          "kd", "kh", "kw", "stride", "pd", "ph", "pw", "up2", "act")] + \
                [("slope", C.c_float)] + \
-               [(n, C.c_int32) for n in ("scale_mode", "has_shift", "res_mode", "res_up2", "d2s", "algo")]
+               [(n, C.c_int32) for n in ("scale_mode", "has_shift", "res_mode", "res_up2", "d2s", "d2s_cq", "tap_skip", "algo")]
 
 
 _P = C.c_void_p

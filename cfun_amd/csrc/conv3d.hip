@@ -17,7 +17,7 @@ int cfun_wgrad_c1(const float*, const float*, float*, const CfunConv3dParams*, v
 namespace {
 
 typedef int (*FwdFn)(int, const float*, const float*, const float*, const float*, const float*, float*,
-                     const CfunConv3dParams&, int, hipStream_t);
+                     const CfunConv3dParams&, const cfun_mfma::ConvMode&, hipStream_t);
 typedef void (*PlanFn)(const CfunConv3dParams&, int, cfun_mfma::WgPlan*);
 typedef int (*WgFn)(const float*, const float*, float*, const CfunConv3dParams&, const cfun_mfma::WgPlan&, hipStream_t);
 
@@ -41,6 +41,16 @@ const Shape* find_shape(int kd, int kh, int kw, int s) {
   for (const Shape& sh : kShapes)
     if (sh.kd == kd && sh.kh == kh && sh.kw == kw && sh.s == s) return &sh;
   return nullptr;
+}
+
+using cfun_mfma::ConvMode;
+const ConvMode kPlain = {0, 0, 0, 0, 0};
+
+// tap skipping needs every output-channel tile inside one parity group: largest tile that divides Co/8
+int pick_nsub_parity(int cqp, int max_nsub) {
+  for (int n = max_nsub; n >= 1; --n)
+    if (cqp % (16 * n) == 0) return n;
+  return 0;
 }
 
 // number of 16-channel subtiles per block: minimise padded channels, prefer wide tiles on ties
@@ -69,7 +79,10 @@ bool valid_params(const CfunConv3dParams* p) {
   // output size must match the conv arithmetic
   if (!standard_dims(p)) return false;
   if (p->d2s) {
-    if (p->Co & 7) return false;
+    if ((p->Co & 7) || p->up2 || p->d2s_cq < 0 || p->d2s_cq > (p->Co >> 3)) return false;
+    if (p->tap_skip && !(p->kd == 3 && p->kh == 3 && p->kw == 3 && p->stride == 1)) return false;
+  } else if (p->tap_skip || p->d2s_cq) {
+    return false;
   } else if (p->res_mode && p->res_up2 && ((p->Do | p->Ho | p->Wo) & 1)) {
     return false;
   }
@@ -78,7 +91,11 @@ bool valid_params(const CfunConv3dParams* p) {
 
 const Shape* mfma_shape(const CfunConv3dParams* p) {
   if ((p->Ci & 3) || (p->Co & 3)) return nullptr;
-  if (p->d2s && ((p->Co >> 3) & 3)) return nullptr;   // a lane's float4 must stay inside one parity group
+  if (p->d2s) {   // a lane's float4 must stay inside one parity group; tap skipping needs tile | parity group
+    const int cqp = p->Co >> 3, cq = p->d2s_cq > 0 ? p->d2s_cq : cqp;
+    if ((cqp & 3) || (cq & 3)) return nullptr;
+    if (p->tap_skip && pick_nsub_parity(cqp, 5) == 0) return nullptr;
+  }
   const Shape* s = find_shape(p->kd, p->kh, p->kw, p->stride);
   if (!s) return nullptr;
   if (p->Co > 16 * s->max_nsub && s->max_nsub == 1) return nullptr;
@@ -96,7 +113,7 @@ bool make_dgrad_params(const CfunConv3dParams* p, CfunConv3dParams* q) {
   q->pd = p->kd - 1 - p->pd; q->ph = p->kh - 1 - p->ph; q->pw = p->kw - 1 - p->pw;
   if (q->pd < 0 || q->ph < 0 || q->pw < 0) return false;
   q->up2 = 0; q->act = CFUN_ACT_NONE; q->scale_mode = 0; q->has_shift = 0; q->res_mode = 0; q->res_up2 = 0;
-  q->d2s = 0;
+  q->d2s = 0; q->d2s_cq = 0; q->tap_skip = 0;
   return true;
 }
 
@@ -140,7 +157,13 @@ CfunConv3dParams folded_s2_params(const CfunConv3dParams* p) {
   q.CoP = (8 * p->Ci + 15) / 16 * 16; q.CiP = p->CoP;
   q.kd = q.kh = q.kw = 2; q.stride = 1; q.pd = q.ph = q.pw = 0;
   q.up2 = 0; q.act = CFUN_ACT_NONE; q.scale_mode = 0; q.has_shift = 0; q.res_mode = 0; q.res_up2 = 0; q.d2s = 1;
+  q.d2s_cq = 0; q.tap_skip = 0;
   return q;
+}
+
+int wgrad_nsub(const CfunConv3dParams* p, const Shape* s) {
+  if (p->d2s && p->tap_skip) return pick_nsub_parity(p->Co >> 3, s->max_nsub);
+  return pick_nsub(p->CoP, s->max_nsub);
 }
 
 bool use_mfma_dgrad(const CfunConv3dParams* p, CfunConv3dParams* q, const Shape** s) {
@@ -176,7 +199,10 @@ int cfun_conv3d_fwd(const float* x, const float* wp, const float* scale, const f
     if (!cfun_aligned16(x) || !cfun_aligned16(wp) || !cfun_aligned16(y) || (scale && !cfun_aligned16(scale)) ||
         (shift && !cfun_aligned16(shift)) || (res && !cfun_aligned16(res)))
       return CFUN_EALIGN;
-    return s->fwd(pick_nsub(p->Co, s->max_nsub), x, wp, scale, shift, res, y, *p, 0, cfun_st(stream));
+    ConvMode md = kPlain;
+    int nsub = pick_nsub(p->Co, s->max_nsub);
+    if (p->d2s && p->tap_skip) { md.tap_skip = 1; nsub = pick_nsub_parity(p->Co >> 3, s->max_nsub); }
+    return s->fwd(nsub, x, wp, scale, shift, res, y, *p, md, cfun_st(stream));
   }
   if (p->algo == CFUN_ALGO_MFMA) return CFUN_EINVAL;
   return cfun_conv_fwd_direct(x, wp, scale, shift, res, y, p, cfun_st(stream));
@@ -206,14 +232,22 @@ int cfun_conv3d_bwd_data(const float* g, const float* wpT, float* dx, const Cfun
                        (float*)ws, p->Ci, p->Co, p->CiP, q.CoP);
     CFUN_LAUNCH_CHECK();
     const Shape* s2 = find_shape(2, 2, 2, 1);
-    return s2->fwd(pick_nsub(q.Co, s2->max_nsub), g, (const float*)ws, nullptr, nullptr, nullptr, dx, q, 0, cfun_st(stream));
+    return s2->fwd(pick_nsub(q.Co, s2->max_nsub), g, (const float*)ws, nullptr, nullptr, nullptr, dx, q, kPlain, cfun_st(stream));
   }
   if (use_mfma_dgrad(p, &q, &s)) {
     if (!cfun_aligned16(g) || !cfun_aligned16(wpT) || !cfun_aligned16(dx)) return CFUN_EALIGN;
     const int nsub = pick_nsub(q.Co, s->max_nsub);
-    if (!p->up2) return s->fwd(nsub, g, wpT, nullptr, nullptr, nullptr, dx, q, 1, cfun_st(stream));
+    ConvMode md = kPlain;
+    md.flip = 1;
+    if (p->d2s) {   // g is the hi-res gradient of y: gather the parities while staging, skip folded-zero taps
+      md.in_s2d = 1;
+      md.in_cqp = p->Co >> 3;
+      md.in_cq = p->d2s_cq > 0 ? p->d2s_cq : md.in_cqp;
+      md.tap_skip = p->tap_skip ? 2 : 0;
+    }
+    if (!p->up2) return s->fwd(nsub, g, wpT, nullptr, nullptr, nullptr, dx, q, md, cfun_st(stream));
     if (ws_bytes < cfun_conv3d_bwd_data_workspace_bytes(p) || !cfun_aligned16(ws)) return CFUN_EWORKSPACE;
-    const int rc = s->fwd(nsub, g, wpT, nullptr, nullptr, nullptr, (float*)ws, q, 1, cfun_st(stream));
+    const int rc = s->fwd(nsub, g, wpT, nullptr, nullptr, nullptr, (float*)ws, q, md, cfun_st(stream));
     if (rc) return rc;
     return cfun_upsample2_bwd((const float*)ws, dx, p->N, p->Di, p->Hi, p->Wi, p->Ci, stream);
   }
@@ -227,7 +261,7 @@ size_t cfun_conv3d_bwd_weight_workspace_bytes(const CfunConv3dParams* p) {
   const Shape* s = p->algo == CFUN_ALGO_DIRECT ? nullptr : mfma_shape(p);
   if (s) {
     cfun_mfma::WgPlan w;
-    s->plan(*p, pick_nsub(p->CoP, s->max_nsub), &w);
+    s->plan(*p, wgrad_nsub(p, s), &w);
     return cfun_align_up((size_t)w.nchunks * w.kslots * p->kd * p->kh * p->kw * p->Ci * p->CoP * sizeof(float), 256);
   }
   return cfun_align_up(cfun_direct_wgrad_ws(p), 256);
@@ -246,7 +280,7 @@ int cfun_conv3d_bwd_weight(const float* x, const float* g, float* dwp, const Cfu
     if (ws_bytes < cfun_conv3d_bwd_weight_workspace_bytes(p)) return CFUN_EWORKSPACE;
     const int64_t nout = (int64_t)p->kd * p->kh * p->kw * p->Ci * p->CoP;
     cfun_mfma::WgPlan w;
-    s->plan(*p, pick_nsub(p->CoP, s->max_nsub), &w);
+    s->plan(*p, wgrad_nsub(p, s), &w);
     if (w.ntiles == 0) return (int)hipMemsetAsync(dwp, 0, nout * sizeof(float), cfun_st(stream));
     const int rc = s->wgrad(x, g, (float*)ws, *p, w, cfun_st(stream));
     if (rc) return rc;

@@ -64,7 +64,7 @@ k_conv_fwd_direct(const float* __restrict__ x, const float* __restrict__ wp, con
                ? ((((int64_t)o.n * (p.Do >> 1) + (o.z >> 1)) * (p.Ho >> 1) + (o.y >> 1)) * (p.Wo >> 1) + (o.x >> 1))
                : v;
   }
-  const int Cq = p.Co >> 3;   // d2s only
+  const int CqP = p.Co >> 3, Cq = p.d2s_cq > 0 ? p.d2s_cq : CqP;   // d2s only: padded / valid channels per parity
 #pragma unroll
   for (int j = 0; j < COT; ++j) {
     const int co = co0 + j;
@@ -74,7 +74,8 @@ k_conv_fwd_direct(const float* __restrict__ x, const float* __restrict__ wp, con
       else if (p.scale_mode == 2) r *= scale[o.n * p.Co + co];
       if (p.has_shift) r += shift[co];
       if (p.d2s) {
-        const int q = co / Cq, oc = co - q * Cq;
+        const int q = co / CqP, oc = co - q * CqP;
+        if (oc >= Cq) continue;
         if (p.res_mode) r += res[ridx * Cq + oc];
         const int64_t hv = (((int64_t)o.n * 2 * p.Do + 2 * o.z + (q >> 2)) * 2 * p.Ho + 2 * o.y + ((q >> 1) & 1)) * 2 * p.Wo +
                            2 * o.x + (q & 1);
@@ -122,8 +123,17 @@ k_conv_bwd_data_direct(const float* __restrict__ g, const float* __restrict__ wp
               const int tap = (dz * p.kh + dy) * p.kw + dxx;
               const float* gp = g + ((((int64_t)i.n * p.Do + zo) * p.Ho + yo) * p.Wo + xo) * p.Co;
               const float* wrow = wpT + (int64_t)tap * p.Co * p.CiP + ci0;
+              const int CqP = p.Co >> 3, Cq = p.d2s_cq > 0 ? p.d2s_cq : CqP;
               for (int co = 0; co < p.Co; ++co) {
-                const float gv = gp[co];
+                float gv;
+                if (p.d2s) {   // g is the hi-res gradient of y [N,2Do,2Ho,2Wo,Cq]
+                  const int q = co / CqP, oc = co - q * CqP;
+                  if (oc >= Cq) continue;
+                  gv = g[((((int64_t)i.n * 2 * p.Do + 2 * zo + (q >> 2)) * 2 * p.Ho + 2 * yo + ((q >> 1) & 1)) * 2 * p.Wo +
+                          2 * xo + (q & 1)) * Cq + oc];
+                } else {
+                  gv = gp[co];
+                }
 #pragma unroll
                 for (int j = 0; j < CIT; ++j) acc[j] = fmaf(gv, wrow[(int64_t)co * p.CiP + j], acc[j]);
               }
@@ -161,7 +171,20 @@ k_conv_bwd_weight_direct(const float* __restrict__ x, const float* __restrict__ 
     if (iz >= 0 && iz < Dv && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv) {
       const float xv = x[((((int64_t)o.n * p.Di + (iz >> sh)) * p.Hi + (iy >> sh)) * p.Wi + (ix >> sh)) * p.Ci + ci];
       const float* gp = g + v * p.Co + co;
-      if (co + 3 < p.Co) {
+      if (p.d2s) {   // gather the 4 columns (q, oc) from the hi-res gradient
+        const int CqP = p.Co >> 3, Cq = p.d2s_cq > 0 ? p.d2s_cq : CqP;
+        float gg[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) {
+          const int cj = co + j;
+          if (cj < p.Co) {
+            const int q = cj / CqP, oc = cj - q * CqP;
+            if (oc < Cq)
+              gg[j] = g[((((int64_t)o.n * 2 * p.Do + 2 * o.z + (q >> 2)) * 2 * p.Ho + 2 * o.y + ((q >> 1) & 1)) * 2 * p.Wo +
+                         2 * o.x + (q & 1)) * Cq + oc];
+          }
+        }
+        a0 = fmaf(xv, gg[0], a0); a1 = fmaf(xv, gg[1], a1); a2 = fmaf(xv, gg[2], a2); a3 = fmaf(xv, gg[3], a3);
+      } else if (co + 3 < p.Co) {
         a0 = fmaf(xv, gp[0], a0); a1 = fmaf(xv, gp[1], a1); a2 = fmaf(xv, gp[2], a2); a3 = fmaf(xv, gp[3], a3);
       } else {
         if (co + 0 < p.Co) a0 = fmaf(xv, gp[0], a0);

@@ -36,6 +36,29 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
   return base + local;
 }
 
+// Internal launch modes derived by the C entry points (conv3d.hip) from CfunConv3dParams.
+struct ConvMode {
+  int flip;      // mirrored taps: the data gradient of a stride-1 conv
+  int in_s2d;    // the logical input [N,Di,Hi,Wi,8*in_cq] is gathered from a hi-res tensor [N,2Di,2Hi,2Wi,in_cq]
+                 // (the output gradient of a depth-to-space conv); weight rows of parity q start at q*in_cqp
+  int in_cq, in_cqp;
+  int tap_skip;  // 0 none | 1 by the output-channel tile's parity | 2 by the input chunk's parity (flipped taps)
+};
+
+// taps of a parity-folded "nearest x2 -> 3x3x3" kernel that are non-zero for output parity q = (pz,py,px):
+// per axis the 2 low-resolution taps {p, p+1} of {0,1,2}
+__device__ __forceinline__ unsigned parity_tapmask(int q, bool flip) {
+  unsigned m = 0;
+  const int pz = q >> 2, py = (q >> 1) & 1, px = q & 1;
+  for (int dz = pz; dz <= pz + 1; ++dz)
+    for (int dy = py; dy <= py + 1; ++dy)
+      for (int dx = px; dx <= px + 1; ++dx) {
+        const int tap = (dz * 3 + dy) * 3 + dx;
+        m |= 1u << (flip ? 26 - tap : tap);
+      }
+  return m;
+}
+
 template <int KD, int KH, int KW, int S>
 struct FwdTile {
   static constexpr int TD = 4, TH = 4, TW = 16;
@@ -54,7 +77,7 @@ template <int KD, int KH, int KW, int S, int NSUB>
 __global__ void __launch_bounds__(256)
 k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale,
             const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
-            CfunConv3dParams p, int flip, int ntz, int nty, int ntx, int ncot) {
+            CfunConv3dParams p, ConvMode md, int ntz, int nty, int ntx, int ncot) {
   using T = FwdTile<KD, KH, KW, S>;
   constexpr int TAPS = T::TAPS, NT = 16 * NSUB, NTP = pad_row16(NT);
   constexpr int W_ITEMS = TAPS * NT;  // float4 items per weight chunk: TAPS*4 rows x NT/4
@@ -86,15 +109,33 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
       int vz, vy, vx;
       if (T::COMPACT) { vz = (z0 + iz) * S - p.pd; vy = (y0 + iy) * S - p.ph; vx = (x0 + ix) * S - p.pw; }
       else { vz = z0 * S - p.pd + iz; vy = y0 * S - p.ph + iy; vx = x0 * S - p.pw + ix; }
-      if (vz >= 0 && vz < Dv && vy >= 0 && vy < Hv && vx >= 0 && vx < Wv)
-        in_off[i] = ((((int64_t)n * p.Di + (vz >> sh)) * p.Hi + (vy >> sh)) * p.Wi + (vx >> sh)) * p.Ci;
+      if (vz >= 0 && vz < Dv && vy >= 0 && vy < Hv && vx >= 0 && vx < Wv) {
+        if (md.in_s2d)   // parity-0 voxel of the hi-res tensor; the chunk's parity offset is added in prefetch()
+          in_off[i] = ((((int64_t)n * 2 * p.Di + 2 * vz) * 2 * p.Hi + 2 * vy) * 2 * p.Wi + 2 * vx) * md.in_cq;
+        else
+          in_off[i] = ((((int64_t)n * p.Di + (vz >> sh)) * p.Hi + (vy >> sh)) * p.Wi + (vx >> sh)) * p.Ci;
+      }
     }
   }
+  // chunk c -> (offset into x added to in_off, first weight row, parity of the chunk)
+  const int cpq = md.in_s2d ? (md.in_cq >> 2) : 1;   // chunks per parity
+  auto chunk_xoff = [&](int c) -> int64_t {
+    if (!md.in_s2d) return (int64_t)c * 4;
+    const int q = c / cpq, o4 = c - q * cpq;
+    return ((int64_t)((q >> 2) * 2 * p.Hi + ((q >> 1) & 1)) * 2 * p.Wi + (q & 1)) * md.in_cq + o4 * 4;
+  };
+  auto chunk_wrow = [&](int c) -> int {
+    if (!md.in_s2d) return c * 4;
+    const int q = c / cpq, o4 = c - q * cpq;
+    return q * md.in_cqp + o4 * 4;
+  };
   float4 xin[T::IN_LOADS], win[W_LOADS];
-  auto prefetch = [&](int c0) {
+  auto prefetch = [&](int c) {
+    const int64_t xo = chunk_xoff(c);
+    const int wrow = chunk_wrow(c);
 #pragma unroll
     for (int i = 0; i < T::IN_LOADS; ++i)
-      xin[i] = in_off[i] >= 0 ? *reinterpret_cast<const float4*>(x + in_off[i] + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      xin[i] = in_off[i] >= 0 ? *reinterpret_cast<const float4*>(x + in_off[i] + xo) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < W_LOADS; ++i) {
       const int it = tid + i * 256;
@@ -102,9 +143,9 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
       if (it < W_ITEMS) {
         const int row = it / (NT / 4), col = (it % (NT / 4)) * 4;
         const int tap = row >> 2, cc = row & 3;
-        const int tapw = flip ? TAPS - 1 - tap : tap;
+        const int tapw = md.flip ? TAPS - 1 - tap : tap;
         if (cobase + col < p.CoP)
-          win[i] = *reinterpret_cast<const float4*>(wp + ((int64_t)tapw * p.Ci + c0 + cc) * p.CoP + cobase + col);
+          win[i] = *reinterpret_cast<const float4*>(wp + ((int64_t)tapw * p.Ci + wrow + cc) * p.CoP + cobase + col);
       }
     }
   };
@@ -136,13 +177,18 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
   const float* Xw = Xl + (lane >> 4) * T::PLANEP + (wv * T::RS * T::IY) * T::IX + (lane & 15) * T::RS;
   const float* Ww = Wl + (lane >> 4) * NTP + (lane & 15);
 
-  const int nchunks = p.Ci >> 2;
+  // p.Ci is the number of weight rows per tap; with in_s2d only the valid channels of each parity are visited
+  const int nchunks = md.in_s2d ? 8 * cpq : (p.Ci >> 2);
+  const int CqP = p.Co >> 3;   // d2s: padded channels per parity
+  unsigned tapmask = 0xffffffffu;
+  if (TAPS == 27 && md.tap_skip == 1) tapmask = parity_tapmask(cobase / CqP, false);
   prefetch(0);
   for (int c = 0; c < nchunks; ++c) {
     __syncthreads();           // every wave is done reading the previous chunk
     commit();
     __syncthreads();
-    if (c + 1 < nchunks) prefetch((c + 1) * 4);
+    if (c + 1 < nchunks) prefetch(c + 1);
+    if (TAPS == 27 && md.tap_skip == 2) tapmask = parity_tapmask(c / cpq, true);
 #pragma unroll
     for (int dz = 0; dz < KD; ++dz)
 #pragma unroll
@@ -150,6 +196,7 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
 #pragma unroll
         for (int dx = 0; dx < KW; ++dx) {
           const int tap = (dz * KH + dy) * KW + dx;
+          if (TAPS == 27 && !((tapmask >> (tap & 31)) & 1u)) continue;   // wave-uniform: folded-zero taps
           float a[NSUB];
 #pragma unroll
           for (int nn = 0; nn < NSUB; ++nn) a[nn] = Ww[tap * 4 * NTP + nn * 16];
@@ -187,8 +234,9 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
         const float4 t = *reinterpret_cast<const float4*>(shift + co);
         r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
       }
-      const int Cq = p.Co >> 3;
-      const int q = p.d2s ? co / Cq : 0, oc = p.d2s ? co - q * Cq : co;
+      const int Cq = p.d2s_cq > 0 ? p.d2s_cq : CqP;          // valid channels per parity (= channels of y)
+      const int q = p.d2s ? co / CqP : 0, oc = p.d2s ? co - q * CqP : co;
+      if (p.d2s && oc >= Cq) continue;                        // per-parity channel padding
       if (p.res_mode) {
         const float4 t = *reinterpret_cast<const float4*>(res + rv * (p.d2s ? Cq : p.Co) + oc);
         r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
@@ -208,7 +256,7 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
 
 template <int KD, int KH, int KW, int S, int NSUB>
 int launch_conv_mfma(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
-                     float* y, const CfunConv3dParams& p, int flip, hipStream_t st) {
+                     float* y, const CfunConv3dParams& p, const ConvMode& md, hipStream_t st) {
   using T = FwdTile<KD, KH, KW, S>;
   constexpr int NT = 16 * NSUB, NTP = pad_row16(NT);
   const int ntz = cdiv(p.Do, T::TD), nty = cdiv(p.Ho, T::TH), ntx = cdiv(p.Wo, T::TW), ncot = cdiv(p.Co, NT);
@@ -221,7 +269,7 @@ int launch_conv_mfma(const float* x, const float* wp, const float* scale, const 
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, x, wp, scale, shift, res, y, p, flip, ntz, nty, ntx, ncot);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, x, wp, scale, shift, res, y, p, md, ntz, nty, ntx, ncot);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }
@@ -231,7 +279,7 @@ constexpr int max_nsub() { return KD * KH * KW > 27 ? 1 : 5; }   // 5x5x5: LDS /
 
 template <int KD, int KH, int KW, int S>
 int dispatch_nsub(int nsub, const float* x, const float* wp, const float* scale, const float* shift, const float* res,
-                  float* y, const CfunConv3dParams& p, int flip, hipStream_t st) {
+                  float* y, const CfunConv3dParams& p, const ConvMode& flip, hipStream_t st) {
   if constexpr (max_nsub<KD, KH, KW, S>() == 1) {
     if (nsub != 1) return CFUN_EINVAL;
     return launch_conv_mfma<KD, KH, KW, S, 1>(x, wp, scale, shift, res, y, p, flip, st);
@@ -324,9 +372,19 @@ k_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ g, float* __
         const int vox = it / (NT / 4), col = (it % (NT / 4)) * 4;
         const int lx = vox % T::TW, ly = (vox / T::TW) % T::TH, lz = vox / (T::TW * T::TH);
         const int oz = z0 + lz, oy = y0 + ly, ox = x0 + lx;
-        if (cobase + col < p.Co && oz < p.Do && oy < p.Ho && ox < p.Wo)
-          gin[i] = *reinterpret_cast<const float4*>(
-              g + ((((int64_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * p.Co + cobase + col);
+        if (cobase + col < p.Co && oz < p.Do && oy < p.Ho && ox < p.Wo) {
+          if (p.d2s) {   // g is the hi-res gradient of y [N,2Do,2Ho,2Wo,Cq]: gather parity q, channel o
+            const int CqP = p.Co >> 3, Cq = p.d2s_cq > 0 ? p.d2s_cq : CqP;
+            const int co = cobase + col, q = co / CqP, o = co - q * CqP;
+            if (o < Cq)
+              gin[i] = *reinterpret_cast<const float4*>(
+                  g + ((((int64_t)n * 2 * p.Do + 2 * oz + (q >> 2)) * 2 * p.Ho + 2 * oy + ((q >> 1) & 1)) * 2 * p.Wo +
+                       2 * ox + (q & 1)) * Cq + o);
+          } else {
+            gin[i] = *reinterpret_cast<const float4*>(
+                g + ((((int64_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * p.Co + cobase + col);
+          }
+        }
       }
     }
   };
@@ -355,6 +413,8 @@ k_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ g, float* __
     const int tap = t * T::TSPLIT + tslot;
     const int dz = tap / (KH * KW), dy = (tap / KW) % KH, dx = tap % KW;
     toff[t] = tap < TAPS ? ((dz * T::IY + dy) * T::IX + dx) * T::XS : -1;
+    // parity-folded up2 kernel: this co tile lies inside one parity group, taps outside its 2x2x2 are zero
+    if (TAPS == 27 && p.tap_skip && tap < TAPS && !((parity_tapmask(cobase / (p.Co >> 3), false) >> tap) & 1u)) toff[t] = -1;
   }
 
   if (t_begin < t_end) prefetch(t_begin);
@@ -466,14 +526,16 @@ int dispatch_wgrad(const float* x, const float* g, float* partial, const CfunCon
 // per-shape translation units (conv3d_mfma_*.hip) export these C++ entry points
 #define CFUN_MFMA_DECL(NAME)                                                                                        \
   int cfun_mfma_fwd_##NAME(int nsub, const float* x, const float* wp, const float* scale, const float* shift,       \
-                           const float* res, float* y, const CfunConv3dParams& p, int flip, hipStream_t st);        \
+                           const float* res, float* y, const CfunConv3dParams& p, const cfun_mfma::ConvMode& flip,  \
+                           hipStream_t st);                                                                         \
   void cfun_mfma_wgrad_plan_##NAME(const CfunConv3dParams& p, int nsub, cfun_mfma::WgPlan* w);                      \
   int cfun_mfma_wgrad_##NAME(const float* x, const float* g, float* partial, const CfunConv3dParams& p,             \
                              const cfun_mfma::WgPlan& w, hipStream_t st);
 
 #define CFUN_MFMA_DEFINE(NAME, KD, KH, KW, S)                                                                       \
   int cfun_mfma_fwd_##NAME(int nsub, const float* x, const float* wp, const float* scale, const float* shift,       \
-                           const float* res, float* y, const CfunConv3dParams& p, int flip, hipStream_t st) {       \
+                           const float* res, float* y, const CfunConv3dParams& p, const cfun_mfma::ConvMode& flip,  \
+                           hipStream_t st) {                                                                        \
     return cfun_mfma::dispatch_nsub<KD, KH, KW, S>(nsub, x, wp, scale, shift, res, y, p, flip, st);                 \
   }                                                                                                                 \
   void cfun_mfma_wgrad_plan_##NAME(const CfunConv3dParams& p, int nsub, cfun_mfma::WgPlan* w) {                     \

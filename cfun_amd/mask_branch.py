@@ -72,12 +72,26 @@ class Modified3DUNet(nn.Module):
         b, keep = self.base_n_filter, 1.0 - self.dropout_p
         return [torch.empty((n, c), device=device).bernoulli_(keep).div_(keep) for c in (b, 2 * b, 4 * b, 8 * b, 16 * b)]
 
+    @staticmethod
+    def _up_conv(h, conv):
+        """conv3x3x3(nearest_up2(h)).  On the up-sampled grid each output parity only sees 2x2x2 distinct
+        low-resolution voxels, so the weights are folded per parity (ops.fold_up2_weight, differentiable) and the
+        conv runs on the LOW-resolution tensor with a depth-to-space epilogue, skipping the 19 folded-zero taps:
+        8/27 of the FLOPs of the straightforward "read (z>>1,y>>1,x>>1)" form, for forward, dgrad and wgrad."""
+        ci, co = conv.in_channels, conv.out_channels
+        if ci % 4 or co % 4:
+            return conv(h, up2=True)
+        cqp = (co + 15) // 16 * 16
+        spec = ops.ConvSpec(k=(3, 3, 3), co=8 * cqp, pad=(1, 1, 1), d2s=True, d2s_cq=co, tap_skip=True,
+                            algo=default_algo())
+        return ops.conv3d(h, ops.pack_weight(ops.fold_up2_weight(conv.weight, cqp)), spec)
+
     def forward_ndhwc(self, x):
         nl = ops.instnorm_lrelu
         drop = self._drop_masks(x.shape[0], x.device)
 
-        def nluc(h, holder):   # norm -> lrelu -> (up x2 folded into the conv) -> conv -> norm -> lrelu
-            return nl(holder[3](nl(h), up2=True))
+        def nluc(h, holder):   # norm -> lrelu -> nearest x2 -> 3x3x3 conv -> norm -> lrelu  (mask_branch.py:108-116)
+            return nl(self._up_conv(nl(h), holder[3]))
 
         # level 1: residual is the pre-activation stem output, context_1 is taken before the norm
         res = self.conv3d_c1_1(x)

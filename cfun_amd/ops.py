@@ -29,7 +29,7 @@ def pack_weight(w):
     return wp.contiguous()
 
 
-def fold_up2_weight(w):
+def fold_up2_weight(w, cqp=None):
     """Fold "nearest x2 upsample -> conv k^3 (pad k//2)" into a 3x3x3 conv (pad 1) on the LOW-resolution input
     that produces the 8 output parities as channels: [O,I,k,k,k] -> [8*O, I, 3,3,3], channel ((pz*2+py)*2+px)*O + o.
     Hi-res tap t of output parity p reads low-res offset floor((p + t - k//2) / 2) in {-1,0,1}; taps that hit the
@@ -43,6 +43,9 @@ def fold_up2_weight(w):
         for t in range(k):
             f[p, (p + t - k // 2) // 2 + 1, t] = 1.0
     wf = torch.einsum("pat,qbu,rcv,oituv->pqroiabc", f, f, f, w)
+    if cqp is not None and cqp != o:   # pad every parity group to cqp output channels (tile-aligned tap skipping)
+        wf = torch.nn.functional.pad(wf, (0, 0, 0, 0, 0, 0, 0, 0, 0, cqp - o))
+        o = cqp
     return wf.reshape(8 * o, i, 3, 3, 3)
 
 
@@ -65,7 +68,9 @@ class ConvSpec:
     act: int = ACT_NONE
     res_up2: bool = False
     scale_per_n: bool = False   # scale is [N, Co] (Dropout3d mask) instead of [Co]
-    d2s: bool = False           # depth-to-space x2 epilogue (co = 8*Cq), see include/cfun_hip.h
+    d2s: bool = False           # depth-to-space x2 epilogue (co = 8*CqP), see include/cfun_hip.h
+    d2s_cq: int = 0             # valid channels per parity (0: co/8)
+    tap_skip: bool = False      # parity-folded 'nearest x2 -> 3x3x3' weights: skip the folded-zero taps
     algo: int = ALGO_AUTO
 
 
@@ -94,6 +99,8 @@ def _params(spec, x_shape, has_scale, has_shift, has_res):
     p.res_mode = int(has_res)
     p.res_up2 = int(spec.res_up2 and has_res)
     p.d2s = int(spec.d2s)
+    p.d2s_cq = int(spec.d2s_cq)
+    p.tap_skip = int(spec.tap_skip)
     p.algo = spec.algo
     return p
 
@@ -135,7 +142,8 @@ class _Conv3d(torch.autograd.Function):
         if wp.shape != (p.kd * p.kh * p.kw, p.Ci, p.CoP):
             raise RuntimeError("packed weight %s does not match conv %s" % (tuple(wp.shape), spec))
         if spec.d2s:
-            y = torch.empty((p.N, 2 * p.Do, 2 * p.Ho, 2 * p.Wo, p.Co // 8), dtype=torch.float32, device=x.device)
+            cq = spec.d2s_cq or p.Co // 8
+            y = torch.empty((p.N, 2 * p.Do, 2 * p.Ho, 2 * p.Wo, cq), dtype=torch.float32, device=x.device)
         else:
             y = torch.empty((p.N, p.Do, p.Ho, p.Wo, p.Co), dtype=torch.float32, device=x.device)
         timed = _TIMER is not None and x.is_cuda and _TIMER.match(p)
@@ -171,11 +179,7 @@ class _Conv3d(torch.autograd.Function):
             gp = torch.empty_like(dy)
             check(lib.cfun_act_bwd(ptr(y), ptr(dy), None, ptr(gp), dy.numel() // dy.shape[-1], dy.shape[-1],
                                    p.Do * p.Ho * p.Wo * (8 if spec.d2s else 1), spec.act, LRELU_SLOPE, 0, st), "act_bwd")
-        gp_out = gp     # in the layout of y (what the residual sees)
-        if spec.d2s:    # space-to-depth: [N,2D,2H,2W,Cq] -> [N,D,H,W,(pz,py,px,Cq)]
-            cq = p.Co // 8
-            gp = gp.view(p.N, p.Do, 2, p.Ho, 2, p.Wo, 2, cq).permute(0, 1, 3, 5, 2, 4, 6, 7).reshape(
-                p.N, p.Do, p.Ho, p.Wo, p.Co).contiguous()
+        gp_out = gp     # for d2s convs the kernels take the gradient in y's hi-res layout and gather the parities
         g = gp
         if scale is not None:
             g = torch.empty_like(dy)
@@ -200,7 +204,7 @@ class _Conv3d(torch.autograd.Function):
         if need_res:
             if spec.d2s:
                 dres = torch.empty(ctx.res_shape, dtype=torch.float32, device=dy.device)
-                check(lib.cfun_upsample2_bwd(ptr(gp_out), ptr(dres), p.N, p.Do, p.Ho, p.Wo, p.Co // 8, st),
+                check(lib.cfun_upsample2_bwd(ptr(gp_out), ptr(dres), p.N, p.Do, p.Ho, p.Wo, gp_out.shape[-1], st),
                       "upsample2_bwd")
             elif p.res_up2:
                 dres = torch.empty(ctx.res_shape, dtype=torch.float32, device=dy.device)

@@ -59,7 +59,8 @@ const char* cfun_error_string(int code);
  *     s      = scale[co] (scale_mode 1) | scale[n*Co+co] (scale_mode 2: Dropout3d channel mask) | 1
  *     t      = shift[co] (bias and/or folded BatchNorm) | 0
  *     r      = res[...] (res_mode 1) read at (zo>>1,yo>>1,xo>>1) when res_up2 | 0
- *   (bwd_data / bwd_weight always take g = dL/d(conv sum) as [N,Do,Ho,Wo,Co], also for d2s convs)
+ *   bwd_data / bwd_weight take g = dL/d(conv sum) in the layout of y: [N,Do,Ho,Wo,Co], or for d2s convs the
+ *   high-resolution [N,2Do,2Ho,2Wo,Cq] tensor (the kernels gather the parities themselves).
  *
  * Packed weights: wp[tap][ci][CoP] fp32, tap = (dz*kh+dy)*kw+dx, CoP = Co rounded up to 16, pad = 0.
  * bwd_data takes the transposed pack wpT[tap][co][CiP] (same tap order, CiP = Ci rounded up to 16).
@@ -85,6 +86,11 @@ typedef struct CfunConv3dParams {
                                    the residual (if any) is [N,Do,Ho,Wo,Cq] = nearest-x2 up-sampled into y.
                                    Used to run "nearest x2 upsample -> 5x5x5 conv" (mask_branch.py:118-122) as a
                                    3x3x3 conv with parity-folded weights: 27/125 of the FLOPs, same result. */
+  int32_t d2s_cq;               /* d2s: valid channels per parity (channels of y); 0 = Co/8.  Co/8 is the padded
+                                   per-parity column stride of the packed weights. */
+  int32_t tap_skip;             /* d2s + 3x3x3: the weights are a parity-folded "nearest x2 -> 3x3x3" kernel
+                                   (ops.fold_up2_weight): only the 2x2x2 taps {p,p+1}^3 of each output parity are
+                                   non-zero and the kernels skip the rest (8/27 of the FLOPs). */
   int32_t algo;                 /* CFUN_ALGO_* */
 } CfunConv3dParams;
 

@@ -175,6 +175,26 @@ def check_fold_up2(device, seed=7):
     assert_close(wd.grad, wr.grad, "dw")
 
 
+def check_fold_up2_conv3(device, ci, co, dhw, algo=ALGO_AUTO, n=2, seed=8):
+    """nearest x2 upsample -> 3x3x3 conv == parity-folded conv (2x2x2 live taps per parity, the rest skipped)
+    with depth-to-space epilogue; forward, dx and dw (through the differentiable fold)."""
+    gen = _gen(seed)
+    x = randn(gen, n, *dhw, ci)
+    w = randn(gen, co, ci, 3, 3, 3) / float(27 * ci) ** 0.5
+    gy = randn(gen, n, 2 * dhw[0], 2 * dhw[1], 2 * dhw[2], co)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv3d(F.interpolate(xr.permute(0, 4, 1, 2, 3), scale_factor=2, mode="nearest"), wr, padding=1).permute(0, 2, 3, 4, 1)
+    yr.backward(gy)
+    xd, wd = x.clone().to(device).requires_grad_(True), w.clone().to(device).requires_grad_(True)
+    cqp = (co + 15) // 16 * 16
+    spec = ops.ConvSpec(k=(3, 3, 3), co=8 * cqp, pad=(1, 1, 1), d2s=True, d2s_cq=co, tap_skip=True, algo=algo)
+    y = ops.conv3d(xd, ops.pack_weight(ops.fold_up2_weight(wd, cqp)), spec)
+    y.backward(gy.to(device))
+    assert_close(y, yr, "y")
+    assert_close(xd.grad, xr.grad, "dx")
+    assert_close(wd.grad, wr.grad, "dw")
+
+
 def check_elementwise(device, seed=2):
     gen = _gen(seed)
     for shape in ((2, 3, 4, 5, 8), (1, 3, 3, 3, 3), (1, 2, 2, 2, 1)):

@@ -24,6 +24,13 @@ def test_fold_up2_conv5(emu):
     kc.check_fold_up2(emu)
 
 
+@pytest.mark.parametrize("algo", ["mfma", "direct"])
+def test_fold_up2_conv3(emu, algo):
+    a = kc.ALGO_MFMA if algo == "mfma" else kc.ALGO_DIRECT
+    kc.check_fold_up2_conv3(emu, 8, 20, (3, 4, 5), a)
+    kc.check_fold_up2_conv3(emu, 12, 40, (2, 3, 9), a)
+
+
 def test_elementwise(emu):
     kc.check_elementwise(emu)
 

@@ -34,6 +34,15 @@ def test_fold_up2_conv5(gpu):
     kc.check_fold_up2(gpu)
 
 
+@pytest.mark.parametrize("algo", ["mfma", "direct"])
+def test_fold_up2_conv3(gpu, algo):
+    a = kc.ALGO_MFMA if algo == "mfma" else kc.ALGO_DIRECT
+    kc.check_fold_up2_conv3(gpu, 8, 20, (3, 4, 5), a)
+    kc.check_fold_up2_conv3(gpu, 12, 40, (2, 3, 9), a)
+    kc.check_fold_up2_conv3(gpu, 80, 40, (24, 24, 24))
+    kc.check_fold_up2_conv3(gpu, 320, 160, (6, 6, 6), n=4)
+
+
 def test_elementwise(gpu):
     kc.check_elementwise(gpu)
 
