@@ -17,20 +17,22 @@ int cfun_wgrad_c1(const float*, const float*, float*, const CfunConv3dParams*, v
 namespace {
 
 typedef int (*FwdFn)(int, const float*, const float*, const float*, const float*, const float*, float*,
-                     const CfunConv3dParams&, const cfun_mfma::ConvMode&, hipStream_t);
+                     const CfunConv3dParams&, const cfun_mfma::ConvMode&, void*, size_t, hipStream_t);
+typedef size_t (*FwdWsFn)(int, const CfunConv3dParams&, const cfun_mfma::ConvMode&);
 typedef void (*PlanFn)(const CfunConv3dParams&, int, cfun_mfma::WgPlan*);
 typedef int (*WgFn)(const float*, const float*, float*, const CfunConv3dParams&, const cfun_mfma::WgPlan&, hipStream_t);
 
 struct Shape {
   int kd, kh, kw, s;
   FwdFn fwd;
+  FwdWsFn fwd_ws;
   PlanFn plan;
   WgFn wgrad;
   int max_nsub;
 };
 
 #define SHAPE(NAME, KD, KH, KW, S, MAXN) \
-  { KD, KH, KW, S, cfun_mfma_fwd_##NAME, cfun_mfma_wgrad_plan_##NAME, cfun_mfma_wgrad_##NAME, MAXN }
+  { KD, KH, KW, S, cfun_mfma_fwd_##NAME, cfun_mfma_fwd_ws_##NAME, cfun_mfma_wgrad_plan_##NAME, cfun_mfma_wgrad_##NAME, MAXN }
 const Shape kShapes[] = {
     SHAPE(k333s1, 3, 3, 3, 1, 5), SHAPE(k333s2, 3, 3, 3, 2, 5), SHAPE(k111s1, 1, 1, 1, 1, 5),
     SHAPE(k111s2, 1, 1, 1, 2, 5), SHAPE(k133s1, 1, 3, 3, 1, 5), SHAPE(k311s1, 3, 1, 1, 1, 5),
@@ -173,7 +175,60 @@ bool use_mfma_dgrad(const CfunConv3dParams* p, CfunConv3dParams* q, const Shape*
   return *s != nullptr;
 }
 
+// y = act(scale * sum_k partial[k] + shift + res): the epilogue of a split-K conv (plain layout)
+__global__ void __launch_bounds__(256)
+k_splitk_finish(const float4* __restrict__ partial, int ksplit, const float* __restrict__ scale,
+                const float* __restrict__ shift, const float* __restrict__ res, float4* __restrict__ y,
+                CfunConv3dParams p, int64_t total4) {
+  const int C4 = p.Co >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    float4 a = partial[i];
+    for (int k = 1; k < ksplit; ++k) {
+      const float4 b = partial[(int64_t)k * total4 + i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    const int64_t v = i / C4;
+    const int co = (int)(i - v * C4) * 4;
+    if (p.scale_mode) {
+      const int64_t n = v / ((int64_t)p.Do * p.Ho * p.Wo);
+      const float4 s4 = *reinterpret_cast<const float4*>(scale + (p.scale_mode == 2 ? n * p.Co : 0) + co);
+      a.x *= s4.x; a.y *= s4.y; a.z *= s4.z; a.w *= s4.w;
+    }
+    if (p.has_shift) {
+      const float4 t = *reinterpret_cast<const float4*>(shift + co);
+      a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+    }
+    if (p.res_mode) {
+      int64_t rv = v;
+      if (p.res_up2) {
+        int64_t t = v;
+        const int ox = (int)(t % p.Wo); t /= p.Wo;
+        const int oy = (int)(t % p.Ho); t /= p.Ho;
+        const int oz = (int)(t % p.Do);
+        const int64_t n = t / p.Do;
+        rv = ((n * (p.Do >> 1) + (oz >> 1)) * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
+      }
+      const float4 t4 = *reinterpret_cast<const float4*>(res + rv * p.Co + co);
+      a.x += t4.x; a.y += t4.y; a.z += t4.z; a.w += t4.w;
+    }
+    a.x = cfun_apply_act(a.x, p.act, p.slope); a.y = cfun_apply_act(a.y, p.act, p.slope);
+    a.z = cfun_apply_act(a.z, p.act, p.slope); a.w = cfun_apply_act(a.w, p.act, p.slope);
+    y[i] = a;
+  }
+}
+
 }  // namespace
+
+int cfun_splitk_finish(const float* partial, int ksplit, const float* scale, const float* shift, const float* res,
+                       float* y, const CfunConv3dParams* p, hipStream_t st) {
+  const int64_t total4 = (int64_t)p->N * p->Do * p->Ho * p->Wo * (p->Co >> 2);
+  int64_t blocks = (total4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_splitk_finish, dim3((unsigned)blocks), dim3(256), 0, st, (const float4*)partial, ksplit, scale, shift,
+                     res, (float4*)y, *p, total4);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
 
 extern "C" {
 
@@ -189,8 +244,24 @@ const char* cfun_error_string(int code) {
   }
 }
 
+static void fwd_mode(const CfunConv3dParams* p, const Shape* s, ConvMode* md, int* nsub) {
+  *md = kPlain;
+  *nsub = pick_nsub(p->Co, s->max_nsub);
+  if (p->d2s && p->tap_skip) { md->tap_skip = 1; *nsub = pick_nsub_parity(p->Co >> 3, s->max_nsub); }
+}
+
+size_t cfun_conv3d_fwd_workspace_bytes(const CfunConv3dParams* p) {
+  if (!valid_params(p)) return 0;
+  const Shape* s = p->algo == CFUN_ALGO_DIRECT ? nullptr : mfma_shape(p);
+  if (!s) return 256;
+  ConvMode md;
+  int nsub;
+  fwd_mode(p, s, &md, &nsub);
+  return cfun_align_up(s->fwd_ws(nsub, *p, md) + 256, 256);
+}
+
 int cfun_conv3d_fwd(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
-                    float* y, const CfunConv3dParams* p, cfun_stream_t stream) {
+                    float* y, const CfunConv3dParams* p, void* ws, size_t ws_bytes, cfun_stream_t stream) {
   if (!valid_params(p)) return CFUN_EINVAL;
   if ((p->scale_mode && !scale) || (p->has_shift && !shift) || (p->res_mode && !res)) return CFUN_EINVAL;
   if (p->scale_mode < 0 || p->scale_mode > 2 || p->res_mode < 0 || p->res_mode > 1) return CFUN_EINVAL;
@@ -199,10 +270,11 @@ int cfun_conv3d_fwd(const float* x, const float* wp, const float* scale, const f
     if (!cfun_aligned16(x) || !cfun_aligned16(wp) || !cfun_aligned16(y) || (scale && !cfun_aligned16(scale)) ||
         (shift && !cfun_aligned16(shift)) || (res && !cfun_aligned16(res)))
       return CFUN_EALIGN;
-    ConvMode md = kPlain;
-    int nsub = pick_nsub(p->Co, s->max_nsub);
-    if (p->d2s && p->tap_skip) { md.tap_skip = 1; nsub = pick_nsub_parity(p->Co >> 3, s->max_nsub); }
-    return s->fwd(nsub, x, wp, scale, shift, res, y, *p, md, cfun_st(stream));
+    ConvMode md;
+    int nsub;
+    fwd_mode(p, s, &md, &nsub);
+    if (ws && !cfun_aligned16(ws)) return CFUN_EALIGN;
+    return s->fwd(nsub, x, wp, scale, shift, res, y, *p, md, ws, ws ? ws_bytes : 0, cfun_st(stream));
   }
   if (p->algo == CFUN_ALGO_MFMA) return CFUN_EINVAL;
   return cfun_conv_fwd_direct(x, wp, scale, shift, res, y, p, cfun_st(stream));
@@ -213,8 +285,13 @@ size_t cfun_conv3d_bwd_data_workspace_bytes(const CfunConv3dParams* p) {
   CfunConv3dParams q;
   const Shape* s;
   if (use_folded_s2_dgrad(p)) return cfun_align_up((size_t)8 * p->Co * ((8 * p->Ci + 15) / 16 * 16) * sizeof(float), 256);
-  if (use_mfma_dgrad(p, &q, &s) && p->up2)
-    return cfun_align_up((size_t)q.N * q.Do * q.Ho * q.Wo * q.Co * sizeof(float), 256);
+  if (use_mfma_dgrad(p, &q, &s)) {
+    if (p->up2) return cfun_align_up((size_t)q.N * q.Do * q.Ho * q.Wo * q.Co * sizeof(float), 256);
+    ConvMode md = kPlain;
+    md.flip = 1;
+    if (p->d2s) { md.in_s2d = 1; md.in_cqp = p->Co >> 3; md.in_cq = p->d2s_cq > 0 ? p->d2s_cq : md.in_cqp; }
+    return cfun_align_up(s->fwd_ws(pick_nsub(q.Co, s->max_nsub), q, md) + 256, 256);   // split-K partials
+  }
   return 256;
 }
 
@@ -232,7 +309,7 @@ int cfun_conv3d_bwd_data(const float* g, const float* wpT, float* dx, const Cfun
                        (float*)ws, p->Ci, p->Co, p->CiP, q.CoP);
     CFUN_LAUNCH_CHECK();
     const Shape* s2 = find_shape(2, 2, 2, 1);
-    return s2->fwd(pick_nsub(q.Co, s2->max_nsub), g, (const float*)ws, nullptr, nullptr, nullptr, dx, q, kPlain, cfun_st(stream));
+    return s2->fwd(pick_nsub(q.Co, s2->max_nsub), g, (const float*)ws, nullptr, nullptr, nullptr, dx, q, kPlain, nullptr, 0, cfun_st(stream));
   }
   if (use_mfma_dgrad(p, &q, &s)) {
     if (!cfun_aligned16(g) || !cfun_aligned16(wpT) || !cfun_aligned16(dx)) return CFUN_EALIGN;
@@ -245,9 +322,9 @@ int cfun_conv3d_bwd_data(const float* g, const float* wpT, float* dx, const Cfun
       md.in_cq = p->d2s_cq > 0 ? p->d2s_cq : md.in_cqp;
       md.tap_skip = p->tap_skip ? 2 : 0;
     }
-    if (!p->up2) return s->fwd(nsub, g, wpT, nullptr, nullptr, nullptr, dx, q, md, cfun_st(stream));
+    if (!p->up2) return s->fwd(nsub, g, wpT, nullptr, nullptr, nullptr, dx, q, md, ws, cfun_aligned16(ws) ? ws_bytes : 0, cfun_st(stream));
     if (ws_bytes < cfun_conv3d_bwd_data_workspace_bytes(p) || !cfun_aligned16(ws)) return CFUN_EWORKSPACE;
-    const int rc = s->fwd(nsub, g, wpT, nullptr, nullptr, nullptr, (float*)ws, q, md, cfun_st(stream));
+    const int rc = s->fwd(nsub, g, wpT, nullptr, nullptr, nullptr, (float*)ws, q, md, nullptr, 0, cfun_st(stream));
     if (rc) return rc;
     return cfun_upsample2_bwd((const float*)ws, dx, p->N, p->Di, p->Hi, p->Wi, p->Ci, stream);
   }

@@ -23,6 +23,10 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// conv3d.hip: sums split-K partials in order and applies the fused epilogue
+int cfun_splitk_finish(const float* partial, int ksplit, const float* scale, const float* shift, const float* res,
+                       float* y, const CfunConv3dParams* p, hipStream_t st);
+
 namespace cfun_mfma {
 
 constexpr int pad_plane(int v, int rs) { return rs == 1 ? v + ((16 - (v % 32)) + 32) % 32 : (v | 1); }
@@ -73,11 +77,14 @@ struct FwdTile {
   static constexpr int IN_LOADS = cdiv(IVOX, 256);
 };
 
-template <int KD, int KH, int KW, int S, int NSUB>
+// SPECIAL = false: plain conv (md.in_s2d == 0, md.tap_skip == 0) -- the hot instantiation carries none of the
+// parity-fold bookkeeping.  SPECIAL = true (3x3x3 stride 1 only): s2d gather of the input and/or tap skipping.
+template <int KD, int KH, int KW, int S, int NSUB, bool SPECIAL>
 __global__ void __launch_bounds__(256)
 k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale,
             const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
-            CfunConv3dParams p, ConvMode md, int ntz, int nty, int ntx, int ncot) {
+            CfunConv3dParams p, ConvMode md, int ntz, int nty, int ntx, int ncot, float* __restrict__ partial,
+            int chunks_per_split) {
   using T = FwdTile<KD, KH, KW, S>;
   constexpr int TAPS = T::TAPS, NT = 16 * NSUB, NTP = pad_row16(NT);
   constexpr int W_ITEMS = TAPS * NT;  // float4 items per weight chunk: TAPS*4 rows x NT/4
@@ -110,7 +117,7 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
       if (T::COMPACT) { vz = (z0 + iz) * S - p.pd; vy = (y0 + iy) * S - p.ph; vx = (x0 + ix) * S - p.pw; }
       else { vz = z0 * S - p.pd + iz; vy = y0 * S - p.ph + iy; vx = x0 * S - p.pw + ix; }
       if (vz >= 0 && vz < Dv && vy >= 0 && vy < Hv && vx >= 0 && vx < Wv) {
-        if (md.in_s2d)   // parity-0 voxel of the hi-res tensor; the chunk's parity offset is added in prefetch()
+        if (SPECIAL && md.in_s2d)   // parity-0 voxel of the hi-res tensor; the chunk's parity offset is added in prefetch()
           in_off[i] = ((((int64_t)n * 2 * p.Di + 2 * vz) * 2 * p.Hi + 2 * vy) * 2 * p.Wi + 2 * vx) * md.in_cq;
         else
           in_off[i] = ((((int64_t)n * p.Di + (vz >> sh)) * p.Hi + (vy >> sh)) * p.Wi + (vx >> sh)) * p.Ci;
@@ -118,14 +125,14 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
     }
   }
   // chunk c -> (offset into x added to in_off, first weight row, parity of the chunk)
-  const int cpq = md.in_s2d ? (md.in_cq >> 2) : 1;   // chunks per parity
+  const int cpq = (SPECIAL && md.in_s2d) ? (md.in_cq >> 2) : 1;   // chunks per parity
   auto chunk_xoff = [&](int c) -> int64_t {
-    if (!md.in_s2d) return (int64_t)c * 4;
+    if (!SPECIAL || !md.in_s2d) return (int64_t)c * 4;
     const int q = c / cpq, o4 = c - q * cpq;
     return ((int64_t)((q >> 2) * 2 * p.Hi + ((q >> 1) & 1)) * 2 * p.Wi + (q & 1)) * md.in_cq + o4 * 4;
   };
   auto chunk_wrow = [&](int c) -> int {
-    if (!md.in_s2d) return c * 4;
+    if (!SPECIAL || !md.in_s2d) return c * 4;
     const int q = c / cpq, o4 = c - q * cpq;
     return q * md.in_cqp + o4 * 4;
   };
@@ -178,17 +185,21 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
   const float* Ww = Wl + (lane >> 4) * NTP + (lane & 15);
 
   // p.Ci is the number of weight rows per tap; with in_s2d only the valid channels of each parity are visited
-  const int nchunks = md.in_s2d ? 8 * cpq : (p.Ci >> 2);
+  const int nchunks = (SPECIAL && md.in_s2d) ? 8 * cpq : (p.Ci >> 2);
   const int CqP = p.Co >> 3;   // d2s: padded channels per parity
   unsigned tapmask = 0xffffffffu;
-  if (TAPS == 27 && md.tap_skip == 1) tapmask = parity_tapmask(cobase / CqP, false);
-  prefetch(0);
-  for (int c = 0; c < nchunks; ++c) {
+  if (SPECIAL && TAPS == 27 && md.tap_skip == 1) tapmask = parity_tapmask(cobase / CqP, false);
+  // split-K (small volumes: too few tiles to fill 256 CUs): blockIdx.y owns a range of channel chunks and
+  // stores raw accumulators to partial[blockIdx.y]; cfun_splitk_finish sums them in order and runs the epilogue
+  const int c_begin = blockIdx.y * chunks_per_split;
+  const int c_end = (c_begin + chunks_per_split < nchunks) ? c_begin + chunks_per_split : nchunks;
+  if (c_begin < c_end) prefetch(c_begin);
+  for (int c = c_begin; c < c_end; ++c) {
     __syncthreads();           // every wave is done reading the previous chunk
     commit();
     __syncthreads();
-    if (c + 1 < nchunks) prefetch(c + 1);
-    if (TAPS == 27 && md.tap_skip == 2) tapmask = parity_tapmask(c / cpq, true);
+    if (c + 1 < c_end) prefetch(c + 1);
+    if (SPECIAL && TAPS == 27 && md.tap_skip == 2) tapmask = parity_tapmask(c / cpq, true);
 #pragma unroll
     for (int dz = 0; dz < KD; ++dz)
 #pragma unroll
@@ -196,7 +207,7 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
 #pragma unroll
         for (int dx = 0; dx < KW; ++dx) {
           const int tap = (dz * KH + dy) * KW + dx;
-          if (TAPS == 27 && !((tapmask >> (tap & 31)) & 1u)) continue;   // wave-uniform: folded-zero taps
+          if (SPECIAL && TAPS == 27 && !((tapmask >> (tap & 31)) & 1u)) continue;   // wave-uniform: folded-zero taps
           float a[NSUB];
 #pragma unroll
           for (int nn = 0; nn < NSUB; ++nn) a[nn] = Ww[tap * 4 * NTP + nn * 16];
@@ -218,6 +229,16 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
     const int oy = y0 + m;
     if (oy >= p.Ho) continue;
     const int64_t v = (((int64_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox;
+    if (gridDim.y > 1) {       // split-K partial: raw sums, plain layout
+      float* pp = partial + ((int64_t)blockIdx.y * p.N * p.Do * p.Ho * p.Wo + v) * p.Co;
+#pragma unroll
+      for (int nn = 0; nn < NSUB; ++nn) {
+        const int co = cobase + nn * 16 + (lane >> 4) * 4;
+        if (co < p.Co)
+          *reinterpret_cast<float4*>(pp + co) = make_float4(acc[m][nn][0], acc[m][nn][1], acc[m][nn][2], acc[m][nn][3]);
+      }
+      continue;
+    }
     int64_t rv = v;
     if (p.res_mode && p.res_up2 && !p.d2s)
       rv = (((int64_t)n * (p.Do >> 1) + (oz >> 1)) * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
@@ -254,9 +275,24 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
   }
 }
 
+// how many ways to split the channel chunks so that a small volume still fills the chip (0 workspace => 1)
+inline int splitk_factor(int64_t nblk, int nchunks, const CfunConv3dParams& p, size_t ws_bytes) {
+  if (p.d2s || nblk >= 256 || nchunks < 8) return 1;
+  int k = (int)((512 + nblk - 1) / nblk);
+  if (k > nchunks / 4) k = nchunks / 4;
+  if (k > 16) k = 16;
+  const size_t per = (size_t)p.N * p.Do * p.Ho * p.Wo * p.Co * sizeof(float);
+  while (k > 1 && (size_t)k * per > ws_bytes) --k;
+  return k < 1 ? 1 : k;
+}
+inline size_t splitk_workspace(int64_t nblk, int nchunks, const CfunConv3dParams& p) {
+  const int k = splitk_factor(nblk, nchunks, p, (size_t)-1);
+  return k > 1 ? (size_t)k * p.N * p.Do * p.Ho * p.Wo * p.Co * sizeof(float) : 0;
+}
+
 template <int KD, int KH, int KW, int S, int NSUB>
 int launch_conv_mfma(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
-                     float* y, const CfunConv3dParams& p, const ConvMode& md, hipStream_t st) {
+                     float* y, const CfunConv3dParams& p, const ConvMode& md, void* ws, size_t ws_bytes, hipStream_t st) {
   using T = FwdTile<KD, KH, KW, S>;
   constexpr int NT = 16 * NSUB, NTP = pad_row16(NT);
   const int ntz = cdiv(p.Do, T::TD), nty = cdiv(p.Ho, T::TH), ntx = cdiv(p.Wo, T::TW), ncot = cdiv(p.Co, NT);
@@ -264,14 +300,34 @@ int launch_conv_mfma(const float* x, const float* wp, const float* scale, const 
   if (nblk == 0) return CFUN_OK;
   if (nblk > 0x7fffffffLL) return CFUN_EINVAL;
   const size_t lds = (size_t)(4 * T::PLANEP + T::TAPS * 4 * NTP) * sizeof(float);
-  auto kern = k_conv_mfma<KD, KH, KW, S, NSUB>;
+  constexpr bool kHasSpecial = (KD == 3 && KH == 3 && KW == 3 && S == 1);
+  const bool special = md.in_s2d || md.tap_skip;
+  if (special && !kHasSpecial) return CFUN_EINVAL;
+  auto kern = k_conv_mfma<KD, KH, KW, S, NSUB, false>;
+  if constexpr (kHasSpecial) {
+    if (special) kern = k_conv_mfma<KD, KH, KW, S, NSUB, true>;
+  }
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, x, wp, scale, shift, res, y, p, md, ntz, nty, ntx, ncot);
+  const int nchunks = md.in_s2d ? 8 * (md.in_cq >> 2) : (p.Ci >> 2);
+  const int ksplit = splitk_factor(nblk, nchunks, p, ws_bytes);
+  const int cps = cdiv(nchunks, ksplit);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)ksplit), dim3(256), lds, st, x, wp, scale, shift, res, y, p, md,
+                     ntz, nty, ntx, ncot, (float*)ws, cps);
   CFUN_LAUNCH_CHECK();
+  if (ksplit > 1) return cfun_splitk_finish((const float*)ws, ksplit, scale, shift, res, y, &p, st);
   return CFUN_OK;
+}
+
+template <int KD, int KH, int KW, int S>
+size_t fwd_workspace(int nsub, const CfunConv3dParams& p, const ConvMode& md) {
+  using T = FwdTile<KD, KH, KW, S>;
+  const int nt = 16 * nsub;
+  const int64_t nblk = (int64_t)p.N * cdiv(p.Do, T::TD) * cdiv(p.Ho, T::TH) * cdiv(p.Wo, T::TW) * cdiv(p.Co, nt);
+  const int nchunks = md.in_s2d ? 8 * (md.in_cq >> 2) : (p.Ci >> 2);
+  return splitk_workspace(nblk, nchunks, p);
 }
 
 template <int KD, int KH, int KW, int S>
@@ -279,17 +335,17 @@ constexpr int max_nsub() { return KD * KH * KW > 27 ? 1 : 5; }   // 5x5x5: LDS /
 
 template <int KD, int KH, int KW, int S>
 int dispatch_nsub(int nsub, const float* x, const float* wp, const float* scale, const float* shift, const float* res,
-                  float* y, const CfunConv3dParams& p, const ConvMode& flip, hipStream_t st) {
+                  float* y, const CfunConv3dParams& p, const ConvMode& flip, void* ws, size_t wsb, hipStream_t st) {
   if constexpr (max_nsub<KD, KH, KW, S>() == 1) {
     if (nsub != 1) return CFUN_EINVAL;
-    return launch_conv_mfma<KD, KH, KW, S, 1>(x, wp, scale, shift, res, y, p, flip, st);
+    return launch_conv_mfma<KD, KH, KW, S, 1>(x, wp, scale, shift, res, y, p, flip, ws, wsb, st);
   } else {
     switch (nsub) {
-      case 1: return launch_conv_mfma<KD, KH, KW, S, 1>(x, wp, scale, shift, res, y, p, flip, st);
-      case 2: return launch_conv_mfma<KD, KH, KW, S, 2>(x, wp, scale, shift, res, y, p, flip, st);
-      case 3: return launch_conv_mfma<KD, KH, KW, S, 3>(x, wp, scale, shift, res, y, p, flip, st);
-      case 4: return launch_conv_mfma<KD, KH, KW, S, 4>(x, wp, scale, shift, res, y, p, flip, st);
-      default: return launch_conv_mfma<KD, KH, KW, S, 5>(x, wp, scale, shift, res, y, p, flip, st);
+      case 1: return launch_conv_mfma<KD, KH, KW, S, 1>(x, wp, scale, shift, res, y, p, flip, ws, wsb, st);
+      case 2: return launch_conv_mfma<KD, KH, KW, S, 2>(x, wp, scale, shift, res, y, p, flip, ws, wsb, st);
+      case 3: return launch_conv_mfma<KD, KH, KW, S, 3>(x, wp, scale, shift, res, y, p, flip, ws, wsb, st);
+      case 4: return launch_conv_mfma<KD, KH, KW, S, 4>(x, wp, scale, shift, res, y, p, flip, ws, wsb, st);
+      default: return launch_conv_mfma<KD, KH, KW, S, 5>(x, wp, scale, shift, res, y, p, flip, ws, wsb, st);
     }
   }
 }
@@ -527,7 +583,8 @@ int dispatch_wgrad(const float* x, const float* g, float* partial, const CfunCon
 #define CFUN_MFMA_DECL(NAME)                                                                                        \
   int cfun_mfma_fwd_##NAME(int nsub, const float* x, const float* wp, const float* scale, const float* shift,       \
                            const float* res, float* y, const CfunConv3dParams& p, const cfun_mfma::ConvMode& flip,  \
-                           hipStream_t st);                                                                         \
+                           void* ws, size_t wsb, hipStream_t st);                                                   \
+  size_t cfun_mfma_fwd_ws_##NAME(int nsub, const CfunConv3dParams& p, const cfun_mfma::ConvMode& md);               \
   void cfun_mfma_wgrad_plan_##NAME(const CfunConv3dParams& p, int nsub, cfun_mfma::WgPlan* w);                      \
   int cfun_mfma_wgrad_##NAME(const float* x, const float* g, float* partial, const CfunConv3dParams& p,             \
                              const cfun_mfma::WgPlan& w, hipStream_t st);
@@ -535,8 +592,11 @@ int dispatch_wgrad(const float* x, const float* g, float* partial, const CfunCon
 #define CFUN_MFMA_DEFINE(NAME, KD, KH, KW, S)                                                                       \
   int cfun_mfma_fwd_##NAME(int nsub, const float* x, const float* wp, const float* scale, const float* shift,       \
                            const float* res, float* y, const CfunConv3dParams& p, const cfun_mfma::ConvMode& flip,  \
-                           hipStream_t st) {                                                                        \
-    return cfun_mfma::dispatch_nsub<KD, KH, KW, S>(nsub, x, wp, scale, shift, res, y, p, flip, st);                 \
+                           void* ws, size_t wsb, hipStream_t st) {                                                  \
+    return cfun_mfma::dispatch_nsub<KD, KH, KW, S>(nsub, x, wp, scale, shift, res, y, p, flip, ws, wsb, st);        \
+  }                                                                                                                 \
+  size_t cfun_mfma_fwd_ws_##NAME(int nsub, const CfunConv3dParams& p, const cfun_mfma::ConvMode& md) {              \
+    return cfun_mfma::fwd_workspace<KD, KH, KW, S>(nsub, p, md);                                                    \
   }                                                                                                                 \
   void cfun_mfma_wgrad_plan_##NAME(const CfunConv3dParams& p, int nsub, cfun_mfma::WgPlan* w) {                     \
     *w = cfun_mfma::wgrad_plan<KD, KH, KW, S>(p, nsub);                                                             \

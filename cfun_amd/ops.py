@@ -150,8 +150,9 @@ class _Conv3d(torch.autograd.Function):
         if timed:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        check(lib.cfun_conv3d_fwd(ptr(x), ptr(wp), ptr(scale), ptr(shift), ptr(res), ptr(y), C.byref(p), stream(x)),
-              "conv3d_fwd")
+        ws = workspace(lib.cfun_conv3d_fwd_workspace_bytes(C.byref(p)), x)
+        check(lib.cfun_conv3d_fwd(ptr(x), ptr(wp), ptr(scale), ptr(shift), ptr(res), ptr(y), C.byref(p), ptr(ws),
+                                  ws.numel(), stream(x)), "conv3d_fwd")
         if timed:
             ev1.record()
             _TIMER.events.append((ev0, ev1))

@@ -94,8 +94,11 @@ typedef struct CfunConv3dParams {
   int32_t algo;                 /* CFUN_ALGO_* */
 } CfunConv3dParams;
 
+/* ws: cfun_conv3d_fwd_workspace_bytes(p) bytes (split-K partials for volumes too small to fill the chip);
+ * ws may be NULL -- the kernel then runs unsplit. */
+size_t cfun_conv3d_fwd_workspace_bytes(const CfunConv3dParams* p);
 int cfun_conv3d_fwd(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
-                    float* y, const CfunConv3dParams* p, cfun_stream_t stream);
+                    float* y, const CfunConv3dParams* p, void* ws, size_t ws_bytes, cfun_stream_t stream);
 /* dx[n,zi,yi,xi,ci] (stored-input resolution) = sum over outputs/taps that read it of g * W. g = dL/d(conv sum). */
 size_t cfun_conv3d_bwd_data_workspace_bytes(const CfunConv3dParams* p);
 int cfun_conv3d_bwd_data(const float* g, const float* wpT, float* dx, const CfunConv3dParams* p, void* ws,

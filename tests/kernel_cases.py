@@ -84,6 +84,8 @@ CONV_CASES = {
     "auto_stem_c1_wgrad_mfma": (2, (5, 6, 18), 1, 20, (3, 3, 3), dict(algo=ALGO_AUTO)),
     "auto_p3d_stem_wgrad_mfma": (1, (6, 10, 36), 1, 16, (3, 7, 7), dict(stride=2, pad=(1, 3, 3), act=ACT_RELU, scale=True, shift=True, algo=ALGO_AUTO)),
     "auto_lits_stem_wgrad_mfma": (1, (6, 8, 8), 1, 24, (5, 7, 7), dict(stride=2, pad=(2, 3, 3), algo=ALGO_AUTO)),
+    "mfma_333_splitk_epilogue": (2, (4, 4, 8), 32, 16, (3, 3, 3), dict(algo=ALGO_MFMA, act=ACT_LRELU, scale=True, per_n=True, shift=True, res=True)),
+    "mfma_111_splitk_res_up2": (1, (4, 4, 8), 64, 8, (1, 1, 1), dict(algo=ALGO_MFMA, res=True, res_up2=True)),
     "mfma_333_d2s_res": (2, (3, 4, 5), 8, 64, (3, 3, 3), dict(algo=ALGO_MFMA, d2s=True, res=True)),
     "direct_333_d2s_res_cq3": (1, (3, 4, 5), 3, 24, (3, 3, 3), dict(algo=ALGO_DIRECT, d2s=True, res=True, act=ACT_LRELU)),
 }
