@@ -1,5 +1,7 @@
 // C ABI of the convolution family: algorithm selection between the MFMA implicit-GEMM kernels
 // (conv3d_mfma.h) and the generic direct kernels (conv3d_direct.hip).
+#include <stdlib.h>
+
 #include "conv3d_mfma.h"
 
 // conv3d_direct.hip
@@ -163,9 +165,19 @@ CfunConv3dParams folded_s2_params(const CfunConv3dParams* p) {
   return q;
 }
 
+int wgrad_max_nsub(const Shape* s) {
+  static int cap = -1;   // tuning knob (tools/bench_layers.py): CFUN_WGRAD_MAX_NSUB
+  if (cap < 0) {
+    const char* e = getenv("CFUN_WGRAD_MAX_NSUB");
+    cap = e ? atoi(e) : 5;
+    if (cap < 1 || cap > 5) cap = 5;
+  }
+  return s->max_nsub < cap ? s->max_nsub : cap;
+}
+
 int wgrad_nsub(const CfunConv3dParams* p, const Shape* s) {
-  if (p->d2s && p->tap_skip) return pick_nsub_parity(p->Co >> 3, s->max_nsub);
-  return pick_nsub(p->CoP, s->max_nsub);
+  if (p->d2s && p->tap_skip) return pick_nsub_parity(p->Co >> 3, wgrad_max_nsub(s));
+  return pick_nsub(p->CoP, wgrad_max_nsub(s));
 }
 
 bool use_mfma_dgrad(const CfunConv3dParams* p, CfunConv3dParams* q, const Shape** s) {

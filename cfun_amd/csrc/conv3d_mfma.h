@@ -277,8 +277,9 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
 
 // how many ways to split the channel chunks so that a small volume still fills the chip (0 workspace => 1)
 inline int splitk_factor(int64_t nblk, int nchunks, const CfunConv3dParams& p, size_t ws_bytes) {
-  if (p.d2s || nblk >= 256 || nchunks < 8) return 1;
-  int k = (int)((512 + nblk - 1) / nblk);
+  // fewer than ~3 workgroups per CU leaves the SIMDs with a single wave each: split until ~1024 workgroups
+  if (p.d2s || nblk >= 768 || nchunks < 8) return 1;
+  int k = nblk <= 128 ? (int)((512 + nblk - 1) / nblk) : (int)((1024 + nblk - 1) / nblk);
   if (k > nchunks / 4) k = nchunks / 4;
   if (k > 16) k = 16;
   const size_t per = (size_t)p.N * p.Do * p.Ho * p.Wo * p.Co * sizeof(float);
@@ -369,12 +370,15 @@ struct WgTile {
   static constexpr int TPW = cdiv(TAPS, TSPLIT);        // taps per wave
 };
 
-template <int KD, int KH, int KW, int S, int NSUB>
+// TSKIP = true (3x3x3 stride 1, parity-folded up2 weights): each co tile lies inside one parity group whose 8 live
+// taps {p,p+1}^3 are dealt 2 per wave; the 19 folded-zero taps are written as zeros.  The hot loop is branch-free.
+template <int KD, int KH, int KW, int S, int NSUB, bool TSKIP>
 __global__ void __launch_bounds__(256)
 k_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ partial,
              CfunConv3dParams p, int ntz, int nty, int ntx, int ncisub, int ncot, int tiles_per_chunk, int ntiles) {
   using T = WgTile<KD, KH, KW, S>;
   constexpr int TAPS = T::TAPS, NT = 16 * NSUB, GS = pad_row16(NT);
+  constexpr int TPW = TSKIP ? 2 : T::TPW;
   constexpr int G_ITEMS = T::TVOX * (NT / 4);
   constexpr int G_LOADS = cdiv(G_ITEMS, 256);
   CFUN_DYN_LDS(float, smem);
@@ -391,9 +395,9 @@ k_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ g, float* __
   const int Dv = p.Di << sh, Hv = p.Hi << sh, Wv = p.Wi << sh;
   const int tslot = wv % T::TSPLIT, kslot = wv / T::TSPLIT;
 
-  f32x4 acc[T::TPW][NSUB];
+  f32x4 acc[TPW][NSUB];
 #pragma unroll
-  for (int t = 0; t < T::TPW; ++t)
+  for (int t = 0; t < TPW; ++t)
 #pragma unroll
     for (int nn = 0; nn < NSUB; ++nn) acc[t][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -463,14 +467,24 @@ k_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ g, float* __
   const float* Xw = Xl + (lane >> 4) * T::RS * T::XS + (lane & 15);
   const float* Gw = Gl + (lane >> 4) * GS + (lane & 15);
 
-  int toff[T::TPW];  // LDS offset of each of this wave's taps (wave-uniform)
+  // this wave's taps: tap index (for the store) and LDS offset (for the gather); always a valid offset, so the hot
+  // loop has no branches -- a wave's surplus slot (27 taps over 4 waves) recomputes tap 26 and is not stored
+  int tapid[TPW], toff[TPW];
+  const int qpar = TSKIP ? cobase / (p.Co >> 3) : 0;
 #pragma unroll
-  for (int t = 0; t < T::TPW; ++t) {
-    const int tap = t * T::TSPLIT + tslot;
-    const int dz = tap / (KH * KW), dy = (tap / KW) % KH, dx = tap % KW;
-    toff[t] = tap < TAPS ? ((dz * T::IY + dy) * T::IX + dx) * T::XS : -1;
-    // parity-folded up2 kernel: this co tile lies inside one parity group, taps outside its 2x2x2 are zero
-    if (TAPS == 27 && p.tap_skip && tap < TAPS && !((parity_tapmask(cobase / (p.Co >> 3), false) >> tap) & 1u)) toff[t] = -1;
+  for (int t = 0; t < TPW; ++t) {
+    int tap, dz, dy, dx;
+    if (TSKIP) {
+      const int j = t * 4 + tslot;   // 8 live taps of parity (pz,py,px): offsets {p, p+1} per axis
+      dz = (qpar >> 2) + (j >> 2); dy = ((qpar >> 1) & 1) + ((j >> 1) & 1); dx = (qpar & 1) + (j & 1);
+      tap = (dz * 3 + dy) * 3 + dx;
+    } else {
+      tap = t * T::TSPLIT + tslot;
+      const int tc = tap < TAPS ? tap : TAPS - 1;
+      dz = tc / (KH * KW); dy = (tc / KW) % KH; dx = tc % KW;
+    }
+    tapid[t] = tap;
+    toff[t] = ((dz * T::IY + dy) * T::IX + dx) * T::XS;
   }
 
   if (t_begin < t_end) prefetch(t_begin);
@@ -480,29 +494,28 @@ k_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ g, float* __
     __syncthreads();
     if (tile + 1 < t_end) prefetch(tile + 1);
     // voxel groups: (lz, ly, xq) with 4 consecutive x per group
+#pragma unroll 4
     for (int grp = kslot; grp < T::TVOX / 4; grp += T::KSPLIT) {
       const int xq = grp & 3, ly = (grp >> 2) & 3, lz = grp >> 4;
-      float b[NSUB];
+      float b[NSUB], a[TPW];
 #pragma unroll
       for (int nn = 0; nn < NSUB; ++nn) b[nn] = Gw[(grp * 4) * GS + nn * 16];
       const float* Xg = Xw + ((lz * T::RS * T::IY + ly * T::RS) * T::IX + xq * 4 * T::RS) * T::XS;
 #pragma unroll
-      for (int t = 0; t < T::TPW; ++t) {
-        if (toff[t] >= 0) {
-          const float a = Xg[toff[t]];
+      for (int t = 0; t < TPW; ++t) a[t] = Xg[toff[t]];
 #pragma unroll
-          for (int nn = 0; nn < NSUB; ++nn)
-            acc[t][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[nn], acc[t][nn], 0, 0, 0);
-        }
-      }
+      for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int nn = 0; nn < NSUB; ++nn)
+          acc[t][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[nn], acc[t][nn], 0, 0, 0);
     }
   }
 
   // partial[(chunk*KSPLIT + kslot)][tap][ci][CoP]; D[i=ci][j=co]: lane -> co = lane&15, ci = (lane>>4)*4 + r
   float* out = partial + (int64_t)(chunk * T::KSPLIT + kslot) * TAPS * p.Ci * p.CoP;
 #pragma unroll
-  for (int t = 0; t < T::TPW; ++t) {
-    const int tap = t * T::TSPLIT + tslot;
+  for (int t = 0; t < TPW; ++t) {
+    const int tap = tapid[t];
     if (tap >= TAPS) continue;
 #pragma unroll
     for (int nn = 0; nn < NSUB; ++nn) {
@@ -512,6 +525,16 @@ k_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ g, float* __
       for (int r = 0; r < 4; ++r) {
         const int ci = ci0 + (lane >> 4) * 4 + r;
         if (ci < p.Ci) out[((int64_t)tap * p.Ci + ci) * p.CoP + co] = acc[t][nn][r];
+      }
+    }
+  }
+  if (TSKIP) {   // the folded-zero taps of this (ci subtile, co tile) region
+    const unsigned live = parity_tapmask(qpar, false);
+    for (int tap = 0; tap < TAPS; ++tap) {
+      if ((live >> tap) & 1u) continue;
+      for (int e = tid; e < 16 * NT; e += 256) {
+        const int ci = ci0 + e / NT, co = cobase + e % NT;
+        if (ci < p.Ci && co < p.CoP) out[((int64_t)tap * p.Ci + ci) * p.CoP + co] = 0.f;
       }
     }
   }
@@ -548,7 +571,10 @@ int launch_wgrad_mfma(const float* x, const float* g, float* partial, const Cfun
   using T = WgTile<KD, KH, KW, S>;
   constexpr int NT = 16 * NSUB, GS = pad_row16(NT);
   const size_t lds = (size_t)(T::IVOX * T::XS + T::TVOX * GS) * sizeof(float);
-  auto kern = k_wgrad_mfma<KD, KH, KW, S, NSUB>;
+  auto kern = k_wgrad_mfma<KD, KH, KW, S, NSUB, false>;
+  if constexpr (KD == 3 && KH == 3 && KW == 3 && S == 1) {
+    if (p.d2s && p.tap_skip) kern = k_wgrad_mfma<KD, KH, KW, S, NSUB, true>;
+  }
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;

@@ -131,91 +131,112 @@ k_ce_bwd(const float* __restrict__ logits, const uint8_t* __restrict__ labels, c
 // ------------------------------------------------------------------ Sobel edge loss
 // kernel_x[dz][dy][dx] = A[dz]*B[dy]*A[dx] (derivative along y), kernel_y = A[dy]*B[dz]*A[dx] (derivative
 // along z), A = (1,2,1), B = (1,0,-1)  (model.py:947-951; F.conv3d is a cross-correlation, valid padding).
-__device__ __forceinline__ void sobel_w(int dz, int dy, int dx, float* w0, float* w1) {
-  const float A[3] = {1.f, 2.f, 1.f}, B[3] = {1.f, 0.f, -1.f};
-  *w0 = A[dz] * B[dy] * A[dx];
-  *w1 = A[dy] * B[dz] * A[dx];
-}
-
-template <int CT>  // classes incl. background; channels 1..CT-1 contribute
-__device__ __forceinline__ void sobel_at(const float* __restrict__ probs, const uint8_t* __restrict__ labels,
-                                         int64_t nbase, int z, int y, int x, int H, int W, float (&p0)[CT],
-                                         float (&p1)[CT], float (&t0)[CT], float (&t1)[CT]) {
-#pragma unroll
-  for (int c = 0; c < CT; ++c) { p0[c] = 0.f; p1[c] = 0.f; t0[c] = 0.f; t1[c] = 0.f; }
-#pragma unroll
-  for (int dz = 0; dz < 3; ++dz)
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        float w0, w1;
-        sobel_w(dz, dy, dx, &w0, &w1);
-        if (w0 == 0.f && w1 == 0.f) continue;
-        const int64_t vi = nbase + ((int64_t)(z + dz) * H + (y + dy)) * W + (x + dx);
-        const float* pp = probs + vi * CT;
-        const int lab = labels[vi];
-#pragma unroll
-        for (int c = 1; c < CT; ++c) {
-          const float pv = pp[c];
-          const float tv = (c == lab) ? 1.f : 0.f;
-          p0[c] += w0 * pv; p1[c] += w1 * pv;
-          t0[c] += w0 * tv; t1[c] += w1 * tv;
-        }
-      }
-}
+// Both are separable, so every kernel MARCHES along z: a thread owns one (y,x) column segment, turns each input
+// plane's 3x3 (y,x) neighbourhood into the two in-plane sums  dy = B(y)A(x)*f  and  sm = A(y)A(x)*f  (9 loads
+// instead of 27 per voxel) and combines a ring of three planes:  c0 = A(z)*dy,  c1 = B(z)*sm.
+constexpr int kZSeg = 16;   // output planes per thread
 
 template <int CT>
+struct PlaneSums {   // classes 1..CT-1 are stored at index c-1
+  float dy[CT - 1], sm[CT - 1];
+};
+
+// in-plane sums of the probabilities and of the one-hot targets at input plane z, window (y..y+2, x..x+2)
+template <int CT>
+__device__ __forceinline__ void plane_sums(const float* __restrict__ probs, const uint8_t* __restrict__ labels,
+                                           int64_t nbase, int z, int y, int x, int H, int W, PlaneSums<CT>& P,
+                                           PlaneSums<CT>& T) {
+  const float A[3] = {1.f, 2.f, 1.f}, B[3] = {1.f, 0.f, -1.f};
+#pragma unroll
+  for (int c = 0; c < CT - 1; ++c) { P.dy[c] = 0.f; P.sm[c] = 0.f; T.dy[c] = 0.f; T.sm[c] = 0.f; }
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int64_t vi = nbase + ((int64_t)z * H + (y + j)) * W + (x + i);
+      const float wd = B[j] * A[i], ws = A[j] * A[i];
+      const float* pp = probs + vi * CT;
+      const int lab = labels[vi];
+#pragma unroll
+      for (int c = 1; c < CT; ++c) {
+        const float pv = pp[c];
+        P.dy[c - 1] += wd * pv;
+        P.sm[c - 1] += ws * pv;
+        if (c == lab) { T.dy[c - 1] += wd; T.sm[c - 1] += ws; }
+      }
+    }
+}
+
+// MODE 0: accumulate sum (|grad p| - |grad t|)^2 ; MODE 1: write dc[o][c-1][0..1] = dL/d(c0), dL/d(c1)
+template <int CT, int MODE>
 __global__ void __launch_bounds__(kBlock)
-k_edge_fwd(const float* __restrict__ probs, const uint8_t* __restrict__ labels, double* __restrict__ partial, int n,
-           int D, int H, int W) {
+k_edge_march(const float* __restrict__ probs, const uint8_t* __restrict__ labels, const float* __restrict__ gscale,
+             double* __restrict__ partial, float* __restrict__ dc, int n, int D, int H, int W) {
   const int Do = D - 2, Ho = H - 2, Wo = W - 2;
-  const int64_t per = (int64_t)Do * Ho * Wo, total = per * n;
+  const int nseg = (Do + kZSeg - 1) / kZSeg;
+  const int64_t total = (int64_t)n * nseg * Ho * Wo;
+  const float gs = MODE == 1 ? gscale[0] * 2.f / ((float)Do * (float)Ho * (float)Wo * (float)n) : 0.f;
   double acc = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
     int64_t t = i;
     const int x = (int)(t % Wo); t /= Wo;
     const int y = (int)(t % Ho); t /= Ho;
-    const int z = (int)(t % Do);
-    const int64_t r = t / Do;
-    float p0[CT], p1[CT], t0[CT], t1[CT];
-    sobel_at<CT>(probs, labels, r * D * H * W, z, y, x, H, W, p0, p1, t0, t1);
+    const int seg = (int)(t % nseg);
+    const int64_t r = t / nseg;
+    const int64_t nbase = r * D * H * W;
+    const int z0 = seg * kZSeg;
+    const int z1 = z0 + kZSeg < Do ? z0 + kZSeg : Do;     // outputs [z0, z1) need input planes [z0, z1 + 2)
+    PlaneSums<CT> P[3], T[3];
+    plane_sums<CT>(probs, labels, nbase, z0, y, x, H, W, P[0], T[0]);
+    plane_sums<CT>(probs, labels, nbase, z0 + 1, y, x, H, W, P[1], T[1]);
+    for (int zo = z0; zo < z1; ++zo) {
+      plane_sums<CT>(probs, labels, nbase, zo + 2, y, x, H, W, P[2], T[2]);
+      float* o = MODE == 1 ? dc + ((((r * Do + zo) * Ho + y) * Wo + x)) * (2 * (CT - 1)) : nullptr;
 #pragma unroll
-    for (int c = 1; c < CT; ++c) {
-      const float pm = sqrtf(p0[c] * p0[c] + p1[c] * p1[c] + p0[c] * p0[c]);   // channel 0 twice (model.py:969-972)
-      const float tm = sqrtf(t0[c] * t0[c] + t1[c] * t1[c] + t0[c] * t0[c]);
-      const float d = pm - tm;
-      acc += (double)(d * d);
+      for (int c = 0; c < CT - 1; ++c) {
+        const float p0 = P[0].dy[c] + 2.f * P[1].dy[c] + P[2].dy[c], p1 = P[0].sm[c] - P[2].sm[c];
+        const float t0 = T[0].dy[c] + 2.f * T[1].dy[c] + T[2].dy[c], t1 = T[0].sm[c] - T[2].sm[c];
+        const float pm = sqrtf(p0 * p0 + p1 * p1 + p0 * p0);   // channel 0 twice (model.py:969-972)
+        const float tm = sqrtf(t0 * t0 + t1 * t1 + t0 * t0);
+        if (MODE == 0) {
+          const float d = pm - tm;
+          acc += (double)(d * d);
+        } else {
+          const float k = gs * (pm - tm) / pm;      // 0/0 -> NaN exactly like torch's sqrt backward (App. A-13)
+          o[c * 2] = k * 2.f * p0;
+          o[c * 2 + 1] = k * p1;
+        }
+      }
+      P[0] = P[1]; P[1] = P[2]; T[0] = T[1]; T[1] = T[2];
     }
   }
-  const double s = block_sum(acc);
-  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+  if (MODE == 0) {
+    const double s = block_sum(acc);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+  }
 }
 
-// dc[o][c][0..1] = dL/d(c0), dL/d(c1) at every valid output voxel o
+// transposed stencil, marching along z over the OUTPUT planes:  Q0[zo](y,x) = sum_{j,i} B[j]A[i] dc0[zo, y-j, x-i],
+// Q1[zo](y,x) = sum A[j]A[i] dc1[zo, y-j, x-i];  dprob[z] = sum_dz A[dz]*Q0[z-dz] + B[dz]*Q1[z-dz]
 template <int CT>
-__global__ void __launch_bounds__(kBlock)
-k_edge_bwd_dc(const float* __restrict__ probs, const uint8_t* __restrict__ labels, const float* __restrict__ gscale,
-              float* __restrict__ dc, int n, int D, int H, int W) {
-  const int Do = D - 2, Ho = H - 2, Wo = W - 2;
-  const int64_t per = (int64_t)Do * Ho * Wo, total = per * n;
-  const float gs = gscale[0] * 2.f / ((float)per * (float)n);
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
-    int64_t t = i;
-    const int x = (int)(t % Wo); t /= Wo;
-    const int y = (int)(t % Ho); t /= Ho;
-    const int z = (int)(t % Do);
-    const int64_t r = t / Do;
-    float p0[CT], p1[CT], t0[CT], t1[CT];
-    sobel_at<CT>(probs, labels, r * D * H * W, z, y, x, H, W, p0, p1, t0, t1);
-    float* o = dc + i * (2 * (CT - 1));
+__device__ __forceinline__ void plane_adj(const float* __restrict__ dc, int64_t r, int zo, int y, int x, int Do, int Ho,
+                                          int Wo, float (&q0)[CT - 1], float (&q1)[CT - 1]) {
+  const float A[3] = {1.f, 2.f, 1.f}, B[3] = {1.f, 0.f, -1.f};
 #pragma unroll
-    for (int c = 1; c < CT; ++c) {
-      const float pm = sqrtf(p0[c] * p0[c] + p1[c] * p1[c] + p0[c] * p0[c]);
-      const float tm = sqrtf(t0[c] * t0[c] + t1[c] * t1[c] + t0[c] * t0[c]);
-      const float k = gs * (pm - tm) / pm;        // 0/0 -> NaN exactly like torch's sqrt backward (App. A-13)
-      o[(c - 1) * 2] = k * 2.f * p0[c];
-      o[(c - 1) * 2 + 1] = k * p1[c];
+  for (int c = 0; c < CT - 1; ++c) { q0[c] = 0.f; q1[c] = 0.f; }
+  if (zo < 0 || zo >= Do) return;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int oy = y - j;
+    if (oy < 0 || oy >= Ho) continue;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int ox = x - i;
+      if (ox < 0 || ox >= Wo) continue;
+      const float* d = dc + (((r * Do + zo) * Ho + oy) * Wo + ox) * (2 * (CT - 1));
+      const float wd = B[j] * A[i], ws = A[j] * A[i];
+#pragma unroll
+      for (int c = 0; c < CT - 1; ++c) { q0[c] += wd * d[c * 2]; q1[c] += ws * d[c * 2 + 1]; }
     }
   }
 }
@@ -224,33 +245,30 @@ template <int CT>
 __global__ void __launch_bounds__(kBlock)
 k_edge_bwd_gather(const float* __restrict__ dc, float* __restrict__ dprobs, int n, int D, int H, int W) {
   const int Do = D - 2, Ho = H - 2, Wo = W - 2;
-  const int64_t total = (int64_t)n * D * H * W;
+  const int nseg = (D + kZSeg - 1) / kZSeg;
+  const int64_t total = (int64_t)n * nseg * H * W;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
     int64_t t = i;
     const int x = (int)(t % W); t /= W;
     const int y = (int)(t % H); t /= H;
-    const int z = (int)(t % D);
-    const int64_t r = t / D;
-    float g[CT];
+    const int seg = (int)(t % nseg);
+    const int64_t r = t / nseg;
+    const int z0 = seg * kZSeg;
+    const int z1 = z0 + kZSeg < D ? z0 + kZSeg : D;
+    // input plane z receives from output planes z, z-1, z-2 (dz = 0, 1, 2)
+    float q0[3][CT - 1], q1[3][CT - 1];   // ring: [0] = zo = z-2, [1] = z-1, [2] = z
+    plane_adj<CT>(dc, r, z0 - 2, y, x, Do, Ho, Wo, q0[0], q1[0]);
+    plane_adj<CT>(dc, r, z0 - 1, y, x, Do, Ho, Wo, q0[1], q1[1]);
+    for (int z = z0; z < z1; ++z) {
+      plane_adj<CT>(dc, r, z, y, x, Do, Ho, Wo, q0[2], q1[2]);
+      float* o = dprobs + (((r * D + z) * H + y) * W + x) * CT;
+      o[0] = 0.f;
 #pragma unroll
-    for (int c = 0; c < CT; ++c) g[c] = 0.f;
+      for (int c = 0; c < CT - 1; ++c)   // A[dz]: dz=0 -> zo=z, dz=1 -> z-1, dz=2 -> z-2 ; B[dz] = (1,0,-1)
+        o[c + 1] = (q0[2][c] + 2.f * q0[1][c] + q0[0][c]) + (q1[2][c] - q1[0][c]);
 #pragma unroll
-    for (int dz = 0; dz < 3; ++dz)
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          float w0, w1;
-          sobel_w(dz, dy, dx, &w0, &w1);
-          if (w0 == 0.f && w1 == 0.f) continue;
-          const int oz = z - dz, oy = y - dy, ox = x - dx;
-          if (oz < 0 || oz >= Do || oy < 0 || oy >= Ho || ox < 0 || ox >= Wo) continue;
-          const float* d = dc + (((r * Do + oz) * Ho + oy) * Wo + ox) * (2 * (CT - 1));
-#pragma unroll
-          for (int c = 1; c < CT; ++c) g[c] += w0 * d[(c - 1) * 2] + w1 * d[(c - 1) * 2 + 1];
-        }
-#pragma unroll
-    for (int c = 0; c < CT; ++c) dprobs[i * CT + c] = g[c];
+      for (int c = 0; c < CT - 1; ++c) { q0[0][c] = q0[1][c]; q0[1][c] = q0[2][c]; q1[0][c] = q1[1][c]; q1[1][c] = q1[2][c]; }
+    }
   }
 }
 
@@ -318,9 +336,10 @@ int cfun_edge_loss_fwd(const float* probs, const uint8_t* labels, float* loss, i
   if (n <= 0 || D < 3 || H < 3 || W < 3) return (int)hipMemsetAsync(loss, 0, sizeof(float), cfun_st(stream));
   if (ws_bytes < kMaxBlocks * sizeof(double)) return CFUN_EWORKSPACE;
   const int64_t per = (int64_t)(D - 2) * (H - 2) * (W - 2);
-  const unsigned blocks = vox_grid(per * n);
-  if (C == 8) hipLaunchKernelGGL(k_edge_fwd<8>, dim3(blocks), dim3(kBlock), 0, cfun_st(stream), probs, labels, (double*)ws, n, D, H, W);
-  else hipLaunchKernelGGL(k_edge_fwd<3>, dim3(blocks), dim3(kBlock), 0, cfun_st(stream), probs, labels, (double*)ws, n, D, H, W);
+  const int64_t cols = (int64_t)n * ((D - 2 + kZSeg - 1) / kZSeg) * (H - 2) * (W - 2);
+  const unsigned blocks = vox_grid(cols);
+  if (C == 8) hipLaunchKernelGGL((k_edge_march<8, 0>), dim3(blocks), dim3(kBlock), 0, cfun_st(stream), probs, labels, (const float*)nullptr, (double*)ws, (float*)nullptr, n, D, H, W);
+  else hipLaunchKernelGGL((k_edge_march<3, 0>), dim3(blocks), dim3(kBlock), 0, cfun_st(stream), probs, labels, (const float*)nullptr, (double*)ws, (float*)nullptr, n, D, H, W);
   hipLaunchKernelGGL(k_finalize_sum, dim3(1), dim3(64), 0, cfun_st(stream), (const double*)ws, (int)blocks,
                      1.0 / ((double)per * (double)n), loss);
   CFUN_LAUNCH_CHECK();
@@ -339,13 +358,14 @@ int cfun_edge_loss_bwd(const float* probs, const uint8_t* labels, const float* g
   if (total <= 0) return CFUN_OK;
   if (D < 3 || H < 3 || W < 3) return (int)hipMemsetAsync(dprobs, 0, total * C * sizeof(float), cfun_st(stream));
   if (ws_bytes < cfun_edge_loss_bwd_workspace_bytes(n, D, H, W, C)) return CFUN_EWORKSPACE;
-  const int64_t per = (int64_t)(D - 2) * (H - 2) * (W - 2);
+  const int64_t cols_o = (int64_t)n * ((D - 2 + kZSeg - 1) / kZSeg) * (H - 2) * (W - 2);
+  const int64_t cols_i = (int64_t)n * ((D + kZSeg - 1) / kZSeg) * H * W;
   if (C == 8) {
-    hipLaunchKernelGGL(k_edge_bwd_dc<8>, dim3(vox_grid(per * n)), dim3(kBlock), 0, cfun_st(stream), probs, labels, gscale, (float*)ws, n, D, H, W);
-    hipLaunchKernelGGL(k_edge_bwd_gather<8>, dim3(vox_grid(total)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dprobs, n, D, H, W);
+    hipLaunchKernelGGL((k_edge_march<8, 1>), dim3(vox_grid(cols_o)), dim3(kBlock), 0, cfun_st(stream), probs, labels, gscale, (double*)nullptr, (float*)ws, n, D, H, W);
+    hipLaunchKernelGGL(k_edge_bwd_gather<8>, dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dprobs, n, D, H, W);
   } else {
-    hipLaunchKernelGGL(k_edge_bwd_dc<3>, dim3(vox_grid(per * n)), dim3(kBlock), 0, cfun_st(stream), probs, labels, gscale, (float*)ws, n, D, H, W);
-    hipLaunchKernelGGL(k_edge_bwd_gather<3>, dim3(vox_grid(total)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dprobs, n, D, H, W);
+    hipLaunchKernelGGL((k_edge_march<3, 1>), dim3(vox_grid(cols_o)), dim3(kBlock), 0, cfun_st(stream), probs, labels, gscale, (double*)nullptr, (float*)ws, n, D, H, W);
+    hipLaunchKernelGGL(k_edge_bwd_gather<3>, dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dprobs, n, D, H, W);
   }
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;

@@ -60,6 +60,14 @@ def test_mask_losses_golden(emu):
     kc.check_mask_losses(emu, g["logits"], g["labels"], g)
 
 
+def test_mask_losses_multi_segment(emu):
+    """D > 18: the z-marching edge kernels cross a segment boundary (and end on a ragged one)."""
+    rng = np.random.default_rng(4)
+    logits = rng.normal(size=(1, 8, 37, 5, 6)).astype(np.float32)
+    labels = rng.integers(0, 8, size=(1, 37, 5, 6)).astype(np.uint8)
+    kc.check_mask_losses(emu, logits, labels)
+
+
 def test_mask_losses_3class(emu):
     rng = np.random.default_rng(0)
     logits = rng.normal(size=(1, 3, 6, 7, 8)).astype(np.float32)
