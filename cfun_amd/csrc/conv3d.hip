@@ -98,7 +98,7 @@ const Shape* mfma_shape(const CfunConv3dParams* p) {
   if (p->d2s) {   // a lane's float4 must stay inside one parity group; tap skipping needs tile | parity group
     const int cqp = p->Co >> 3, cq = p->d2s_cq > 0 ? p->d2s_cq : cqp;
     if ((cqp & 3) || (cq & 3)) return nullptr;
-    if (p->tap_skip && pick_nsub_parity(cqp, 5) == 0) return nullptr;
+    if (p->tap_skip && cqp != 20 && cqp != 40 && cqp != 8 && pick_nsub_parity(cqp, 5) == 0) return nullptr;
   }
   const Shape* s = find_shape(p->kd, p->kh, p->kw, p->stride);
   if (!s) return nullptr;
@@ -176,7 +176,11 @@ int wgrad_max_nsub(const Shape* s) {
 }
 
 int wgrad_nsub(const CfunConv3dParams* p, const Shape* s) {
-  if (p->d2s && p->tap_skip) return pick_nsub_parity(p->Co >> 3, wgrad_max_nsub(s));
+  if (p->d2s && p->tap_skip) {   // tiles live inside one parity group (Co/8 columns): fewest, widest tiles
+    const int cqp = p->Co >> 3, mx = wgrad_max_nsub(s);
+    const int tiles = (cqp + 16 * mx - 1) / (16 * mx);
+    return (cqp + 16 * tiles - 1) / (16 * tiles);
+  }
   return pick_nsub(p->CoP, wgrad_max_nsub(s));
 }
 
@@ -256,10 +260,21 @@ const char* cfun_error_string(int code) {
   }
 }
 
+// tile code: NSUB + 8*REM (conv3d_mfma.h).  Exact 20 / 40 / 8 channel tiles use remainder quads (no padding).
+static int pick_tile(const Shape* s, int co, bool per_parity) {
+  const bool rem_ok = (s->kd == 3 && s->kh == 3 && s->kw == 3) || (s->kd == 1 && s->kh == 1 && s->kw == 1 && s->s == 1);
+  if (rem_ok && s->max_nsub > 1) {
+    if (co == 20) return 1 + 8 * 1;
+    if (co == 40) return 2 + 8 * 2;
+    if (co == 8) return 0 + 8 * 2;
+  }
+  return per_parity ? pick_nsub_parity(co, s->max_nsub) : pick_nsub(co, s->max_nsub);
+}
+
 static void fwd_mode(const CfunConv3dParams* p, const Shape* s, ConvMode* md, int* nsub) {
   *md = kPlain;
-  *nsub = pick_nsub(p->Co, s->max_nsub);
-  if (p->d2s && p->tap_skip) { md->tap_skip = 1; *nsub = pick_nsub_parity(p->Co >> 3, s->max_nsub); }
+  *nsub = pick_tile(s, p->Co, false);
+  if (p->d2s && p->tap_skip) { md->tap_skip = 1; *nsub = pick_tile(s, p->Co >> 3, true); }
 }
 
 size_t cfun_conv3d_fwd_workspace_bytes(const CfunConv3dParams* p) {
@@ -302,7 +317,7 @@ size_t cfun_conv3d_bwd_data_workspace_bytes(const CfunConv3dParams* p) {
     ConvMode md = kPlain;
     md.flip = 1;
     if (p->d2s) { md.in_s2d = 1; md.in_cqp = p->Co >> 3; md.in_cq = p->d2s_cq > 0 ? p->d2s_cq : md.in_cqp; }
-    return cfun_align_up(s->fwd_ws(pick_nsub(q.Co, s->max_nsub), q, md) + 256, 256);   // split-K partials
+    return cfun_align_up(s->fwd_ws(pick_tile(s, q.Co, false), q, md) + 256, 256);   // split-K partials
   }
   return 256;
 }
@@ -325,7 +340,7 @@ int cfun_conv3d_bwd_data(const float* g, const float* wpT, float* dx, const Cfun
   }
   if (use_mfma_dgrad(p, &q, &s)) {
     if (!cfun_aligned16(g) || !cfun_aligned16(wpT) || !cfun_aligned16(dx)) return CFUN_EALIGN;
-    const int nsub = pick_nsub(q.Co, s->max_nsub);
+    const int nsub = pick_tile(s, q.Co, false);
     ConvMode md = kPlain;
     md.flip = 1;
     if (p->d2s) {   // g is the hi-res gradient of y: gather the parities while staging, skip folded-zero taps

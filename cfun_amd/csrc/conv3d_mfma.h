@@ -32,6 +32,9 @@ namespace cfun_mfma {
 constexpr int pad_plane(int v, int rs) { return rs == 1 ? v + ((16 - (v % 32)) + 32) % 32 : (v | 1); }
 constexpr int pad_row16(int v) { return (v % 32 == 16) ? v : v + 16; }  // v is a multiple of 16
 constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+// LDS row stride (floats) of a weight / gradient row of nt channels: = 16 (mod 32) so that the four k-rows of an
+// MFMA fragment read fall on disjoint banks
+constexpr int row_stride(int nt) { return nt <= 16 ? 16 : nt <= 48 ? 48 : nt <= 80 ? 80 : pad_row16((nt + 15) / 16 * 16); }
 
 // bijective XCD-aware remap: consecutive logical ids stay on one XCD (blocks are dealt round-robin to the 8 XCDs)
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
@@ -79,14 +82,18 @@ struct FwdTile {
 
 // SPECIAL = false: plain conv (md.in_s2d == 0, md.tap_skip == 0) -- the hot instantiation carries none of the
 // parity-fold bookkeeping.  SPECIAL = true (3x3x3 stride 1 only): s2d gather of the input and/or tap skipping.
-template <int KD, int KH, int KW, int S, int NSUB, bool SPECIAL>
+// Output-channel tile = 16*NSUB + 4*REM channels.  The REM (0..2) trailing 4-channel groups run on
+// v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 outer products: lane 4b+j supplies voxel j of block b, lane 4b+i the
+// weight of channel i; result lane = voxel, 4 registers = 4 channels -- measured with tools/probe_mfma.py), so
+// Co = 20 / 40 / 8 tiles carry no channel padding (a 16-wide MFMA subtile would be 75 % / 50 % / 50 % idle).
+template <int KD, int KH, int KW, int S, int NSUB, bool SPECIAL, int REM>
 __global__ void __launch_bounds__(256)
 k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale,
             const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
             CfunConv3dParams p, ConvMode md, int ntz, int nty, int ntx, int ncot, float* __restrict__ partial,
             int chunks_per_split) {
   using T = FwdTile<KD, KH, KW, S>;
-  constexpr int TAPS = T::TAPS, NT = 16 * NSUB, NTP = pad_row16(NT);
+  constexpr int TAPS = T::TAPS, NT = 16 * NSUB + 4 * REM, NTP = row_stride(NT), NS1 = NSUB > 0 ? NSUB : 1;
   constexpr int W_ITEMS = TAPS * NT;  // float4 items per weight chunk: TAPS*4 rows x NT/4
   constexpr int W_LOADS = cdiv(W_ITEMS, 256);
   CFUN_DYN_LDS(float, smem);
@@ -175,14 +182,19 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
     }
   };
 
-  f32x4 acc[4][NSUB];
+  f32x4 acc[4][NS1], accr[REM > 0 ? REM : 1];
 #pragma unroll
   for (int m = 0; m < 4; ++m)
 #pragma unroll
-    for (int nn = 0; nn < NSUB; ++nn) acc[m][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nn = 0; nn < NS1; ++nn) acc[m][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < (REM > 0 ? REM : 1); ++q) accr[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const float* Xw = Xl + (lane >> 4) * T::PLANEP + (wv * T::RS * T::IY) * T::IX + (lane & 15) * T::RS;
   const float* Ww = Wl + (lane >> 4) * NTP + (lane & 15);
+  // remainder quads: lane = voxel (row lane>>4, x = lane&15) of the wave's 4x16 plane; weights of channel lane&3
+  const float* Xr = Xl + ((wv * T::RS) * T::IY + (lane >> 4) * T::RS) * T::IX + (lane & 15) * T::RS;
+  const float* Wr = Wl + 16 * NSUB + (lane & 3);
 
   // p.Ci is the number of weight rows per tap; with in_s2d only the valid channels of each parity are visited
   const int nchunks = (SPECIAL && md.in_s2d) ? 8 * cpq : (p.Ci >> 2);
@@ -208,70 +220,80 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
         for (int dx = 0; dx < KW; ++dx) {
           const int tap = (dz * KH + dy) * KW + dx;
           if (SPECIAL && TAPS == 27 && !((tapmask >> (tap & 31)) & 1u)) continue;   // wave-uniform: folded-zero taps
-          float a[NSUB];
+          if constexpr (NSUB > 0) {
+            float a[NS1];
 #pragma unroll
-          for (int nn = 0; nn < NSUB; ++nn) a[nn] = Ww[tap * 4 * NTP + nn * 16];
+            for (int nn = 0; nn < NSUB; ++nn) a[nn] = Ww[tap * 4 * NTP + nn * 16];
 #pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            const float b = Xw[(dz * T::IY + (m * T::RS + dy)) * T::IX + dx];
+            for (int m = 0; m < 4; ++m) {
+              const float b = Xw[(dz * T::IY + (m * T::RS + dy)) * T::IX + dx];
 #pragma unroll
-            for (int nn = 0; nn < NSUB; ++nn)
-              acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nn], b, acc[m][nn], 0, 0, 0);
+              for (int nn = 0; nn < NSUB; ++nn)
+                acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nn], b, acc[m][nn], 0, 0, 0);
+            }
+          }
+          if constexpr (REM > 0) {
+            float xb[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) xb[cc] = Xr[cc * T::PLANEP + (dz * T::IY + dy) * T::IX + dx];
+#pragma unroll
+            for (int q = 0; q < REM; ++q)
+#pragma unroll
+              for (int cc = 0; cc < 4; ++cc)
+                accr[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(Wr[(tap * 4 + cc) * NTP + 4 * q], xb[cc], accr[q], 0, 0, 0);
           }
         }
   }
 
-  // ---- epilogue: lane owns voxel (z0+wv, y0+m, x0+(lane&15)), channels cobase + nn*16 + (lane>>4)*4 .. +3
+  // ---- epilogue.  16-wide subtiles: lane owns voxel (z0+wv, y0+m, x0+(lane&15)), channels nn*16 + (lane>>4)*4..+3;
+  // remainder quads: lane owns voxel (z0+wv, y0+(lane>>4), x0+(lane&15)), channels 16*NSUB + 4q..+3
   const int oz = z0 + wv, ox = x0 + (lane & 15);
   if (oz >= p.Do || ox >= p.Wo) return;
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const int oy = y0 + m;
-    if (oy >= p.Ho) continue;
+  auto emit = [&](int oy, int co, const f32x4& a4) {
+    if (oy >= p.Ho || co >= p.Co) return;
     const int64_t v = (((int64_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox;
+    float4 r = make_float4(a4[0], a4[1], a4[2], a4[3]);
     if (gridDim.y > 1) {       // split-K partial: raw sums, plain layout
-      float* pp = partial + ((int64_t)blockIdx.y * p.N * p.Do * p.Ho * p.Wo + v) * p.Co;
-#pragma unroll
-      for (int nn = 0; nn < NSUB; ++nn) {
-        const int co = cobase + nn * 16 + (lane >> 4) * 4;
-        if (co < p.Co)
-          *reinterpret_cast<float4*>(pp + co) = make_float4(acc[m][nn][0], acc[m][nn][1], acc[m][nn][2], acc[m][nn][3]);
-      }
-      continue;
+      *reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.y * p.N * p.Do * p.Ho * p.Wo + v) * p.Co + co) = r;
+      return;
     }
-    int64_t rv = v;
-    if (p.res_mode && p.res_up2 && !p.d2s)
-      rv = (((int64_t)n * (p.Do >> 1) + (oz >> 1)) * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
-#pragma unroll
-    for (int nn = 0; nn < NSUB; ++nn) {
-      const int co = cobase + nn * 16 + (lane >> 4) * 4;
-      if (co >= p.Co) continue;
-      float4 r = make_float4(acc[m][nn][0], acc[m][nn][1], acc[m][nn][2], acc[m][nn][3]);
-      if (p.scale_mode) {
-        const float4 s = *reinterpret_cast<const float4*>(scale + (p.scale_mode == 2 ? n * p.Co : 0) + co);
-        r.x *= s.x; r.y *= s.y; r.z *= s.z; r.w *= s.w;
-      }
-      if (p.has_shift) {
-        const float4 t = *reinterpret_cast<const float4*>(shift + co);
-        r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
-      }
-      const int Cq = p.d2s_cq > 0 ? p.d2s_cq : CqP;          // valid channels per parity (= channels of y)
-      const int q = p.d2s ? co / CqP : 0, oc = p.d2s ? co - q * CqP : co;
-      if (p.d2s && oc >= Cq) continue;                        // per-parity channel padding
-      if (p.res_mode) {
-        const float4 t = *reinterpret_cast<const float4*>(res + rv * (p.d2s ? Cq : p.Co) + oc);
-        r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
-      }
-      r.x = cfun_apply_act(r.x, p.act, p.slope); r.y = cfun_apply_act(r.y, p.act, p.slope);
-      r.z = cfun_apply_act(r.z, p.act, p.slope); r.w = cfun_apply_act(r.w, p.act, p.slope);
-      if (p.d2s) {
-        const int64_t hv = (((int64_t)n * 2 * p.Do + 2 * oz + (q >> 2)) * 2 * p.Ho + 2 * oy + ((q >> 1) & 1)) * 2 * p.Wo +
-                           2 * ox + (q & 1);
-        *reinterpret_cast<float4*>(y + hv * Cq + oc) = r;
-      } else {
-        *reinterpret_cast<float4*>(y + v * p.Co + co) = r;
-      }
+    if (p.scale_mode) {
+      const float4 s4 = *reinterpret_cast<const float4*>(scale + (p.scale_mode == 2 ? n * p.Co : 0) + co);
+      r.x *= s4.x; r.y *= s4.y; r.z *= s4.z; r.w *= s4.w;
     }
+    if (p.has_shift) {
+      const float4 t = *reinterpret_cast<const float4*>(shift + co);
+      r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+    }
+    const int Cq = p.d2s_cq > 0 ? p.d2s_cq : CqP;          // valid channels per parity (= channels of y)
+    const int q = p.d2s ? co / CqP : 0, oc = p.d2s ? co - q * CqP : co;
+    if (p.d2s && oc >= Cq) return;                          // per-parity channel padding
+    if (p.res_mode) {
+      int64_t rv = v;
+      if (p.res_up2 && !p.d2s)
+        rv = (((int64_t)n * (p.Do >> 1) + (oz >> 1)) * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
+      const float4 t = *reinterpret_cast<const float4*>(res + rv * (p.d2s ? Cq : p.Co) + oc);
+      r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+    }
+    r.x = cfun_apply_act(r.x, p.act, p.slope); r.y = cfun_apply_act(r.y, p.act, p.slope);
+    r.z = cfun_apply_act(r.z, p.act, p.slope); r.w = cfun_apply_act(r.w, p.act, p.slope);
+    if (p.d2s) {
+      const int64_t hv = (((int64_t)n * 2 * p.Do + 2 * oz + (q >> 2)) * 2 * p.Ho + 2 * oy + ((q >> 1) & 1)) * 2 * p.Wo +
+                         2 * ox + (q & 1);
+      *reinterpret_cast<float4*>(y + hv * Cq + oc) = r;
+    } else {
+      *reinterpret_cast<float4*>(y + v * p.Co + co) = r;
+    }
+  };
+  if constexpr (NSUB > 0) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int nn = 0; nn < NSUB; ++nn) emit(y0 + m, cobase + nn * 16 + (lane >> 4) * 4, acc[m][nn]);
+  }
+  if constexpr (REM > 0) {
+#pragma unroll
+    for (int q = 0; q < REM; ++q) emit(y0 + (lane >> 4), cobase + 16 * NSUB + 4 * q, accr[q]);
   }
 }
 
@@ -291,11 +313,12 @@ inline size_t splitk_workspace(int64_t nblk, int nchunks, const CfunConv3dParams
   return k > 1 ? (size_t)k * p.N * p.Do * p.Ho * p.Wo * p.Co * sizeof(float) : 0;
 }
 
-template <int KD, int KH, int KW, int S, int NSUB>
+template <int KD, int KH, int KW, int S, int NSUB, int REM = 0>
 int launch_conv_mfma(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
                      float* y, const CfunConv3dParams& p, const ConvMode& md, void* ws, size_t ws_bytes, hipStream_t st) {
   using T = FwdTile<KD, KH, KW, S>;
-  constexpr int NT = 16 * NSUB, NTP = pad_row16(NT);
+  constexpr int NT = 16 * NSUB + 4 * REM, NTP = row_stride(NT);
+  if (REM > 0 && (p.Co % NT) != 0) return CFUN_EINVAL;
   const int ntz = cdiv(p.Do, T::TD), nty = cdiv(p.Ho, T::TH), ntx = cdiv(p.Wo, T::TW), ncot = cdiv(p.Co, NT);
   const int64_t nblk = (int64_t)p.N * ntz * nty * ntx * ncot;
   if (nblk == 0) return CFUN_OK;
@@ -304,9 +327,9 @@ int launch_conv_mfma(const float* x, const float* wp, const float* scale, const 
   constexpr bool kHasSpecial = (KD == 3 && KH == 3 && KW == 3 && S == 1);
   const bool special = md.in_s2d || md.tap_skip;
   if (special && !kHasSpecial) return CFUN_EINVAL;
-  auto kern = k_conv_mfma<KD, KH, KW, S, NSUB, false>;
+  auto kern = k_conv_mfma<KD, KH, KW, S, NSUB, false, REM>;
   if constexpr (kHasSpecial) {
-    if (special) kern = k_conv_mfma<KD, KH, KW, S, NSUB, true>;
+    if (special) kern = k_conv_mfma<KD, KH, KW, S, NSUB, true, REM>;
   }
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -325,10 +348,16 @@ int launch_conv_mfma(const float* x, const float* wp, const float* scale, const 
 template <int KD, int KH, int KW, int S>
 size_t fwd_workspace(int nsub, const CfunConv3dParams& p, const ConvMode& md) {
   using T = FwdTile<KD, KH, KW, S>;
-  const int nt = 16 * nsub;
+  const int nt = 16 * (nsub & 7) + 4 * (nsub >> 3);
   const int64_t nblk = (int64_t)p.N * cdiv(p.Do, T::TD) * cdiv(p.Ho, T::TH) * cdiv(p.Wo, T::TW) * cdiv(p.Co, nt);
   const int nchunks = md.in_s2d ? 8 * (md.in_cq >> 2) : (p.Ci >> 2);
   return splitk_workspace(nblk, nchunks, p);
+}
+
+// shapes that instantiate the remainder-quad tiles (the level-1 U-Net convs and the 8-channel heads)
+template <int KD, int KH, int KW, int S>
+constexpr bool has_rem_tiles() {
+  return (KD == 3 && KH == 3 && KW == 3) || (KD == 1 && KH == 1 && KW == 1 && S == 1);
 }
 
 template <int KD, int KH, int KW, int S>
@@ -337,6 +366,13 @@ constexpr int max_nsub() { return KD * KH * KW > 27 ? 1 : 5; }   // 5x5x5: LDS /
 template <int KD, int KH, int KW, int S>
 int dispatch_nsub(int nsub, const float* x, const float* wp, const float* scale, const float* shift, const float* res,
                   float* y, const CfunConv3dParams& p, const ConvMode& flip, void* ws, size_t wsb, hipStream_t st) {
+  // nsub >= 8 encodes a tile with remainder quads: nsub = NSUB + 8*REM  (tiles 20 = (1,1), 40 = (2,2), 8 = (0,2))
+  if constexpr (has_rem_tiles<KD, KH, KW, S>()) {
+    if (nsub == 1 + 8 * 1) return launch_conv_mfma<KD, KH, KW, S, 1, 1>(x, wp, scale, shift, res, y, p, flip, ws, wsb, st);
+    if (nsub == 2 + 8 * 2) return launch_conv_mfma<KD, KH, KW, S, 2, 2>(x, wp, scale, shift, res, y, p, flip, ws, wsb, st);
+    if (nsub == 0 + 8 * 2) return launch_conv_mfma<KD, KH, KW, S, 0, 2>(x, wp, scale, shift, res, y, p, flip, ws, wsb, st);
+  }
+  if (nsub >= 8 || nsub < 1) return CFUN_EINVAL;
   if constexpr (max_nsub<KD, KH, KW, S>() == 1) {
     if (nsub != 1) return CFUN_EINVAL;
     return launch_conv_mfma<KD, KH, KW, S, 1>(x, wp, scale, shift, res, y, p, flip, ws, wsb, st);
@@ -390,7 +426,16 @@ k_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ g, float* __
   const int cot = lid % ncot; lid /= ncot;
   const int cis = lid % ncisub;
   const int chunk = lid / ncisub;
-  const int ci0 = cis * 16, cobase = cot * NT;
+  const int ci0 = cis * 16;
+  // co tile: plain = cot*NT; TSKIP = tile t of parity group q (groups are CqP columns wide, tiles never straddle one)
+  int cobase = cot * NT, colimit = NT, qpar = 0;
+  if (TSKIP) {
+    const int CqP = p.Co >> 3, tpp = cdiv(CqP, NT);
+    qpar = cot / tpp;
+    const int t = cot - qpar * tpp;
+    cobase = qpar * CqP + t * NT;
+    colimit = CqP - t * NT < NT ? CqP - t * NT : NT;
+  }
   const int sh = p.up2 ? 1 : 0;
   const int Dv = p.Di << sh, Hv = p.Hi << sh, Wv = p.Wi << sh;
   const int tslot = wv % T::TSPLIT, kslot = wv / T::TSPLIT;
@@ -432,7 +477,7 @@ k_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ g, float* __
         const int vox = it / (NT / 4), col = (it % (NT / 4)) * 4;
         const int lx = vox % T::TW, ly = (vox / T::TW) % T::TH, lz = vox / (T::TW * T::TH);
         const int oz = z0 + lz, oy = y0 + ly, ox = x0 + lx;
-        if (cobase + col < p.Co && oz < p.Do && oy < p.Ho && ox < p.Wo) {
+        if (col < colimit && cobase + col < p.Co && oz < p.Do && oy < p.Ho && ox < p.Wo) {
           if (p.d2s) {   // g is the hi-res gradient of y [N,2Do,2Ho,2Wo,Cq]: gather parity q, channel o
             const int CqP = p.Co >> 3, Cq = p.d2s_cq > 0 ? p.d2s_cq : CqP;
             const int co = cobase + col, q = co / CqP, o = co - q * CqP;
@@ -470,7 +515,6 @@ k_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ g, float* __
   // this wave's taps: tap index (for the store) and LDS offset (for the gather); always a valid offset, so the hot
   // loop has no branches -- a wave's surplus slot (27 taps over 4 waves) recomputes tap 26 and is not stored
   int tapid[TPW], toff[TPW];
-  const int qpar = TSKIP ? cobase / (p.Co >> 3) : 0;
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
     int tap, dz, dy, dx;
@@ -520,7 +564,7 @@ k_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ g, float* __
 #pragma unroll
     for (int nn = 0; nn < NSUB; ++nn) {
       const int co = cobase + nn * 16 + (lane & 15);
-      if (co >= p.CoP) continue;
+      if (co >= p.CoP || nn * 16 + (lane & 15) >= colimit) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ci = ci0 + (lane >> 4) * 4 + r;
@@ -533,8 +577,8 @@ k_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ g, float* __
     for (int tap = 0; tap < TAPS; ++tap) {
       if ((live >> tap) & 1u) continue;
       for (int e = tid; e < 16 * NT; e += 256) {
-        const int ci = ci0 + e / NT, co = cobase + e % NT;
-        if (ci < p.Ci && co < p.CoP) out[((int64_t)tap * p.Ci + ci) * p.CoP + co] = 0.f;
+        const int ci = ci0 + e / NT, col = e % NT, co = cobase + col;
+        if (ci < p.Ci && col < colimit && co < p.CoP) out[((int64_t)tap * p.Ci + ci) * p.CoP + co] = 0.f;
       }
     }
   }
@@ -552,7 +596,7 @@ WgPlan wgrad_plan(const CfunConv3dParams& p, int nsub) {
   w.ntz = cdiv(p.Do, T::TD); w.nty = cdiv(p.Ho, T::TH); w.ntx = cdiv(p.Wo, T::TW);
   w.ntiles = p.N * w.ntz * w.nty * w.ntx;
   w.ncisub = cdiv(p.Ci, 16);
-  w.ncot = cdiv(p.CoP, 16 * nsub);
+  w.ncot = (p.d2s && p.tap_skip) ? 8 * cdiv(p.Co >> 3, 16 * nsub) : cdiv(p.CoP, 16 * nsub);
   int want = 512 / (w.ncisub * w.ncot);   // ~2 workgroups per CU in total; fewer partials to reduce
   if (want < 1) want = 1;
   if (want > w.ntiles) want = w.ntiles;

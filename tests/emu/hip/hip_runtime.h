@@ -116,3 +116,21 @@ inline hipemu_f32x4 hipemu_mfma_16x16x4f32(float a, float b, hipemu_f32x4 c, int
   return d;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_16x16x4f32
+
+// v_mfma_f32_4x4x1_16b_f32: 16 independent blocks b = lane>>2; D_b[i][j] = C + A_b[i]*B_b[j] with A_b[i] from lane
+// 4b+i, B_b[j] from lane 4b+j; result lane 4b+j, register i  (layout measured on MI355X: tools/probe_mfma.py)
+inline hipemu_f32x4 hipemu_mfma_4x4x1f32(float a, float b, hipemu_f32x4 c, int, int, int) {
+  float ab[2] = {a, b};
+  hipemu::Slot* s = hipemu::wave_exchange(ab, sizeof(ab));
+  const int l = hipemu::lane_id(), blk = l >> 2;
+  float bv;
+  memcpy(&bv, s[l].b + 4, 4);
+  hipemu_f32x4 d = c;
+  for (int i = 0; i < 4; ++i) {
+    float av;
+    memcpy(&av, s[4 * blk + i].b, 4);
+    d[i] = fmaf(av, bv, c[i]);
+  }
+  return d;
+}
+#define __builtin_amdgcn_mfma_f32_4x4x1f32 hipemu_mfma_4x4x1f32

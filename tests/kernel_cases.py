@@ -86,6 +86,11 @@ CONV_CASES = {
     "auto_lits_stem_wgrad_mfma": (1, (6, 8, 8), 1, 24, (5, 7, 7), dict(stride=2, pad=(2, 3, 3), algo=ALGO_AUTO)),
     "mfma_333_splitk_epilogue": (2, (4, 4, 8), 32, 16, (3, 3, 3), dict(algo=ALGO_MFMA, act=ACT_LRELU, scale=True, per_n=True, shift=True, res=True)),
     "mfma_111_splitk_res_up2": (1, (4, 4, 8), 64, 8, (1, 1, 1), dict(algo=ALGO_MFMA, res=True, res_up2=True)),
+    "mfma_333_rem_20_20": (1, (5, 6, 18), 20, 20, (3, 3, 3), dict(algo=ALGO_MFMA, act=ACT_LRELU, res=True, scale=True, per_n=True)),
+    "mfma_333_rem_40_40": (2, (4, 5, 7), 40, 40, (3, 3, 3), dict(algo=ALGO_MFMA)),
+    "mfma_333_rem_16_8": (1, (4, 5, 17), 16, 8, (3, 3, 3), dict(algo=ALGO_MFMA, shift=True)),
+    "mfma_111_rem_40_8_res_up2": (1, (4, 6, 18), 40, 8, (1, 1, 1), dict(algo=ALGO_MFMA, res=True, res_up2=True)),
+    "mfma_333_s2_rem_20_40": (1, (8, 8, 10), 20, 40, (3, 3, 3), dict(algo=ALGO_MFMA, stride=2)),
     "mfma_333_d2s_res": (2, (3, 4, 5), 8, 64, (3, 3, 3), dict(algo=ALGO_MFMA, d2s=True, res=True)),
     "direct_333_d2s_res_cq3": (1, (3, 4, 5), 3, 24, (3, 3, 3), dict(algo=ALGO_DIRECT, d2s=True, res=True, act=ACT_LRELU)),
 }
@@ -188,7 +193,7 @@ def check_fold_up2_conv3(device, ci, co, dhw, algo=ALGO_AUTO, n=2, seed=8):
     yr = F.conv3d(F.interpolate(xr.permute(0, 4, 1, 2, 3), scale_factor=2, mode="nearest"), wr, padding=1).permute(0, 2, 3, 4, 1)
     yr.backward(gy)
     xd, wd = x.clone().to(device).requires_grad_(True), w.clone().to(device).requires_grad_(True)
-    cqp = (co + 15) // 16 * 16
+    cqp = co if co in (8, 20, 40) else (co + 15) // 16 * 16
     spec = ops.ConvSpec(k=(3, 3, 3), co=8 * cqp, pad=(1, 1, 1), d2s=True, d2s_cq=co, tap_skip=True, algo=algo)
     y = ops.conv3d(xd, ops.pack_weight(ops.fold_up2_weight(wd, cqp)), spec)
     y.backward(gy.to(device))
