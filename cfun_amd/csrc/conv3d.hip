@@ -263,10 +263,11 @@ const char* cfun_error_string(int code) {
 // tile code: NSUB + 8*REM (conv3d_mfma.h).  Exact 20 / 40 / 8 channel tiles use remainder quads (no padding).
 static int pick_tile(const Shape* s, int co, bool per_parity) {
   const bool rem_ok = (s->kd == 3 && s->kh == 3 && s->kw == 3) || (s->kd == 1 && s->kh == 1 && s->kw == 1 && s->s == 1);
+  // measured (tools/bench_layers.py): v_mfma_f32_4x4x1_16b issues at half the 16x16x4 MAC rate, so a remainder quad
+  // pays off for 20 = 16 + 4 (1.2x) and for the 8-channel 3x3x3 data gradient (1.3x), not for 40 = 32 + 8
   if (rem_ok && s->max_nsub > 1) {
     if (co == 20) return 1 + 8 * 1;
-    if (co == 40) return 2 + 8 * 2;
-    if (co == 8) return 0 + 8 * 2;
+    if (co == 8 && s->kd == 3) return 0 + 8 * 2;
   }
   return per_parity ? pick_nsub_parity(co, s->max_nsub) : pick_nsub(co, s->max_nsub);
 }

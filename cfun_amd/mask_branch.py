@@ -81,7 +81,7 @@ class Modified3DUNet(nn.Module):
         ci, co = conv.in_channels, conv.out_channels
         if ci % 4 or co % 4:
             return conv(h, up2=True)
-        cqp = co if co in (8, 20, 40) else (co + 15) // 16 * 16   # exact 16+4 / 32+8 / 4+4 MFMA tiles, else pad to 16
+        cqp = (co + 15) // 16 * 16
         spec = ops.ConvSpec(k=(3, 3, 3), co=8 * cqp, pad=(1, 1, 1), d2s=True, d2s_cq=co, tap_skip=True,
                             algo=default_algo())
         return ops.conv3d(h, ops.pack_weight(ops.fold_up2_weight(conv.weight, cqp)), spec)

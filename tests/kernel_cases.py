@@ -193,7 +193,7 @@ def check_fold_up2_conv3(device, ci, co, dhw, algo=ALGO_AUTO, n=2, seed=8):
     yr = F.conv3d(F.interpolate(xr.permute(0, 4, 1, 2, 3), scale_factor=2, mode="nearest"), wr, padding=1).permute(0, 2, 3, 4, 1)
     yr.backward(gy)
     xd, wd = x.clone().to(device).requires_grad_(True), w.clone().to(device).requires_grad_(True)
-    cqp = co if co in (8, 20, 40) else (co + 15) // 16 * 16
+    cqp = (co + 15) // 16 * 16
     spec = ops.ConvSpec(k=(3, 3, 3), co=8 * cqp, pad=(1, 1, 1), d2s=True, d2s_cq=co, tap_skip=True, algo=algo)
     y = ops.conv3d(xd, ops.pack_weight(ops.fold_up2_weight(wd, cqp)), spec)
     y.backward(gy.to(device))

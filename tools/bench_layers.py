@@ -48,7 +48,7 @@ def build(name, n, dhw, ci, co, k, stride, mode, dev):
     pad = (k // 2,) * 3
     taps = k ** 3
     if mode == "fold3":
-        cqp = co if co in (8, 20, 40) else (co + 15) // 16 * 16
+        cqp = (co + 15) // 16 * 16
         spec = ops.ConvSpec(k=(3, 3, 3), co=8 * cqp, pad=(1, 1, 1), d2s=True, d2s_cq=co, tap_skip=True)
         wp = ops.pack_weight(ops.fold_up2_weight(w, cqp))
         out_vox = n * 8 * dhw[0] * dhw[1] * dhw[2]
