@@ -46,6 +46,17 @@ def dominant_kernel_match(cfg):
     return match
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
+    (FETCH_SIZE / WRITE_SIZE collected in their own runs and corrected as MI355X_MICROARCH.md prescribes)."""
+    path = os.path.join(ROOT, "profiles", "round1_pmc_conv_l4_0.json")
+    try:
+        with open(path) as f:
+            return float(json.load(f)["traffic_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(cfg, threads):
     """The oracle (plain fp32 torch-CPU restatement of the reference path) on the host cores: bounded sample =
     FPN+RPN forward+backward on the full volume + U-Net mask head forward+backward on ONE 96^3 RoI;
@@ -162,7 +173,8 @@ def main():
                                       else "single GPU"},
             "losses": lv,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                         "traffic": pmc_traffic() if args.workload == "cfg2" else None,
                          "kernel": "k_conv_mfma<3,3,3,1,3> (conv_norm_lrelu_l4.0: 3x3x3 %d->%d @ %dx%d^3)"
                                    % (2 * b, 2 * b, 4, side[0]),
                          "flops_per_launch": flops, "avg_launch_ms": t_k * 1e3, "launches_timed": len(durs)},

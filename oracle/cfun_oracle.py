@@ -455,11 +455,11 @@ LOSS_WEIGHTS = (100.0, 50.0, 1.0, 20.0, 1.0, 1.0)  # heart_main.py:161-168
 
 def training_step(sd, image, anchors, rpn_match, rpn_bbox_t, p_rois, n_rois, target_class_ids,
                   target_deltas, target_mask, stage, pool_size, mask_pool_size, dropout_masks=None,
-                  proposal_count=500, nms_threshold=0.7, pre_nms_limit=1000):
+                  proposal_count=500, nms_threshold=0.7, pre_nms_limit=1000, layers=(2, 3), stem_pad=(1, 3, 3)):
     """predict('training') dataflow (model.py:1391-1514) + compute_losses (984-1000) with the
     head RoIs injected (p_rois positives first, then n_rois).  image [1,1,D,H,W].
     Returns dict of outputs and the 6 losses."""
-    p2, p3 = fpn(image, sd)
+    p2, p3 = fpn(image, sd, layers=layers, stem_pad=stem_pad)
     l2, pr2, b2 = rpn(p2, sd)
     l3, pr3, b3 = rpn(p3, sd)
     rpn_logits = torch.cat([l2, l3], dim=1)

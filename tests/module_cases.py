@@ -191,6 +191,19 @@ def tiny_config(stage="finetune"):
     return cfg
 
 
+def tiny_lits_config(stage="beginning"):
+    """The LiTS fork's shapes (BASELINE.json configs[4]) shrunk: P3D35 ([4,5] blocks, 5x7x7 stem), 3 classes,
+    channel counts in the fork's 3:6 ratios, no dropout, non-cubic mask crops."""
+    from cfun_amd import config
+    cls = type("TinyLiTS", (config.LiTSConfig,), dict(
+        IMAGE_MAX_DIM=32, IMAGE_MIN_DIM=16, MASK_POOL_SIZE=[32, 48, 32], POOL_SIZE=[4, 4, 4], BACKBONE_CHANNELS=[12, 24],
+        UNET_MASK_BRANCH_CHANNEL=4, TOP_DOWN_PYRAMID_SIZE=20, RPN_CONV_CHANNELS=40, FPN_CLASSIFY_FC_LAYERS_SIZE=16,
+        RPN_ANCHOR_SCALES=(16, 32), PRE_NMS_LIMIT=64, POST_NMS_ROIS_TRAINING=16))
+    cfg = cls(stage)
+    cfg.MASK_SHAPE = cfg.MINI_MASK_SHAPE = (32, 48, 32)
+    return cfg
+
+
 def check_training_step_vs_oracle(device, cfg, seed=0, n_pos=None):
     """One training step of cfun_amd.step (forward, 6 losses, backward) against oracle.training_step on the
     same weights, inputs and dropout masks."""
@@ -207,6 +220,8 @@ def check_training_step_vs_oracle(device, cfg, seed=0, n_pos=None):
     gen = torch.Generator().manual_seed(seed + 1)
     npos = s["p_rois"].shape[0]
     masks = [torch.empty(npos, c).bernoulli_(0.4, generator=gen) / 0.4 for c in (b, 2 * b, 4 * b, 8 * b, 16 * b)]
+    if getattr(cfg, "UNET_DROPOUT", 0.6) <= 0:
+        masks = None
     net.mask.modified_u_net.dropout_masks = masks
     out, losses, total = step.training_step(net, s)
 
@@ -219,7 +234,8 @@ def check_training_step_vs_oracle(device, cfg, seed=0, n_pos=None):
                             cpu["n_rois"], cpu["target_class_ids"], cpu["target_deltas"], onehot, cfg.STAGE,
                             cfg.POOL_SIZE, cfg.MASK_POOL_SIZE, dropout_masks=masks,
                             proposal_count=cfg.POST_NMS_ROIS_TRAINING, nms_threshold=cfg.RPN_NMS_THRESHOLD,
-                            pre_nms_limit=cfg.PRE_NMS_LIMIT)
+                            pre_nms_limit=cfg.PRE_NMS_LIMIT, layers=tuple(getattr(cfg, "BACKBONE_LAYERS", (2, 3))),
+                            stem_pad=(getattr(cfg, "BACKBONE_STEM_KD", 3) // 2, 3, 3))
     ref["total"].backward()
     # forward parity
     np.testing.assert_allclose(out["rpn_class_logits"].detach().cpu().numpy(), ref["rpn_logits"].detach().numpy(),

@@ -57,3 +57,8 @@ def test_nms_dropin(emu):
 def test_training_step_vs_oracle(emu_direct, stage):
     r = mc.check_training_step_vs_oracle(emu_direct, mc.tiny_config(stage), n_pos=1)
     assert all(l == l for l in r["losses"])   # finite
+
+
+def test_training_step_lits_shapes(emu_direct):
+    """LiTS fork shapes: P3D35, (5,7,7) stem, 3 classes (C % 4 != 0 heads on the direct kernels), no dropout."""
+    mc.check_training_step_vs_oracle(emu_direct, mc.tiny_lits_config(), n_pos=1)

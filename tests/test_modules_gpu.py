@@ -49,6 +49,42 @@ def test_training_step_cfg0_vs_oracle(gpu):
     mc.check_training_step_vs_oracle(gpu, config.heart_config("beginning", 64, 64, 32), n_pos=2)
 
 
+def test_training_step_lits_shapes(gpu):
+    """BASELINE.json configs[4] shapes (shrunk): P3D35, (5,7,7) stem, 3 classes, no dropout, non-cubic crops."""
+    mc.check_training_step_vs_oracle(gpu, mc.tiny_lits_config())
+
+
+def test_cfg1_forward_vs_oracle(gpu):
+    """BASELINE.json configs[1]: 128x128x64 volume, P3D backbone + FPN + RPN + mask head forward ('beginning',
+    b = 20, 96^3 crops, 2 RoIs) against the oracle."""
+    from cfun_amd import config, step
+    from oracle import cfun_oracle as orc
+    cfg = config.heart_config("beginning", 128, 128, 64)
+    torch.manual_seed(0)
+    net = step.CFUNHotPath(cfg).to(gpu).eval()
+    s = step.synthetic_inputs(cfg, gpu, 0)
+    with torch.no_grad():
+        p2, p3, logits, probs, bbox = net.backbone_rpn(s["image"])
+        rois = net.proposals(probs, bbox, "inference")
+        ml, mp = net.mask.forward_ndhwc(s["image"][0].permute(1, 2, 3, 0).contiguous(), s["p_rois"][:2])
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    img = s["image"].cpu()
+    with torch.no_grad():
+        rp2, rp3 = orc.fpn(img, sd)
+        r2, r3 = orc.rpn(rp2, sd), orc.rpn(rp3, sd)
+        rprobs = torch.cat([r2[1], r3[1]], dim=1)
+        rbbox = torch.cat([r2[2], r3[2]], dim=1)
+        rrois, _, _ = orc.proposal_layer(rprobs[0], rbbox[0], net.anchors.cpu(), cfg.POST_NMS_ROIS_INFERENCE, 0.7,
+                                         cfg.image_dhw, cfg.PRE_NMS_LIMIT)
+        rl, rp = orc.mask_head(img[0], s["p_rois"][:2].cpu(), sd, cfg.MASK_POOL_SIZE, "beginning")
+    np.testing.assert_allclose(p2.cpu().permute(0, 4, 1, 2, 3).numpy(), rp2.numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(bbox.cpu().numpy(), rbbox.numpy(), rtol=1e-4, atol=2e-5)
+    assert rois.shape[1] == rrois.shape[0]
+    np.testing.assert_allclose(rois[0].cpu().numpy(), rrois.numpy(), rtol=0, atol=1e-5)
+    assert np.abs(ml.cpu().permute(0, 4, 1, 2, 3).numpy() - rl.numpy()).max() < 1e-3
+    assert float((mp.cpu().permute(0, 4, 1, 2, 3).numpy().argmax(1) != rp.numpy().argmax(1)).mean()) <= 1e-4
+
+
 def test_unet_b20_96_forward_properties(gpu):
     """Full-size mask head (b = 20, 96^3 -> 192^3, 'finetune'): size-independent properties --
     softmax rows sum to 1, eval is deterministic, batch entries are independent (InstanceNorm is per sample)."""
