@@ -100,7 +100,7 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
   float* Xl = smem;                      // [4][PLANEP]
   float* Wl = smem + 4 * T::PLANEP;      // [TAPS*4][NTP]
 
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform
   unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
   const int cot = lid % ncot; lid /= ncot;
   const int tx = lid % ntx; lid /= ntx;
@@ -408,24 +408,26 @@ struct WgTile {
 
 // TSKIP = true (3x3x3 stride 1, parity-folded up2 weights): each co tile lies inside one parity group whose 8 live
 // taps {p,p+1}^3 are dealt 2 per wave; the 19 folded-zero taps are written as zeros.  The hot loop is branch-free.
-template <int KD, int KH, int KW, int S, int NSUB, bool TSKIP>
-__global__ void __launch_bounds__(256)
-k_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ partial,
-             CfunConv3dParams p, int ntz, int nty, int ntx, int ncisub, int ncot, int tiles_per_chunk, int ntiles) {
+//
+// PACK > 1 (27-tap shapes whose C_in <= R = 16/PACK, i.e. <= 8): the 16 rows of the A fragment carry PACK taps x R
+// channels instead of 1 tap x 16 (mostly zero) channels -- row i reads tap group*PACK + i/R, channel i%R -- so the
+// block runs ceil(27/PACK) instead of 27 tap rows of MFMA work.
+template <int KD, int KH, int KW, int S, int NSUB, bool TSKIP, int PACK>
+__device__ __forceinline__ void
+wgrad_body(float* smem, const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ partial,
+           const CfunConv3dParams& p, int ntz, int nty, int ntx, int cot, int cis, int chunk, int tiles_per_chunk,
+           int ntiles) {
   using T = WgTile<KD, KH, KW, S>;
   constexpr int TAPS = T::TAPS, NT = 16 * NSUB, GS = pad_row16(NT);
-  constexpr int TPW = TSKIP ? 2 : T::TPW;
+  constexpr int NLIVE = TSKIP ? 8 : TAPS;                         // taps this block accumulates
+  constexpr int R = 16 / PACK;                                    // channels per packed tap
+  constexpr int TPW = cdiv(cdiv(NLIVE, PACK), T::TSPLIT);         // tap groups per wave
   constexpr int G_ITEMS = T::TVOX * (NT / 4);
   constexpr int G_LOADS = cdiv(G_ITEMS, 256);
-  CFUN_DYN_LDS(float, smem);
   float* Xl = smem;                       // [IVOX][16]
   float* Gl = smem + T::IVOX * T::XS;     // [TVOX][GS]
 
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int cot = lid % ncot; lid /= ncot;
-  const int cis = lid % ncisub;
-  const int chunk = lid / ncisub;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform
   const int ci0 = cis * 16;
   // co tile: plain = cot*NT; TSKIP = tile t of parity group q (groups are CqP columns wide, tiles never straddle one)
   int cobase = cot * NT, colimit = NT, qpar = 0;
@@ -508,27 +510,31 @@ k_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ g, float* __
 
   const int t_begin = chunk * tiles_per_chunk;
   const int t_end = (t_begin + tiles_per_chunk < ntiles) ? t_begin + tiles_per_chunk : ntiles;
-  // A fragment: lane -> ci = lane&15, voxel k = lane>>4 ; B fragment: lane -> co = lane&15, voxel k = lane>>4
-  const float* Xw = Xl + (lane >> 4) * T::RS * T::XS + (lane & 15);
+  // A fragment: lane -> row i = lane&15 (ci, or PACK taps x R ci), voxel k = lane>>4 ; B: co = lane&15, voxel k
+  const float* Xw = Xl + (lane >> 4) * T::RS * T::XS + (PACK == 1 ? (lane & 15) : 0);
   const float* Gw = Gl + (lane >> 4) * GS + (lane & 15);
 
-  // this wave's taps: tap index (for the store) and LDS offset (for the gather); always a valid offset, so the hot
-  // loop has no branches -- a wave's surplus slot (27 taps over 4 waves) recomputes tap 26 and is not stored
-  int tapid[TPW], toff[TPW];
-#pragma unroll
-  for (int t = 0; t < TPW; ++t) {
-    int tap, dz, dy, dx;
-    if (TSKIP) {
-      const int j = t * 4 + tslot;   // 8 live taps of parity (pz,py,px): offsets {p, p+1} per axis
+  // live tap j -> (tap index, LDS offset of its halo shift); j is clamped, so every offset is valid and the hot loop
+  // has no branches -- surplus slots (27 taps over 4 waves) recompute the last tap and are not stored
+  auto live_tap = [&](int j, int& tap, int& off) {
+    int dz, dy, dx;
+    if (TSKIP) {   // 8 live taps of parity (pz,py,px): offsets {p, p+1} per axis
       dz = (qpar >> 2) + (j >> 2); dy = ((qpar >> 1) & 1) + ((j >> 1) & 1); dx = (qpar & 1) + (j & 1);
       tap = (dz * 3 + dy) * 3 + dx;
     } else {
-      tap = t * T::TSPLIT + tslot;
-      const int tc = tap < TAPS ? tap : TAPS - 1;
-      dz = tc / (KH * KW); dy = (tc / KW) % KH; dx = tc % KW;
+      tap = j;
+      dz = j / (KH * KW); dy = (j / KW) % KH; dx = j % KW;
     }
-    tapid[t] = tap;
-    toff[t] = ((dz * T::IY + dy) * T::IX + dx) * T::XS;
+    off = ((dz * T::IY + dy) * T::IX + dx) * T::XS;
+  };
+  // PACK == 1: toff is wave-uniform; PACK > 1: per lane (row i -> tap group*PACK + i/R, channel i%R)
+  int toff[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    int j = (t * T::TSPLIT + tslot) * PACK + (PACK == 1 ? 0 : (lane & 15) / R), tap;
+    if (j >= NLIVE) j = NLIVE - 1;
+    live_tap(j, tap, toff[t]);
+    if (PACK > 1) toff[t] += (lane & 15) % R;
   }
 
   if (t_begin < t_end) prefetch(t_begin);
@@ -537,9 +543,12 @@ k_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ g, float* __
     commit();
     __syncthreads();
     if (tile + 1 < t_end) prefetch(tile + 1);
-    // voxel groups: (lz, ly, xq) with 4 consecutive x per group
+    // voxel groups (lz, ly, xq), 4 consecutive x per group = one MFMA k-step; branch-free body, unrolled so that
+    // the fragment reads of the following groups overlap the MFMAs (hand-placed sched_barrier pipelining measured
+    // slower: it pins hipcc's own interleave, tools/bench_layers.py)
 #pragma unroll 4
-    for (int grp = kslot; grp < T::TVOX / 4; grp += T::KSPLIT) {
+    for (int it = 0; it < T::TVOX / 4 / T::KSPLIT; ++it) {   // constant trip count: MFMA loops only unroll evenly
+      const int grp = it * T::KSPLIT + kslot;
       const int xq = grp & 3, ly = (grp >> 2) & 3, lz = grp >> 4;
       float b[NSUB], a[TPW];
 #pragma unroll
@@ -555,20 +564,21 @@ k_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ g, float* __
     }
   }
 
-  // partial[(chunk*KSPLIT + kslot)][tap][ci][CoP]; D[i=ci][j=co]: lane -> co = lane&15, ci = (lane>>4)*4 + r
+  // partial[(chunk*KSPLIT + kslot)][tap][ci][CoP]; D[i][j=co]: lane -> co = lane&15, row i = (lane>>4)*4 + r
   float* out = partial + (int64_t)(chunk * T::KSPLIT + kslot) * TAPS * p.Ci * p.CoP;
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
-    const int tap = tapid[t];
-    if (tap >= TAPS) continue;
 #pragma unroll
-    for (int nn = 0; nn < NSUB; ++nn) {
-      const int co = cobase + nn * 16 + (lane & 15);
-      if (co >= p.CoP || nn * 16 + (lane & 15) >= colimit) continue;
+    for (int r = 0; r < 4; ++r) {
+      const int i = (lane >> 4) * 4 + r;
+      const int j = (t * T::TSPLIT + tslot) * PACK + i / R, ci = ci0 + i % R;
+      if (j >= NLIVE || ci >= p.Ci) continue;
+      int tap, off;
+      live_tap(j, tap, off);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ci = ci0 + (lane >> 4) * 4 + r;
-        if (ci < p.Ci) out[((int64_t)tap * p.Ci + ci) * p.CoP + co] = acc[t][nn][r];
+      for (int nn = 0; nn < NSUB; ++nn) {
+        const int co = cobase + nn * 16 + (lane & 15);
+        if (co < p.CoP && nn * 16 + (lane & 15) < colimit) out[((int64_t)tap * p.Ci + ci) * p.CoP + co] = acc[t][nn][r];
       }
     }
   }
@@ -582,6 +592,23 @@ k_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ g, float* __
       }
     }
   }
+}
+
+// PACK > 1 is used when the whole C_in fits one packed subtile (C_in <= 8: the folded 5x5x5 'finetune' conv).
+// Packing the remainder subtile of C_in = 20 / 40 beside plain subtiles was measured and dropped: the dispatcher
+// deals workgroups round-robin over the CUs (tools/probe_dispatch.py), the light packed workgroups finish early
+// and the kernel time stays that of the plain ones; rebalancing by tile count lost to the per-tile staging cost.
+template <int KD, int KH, int KW, int S, int NSUB, bool TSKIP, int PACK>
+__global__ void __launch_bounds__(256)
+k_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ partial,
+             CfunConv3dParams p, int ntz, int nty, int ntx, int ncisub, int ncot, int tiles_per_chunk, int ntiles) {
+  CFUN_DYN_LDS(float, smem);
+  unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int cot = lid % ncot; lid /= ncot;
+  const int cis = lid % ncisub;
+  const int chunk = lid / ncisub;
+  wgrad_body<KD, KH, KW, S, NSUB, TSKIP, PACK>(smem, x, g, partial, p, ntz, nty, ntx, cot, cis, chunk,
+                                               tiles_per_chunk, ntiles);
 }
 
 struct WgPlan {
@@ -615,9 +642,18 @@ int launch_wgrad_mfma(const float* x, const float* g, float* partial, const Cfun
   using T = WgTile<KD, KH, KW, S>;
   constexpr int NT = 16 * NSUB, GS = pad_row16(NT);
   const size_t lds = (size_t)(T::IVOX * T::XS + T::TVOX * GS) * sizeof(float);
-  auto kern = k_wgrad_mfma<KD, KH, KW, S, NSUB, false>;
-  if constexpr (KD == 3 && KH == 3 && KW == 3 && S == 1) {
-    if (p.d2s && p.tap_skip) kern = k_wgrad_mfma<KD, KH, KW, S, NSUB, true>;
+  auto kern = k_wgrad_mfma<KD, KH, KW, S, NSUB, false, 1>;
+  if constexpr (KD * KH * KW == 27) {   // C_in <= 8: PACK taps per A fragment
+    const int pack = w.ncisub > 1 ? 1 : p.Ci <= 4 ? 4 : p.Ci <= 8 ? 2 : 1;
+    const bool ts = S == 1 && p.d2s && p.tap_skip;
+    if constexpr (S == 1) {
+      if (ts) kern = pack == 4 ? k_wgrad_mfma<KD, KH, KW, S, NSUB, true, 4>
+                   : pack == 2 ? k_wgrad_mfma<KD, KH, KW, S, NSUB, true, 2>
+                               : k_wgrad_mfma<KD, KH, KW, S, NSUB, true, 1>;
+    }
+    if (!ts) kern = pack == 4 ? k_wgrad_mfma<KD, KH, KW, S, NSUB, false, 4>
+                  : pack == 2 ? k_wgrad_mfma<KD, KH, KW, S, NSUB, false, 2>
+                              : k_wgrad_mfma<KD, KH, KW, S, NSUB, false, 1>;
   }
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

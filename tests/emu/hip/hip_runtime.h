@@ -88,6 +88,10 @@ T __shfl(T v, int src, int = 64) { return hipemu::shfl_from(v, src); }
 template <class T>
 T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 
+// scheduling / uniformity hints: no-ops on the host
+inline void __builtin_amdgcn_sched_barrier(int) {}
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
+
 // IEEE single operations without contraction (the emulator is compiled with -ffp-contract=off)
 inline float __fmul_rn(float a, float b) { return a * b; }
 inline float __fadd_rn(float a, float b) { return a + b; }

@@ -29,6 +29,7 @@ def test_fold_up2_conv3(emu, algo):
     a = kc.ALGO_MFMA if algo == "mfma" else kc.ALGO_DIRECT
     kc.check_fold_up2_conv3(emu, 8, 20, (3, 4, 5), a)
     kc.check_fold_up2_conv3(emu, 12, 40, (2, 3, 9), a)
+    kc.check_fold_up2_conv3(emu, 20, 24, (2, 2, 5), a)   # packed remainder subtile (4 taps x 4 channels)
 
 
 def test_elementwise(emu):
