@@ -349,6 +349,42 @@ k_halo_copy(const float* __restrict__ src, float* __restrict__ dst, int64_t per_
   }
 }
 
+// ---------------------------------------------------------------------------------------- weight layouts
+// OIDHW [Co][Ci][T] -> wp [T][Ci][CoP]: one thread per packed element (co fastest: coalesced stores; the strided
+// loads are absorbed by L2 -- the largest weight of the path is 11 MB)
+__global__ void __launch_bounds__(kBlock)
+k_weight_pack(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int T, int CoP, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    const int co = (int)(i % CoP);
+    const int64_t r = i / CoP;
+    const int ci = (int)(r % Ci), t = (int)(r / Ci);
+    wp[i] = co < Co ? w[((int64_t)co * Ci + ci) * T + t] : 0.f;
+  }
+}
+
+// wp [T][Ci][CoP] -> wpT [T][Co][CiP]
+__global__ void __launch_bounds__(kBlock)
+k_weight_pack_transpose(const float* __restrict__ wp, float* __restrict__ wpT, int Co, int Ci, int CoP, int CiP,
+                        int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    const int ci = (int)(i % CiP);
+    const int64_t r = i / CiP;
+    const int co = (int)(r % Co), t = (int)(r / Co);
+    wpT[i] = ci < Ci ? wp[((int64_t)t * Ci + ci) * CoP + co] : 0.f;
+  }
+}
+
+// dwp [T][Ci][CoP] -> dw OIDHW [Co][Ci][T]
+__global__ void __launch_bounds__(kBlock)
+k_weight_unpack(const float* __restrict__ dwp, float* __restrict__ dw, int Co, int Ci, int T, int CoP, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    const int t = (int)(i % T);
+    const int64_t r = i / T;
+    const int ci = (int)(r % Ci), co = (int)(r / Ci);
+    dw[i] = dwp[((int64_t)t * Ci + ci) * CoP + co];
+  }
+}
+
 }  // namespace
 
 // ====================================================================== C ABI
@@ -512,6 +548,34 @@ int cfun_maxpool2_bwd(const float* dy, const uint8_t* idx, float* dx, int32_t N,
   const int64_t total = (int64_t)N * Do * Ho * Wo * C;
   if (total <= 0) return CFUN_OK;
   hipLaunchKernelGGL(k_maxpool2_bwd, dim3(ew_grid(total)), dim3(kBlock), 0, cfun_st(stream), dy, idx, dx, total, Do, Ho, Wo, C);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+int cfun_weight_pack(const float* w, float* wp, int32_t Co, int32_t Ci, int32_t T, cfun_stream_t stream) {
+  if (Co <= 0 || Ci <= 0 || T <= 0) return CFUN_EINVAL;
+  const int CoP = (Co + 15) / 16 * 16;
+  const int64_t total = (int64_t)T * Ci * CoP;
+  hipLaunchKernelGGL(k_weight_pack, dim3(ew_grid(total)), dim3(kBlock), 0, cfun_st(stream), w, wp, Co, Ci, T, CoP, total);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+int cfun_weight_pack_transpose(const float* wp, float* wpT, int32_t Co, int32_t Ci, int32_t T, cfun_stream_t stream) {
+  if (Co <= 0 || Ci <= 0 || T <= 0) return CFUN_EINVAL;
+  const int CoP = (Co + 15) / 16 * 16, CiP = (Ci + 15) / 16 * 16;
+  const int64_t total = (int64_t)T * Co * CiP;
+  hipLaunchKernelGGL(k_weight_pack_transpose, dim3(ew_grid(total)), dim3(kBlock), 0, cfun_st(stream), wp, wpT, Co, Ci,
+                     CoP, CiP, total);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+int cfun_weight_unpack(const float* dwp, float* dw, int32_t Co, int32_t Ci, int32_t T, cfun_stream_t stream) {
+  if (Co <= 0 || Ci <= 0 || T <= 0) return CFUN_EINVAL;
+  const int CoP = (Co + 15) / 16 * 16;
+  const int64_t total = (int64_t)Co * Ci * T;
+  hipLaunchKernelGGL(k_weight_unpack, dim3(ew_grid(total)), dim3(kBlock), 0, cfun_st(stream), dwp, dw, Co, Ci, T, CoP, total);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }

@@ -241,9 +241,13 @@ __device__ __forceinline__ void plane_adj(const float* __restrict__ dc, int64_t 
   }
 }
 
-template <int CT>
+// FUSE = false: dprobs of the edge loss.  FUSE = true: the whole mask-loss backward in this pass --
+//   dlogits = softmax_bwd(probs, dprobs_edge) + gce[0]/nvox * (probs - onehot(label))
+// (what k_softmax_bwd + k_ce_bwd + an add would compute), without materialising dprobs.
+template <int CT, bool FUSE>
 __global__ void __launch_bounds__(kBlock)
-k_edge_bwd_gather(const float* __restrict__ dc, float* __restrict__ dprobs, int n, int D, int H, int W) {
+k_edge_bwd_gather(const float* __restrict__ dc, float* __restrict__ dprobs, int n, int D, int H, int W,
+                  const float* __restrict__ probs, const uint8_t* __restrict__ labels, const float* __restrict__ gce) {
   const int Do = D - 2, Ho = H - 2, Wo = W - 2;
   const int nseg = (D + kZSeg - 1) / kZSeg;
   const int64_t total = (int64_t)n * nseg * H * W;
@@ -261,11 +265,25 @@ k_edge_bwd_gather(const float* __restrict__ dc, float* __restrict__ dprobs, int 
     plane_adj<CT>(dc, r, z0 - 1, y, x, Do, Ho, Wo, q0[1], q1[1]);
     for (int z = z0; z < z1; ++z) {
       plane_adj<CT>(dc, r, z, y, x, Do, Ho, Wo, q0[2], q1[2]);
-      float* o = dprobs + (((r * D + z) * H + y) * W + x) * CT;
-      o[0] = 0.f;
+      const int64_t vox = ((r * D + z) * H + y) * W + x;
+      float* o = dprobs + vox * CT;
+      float g[CT];
+      g[0] = 0.f;
 #pragma unroll
       for (int c = 0; c < CT - 1; ++c)   // A[dz]: dz=0 -> zo=z, dz=1 -> z-1, dz=2 -> z-2 ; B[dz] = (1,0,-1)
-        o[c + 1] = (q0[2][c] + 2.f * q0[1][c] + q0[0][c]) + (q1[2][c] - q1[0][c]);
+        g[c + 1] = (q0[2][c] + 2.f * q0[1][c] + q0[0][c]) + (q1[2][c] - q1[0][c]);
+      if (FUSE) {
+        const float gs = gce[0] / (float)((int64_t)n * D * H * W);
+        const int lab = labels[vox];
+        float pr[CT], dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) { pr[c] = probs[vox * CT + c]; dot += pr[c] * g[c]; }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) o[c] = pr[c] * (g[c] - dot) + gs * (pr[c] - (c == lab ? 1.f : 0.f));
+      } else {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) o[c] = g[c];
+      }
 #pragma unroll
       for (int c = 0; c < CT - 1; ++c) { q0[0][c] = q0[1][c]; q0[1][c] = q0[2][c]; q1[0][c] = q1[1][c]; q1[1][c] = q1[2][c]; }
     }
@@ -362,10 +380,31 @@ int cfun_edge_loss_bwd(const float* probs, const uint8_t* labels, const float* g
   const int64_t cols_i = (int64_t)n * ((D + kZSeg - 1) / kZSeg) * H * W;
   if (C == 8) {
     hipLaunchKernelGGL((k_edge_march<8, 1>), dim3(vox_grid(cols_o)), dim3(kBlock), 0, cfun_st(stream), probs, labels, gscale, (double*)nullptr, (float*)ws, n, D, H, W);
-    hipLaunchKernelGGL(k_edge_bwd_gather<8>, dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dprobs, n, D, H, W);
+    hipLaunchKernelGGL((k_edge_bwd_gather<8, false>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dprobs, n, D, H, W, (const float*)nullptr, (const uint8_t*)nullptr, (const float*)nullptr);
   } else {
     hipLaunchKernelGGL((k_edge_march<3, 1>), dim3(vox_grid(cols_o)), dim3(kBlock), 0, cfun_st(stream), probs, labels, gscale, (double*)nullptr, (float*)ws, n, D, H, W);
-    hipLaunchKernelGGL(k_edge_bwd_gather<3>, dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dprobs, n, D, H, W);
+    hipLaunchKernelGGL((k_edge_bwd_gather<3, false>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dprobs, n, D, H, W, (const float*)nullptr, (const uint8_t*)nullptr, (const float*)nullptr);
+  }
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+int cfun_mask_losses_bwd(const float* probs, const uint8_t* labels, const float* g_ce, const float* g_edge,
+                         float* dlogits, int32_t n, int32_t D, int32_t H, int32_t W, int32_t C, void* ws,
+                         size_t ws_bytes, cfun_stream_t stream) {
+  if (C != 8 && C != 3) return CFUN_EINVAL;
+  const int64_t total = (int64_t)n * D * H * W;
+  if (total <= 0) return CFUN_OK;
+  if (D < 3 || H < 3 || W < 3) return CFUN_EINVAL;   // no edge term: use cfun_softmax_ce_bwd
+  if (ws_bytes < cfun_edge_loss_bwd_workspace_bytes(n, D, H, W, C)) return CFUN_EWORKSPACE;
+  const int64_t cols_o = (int64_t)n * ((D - 2 + kZSeg - 1) / kZSeg) * (H - 2) * (W - 2);
+  const int64_t cols_i = (int64_t)n * ((D + kZSeg - 1) / kZSeg) * H * W;
+  if (C == 8) {
+    hipLaunchKernelGGL((k_edge_march<8, 1>), dim3(vox_grid(cols_o)), dim3(kBlock), 0, cfun_st(stream), probs, labels, g_edge, (double*)nullptr, (float*)ws, n, D, H, W);
+    hipLaunchKernelGGL((k_edge_bwd_gather<8, true>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dlogits, n, D, H, W, probs, labels, g_ce);
+  } else {
+    hipLaunchKernelGGL((k_edge_march<3, 1>), dim3(vox_grid(cols_o)), dim3(kBlock), 0, cfun_st(stream), probs, labels, g_edge, (double*)nullptr, (float*)ws, n, D, H, W);
+    hipLaunchKernelGGL((k_edge_bwd_gather<3, true>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dlogits, n, D, H, W, probs, labels, g_ce);
   }
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;

@@ -58,11 +58,8 @@ class Conv3dParams(nn.Module):
             x = dist.halo_exchange(x, lo, hi, shard)
             pad = (0, self.padding[1], self.padding[2])
         if bn is not None:
-            eps = bn.eps if bn_eps is None else bn_eps
-            s = bn.weight * torch.rsqrt(bn.running_var + eps)
-            b = self.bias if self.bias is not None else 0.0
-            shift = (b - bn.running_mean) * s + bn.bias
-            scale = s.detach()
+            scale, t = folded_bn(bn, bn.eps if bn_eps is None else bn_eps)
+            shift = t if self.bias is None else torch.addcmul(t, self.bias, scale)   # (b - mean) * s + beta
         elif scale is not None:
             per_n = True
         return ops.conv3d(x, self.packed(), self.spec(act, up2, res_up2, per_n, pad), scale=scale, shift=shift, res=res)
@@ -70,6 +67,23 @@ class Conv3dParams(nn.Module):
     def extra_repr(self):
         return "%d, %d, kernel_size=%s, stride=%d, padding=%s, bias=%s" % (
             self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding, self.bias is not None)
+
+
+def folded_bn(bn, eps):
+    """The constant affine of a frozen BatchNorm3d: s = gamma / sqrt(var + eps),
+    t = beta - mean * s, so that bn(conv + b) = conv * s + (b * s + t).  The four tensors never receive gradients
+    on this path (model.py:1297-1304), so (s, t) are cached and recomputed only when one of them is written
+    (load_state_dict, .to(), in-place edits bump ``_version``)."""
+    src = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    key = (float(eps),) + tuple((t.data_ptr(), t._version, t.device) for t in src)
+    cached = getattr(bn, "_cfun_fold", None)
+    if cached is None or cached[0] != key:
+        with torch.no_grad():
+            s = bn.weight * torch.rsqrt(bn.running_var + eps)
+            t = bn.bias - bn.running_mean * s
+        cached = (key, s, t)
+        bn._cfun_fold = cached
+    return cached[1], cached[2]
 
 
 def frozen_bn(channels, eps=1e-5, momentum=0.1):

@@ -10,7 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import mask_branch, ops, utils
-from .layers import Conv3dParams, default_algo, frozen_bn
+from .layers import Conv3dParams, default_algo, folded_bn, frozen_bn
 from .ops import ACT_NONE, ACT_RELU
 
 
@@ -167,8 +167,8 @@ class Classifier(nn.Module):
 
     @staticmethod
     def _bn(x, bn):
-        s = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).detach()
-        return F.relu((x - bn.running_mean) * s + bn.bias)
+        s, t = folded_bn(bn, bn.eps)
+        return F.relu(torch.addcmul(t, x, s))
 
     def forward_ndhwc(self, feature_maps, rois):
         x = pyramid_roi_align_ndhwc(rois, feature_maps, self.pool_size)            # [R,pd,ph,pw,C]

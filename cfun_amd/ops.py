@@ -1,8 +1,9 @@
 """torch.autograd bindings of the HIP kernels (libcfun_hip.so).
 
 All activations are fp32 tensors shaped [N, D, H, W, C] and contiguous (NDHWC).  Weight packing
-(OIDHW -> [tap][ci][CoP]) is done with differentiable torch ops, so parameter gradients arrive in the
-reference's OIDHW layout and shared weights (mask_branch.py:141/143 ...) are summed by autograd.
+(OIDHW -> [tap][ci][CoP]) is a differentiable one-launch op (cfun_weight_pack / cfun_weight_unpack), so parameter
+gradients arrive in the reference's OIDHW layout and shared weights (mask_branch.py:141/143 ...) are summed by
+autograd.
 """
 import ctypes as C
 from dataclasses import dataclass
@@ -19,14 +20,29 @@ def _round16(v):
     return (v + 15) // 16 * 16
 
 
+class _PackWeight(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w):
+        co, ci = w.shape[0], w.shape[1]
+        t = w.shape[2] * w.shape[3] * w.shape[4]
+        w = w.contiguous()
+        wp = torch.empty((t, ci, _round16(co)), dtype=torch.float32, device=w.device)
+        check(_lib.load().cfun_weight_pack(ptr(w), ptr(wp), co, ci, t, stream(w)), "weight_pack")
+        ctx.wshape = tuple(w.shape)
+        return wp
+
+    @staticmethod
+    def backward(ctx, dwp):
+        co, ci = ctx.wshape[0], ctx.wshape[1]
+        dwp = dwp.contiguous()
+        dw = torch.empty(ctx.wshape, dtype=torch.float32, device=dwp.device)
+        check(_lib.load().cfun_weight_unpack(ptr(dwp), ptr(dw), co, ci, dwp.shape[0], stream(dwp)), "weight_unpack")
+        return dw
+
+
 def pack_weight(w):
-    """OIDHW [Co,Ci,kd,kh,kw] -> wp [taps, Ci, CoP] (differentiable)."""
-    co, ci, kd, kh, kw = w.shape
-    wp = w.permute(2, 3, 4, 1, 0).reshape(kd * kh * kw, ci, co)
-    cop = _round16(co)
-    if cop != co:
-        wp = torch.nn.functional.pad(wp, (0, cop - co))
-    return wp.contiguous()
+    """OIDHW [Co,Ci,kd,kh,kw] -> wp [taps, Ci, CoP] (differentiable; one kernel each way)."""
+    return _PackWeight.apply(w)
 
 
 def fold_up2_weight(w, cqp=None):
@@ -52,9 +68,8 @@ def fold_up2_weight(w, cqp=None):
 def _transpose_pack(wp, co):
     """wp [T,Ci,CoP] -> wpT [T,Co,CiP] (no grad; used by bwd_data)."""
     t, ci, _ = wp.shape
-    cip = _round16(ci)
-    out = torch.zeros((t, co, cip), dtype=wp.dtype, device=wp.device)
-    out[:, :, :ci] = wp[:, :, :co].transpose(1, 2)
+    out = torch.empty((t, co, _round16(ci)), dtype=wp.dtype, device=wp.device)
+    check(_lib.load().cfun_weight_pack_transpose(ptr(wp), ptr(out), co, ci, t, stream(wp)), "weight_pack_transpose")
     return out
 
 
@@ -486,6 +501,48 @@ class _EdgeLoss(torch.autograd.Function):
 def edge_loss(probs, labels):
     """3-D Sobel edge-agreement loss (model.py:938-981) on NDHWC probabilities and uint8 labels."""
     return _EdgeLoss.apply(probs, labels)
+
+
+class _MaskLosses(torch.autograd.Function):
+    """(CE(logits, labels), edge(probs, labels)) with ONE fused backward pass; probs = softmax(logits) comes from
+    the Mask module (model.py:799) and is taken as a constant here -- its dependence on logits is folded into the
+    backward (softmax_bwd inside cfun_mask_losses_bwd), so no gradient flows through the softmax node."""
+
+    @staticmethod
+    def forward(ctx, logits, probs, labels):
+        lib = _lib.load()
+        logits, probs, labels = _c(logits), _c(probs), _c(labels)
+        n, d, h, w, c = logits.shape
+        nvox = n * d * h * w
+        if labels.dtype != torch.uint8 or labels.numel() != nvox:
+            raise RuntimeError("mask_losses: labels must be uint8 [n,D,H,W]")
+        out = torch.empty((2,), dtype=torch.float32, device=logits.device)
+        ws = workspace(lib.cfun_loss_workspace_bytes(nvox), logits)
+        st = stream(logits)
+        check(lib.cfun_softmax_ce_fwd(ptr(logits), ptr(labels), ptr(out), nvox, c, ptr(ws), ws.numel(), st),
+              "softmax_ce_fwd")
+        check(lib.cfun_edge_loss_fwd(ptr(probs), ptr(labels), ptr(out[1:]), n, d, h, w, c, ptr(ws), ws.numel(), st),
+              "edge_loss_fwd")
+        ctx.save_for_backward(probs, labels)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_ce, g_edge):
+        lib = _lib.load()
+        probs, labels = ctx.saved_tensors
+        n, d, h, w, c = probs.shape
+        g = torch.stack([g_ce.reshape(()).float(), g_edge.reshape(()).float()])
+        dl = torch.empty_like(probs)
+        ws = workspace(lib.cfun_edge_loss_bwd_workspace_bytes(n, d, h, w, c), probs)
+        check(lib.cfun_mask_losses_bwd(ptr(probs), ptr(labels), ptr(g), ptr(g[1:]), ptr(dl), n, d, h, w, c, ptr(ws),
+                                       ws.numel(), stream(probs)), "mask_losses_bwd")
+        return dl, None, None
+
+
+def mask_losses(logits, probs, labels):
+    """Both 'finetune' mask losses (model.py:909-981) of logits [n,D,H,W,C] with probs = softmax(logits):
+    returns (cross entropy, Sobel edge loss); the backward is one fused pass (cfun_mask_losses_bwd)."""
+    return _MaskLosses.apply(logits, probs.detach(), labels)
 
 
 def halo_pack(x, z0, planes):

@@ -95,12 +95,12 @@ class CFUNHotPath(nn.Module):
         losses = [model.compute_rpn_class_loss(rpn_match, out["rpn_class_logits"]),
                   model.compute_rpn_bbox_loss(rpn_bbox_t, rpn_match, out["rpn_bbox"]),
                   model.compute_mrcnn_class_loss(target_class_ids, out["mrcnn_class_logits"]),
-                  model.compute_mrcnn_bbox_loss(target_deltas, target_class_ids, out["mrcnn_bbox"]),
-                  ops.mask_cross_entropy(out["mrcnn_mask_logits"], mask_labels)]
-        if self.config.STAGE == "finetune":
-            losses.append(ops.edge_loss(out["mrcnn_mask"], mask_labels))
+                  model.compute_mrcnn_bbox_loss(target_deltas, target_class_ids, out["mrcnn_bbox"])]
+        if self.config.STAGE == "finetune":   # CE + Sobel edge loss share one fused backward pass
+            losses += list(ops.mask_losses(out["mrcnn_mask_logits"], out["mrcnn_mask"], mask_labels))
         else:
-            losses.append(torch.zeros((), device=mask_labels.device))
+            losses += [ops.mask_cross_entropy(out["mrcnn_mask_logits"], mask_labels),
+                       torch.zeros((), device=mask_labels.device)]
         return losses
 
     def total_loss(self, losses):

@@ -187,6 +187,25 @@ size_t cfun_edge_loss_bwd_workspace_bytes(int32_t n, int32_t D, int32_t H, int32
 int cfun_edge_loss_bwd(const float* probs, const uint8_t* labels, const float* gscale, float* dprobs, int32_t n,
                        int32_t D, int32_t H, int32_t W, int32_t C, void* ws, size_t ws_bytes, cfun_stream_t stream);
 
+/* Backward of BOTH mask losses in one pass over the hi-res tensors (the 'finetune' stage, model.py:909-981):
+ *   dlogits = g_ce[0]/nvox * (probs - onehot(label)) + softmax_bwd(probs, d edge_loss / d probs * g_edge[0])
+ * probs = softmax(logits) as produced by cfun_softmax_fwd; ws as for cfun_edge_loss_bwd. */
+int cfun_mask_losses_bwd(const float* probs, const uint8_t* labels, const float* g_ce, const float* g_edge,
+                         float* dlogits, int32_t n, int32_t D, int32_t H, int32_t W, int32_t C, void* ws,
+                         size_t ws_bytes, cfun_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Weight layout conversion between the reference's state-dict layout and the kernels' packs (one launch
+ * each; replaces the permute / pad / transpose glue around nn.Conv3d.weight):
+ *   pack:       w  OIDHW [Co][Ci][T]  ->  wp  [T][Ci][CoP]   (pad columns = 0)
+ *   transpose:  wp [T][Ci][CoP]       ->  wpT [T][Co][CiP]   (pad columns = 0; the pack bwd_data takes)
+ *   unpack:     dwp [T][Ci][CoP]      ->  dw  OIDHW [Co][Ci][T]   (the weight gradient back in state-dict layout)
+ * T = kd*kh*kw taps in (dz,dy,dx) order; CoP / CiP = Co / Ci rounded up to 16.
+ * ---------------------------------------------------------------------------------------------- */
+int cfun_weight_pack(const float* w, float* wp, int32_t Co, int32_t Ci, int32_t T, cfun_stream_t stream);
+int cfun_weight_pack_transpose(const float* wp, float* wpT, int32_t Co, int32_t Ci, int32_t T, cfun_stream_t stream);
+int cfun_weight_unpack(const float* dwp, float* dw, int32_t Co, int32_t Ci, int32_t T, cfun_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Depth-sharding helpers: copy `planes` depth planes at z0 of a [N,D,H,W,C]
  * tensor into a dense send buffer / write a received buffer into a padded tensor.

@@ -309,6 +309,13 @@ def check_mask_losses(device, logits_ncdhw, labels, expect=None):
     assert abs(float(el) - float(el_r)) < 1e-4 * abs(float(el_r))
     assert_close(g_ce.permute(0, 4, 1, 2, 3), g_ce_r, "dCE/dlogits", 1e-4)
     assert_close(g_el.permute(0, 4, 1, 2, 3), g_el_r, "dEdge/dlogits", 1e-3)
+    # the fused backward (both losses, one pass) = 0.7 * dCE + 1.3 * dEdge of the separate kernels
+    ld.grad = None
+    ce2, el2 = ops.mask_losses(ld, ops.softmax_channels(ld), labd)
+    assert float(ce2) == float(ce) and float(el2) == float(el)
+    (0.7 * ce2 + 1.3 * el2).backward()
+    assert_close(ld.grad, 0.7 * g_ce + 1.3 * g_el, "fused d(CE+Edge)/dlogits", 1e-5)
+    assert_close(ld.grad.permute(0, 4, 1, 2, 3), 0.7 * g_ce_r + 1.3 * g_el_r, "fused vs oracle", 1e-3)
     if expect is not None:
         assert abs(float(ce) - float(expect["ce"])) < 1e-5 * abs(float(expect["ce"]))
         assert abs(float(el) - float(expect["edge"].reshape(-1)[0])) < 1e-4 * abs(float(expect["edge"].reshape(-1)[0]))
