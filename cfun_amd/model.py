@@ -105,6 +105,55 @@ def proposal_layer(inputs, proposal_count, nms_threshold, anchors, config=None):
     return (boxes[keep] / norm).unsqueeze(0)
 
 
+# ------------------------------------------------------------------------------------------ detections
+def clip_to_window(window, boxes):
+    """model.py:570-581."""
+    lo = torch.tensor([window[0], window[1], window[2]] * 2, dtype=boxes.dtype, device=boxes.device)
+    hi = torch.tensor([window[3], window[4], window[5]] * 2, dtype=boxes.dtype, device=boxes.device)
+    return torch.max(torch.min(boxes, hi), lo)
+
+
+def refine_detections(rois, probs, deltas, window, config):
+    """model.py:584-672 with the per-class NMS (threshold DETECTION_NMS_THRESHOLD, DETECTION_MAX_INSTANCES) on the
+    HIP kernel instead of the ``.cpu().numpy()`` round trip of model.py:651.  rois [N,6] normalised, probs [N,K],
+    deltas [N,K,6] -> [M, (z1,y1,x1,z2,y2,x2, class_id, score)] in voxel coordinates, best score first.
+    Where the reference crashes (no box passes the confidence filter: ``nms_keep`` unbound, model.py:662) this
+    returns an empty [0,8] tensor."""
+    n = probs.shape[0]
+    dev = probs.device
+    class_ids = torch.argmax(probs, dim=1)
+    idx = torch.arange(n, device=dev)
+    class_scores = probs[idx, class_ids]
+    std = torch.tensor(np.reshape(config.RPN_BBOX_STD_DEV, [1, 6]), dtype=torch.float32, device=dev)
+    refined = apply_box_deltas(rois, deltas[idx, class_ids] * std)
+    height, width, depth = [float(v) for v in config.IMAGE_SHAPE[:3]]
+    refined = refined * torch.tensor([depth, height, width, depth, height, width], dtype=torch.float32, device=dev)
+    refined = torch.round(clip_to_window([float(v) for v in window], refined))
+    keep_bool = class_ids > 0
+    if config.DETECTION_MIN_CONFIDENCE:
+        keep_bool = keep_bool & (class_scores >= config.DETECTION_MIN_CONFIDENCE)
+    keep = torch.nonzero(keep_bool)[:, 0]
+    if keep.numel() == 0:
+        return torch.zeros((0, 8), dtype=torch.float32, device=dev)
+    pre_ids, pre_scores, pre_rois = class_ids[keep], class_scores[keep], refined[keep]
+    nms_keep = []
+    for cid in torch.unique(pre_ids).tolist():
+        ixs = torch.nonzero(pre_ids == cid)[:, 0]
+        sc, order = pre_scores[ixs].sort(descending=True)
+        picked = utils.nms_device(pre_rois[ixs][order].contiguous(), sc.contiguous(),
+                                  config.DETECTION_NMS_THRESHOLD, config.DETECTION_MAX_INSTANCES)
+        nms_keep.append(keep[ixs[order[picked]]])
+    keep = torch.unique(torch.cat(nms_keep))
+    count = min(int(config.DETECTION_MAX_INSTANCES), keep.numel())
+    keep = keep[class_scores[keep].sort(descending=True)[1][:count]]
+    return torch.cat([refined[keep], class_ids[keep].unsqueeze(1).float(), class_scores[keep].unsqueeze(1)], dim=1)
+
+
+def detection_layer(config, rois, mrcnn_class, mrcnn_bbox, window):
+    """model.py:675-689; ``window`` (z1,y1,x1,z2,y2,x2) is what the reference parses out of image_meta."""
+    return refine_detections(rois.squeeze(0) if rois.dim() == 3 else rois, mrcnn_class, mrcnn_bbox, window, config)
+
+
 # ------------------------------------------------------------------------------------------ RoIAlign
 def roi_levels(boxes):
     """model.py:322-332: clamp(round(4 + log2(h*w*d)/3), 2, 3) on normalised boxes (fp32, half-to-even)."""

@@ -90,6 +90,29 @@ class CFUNHotPath(nn.Module):
                     mrcnn_class_logits=cls_logits, mrcnn_class=cls_probs, mrcnn_bbox=cls_bbox,
                     mrcnn_mask_logits=mask_logits, mrcnn_mask=mask_probs, p2=p2, p3=p3)
 
+    @torch.no_grad()
+    def predict_inference(self, image, window=None):
+        """``predict(mode='inference')`` (model.py:1436-1461): proposals (POST_NMS_ROIS_INFERENCE) -> classifier ->
+        detection_layer / refine_detections -> mask head on the detected boxes.  Returns
+        [detections [1,M,8] in voxels, mrcnn_mask probabilities [1,M,C,d,h,w]]; M may be 0 (the reference crashes
+        there)."""
+        self.eval()
+        cfg = self.config
+        height, width, depth = [int(v) for v in cfg.IMAGE_SHAPE[:3]]
+        if window is None:
+            window = (0, 0, 0, depth, height, width)
+        p2, p3, _, rpn_probs, rpn_bbox = self.backbone_rpn(image)
+        rpn_rois = self.proposals(rpn_probs, rpn_bbox, "inference")
+        _, cls_probs, cls_bbox = self.classifier.forward_ndhwc([p2[0], p3[0]], rpn_rois[0])
+        det = model.detection_layer(cfg, rpn_rois, cls_probs, cls_bbox, window)
+        n_cls = int(cfg.NUM_CLASSES)
+        if det.shape[0] == 0:
+            ms = tuple(int(v) for v in cfg.MASK_SHAPE)
+            return [det.unsqueeze(0), torch.zeros((1, 0, n_cls) + ms, device=det.device)]
+        scale = torch.tensor([depth, height, width, depth, height, width], dtype=torch.float32, device=det.device)
+        _, mask_probs = self.mask.forward_ndhwc(ops.to_ndhwc(image)[0], det[:, :6] / scale)
+        return [det.unsqueeze(0), ops.to_ncdhw(mask_probs).unsqueeze(0)]
+
     def compute_losses(self, out, rpn_match, rpn_bbox_t, target_class_ids, target_deltas, mask_labels):
         """The 6 losses of model.py:984-1000 (mask labels: uint8 [n_pos,d,h,w])."""
         losses = [model.compute_rpn_class_loss(rpn_match, out["rpn_class_logits"]),

@@ -192,6 +192,51 @@ def proposal_layer(rpn_probs, rpn_bbox, anchors, proposal_count, nms_threshold, 
     return boxes / norm, keep, order
 
 
+def clip_to_window(window, boxes):
+    """model.py:570-581: clamp (z, y, x) pairs to the image window."""
+    lo = torch.tensor([window[0], window[1], window[2]] * 2, dtype=boxes.dtype)
+    hi = torch.tensor([window[3], window[4], window[5]] * 2, dtype=boxes.dtype)
+    return torch.max(torch.min(boxes, hi), lo)
+
+
+def refine_detections(rois, probs, deltas, window, image_dhw, min_confidence=0.7, nms_threshold=0.3,
+                      max_instances=32, std_dev=(0.1, 0.1, 0.1, 0.2, 0.2, 0.2)):
+    """model.py:584-672 (the inference NMS site).  rois [N,6] normalised, probs [N,K],
+    deltas [N,K,6] -> detections [M,8] = (z1,y1,x1,z2,y2,x2 in voxels, class id, score), sorted by score.
+
+    Per predicted class: boxes sorted by score, NMS(nms_threshold, max_instances) (utils.py:122-157); the kept
+    indices of all classes are united, intersected with the confidence filter and the top max_instances by score
+    survive.  The reference leaves ``nms_keep`` unbound when nothing passes the filter (model.py:662, App. A-16);
+    this restatement returns an empty [0,8] tensor for that input instead of raising."""
+    n = probs.shape[0]
+    class_ids = torch.argmax(probs, dim=1)
+    idx = torch.arange(n)
+    class_scores = probs[idx, class_ids]
+    deltas_specific = deltas[idx, class_ids]
+    refined = apply_box_deltas(rois, deltas_specific * torch.tensor(std_dev, dtype=torch.float32).view(1, 6))
+    depth, height, width = [float(v) for v in image_dhw]
+    refined = refined * torch.tensor([depth, height, width, depth, height, width], dtype=torch.float32)
+    refined = torch.round(clip_to_window(window, refined))
+    keep_bool = class_ids > 0
+    if min_confidence:
+        keep_bool = keep_bool & (class_scores >= min_confidence)
+    keep = torch.nonzero(keep_bool)[:, 0]
+    if keep.numel() == 0:
+        return torch.zeros((0, 8), dtype=torch.float32)
+    pre_ids, pre_scores, pre_rois = class_ids[keep], class_scores[keep], refined[keep]
+    nms_keep = []
+    for cid in torch.unique(pre_ids).tolist():
+        ixs = torch.nonzero(pre_ids == cid)[:, 0]
+        sc, order = pre_scores[ixs].sort(descending=True)
+        picked = nms(pre_rois[ixs][order].detach().numpy(), sc.detach().numpy(), nms_threshold, max_instances)
+        nms_keep.append(keep[ixs[order[torch.from_numpy(picked).long()]]])
+    keep = torch.unique(torch.cat(nms_keep))           # == intersect1d(keep, unique1d(cat)) : a subset of keep, sorted
+    count = min(max_instances, keep.numel())
+    top = class_scores[keep].sort(descending=True)[1][:count]
+    keep = keep[top]
+    return torch.cat([refined[keep], class_ids[keep].unsqueeze(1).float(), class_scores[keep].unsqueeze(1)], dim=1)
+
+
 def roi_bounds(boxes, dhw):
     """model.py:271-278 / utils.py:160-174: fp32 product, floor lo / ceil hi, int64."""
     scale = torch.tensor([dhw[0], dhw[1], dhw[2]] * 2, dtype=torch.float32)
@@ -481,3 +526,30 @@ def training_step(sd, image, anchors, rpn_match, rpn_bbox_t, p_rois, n_rois, tar
     return dict(p2=p2, p3=p3, rpn_logits=rpn_logits, rpn_probs=rpn_probs, rpn_bbox=rpn_box, rpn_rois=rpn_rois,
                 nms_keep=keep, cls_logits=cls_logits, cls_bbox=cls_bbox, mask_logits=m_logits, mask_probs=m_probs,
                 losses=losses, total=total)
+
+
+def inference_step(sd, image, anchors, stage, pool_size, mask_pool_size, window=None, proposal_count=64,
+                   nms_threshold=0.7, pre_nms_limit=1000, min_confidence=0.7, detection_nms_threshold=0.3,
+                   max_instances=32, layers=(2, 3), stem_pad=(1, 3, 3)):
+    """predict(mode='inference') dataflow (model.py:1408-1461): FPN -> RPN -> proposal_layer
+    (POST_NMS_ROIS_INFERENCE) -> classifier -> detection_layer / refine_detections -> mask head (eval: no dropout)
+    on the detected boxes.  Returns detections [M,8] (voxels) and mask probabilities [M,C,d,h,w]."""
+    with torch.no_grad():
+        p2, p3 = fpn(image, sd, layers=layers, stem_pad=stem_pad)
+        _, pr2, b2 = rpn(p2, sd)
+        _, pr3, b3 = rpn(p3, sd)
+        rpn_probs = torch.cat([pr2, pr3], dim=1)
+        rpn_box = torch.cat([b2, b3], dim=1)
+        D, H, W = [int(v) for v in image.shape[2:]]
+        rpn_rois, _, _ = proposal_layer(rpn_probs[0], rpn_box[0], anchors, proposal_count, nms_threshold, (D, H, W),
+                                        pre_nms_limit)
+        _, cls_probs, cls_bbox = classifier([p2[0], p3[0]], rpn_rois, sd, pool_size)
+        if window is None:
+            window = (0.0, 0.0, 0.0, float(D), float(H), float(W))
+        det = refine_detections(rpn_rois, cls_probs, cls_bbox, window, (D, H, W), min_confidence,
+                                detection_nms_threshold, max_instances)
+        if det.shape[0] == 0:
+            return dict(rpn_rois=rpn_rois, cls_probs=cls_probs, detections=det, mask_probs=None)
+        boxes = det[:, :6] / torch.tensor([D, H, W, D, H, W], dtype=torch.float32)
+        _, m_probs = mask_head(image[0], boxes, sd, mask_pool_size, stage, dropout_masks=None)
+    return dict(rpn_rois=rpn_rois, cls_probs=cls_probs, detections=det, mask_probs=m_probs)

@@ -434,7 +434,32 @@ def case_predict():
     save("predict_cfg0", **arrs)
 
 
-CASES = dict(nms=case_nms, anchors=case_anchors, roi_align=case_roi_align, fpn_rpn=case_fpn_rpn, unet=case_unet,
+def case_refine():
+    """model.refine_detections (model.py:584-672): crafted so that several classes pass the 0.7 filter, some boxes
+    of one class overlap (per-class NMS at 0.3 suppresses them) and more survive than DETECTION_MAX_INSTANCES."""
+    cfg = make_cfg("beginning", 64, 32)
+    d, h, w = cfg.IMAGE_SHAPE[2], cfg.IMAGE_SHAPE[0], cfg.IMAGE_SHAPE[1]
+    n, ncls = 48, 4
+    ctr = formula.uniform("ref.ctr", (n, 3), 0.15, 0.85)
+    ctr[8:16] = ctr[0:8] + formula.uniform("ref.jit", (8, 3), -0.02, 0.02)     # near-duplicates of the first 8
+    half = formula.uniform("ref.half", (n, 3), 0.05, 0.2)
+    rois = np.concatenate([ctr - half, ctr + half], axis=1).astype(np.float32)
+    logits = formula.uniform("ref.logits", (n, ncls), -1, 1) * 6.0
+    logits[8:16] = logits[0:8] + formula.uniform("ref.ljit", (8, ncls), -0.1, 0.1)  # same classes as their twins
+    probs = torch.softmax(torch.from_numpy(logits), dim=1)
+    deltas = torch.from_numpy(formula.uniform("ref.deltas", (n, ncls, 6), -1, 1))
+    window = np.array([0, 0, 0, d, h, w], dtype=np.float32)
+    out = {}
+    for tag, max_inst, min_conf in (("a", 100, 0.7), ("b", 6, 0.7), ("c", 100, 0.0)):
+        cfg.DETECTION_MAX_INSTANCES, cfg.DETECTION_MIN_CONFIDENCE = max_inst, min_conf
+        det = ref_model.refine_detections(torch.from_numpy(rois), probs.clone(), deltas.clone(), window, cfg)
+        out["det_" + tag] = det.numpy()
+        out["cfg_" + tag] = np.array([max_inst, min_conf, cfg.DETECTION_NMS_THRESHOLD], dtype=np.float64)
+    save("refine_detections", rois=rois, probs=probs.numpy(), deltas=deltas.numpy(), window=window,
+         image_dhw=np.array([d, h, w]), std_dev=np.asarray(cfg.RPN_BBOX_STD_DEV, dtype=np.float32), **out)
+
+
+CASES = dict(refine=case_refine, nms=case_nms, anchors=case_anchors, roi_align=case_roi_align, fpn_rpn=case_fpn_rpn, unet=case_unet,
              losses=case_losses, proposal=case_proposal, classifier=case_classifier, predict=case_predict)
 
 if __name__ == "__main__":

@@ -267,3 +267,55 @@ def check_training_step_vs_oracle(device, cfg, seed=0, n_pos=None):
         worst = max(worst, e)
         assert e < UNET_GRAD_L2_TOL, "%s: rel L2 %.3e" % (k, e)
     return dict(losses=[float(l) for l in losses], worst_grad_l2=worst)
+
+
+def check_inference_vs_oracle(device, cfg, seed=0, max_instances=2):
+    """cfun_amd.step.CFUNHotPath.predict_inference (proposals -> classifier -> refine_detections -> mask head)
+    against oracle.inference_step on the same weights and image.  Random-init heads are not confident, so the
+    confidence filter is lowered to 0.5 + margin-free 'class 1 wins' (DETECTION_MIN_CONFIDENCE = 0)."""
+    from cfun_amd import step
+    torch.manual_seed(seed)
+    cfg.DETECTION_MIN_CONFIDENCE = 0.0
+    cfg.DETECTION_MAX_INSTANCES = max_instances
+    net = step.CFUNHotPath(cfg).to(device)
+    with torch.no_grad():   # make the 2-class head decisive and tie-free
+        net.classifier.linear_class.weight.mul_(40.0)
+        net.classifier.linear_bbox.weight.mul_(20.0)
+    s = step.synthetic_inputs(cfg, device, seed)
+    det, masks = net.predict_inference(s["image"])
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    ref = orc.inference_step(sd, s["image"].cpu(), net.anchors.cpu(), cfg.STAGE, cfg.POOL_SIZE, cfg.MASK_POOL_SIZE,
+                             proposal_count=cfg.POST_NMS_ROIS_INFERENCE, nms_threshold=cfg.RPN_NMS_THRESHOLD,
+                             pre_nms_limit=cfg.PRE_NMS_LIMIT, min_confidence=cfg.DETECTION_MIN_CONFIDENCE,
+                             detection_nms_threshold=cfg.DETECTION_NMS_THRESHOLD, max_instances=max_instances,
+                             layers=tuple(getattr(cfg, "BACKBONE_LAYERS", (2, 3))),
+                             stem_pad=(getattr(cfg, "BACKBONE_STEM_KD", 3) // 2, 3, 3))
+    rd = ref["detections"].numpy()
+    assert rd.shape[0] > 0, "test setup: the oracle found no detection"
+    d = det[0].cpu().numpy()
+    assert d.shape == rd.shape
+    np.testing.assert_array_equal(d[:, :7], rd[:, :7])                   # voxel boxes and class ids: exact
+    np.testing.assert_allclose(d[:, 7], rd[:, 7], rtol=1e-4, atol=1e-6)  # scores
+    mp = masks[0].cpu().numpy()
+    assert mp.shape == tuple(ref["mask_probs"].shape)
+    assert np.abs(mp - ref["mask_probs"].numpy()).max() < 5e-4
+    # the empty-detection guard (the reference raises UnboundLocalError there, SURVEY.md App. A-16)
+    cfg.DETECTION_MIN_CONFIDENCE = 1.5
+    det0, masks0 = net.predict_inference(s["image"])
+    assert tuple(det0.shape) == (1, 0, 8) and masks0.shape[1] == 0
+    return dict(n_det=int(d.shape[0]))
+
+
+def check_refine_detections_golden(device):
+    """cfun_amd.model.refine_detections (HIP NMS per class) against the reference's own outputs."""
+    from cfun_amd import config, model
+    g = load_golden("refine_detections")
+    d, h, w = [int(v) for v in g["image_dhw"]]
+    cfg = config.heart_config("beginning", h, w, d)
+    assert tuple(int(v) for v in cfg.IMAGE_SHAPE[:3]) == (h, w, d)
+    for tag in ("a", "b", "c"):
+        cfg.DETECTION_MAX_INSTANCES, cfg.DETECTION_MIN_CONFIDENCE = int(g["cfg_" + tag][0]), float(g["cfg_" + tag][1])
+        cfg.DETECTION_NMS_THRESHOLD = float(g["cfg_" + tag][2])
+        det = model.refine_detections(torch.from_numpy(g["rois"]).to(device), torch.from_numpy(g["probs"]).to(device),
+                                      torch.from_numpy(g["deltas"]).to(device), g["window"], cfg)
+        np.testing.assert_array_equal(det.cpu().numpy(), g["det_" + tag])

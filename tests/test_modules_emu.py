@@ -62,3 +62,13 @@ def test_training_step_vs_oracle(emu_direct, stage):
 def test_training_step_lits_shapes(emu_direct):
     """LiTS fork shapes: P3D35, (5,7,7) stem, 3 classes (C % 4 != 0 heads on the direct kernels), no dropout."""
     mc.check_training_step_vs_oracle(emu_direct, mc.tiny_lits_config(), n_pos=1)
+
+
+def test_refine_detections_golden(emu):
+    mc.check_refine_detections_golden(emu)
+
+
+def test_inference_vs_oracle(emu_direct):
+    """predict('inference') + refine_detections on the tiny config, 1 detection through the U-Net."""
+    r = mc.check_inference_vs_oracle(emu_direct, mc.tiny_config("beginning"), max_instances=1)
+    assert r["n_det"] == 1

@@ -115,3 +115,20 @@ def test_state_dict_contract(gpu):
     assert len(sd) == 220
     for k, v in sd.items():
         assert tuple(v.shape) == ref[k], k
+
+
+def test_refine_detections_golden(gpu):
+    mc.check_refine_detections_golden(gpu)
+
+
+@pytest.mark.parametrize("stage", ["beginning", "finetune"])
+def test_inference_vs_oracle(gpu, stage):
+    r = mc.check_inference_vs_oracle(gpu, mc.tiny_config(stage), max_instances=3)
+    assert r["n_det"] >= 1
+
+
+def test_inference_cfg0(gpu):
+    """predict('inference') at BASELINE configs[0] size (64x64x32, real channel counts) vs the oracle."""
+    from cfun_amd import config
+    # one instance: at this size several clipped proposals coincide, so lower-ranked scores tie exactly
+    mc.check_inference_vs_oracle(gpu, config.heart_config("beginning", 64, 64, 32), max_instances=1)

@@ -138,6 +138,24 @@ def test_proposal_layer(tag):
     np.testing.assert_array_equal(rois.numpy(), g["rois_" + tag][0])
 
 
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_refine_detections(tag):
+    """model.refine_detections (the inference NMS site, A16) vs the reference's own output."""
+    g = load_golden("refine_detections")
+    max_inst, min_conf, thr = g["cfg_" + tag]
+    det = orc.refine_detections(t(g["rois"]), t(g["probs"]), t(g["deltas"]), [float(v) for v in g["window"]],
+                                [int(v) for v in g["image_dhw"]], float(min_conf), float(thr), int(max_inst),
+                                tuple(float(v) for v in g["std_dev"]))
+    np.testing.assert_array_equal(det.numpy(), g["det_" + tag])
+    if tag == "a":   # the case exercises suppression: more candidates pass the filter than survive the NMS
+        ids = np.argmax(g["probs"], axis=1)
+        sc = g["probs"][np.arange(len(ids)), ids]
+        assert ((ids > 0) & (sc >= 0.7)).sum() > det.shape[0]
+    empty = orc.refine_detections(t(g["rois"]), t(g["probs"]), t(g["deltas"]), [float(v) for v in g["window"]],
+                                  [int(v) for v in g["image_dhw"]], 1.5, float(thr), int(max_inst))
+    assert tuple(empty.shape) == (0, 8)
+
+
 def test_classifier():
     g = load_golden("classifier")
     sd = golden_state_dict(g)
