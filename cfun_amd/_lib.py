@@ -66,6 +66,7 @@ _SIGNATURES = {
     "cfun_edge_loss_bwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "cfun_edge_loss_bwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "cfun_mask_losses_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "cfun_mask_target_labels": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "cfun_weight_pack": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "cfun_weight_pack_transpose": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "cfun_weight_unpack": (C.c_int, [_P, _P, _I, _I, _I, _P]),

@@ -228,6 +228,36 @@ inline int next_pow2(int n) {
   return p;
 }
 
+// GT mask targets (model.py:481-493): crop the uint8 label volume with int()-truncated box bounds (computed by the
+// caller in fp32, as the reference does) and nearest-resize it to the mask shape: output voxel o reads input voxel
+// floor((o + 0.5) * in / out) of the crop (the order-0 resize of utils.py:318-339).  One-hot GT channels resized
+// independently and arg-maxed give exactly this label volume.  Empty crop => zeros.
+__global__ void __launch_bounds__(256)
+k_mask_target_labels(const uint8_t* __restrict__ labels, const int32_t* __restrict__ bounds, uint8_t* __restrict__ out,
+                     int64_t total, int D, int H, int W, int md, int mh, int mw) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t t = i;
+    const int x = (int)(t % mw); t /= mw;
+    const int y = (int)(t % mh); t /= mh;
+    const int z = (int)(t % md);
+    const int r = (int)(t / md);
+    const int32_t* b = bounds + r * 6;
+    int z1 = b[0], y1 = b[1], x1 = b[2], z2 = b[3], y2 = b[4], x2 = b[5];
+    z1 = z1 < 0 ? 0 : z1; y1 = y1 < 0 ? 0 : y1; x1 = x1 < 0 ? 0 : x1;
+    z2 = z2 > D ? D : z2; y2 = y2 > H ? H : y2; x2 = x2 > W ? W : x2;
+    uint8_t v = 0;
+    if (z2 > z1 && y2 > y1 && x2 > x1) {
+      const int cd = z2 - z1, ch = y2 - y1, cw = x2 - x1;
+      int sz = (int)floor(((double)z + 0.5) * ((double)cd / (double)md));
+      int sy = (int)floor(((double)y + 0.5) * ((double)ch / (double)mh));
+      int sx = (int)floor(((double)x + 0.5) * ((double)cw / (double)mw));
+      sz = sz > cd - 1 ? cd - 1 : sz; sy = sy > ch - 1 ? ch - 1 : sy; sx = sx > cw - 1 ? cw - 1 : sx;
+      v = labels[((int64_t)(z1 + sz) * H + (y1 + sy)) * W + (x1 + sx)];
+    }
+    out[i] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -252,6 +282,19 @@ int cfun_roi_align3d_bwd(const float* dout, const int32_t* bounds, float* dfm, i
   int64_t blocks = (total + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(k_roi_align_bwd, dim3((unsigned)blocks), dim3(256), 0, cfun_st(stream), dout, bounds, dfm, total, D, H, W, C, pd, ph, pw);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+int cfun_mask_target_labels(const uint8_t* labels, const int32_t* bounds, uint8_t* out, int32_t R, int32_t D,
+                            int32_t H, int32_t W, int32_t md, int32_t mh, int32_t mw, cfun_stream_t stream) {
+  if (R <= 0) return CFUN_OK;
+  if (D <= 0 || H <= 0 || W <= 0 || md <= 0 || mh <= 0 || mw <= 0) return CFUN_EINVAL;
+  const int64_t total = (int64_t)R * md * mh * mw;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(k_mask_target_labels, dim3((unsigned)blocks), dim3(256), 0, cfun_st(stream), labels, bounds, out,
+                     total, D, H, W, md, mh, mw);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }

@@ -105,6 +105,59 @@ def proposal_layer(inputs, proposal_count, nms_threshold, anchors, config=None):
     return (boxes[keep] / norm).unsqueeze(0)
 
 
+# ------------------------------------------------------------------------------------------ training targets
+def bbox_overlaps(boxes1, boxes2):
+    """model.py:373-411: IoU matrix [len(boxes1), len(boxes2)] (fp32, no epsilon)."""
+    b1, b2 = boxes1[:, None, :], boxes2[None, :, :]
+    z1 = torch.max(b1[..., 0], b2[..., 0]); y1 = torch.max(b1[..., 1], b2[..., 1]); x1 = torch.max(b1[..., 2], b2[..., 2])
+    z2 = torch.min(b1[..., 3], b2[..., 3]); y2 = torch.min(b1[..., 4], b2[..., 4]); x2 = torch.min(b1[..., 5], b2[..., 5])
+    inter = (x2 - x1).clamp(min=0) * (y2 - y1).clamp(min=0) * (z2 - z1).clamp(min=0)
+    v1 = (b1[..., 3] - b1[..., 0]) * (b1[..., 4] - b1[..., 1]) * (b1[..., 5] - b1[..., 2])
+    v2 = (b2[..., 3] - b2[..., 0]) * (b2[..., 4] - b2[..., 1]) * (b2[..., 5] - b2[..., 2])
+    return inter / (v1 + v2 - inter)
+
+
+def detection_target_layer(proposals, gt_class_ids, gt_boxes, gt_labels, config, perms=None):
+    """model.py:414-563 on device: IoU of the proposals with the GT boxes, positive
+    (IoU >= 0.5) / negative sampling at ROI_POSITIVE_RATIO, box-refinement targets and the GT mask targets.
+
+    proposals [1,N,6] or [N,6] and gt_boxes [G,6] normalised; gt_class_ids [G]; ``gt_labels`` uint8 [D,H,W] is the
+    class id per voxel (the argmax of the reference's one-hot ``gt_masks``), so the mask targets come back as uint8
+    labels [n_pos, *MASK_SHAPE] instead of the 8-channel float64 host tensor of model.py:480-493 -- the loss kernels
+    take labels.  ``perms`` = (perm_pos, perm_neg) replaces the two torch.randperm draws (model.py:459, 505) for
+    reproducible tests.  Returns (positive_rois, rois, target_class_ids, target_deltas, mask_labels), positives
+    first; with no positive RoI every entry is empty (the reference then skips the heads, model.py:1481-1491)."""
+    proposals = (proposals.squeeze(0) if proposals.dim() == 3 else proposals).detach()   # targets carry no gradient
+    dev = proposals.device
+    overlaps = bbox_overlaps(proposals, gt_boxes)
+    iou_max = overlaps.max(dim=1)[0]
+    pos_idx = torch.nonzero(iou_max >= config.DETECTION_TARGET_IOU_THRESHOLD)[:, 0]
+    if pos_idx.numel() == 0:
+        e = torch.zeros((0, 6), device=dev)
+        return e, e, torch.zeros((0,), dtype=torch.long, device=dev), e, torch.zeros(
+            (0,) + tuple(config.MASK_SHAPE), dtype=torch.uint8, device=dev)
+    want = int(config.TRAIN_ROIS_PER_IMAGE * config.ROI_POSITIVE_RATIO)
+    perm = torch.randperm(pos_idx.numel()) if perms is None else perms[0]
+    pos_idx = pos_idx[perm[:want].to(dev)]
+    n_pos = pos_idx.numel()
+    p_rois = proposals[pos_idx]
+    assign = overlaps[pos_idx].max(dim=1)[1]
+    std = torch.tensor(np.asarray(config.BBOX_STD_DEV, dtype=np.float32), device=dev)
+    deltas = utils.box_refinement(p_rois, gt_boxes[assign]) / std
+    class_ids = gt_class_ids[assign].long()
+    labels = ops.mask_target_labels(gt_labels, p_rois, config.MASK_SHAPE)
+    neg_idx = torch.nonzero(iou_max < config.DETECTION_TARGET_IOU_THRESHOLD)[:, 0]
+    rois = p_rois
+    if neg_idx.numel() != 0:
+        n_neg = int((1.0 / config.ROI_POSITIVE_RATIO) * n_pos - n_pos)
+        perm = torch.randperm(neg_idx.numel()) if perms is None else perms[1]
+        neg_idx = neg_idx[perm[:n_neg].to(dev)]
+        rois = torch.cat([p_rois, proposals[neg_idx]], dim=0)
+        class_ids = torch.cat([class_ids, torch.zeros(neg_idx.numel(), dtype=torch.long, device=dev)])
+        deltas = torch.cat([deltas, torch.zeros((neg_idx.numel(), 6), device=dev)], dim=0)
+    return p_rois, rois, class_ids, deltas, labels
+
+
 # ------------------------------------------------------------------------------------------ detections
 def clip_to_window(window, boxes):
     """model.py:570-581."""

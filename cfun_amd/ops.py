@@ -396,6 +396,24 @@ def roi_align(fm, boxes, pool):
     return _RoIAlign.apply(fm, boxes, tuple(pool))
 
 
+def mask_target_labels(labels, rois, mask_shape):
+    """GT mask targets of model.py:481-493 as uint8 labels: labels [D,H,W] uint8, rois [R,6] normalised ->
+    [R, *mask_shape] uint8 (crop with int(shape*coord) truncation in fp32, nearest resize)."""
+    lib = _lib.load()
+    labels = _c(labels)
+    if labels.dtype != torch.uint8 or labels.dim() != 3:
+        raise RuntimeError("mask_target_labels: labels must be uint8 [D,H,W]")
+    d, h, w = labels.shape
+    scale = torch.tensor([d, h, w, d, h, w], dtype=torch.float32, device=rois.device)
+    bounds = _c((rois.detach().float() * scale).to(torch.int32))          # fp32 product, truncation toward zero
+    r = bounds.shape[0]
+    md, mh, mw = [int(v) for v in mask_shape]
+    out = torch.empty((r, md, mh, mw), dtype=torch.uint8, device=labels.device)
+    check(lib.cfun_mask_target_labels(ptr(labels), ptr(bounds), ptr(out), r, d, h, w, md, mh, mw, stream(labels)),
+          "mask_target_labels")
+    return out
+
+
 def nms3d(boxes, scores, threshold, max_num):
     """Greedy 3-D NMS on device; returns (keep int32 [n], count int32 [1]) -- keep[:count] is the pick order."""
     lib = _lib.load()

@@ -90,6 +90,29 @@ class CFUNHotPath(nn.Module):
                     mrcnn_class_logits=cls_logits, mrcnn_class=cls_probs, mrcnn_bbox=cls_bbox,
                     mrcnn_mask_logits=mask_logits, mrcnn_mask=mask_probs, p2=p2, p3=p3)
 
+    def predict_training_full(self, image, gt_class_ids, gt_boxes, gt_labels, perms=None):
+        """The un-injected ``predict(mode='training')`` (model.py:1462-1514): the RoI sets come from
+        ``detection_target_layer`` on this step's own proposals.  gt_boxes [G,6] in voxels (z1,y1,x1,z2,y2,x2),
+        gt_labels uint8 [D,H,W].  The returned dict also carries the targets; with no positive proposal the head
+        outputs are None (the reference returns empty tensors and ``compute_losses`` yields zeros)."""
+        self.train()
+        cfg = self.config
+        height, width, depth = [float(v) for v in cfg.IMAGE_SHAPE[:3]]
+        p2, p3, rpn_logits, rpn_probs, rpn_bbox = self.backbone_rpn(image)
+        rpn_rois = self.proposals(rpn_probs, rpn_bbox, "training")
+        scale = torch.tensor([depth, height, width, depth, height, width], dtype=torch.float32, device=image.device)
+        p_rois, rois, tcls, tdeltas, tlabels = model.detection_target_layer(
+            rpn_rois, gt_class_ids, gt_boxes.float() / scale, gt_labels, cfg, perms)
+        out = dict(rpn_class_logits=rpn_logits, rpn_probs=rpn_probs, rpn_bbox=rpn_bbox, rpn_rois=rpn_rois, p2=p2, p3=p3,
+                   p_rois=p_rois, rois=rois, target_class_ids=tcls, target_deltas=tdeltas, mask_labels=tlabels,
+                   mrcnn_class_logits=None, mrcnn_class=None, mrcnn_bbox=None, mrcnn_mask_logits=None,
+                   mrcnn_mask=None)
+        if rois.shape[0]:
+            out["mrcnn_class_logits"], out["mrcnn_class"], out["mrcnn_bbox"] = self.classifier.forward_ndhwc(
+                [p2[0], p3[0]], rois)
+            out["mrcnn_mask_logits"], out["mrcnn_mask"] = self.mask.forward_ndhwc(ops.to_ndhwc(image)[0], p_rois)
+        return out
+
     @torch.no_grad()
     def predict_inference(self, image, window=None):
         """``predict(mode='inference')`` (model.py:1436-1461): proposals (POST_NMS_ROIS_INFERENCE) -> classifier ->
@@ -188,6 +211,21 @@ def synthetic_inputs(config, device, seed=0):
     return dict(image=t(img)[None, None], p_rois=t(p_rois), n_rois=t(n_rois), target_class_ids=t(target_class_ids),
                 target_deltas=target_deltas.to(device), mask_labels=t(labels), rpn_match=t(rpn_match),
                 rpn_bbox_t=t(rpn_bbox_t), labels_volume=lab)
+
+
+def training_step_full(net, image, gt_class_ids, gt_boxes, gt_labels, rpn_match, rpn_bbox_t, perms=None):
+    """Forward + 6 losses + backward of the un-injected dataflow (targets sampled on device from the proposals)."""
+    out = net.predict_training_full(image, gt_class_ids, gt_boxes, gt_labels, perms)
+    if out["mrcnn_mask_logits"] is None:
+        z = torch.zeros((), device=image.device)
+        losses = [model.compute_rpn_class_loss(rpn_match, out["rpn_class_logits"]),
+                  model.compute_rpn_bbox_loss(rpn_bbox_t, rpn_match, out["rpn_bbox"]), z, z, z, z]
+    else:
+        losses = net.compute_losses(out, rpn_match, rpn_bbox_t, out["target_class_ids"], out["target_deltas"],
+                                    out["mask_labels"])
+    total = net.total_loss(losses)
+    total.backward()
+    return out, losses, total
 
 
 def training_step(net, s):

@@ -142,6 +142,12 @@ int cfun_maxpool2_fwd(const float* x, float* y, uint8_t* idx, int32_t N, int32_t
 int cfun_maxpool2_bwd(const float* dy, const uint8_t* idx, float* dx, int32_t N, int32_t Do, int32_t Ho, int32_t Wo,
                       int32_t C, cfun_stream_t stream);
 
+/* GT mask targets of detection_target_layer (model.py:481-493, utils.py:318-339) as uint8 class labels:
+ * labels [D,H,W] (class id per voxel = argmax of the one-hot GT), bounds [R,6] int32 voxel crop
+ * (z1,y1,x1,z2,y2,x2) = int(shape * normalised coordinate), out [R,md,mh,mw] = nearest-resized crop. */
+int cfun_mask_target_labels(const uint8_t* labels, const int32_t* bounds, uint8_t* out, int32_t R, int32_t D,
+                            int32_t H, int32_t W, int32_t md, int32_t mh, int32_t mw, cfun_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * 3-D RoIAlign = crop + trilinear(align_corners=True) resize (model.py:265-289, utils.py:160-174).
  * fm [D,H,W,C]; boxes [R,6] normalised (z1,y1,x1,z2,y2,x2); out [R,pd,ph,pw,C];

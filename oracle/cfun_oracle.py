@@ -491,6 +491,49 @@ def mask_targets(p_rois, gt_masks, mask_shape):
     return torch.stack(out, dim=0)
 
 
+def bbox_overlaps(boxes1, boxes2):
+    """model.py:373-411: IoU matrix [len(boxes1), len(boxes2)], fp32, no epsilon (x, y, z factor order)."""
+    b1 = boxes1[:, None, :]
+    b2 = boxes2[None, :, :]
+    z1 = torch.max(b1[..., 0], b2[..., 0]); y1 = torch.max(b1[..., 1], b2[..., 1]); x1 = torch.max(b1[..., 2], b2[..., 2])
+    z2 = torch.min(b1[..., 3], b2[..., 3]); y2 = torch.min(b1[..., 4], b2[..., 4]); x2 = torch.min(b1[..., 5], b2[..., 5])
+    zero = torch.zeros(())
+    inter = torch.max(x2 - x1, zero) * torch.max(y2 - y1, zero) * torch.max(z2 - z1, zero)
+    v1 = (b1[..., 3] - b1[..., 0]) * (b1[..., 4] - b1[..., 1]) * (b1[..., 5] - b1[..., 2])
+    v2 = (b2[..., 3] - b2[..., 0]) * (b2[..., 4] - b2[..., 1]) * (b2[..., 5] - b2[..., 2])
+    return inter / (v1 + v2 - inter)
+
+
+def detection_target_layer(proposals, gt_class_ids, gt_boxes, gt_masks, mask_shape, perm_pos, perm_neg,
+                           train_rois=15, positive_ratio=0.33, iou_threshold=0.5,
+                           std_dev=(0.1, 0.1, 0.1, 0.2, 0.2, 0.2)):
+    """model.py:414-563 with the two torch.randperm draws (459, 505) injected: proposals [N,6] and gt_boxes [G,6]
+    normalised, gt_class_ids [G], gt_masks one-hot [C,D,H,W].  Returns (positive_rois, rois, class_ids, deltas,
+    masks [n_pos,C,*mask_shape]) -- positives first.  Only the 'positives and negatives' / 'positives only' branches
+    are restated (the others return empty sets or hit the NameError of App. A-15)."""
+    overlaps = bbox_overlaps(proposals, gt_boxes)
+    iou_max = overlaps.max(dim=1)[0]
+    pos_idx = torch.nonzero(iou_max >= iou_threshold)[:, 0]
+    if pos_idx.numel() == 0:
+        raise ValueError("no positive RoI: the reference skips the heads for this sample")
+    pos_idx = pos_idx[perm_pos[:int(train_rois * positive_ratio)]]
+    n_pos = pos_idx.numel()
+    p_rois = proposals[pos_idx]
+    assign = overlaps[pos_idx].max(dim=1)[1]
+    deltas = box_refinement(p_rois, gt_boxes[assign]) / torch.tensor(std_dev, dtype=torch.float32)
+    class_ids = gt_class_ids[assign].long()
+    masks = mask_targets(p_rois, gt_masks, mask_shape)
+    neg_idx = torch.nonzero(iou_max < iou_threshold)[:, 0]
+    rois = p_rois
+    if neg_idx.numel() != 0:
+        n_neg = int((1.0 / positive_ratio) * n_pos - n_pos)
+        neg_idx = neg_idx[perm_neg[:n_neg]]
+        rois = torch.cat([p_rois, proposals[neg_idx]], dim=0)
+        class_ids = torch.cat([class_ids, torch.zeros(neg_idx.numel(), dtype=torch.long)])
+        deltas = torch.cat([deltas, torch.zeros(neg_idx.numel(), 6)], dim=0)
+    return p_rois, rois, class_ids, deltas, masks
+
+
 # --------------------------------------------------------------------------------------
 # one training step with injected RoI sets (SURVEY.md section 8(d)); the P row of 8(a)
 # --------------------------------------------------------------------------------------

@@ -333,3 +333,21 @@ def check_halo(device, seed=5):
     ops.halo_unpack(buf, dst, 0)
     assert_close(dst[:, 0:2], x[:, 4:6], "halo_unpack", 1e-9)
     assert float(dst[:, 2:].abs().max()) == 0.0
+
+
+def check_mask_target_labels(device, seed=11):
+    """cfun_mask_target_labels vs the oracle's crop + nearest resize of the one-hot GT (model.py:481-493), bit-exact:
+    ragged, thin (1-voxel) and boundary-touching boxes, up- and down-sampling, non-cubic mask shapes."""
+    gen = _gen(seed)
+    D, H, W, C = 12, 20, 17, 5
+    lab = torch.randint(0, C, (D, H, W), generator=gen, dtype=torch.int64)
+    onehot = torch.stack([(lab == k) for k in range(C)], dim=0).float()
+    lo = torch.rand(9, 3, generator=gen) * 0.6
+    hi = lo + 0.08 + torch.rand(9, 3, generator=gen) * 0.35
+    rois = torch.cat([lo, hi.clamp(max=1.0)], dim=1)
+    rois[0] = torch.tensor([0.0, 0.0, 0.0, 1.0, 1.0, 1.0])            # whole volume
+    rois[1] = torch.tensor([0.5, 0.5, 0.5, 0.5 + 1.01 / D, 1.0, 0.9])  # one plane thick
+    for shape in ((8, 8, 8), (24, 40, 34), (5, 9, 7)):
+        ref = orc.mask_targets(rois, onehot, shape).argmax(1).to(torch.uint8)
+        out = ops.mask_target_labels(lab.to(torch.uint8).to(device), rois.to(device), shape)
+        assert torch.equal(out.cpu(), ref), shape

@@ -319,3 +319,79 @@ def check_refine_detections_golden(device):
         det = model.refine_detections(torch.from_numpy(g["rois"]).to(device), torch.from_numpy(g["probs"]).to(device),
                                       torch.from_numpy(g["deltas"]).to(device), g["window"], cfg)
         np.testing.assert_array_equal(det.cpu().numpy(), g["det_" + tag])
+
+
+def check_predict_cfg0_golden(device):
+    """The product's un-injected training step (proposals -> detection_target_layer on device -> heads -> losses ->
+    backward) against the REFERENCE's own outputs at BASELINE configs[0] (tests/golden/predict_cfg0.npz: same
+    closed-form weights, image, GT, recorded randperm draws and dropout masks)."""
+    from cfun_amd import config, step
+    g = load_golden("predict_cfg0")
+    cfg = config.heart_config("beginning", 64, 64, 32)
+    net = step.CFUNHotPath(cfg)
+    net.load_state_dict(golden_state_dict(g), strict=True)
+    net = net.to(device)
+    net.mask.modified_u_net.dropout_masks = [torch.from_numpy(g["drop%d" % i]) for i in range(5)]
+    dev = torch.device(device)
+    image = torch.from_numpy(g["image"])[None, None].to(dev)
+    out, losses, total = step.training_step_full(
+        net, image, torch.from_numpy(g["gt_class_ids"][0].astype(np.int64)).to(dev),
+        torch.from_numpy(g["gt_boxes"][0]).to(dev), torch.from_numpy(g["gt_masks_labels"]).to(dev),
+        torch.from_numpy(g["rpn_match"]).to(dev), torch.from_numpy(g["rpn_bbox_t"]).to(dev),
+        perms=(torch.from_numpy(g["randperm0"]), torch.from_numpy(g["randperm1"])))
+    np.testing.assert_allclose(out["rpn_class_logits"].detach().cpu().numpy(), g["rpn_class_logits"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(out["rpn_bbox"].detach().cpu().numpy(), g["rpn_pred_bbox"], rtol=1e-4, atol=2e-5)
+    assert out["p_rois"].shape[0] == int(g["n_pos"]) and out["rois"].shape[0] == int(g["n_rois"])
+    # GT boxes are 7 copies of one box: the assigned class is an arg-max tie, only "positive or not" is defined
+    np.testing.assert_array_equal((out["target_class_ids"] > 0).cpu().numpy(), g["target_class_ids"] > 0)
+    np.testing.assert_allclose(out["target_deltas"].cpu().numpy(), g["target_deltas"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_array_equal(out["mask_labels"].cpu().numpy(), g["target_mask_labels"])     # bit-exact
+    np.testing.assert_allclose(out["mrcnn_class_logits"].detach().cpu().numpy(), g["mrcnn_class_logits"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(out["mrcnn_bbox"].detach().cpu().numpy(), g["mrcnn_bbox"], rtol=1e-3, atol=1e-5)
+    ml = out["mrcnn_mask_logits"].detach().cpu().permute(0, 4, 1, 2, 3).numpy()
+    assert np.abs(ml[:, :, ::4, ::4, ::4] - g["mask_logits_sub"]).max() < 1e-3
+    assert abs(np.abs(ml).astype(np.float64).sum() - g["mask_logits_sum"][1]) < 1e-4 * g["mask_logits_sum"][1]
+    for i, (a, r) in enumerate(zip(losses, g["losses"])):
+        assert abs(float(a.detach()) - float(r)) <= 1e-4 * max(abs(float(r)), 1e-3), "loss %d: %g vs %g" % (i, float(a.detach()), r)
+    assert abs(float(total.detach()) - float(g["total"])) <= 1e-4 * abs(float(g["total"]))
+    params = dict(net.named_parameters())
+    for k in [k[5:] for k in g if k.startswith("grad:")]:
+        e = rel_l2(params[k].grad.cpu().numpy(), g["grad:" + k])
+        assert e < UNET_GRAD_L2_TOL, "%s: rel L2 %.3e" % (k, e)
+    return [float(l.detach()) for l in losses]
+
+
+def check_detection_target_layer(device, seed=3):
+    """cfun_amd.model.detection_target_layer vs the oracle restatement (itself pinned to the reference by
+    test_predict_cfg0_full_dataflow) on random proposals, distinct GT boxes, injected permutations."""
+    from cfun_amd import model
+    cfg = tiny_config("beginning")
+    cfg.MASK_SHAPE = (16, 16, 16)
+    gen = torch.Generator().manual_seed(seed)
+    D, H, W = 16, 32, 32
+    gt = torch.tensor([[0.05, 0.1, 0.1, 0.6, 0.55, 0.5], [0.4, 0.5, 0.45, 0.95, 0.95, 0.9]])
+    gt_ids = torch.tensor([3, 5])
+    jit = (torch.rand(20, 6, generator=gen) - 0.5) * 0.2
+    props = torch.cat([(gt[i % 2] + jit[i]).clamp(0, 1)[None] for i in range(20)] +
+                      [torch.tensor([[0.0, 0.0, 0.6, 0.2, 0.2, 0.9]]), torch.tensor([[0.7, 0.0, 0.0, 1.0, 0.3, 0.3]])] * 6)
+    props[:, 3:] = torch.max(props[:, 3:], props[:, :3] + 0.05)
+    lab = torch.randint(0, 8, (D, H, W), generator=gen, dtype=torch.int64)
+    onehot = torch.stack([(lab == k) for k in range(8)], dim=0).float()
+    iou = orc.bbox_overlaps(props, gt).max(1)[0]
+    n_pc, n_nc = int((iou >= 0.5).sum()), int((iou < 0.5).sum())
+    assert n_pc > 5 and n_nc > 10
+    perms = (torch.randperm(n_pc, generator=gen), torch.randperm(n_nc, generator=gen))
+    r = orc.detection_target_layer(props, gt_ids, gt, onehot, cfg.MASK_SHAPE, perms[0], perms[1],
+                                   cfg.TRAIN_ROIS_PER_IMAGE, cfg.ROI_POSITIVE_RATIO)
+    o = model.detection_target_layer(props.to(device)[None], gt_ids.to(device), gt.to(device),
+                                     lab.to(torch.uint8).to(device), cfg, perms)
+    np.testing.assert_array_equal(o[0].cpu().numpy(), r[0].numpy())
+    np.testing.assert_array_equal(o[1].cpu().numpy(), r[1].numpy())
+    np.testing.assert_array_equal(o[2].cpu().numpy(), r[2].numpy())
+    np.testing.assert_allclose(o[3].cpu().numpy(), r[3].numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(o[4].cpu().numpy(), r[4].argmax(1).numpy().astype(np.uint8))
+    assert o[0].shape[0] == int(cfg.TRAIN_ROIS_PER_IMAGE * cfg.ROI_POSITIVE_RATIO)
+    # no positive proposal: every output is empty
+    far = torch.tensor([[0.0, 0.0, 0.0, 0.05, 0.05, 0.05]]).to(device)
+    e = model.detection_target_layer(far, gt_ids.to(device), gt.to(device), lab.to(torch.uint8).to(device), cfg)
+    assert e[0].shape[0] == 0 and e[1].shape[0] == 0 and e[4].shape[0] == 0

@@ -74,3 +74,7 @@ def test_mask_losses_3class(emu):
     logits = rng.normal(size=(1, 3, 6, 7, 8)).astype(np.float32)
     labels = rng.integers(0, 3, size=(1, 6, 7, 8)).astype(np.uint8)
     kc.check_mask_losses(emu, logits, labels)
+
+
+def test_mask_target_labels(emu):
+    kc.check_mask_target_labels(emu)

@@ -128,3 +128,7 @@ def test_mfma_equals_direct_on_device(gpu):
         spec = ops.ConvSpec(k=(3, 3, 3), co=80, pad=(1, 1, 1), algo=algo)
         ys.append(ops.conv3d(x, ops.pack_weight(w), spec))
     kc.assert_close(ys[1], ys[0], "mfma vs direct", 1e-5)
+
+
+def test_mask_target_labels(gpu):
+    kc.check_mask_target_labels(gpu)

@@ -72,3 +72,7 @@ def test_inference_vs_oracle(emu_direct):
     """predict('inference') + refine_detections on the tiny config, 1 detection through the U-Net."""
     r = mc.check_inference_vs_oracle(emu_direct, mc.tiny_config("beginning"), max_instances=1)
     assert r["n_det"] == 1
+
+
+def test_detection_target_layer(emu):
+    mc.check_detection_target_layer(emu)

@@ -132,3 +132,12 @@ def test_inference_cfg0(gpu):
     from cfun_amd import config
     # one instance: at this size several clipped proposals coincide, so lower-ranked scores tie exactly
     mc.check_inference_vs_oracle(gpu, config.heart_config("beginning", 64, 64, 32), max_instances=1)
+
+
+def test_predict_cfg0_reference_golden(gpu):
+    """Un-injected training step vs the reference's own cfg0 outputs (detection_target_layer on device included)."""
+    mc.check_predict_cfg0_golden(gpu)
+
+
+def test_detection_target_layer(gpu):
+    mc.check_detection_target_layer(gpu)

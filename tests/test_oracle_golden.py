@@ -173,3 +173,53 @@ def test_classifier():
     np.testing.assert_allclose(p2.grad.numpy(), g["p2_grad"], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(p3.grad.numpy(), g["p3_grad"], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(params["conv1.weight"].grad.numpy(), g["grad:conv1.weight"], rtol=1e-4, atol=1e-6)
+
+
+def test_predict_cfg0_full_dataflow():
+    """The anchor of the whole path: the reference's OWN un-injected predict('training') + compute_losses +
+    backward at BASELINE configs[0] (64x64x32, 'beginning', real channel counts; gen_golden.case_predict) against
+    the oracle chain FPN -> RPN -> proposal_layer -> detection_target_layer -> classifier / mask head -> 6 losses."""
+    g = load_golden("predict_cfg0")
+    sd = golden_state_dict(g)
+    params = {k: v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v
+              for k, v in sd.items()}
+    image = t(g["image"])[None, None]
+    D, H, W = [int(v) for v in image.shape[2:]]
+    p2, p3 = orc.fpn(image, params)
+    l2, pr2, b2 = orc.rpn(p2, params)
+    l3, pr3, b3 = orc.rpn(p3, params)
+    rpn_logits, rpn_probs, rpn_box = [torch.cat(v, dim=1) for v in ((l2, l3), (pr2, pr3), (b2, b3))]
+    np.testing.assert_allclose(rpn_logits.detach().numpy(), g["rpn_class_logits"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rpn_box.detach().numpy(), g["rpn_pred_bbox"], rtol=1e-4, atol=1e-5)
+    rois_all, _, _ = orc.proposal_layer(rpn_probs[0].detach(), rpn_box[0].detach(), t(g["anchors"]), 500, 0.7, (D, H, W))
+    gt_boxes = t(g["gt_boxes"][0]) / torch.tensor([D, H, W, D, H, W], dtype=torch.float32)
+    lab = torch.from_numpy(g["gt_masks_labels"].astype(np.int64))
+    onehot = torch.stack([(lab == k) for k in range(8)], dim=0).float()
+    p_rois, rois, cls_ids, deltas, masks = orc.detection_target_layer(
+        rois_all, torch.from_numpy(g["gt_class_ids"][0].astype(np.int64)), gt_boxes, onehot, (96, 96, 96),
+        torch.from_numpy(g["randperm0"]), torch.from_numpy(g["randperm1"]))
+    assert p_rois.shape[0] == int(g["n_pos"]) and rois.shape[0] == int(g["n_rois"])
+    np.testing.assert_array_equal(cls_ids.numpy(), g["target_class_ids"])
+    np.testing.assert_allclose(deltas.numpy(), g["target_deltas"], rtol=1e-4, atol=1e-5)   # deltas = d(box)/0.1
+    np.testing.assert_array_equal(masks.argmax(1).numpy().astype(np.uint8), g["target_mask_labels"])
+    cls_logits, _, cls_bbox = orc.classifier([p2[0], p3[0]], rois, params, [12, 12, 12])
+    np.testing.assert_allclose(cls_logits.detach().numpy(), g["mrcnn_class_logits"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(cls_bbox.detach().numpy(), g["mrcnn_bbox"], rtol=1e-4, atol=1e-5)
+    drops = [t(g["drop%d" % i]) for i in range(5)]
+    m_logits, m_probs = orc.mask_head(image[0], p_rois, params, [96, 96, 96], "beginning", dropout_masks=drops)
+    ml = m_logits.detach().numpy()
+    assert np.abs(ml[:, :, ::4, ::4, ::4] - g["mask_logits_sub"]).max() < 1e-3
+    assert abs(np.abs(ml).astype(np.float64).sum() - g["mask_logits_sum"][1]) < 1e-5 * g["mask_logits_sum"][1]
+    losses = [orc.rpn_class_loss(torch.from_numpy(g["rpn_match"]), rpn_logits),
+              orc.rpn_bbox_loss(t(g["rpn_bbox_t"]), torch.from_numpy(g["rpn_match"]), rpn_box),
+              orc.mrcnn_class_loss(cls_ids, cls_logits), orc.mrcnn_bbox_loss(deltas, cls_ids, cls_bbox),
+              orc.mask_ce_loss(masks.double(), m_logits), torch.zeros(())]
+    for i, (a, r) in enumerate(zip(losses, g["losses"])):
+        assert abs(float(a.detach()) - float(r)) <= 1e-4 * max(abs(float(r)), 1e-3), "loss %d vs %g" % (i, r)
+    total = sum(w * l for w, l in zip(orc.LOSS_WEIGHTS, losses))
+    assert abs(float(total) - float(g["total"])) <= 1e-4 * abs(float(g["total"]))
+    total.backward()
+    for k in [k[5:] for k in g if k.startswith("grad:")]:
+        a, r = params[k].grad.numpy(), g["grad:" + k]
+        e = np.linalg.norm((a - r).ravel()) / max(np.linalg.norm(r.ravel()), 1e-30)
+        assert e < 2e-2, "%s: rel L2 %.3e" % (k, e)   # LeakyReLU mask flips, see tests/module_cases.UNET_GRAD_L2_TOL
