@@ -118,16 +118,22 @@ def main():
     net = step.CFUNHotPath(cfg).to(dev)
     sample = step.synthetic_inputs(cfg, dev, seed=rank)
     assert sample["p_rois"].shape[0] == 4 and sample["n_rois"].shape[0] == 8   # heads must not be skipped
-    params = [p for p in net.parameters() if p.requires_grad]
     timer = ops.LaunchTimer(dominant_kernel_match(cfg))
+    # N > 1: data-parallel replicas (one volume per GPU).  Gradients are averaged in 64 MB flat buckets whose RCCL
+    # all-reduce is issued on a side stream as soon as backward has filled them (cfun_amd.dist.GradientReducer)
+    reducer = None
+    if world > 1:
+        from cfun_amd import dist as cdist
+        reducer = cdist.GradientReducer(net.parameters())
 
     def one_step():
-        net.zero_grad(set_to_none=True)
+        if reducer is None:
+            net.zero_grad(set_to_none=True)
+        else:
+            reducer.zero_grad()
         out, losses, total = step.training_step(net, sample)
-        if world > 1:   # data-parallel replicas: one flat gradient all-reduce per step
-            flat = torch.cat([p.grad.reshape(-1) for p in params if p.grad is not None])
-            dist.all_reduce(flat)
-            flat.div_(world)
+        if reducer is not None:
+            reducer.finish()
         return losses
 
     def fence():
@@ -169,7 +175,7 @@ def main():
             "config": {"workload": "%s: %dx%dx%d CT, stage '%s', 4 positive + 8 negative RoIs, U-Net b=%d, "
                                    "96^3 -> %d^3 masks, 6 losses incl. 3-D Sobel edge loss, fwd+bwd"
                                    % (args.workload, h, w, d, stage, b, cfg.MASK_SHAPE[0]),
-                       "parallelism": "1 volume per GPU x %d, gradient all-reduce (RCCL)" % world if world > 1
+                       "parallelism": "1 volume per GPU x %d, bucketed gradient all-reduce (RCCL) overlapped with backward" % world if world > 1
                                       else "single GPU"},
             "losses": lv,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -173,3 +173,108 @@ def sharded_backbone_rpn(net, image_slab):
     logits, probs, bbox = gather_rpn_outputs(local)
     rois = net.proposals(probs, bbox, "inference" if not net.training else "training")
     return p2, p3, logits, probs, bbox, rois
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Data-parallel gradient reduction (SURVEY.md section 8(e) "Gradients" / "Whole-step alternative")
+# ---------------------------------------------------------------------------------------------------------------
+class GradientReducer:
+    """Average the parameter gradients of data-parallel replicas (one volume per GPU), overlapped with backward.
+
+    MI355X-first choices: the gradients live in a few large flat buckets (``p.grad`` are views, so there is no
+    gather copy and each collective moves tens of MB -- xGMI rings are per-link bound, small messages waste them);
+    a bucket's all-reduce is issued on a side HIP stream the moment autograd has accumulated its last gradient
+    (post-accumulate hooks), so RCCL runs under the rest of the backward pass.  The 113 MB classifier weight is
+    reduced while the U-Net and the backbone are still back-propagating.
+
+        red = GradientReducer(net.parameters())
+        per step:  red.zero_grad(); loss.backward(); red.finish()      # then p.grad holds the mean over ranks
+
+    Buckets are filled in reverse parameter order (heads first), the order autograd produces them in.  A parameter
+    that gets no gradient in a step still takes part in its bucket's reduction (its slice stays zero); ``finish``
+    launches whatever bucket did not complete through the hooks.  With world size 1 it is a no-op container
+    (``always_reduce`` keeps the collectives for single-rank tests of the stream logic)."""
+
+    def __init__(self, params, bucket_bytes=64 << 20, group=None, always_reduce=False):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.active = self.world > 1 or (always_reduce and dist.is_available() and dist.is_initialized())
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets = []       # dicts: flat, params, pending, ready, work
+        order = list(reversed(self.params))
+        cur, cur_bytes = [], 0
+        for p in order:
+            nbytes = p.numel() * p.element_size()
+            if cur and cur_bytes + nbytes > bucket_bytes:
+                self._add_bucket(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            self._add_bucket(cur)
+        self._where = {}        # id(param) -> (bucket, slot)
+        for b, bucket in enumerate(self.buckets):
+            for i, p in enumerate(bucket["params"]):
+                self._where[id(p)] = (b, i)
+        self.comm_stream = None
+        if self.params and self.params[0].is_cuda:
+            self.comm_stream = torch.cuda.Stream(device=self.params[0].device)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if self.active else []
+
+    def _add_bucket(self, plist):
+        n = sum(p.numel() for p in plist)
+        flat = torch.zeros(n, dtype=plist[0].dtype, device=plist[0].device)
+        off = 0
+        views = []
+        for p in plist:
+            views.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        self.buckets.append(dict(flat=flat, params=plist, views=views, pending=len(plist), work=None, launched=False))
+
+    def zero_grad(self):
+        """Zero the buckets and (re)attach ``p.grad`` to its bucket view; call instead of ``net.zero_grad()``."""
+        for bucket in self.buckets:
+            bucket["flat"].zero_()
+            bucket["pending"], bucket["work"], bucket["launched"] = len(bucket["params"]), None, False
+            for p, v in zip(bucket["params"], bucket["views"]):
+                p.grad = v
+
+    def _launch(self, bucket):
+        bucket["launched"] = True
+        if not self.active:
+            return
+        flat = bucket["flat"]
+        if self.comm_stream is not None:
+            self.comm_stream.wait_stream(torch.cuda.current_stream(flat.device))   # the gradients are complete
+            with torch.cuda.stream(self.comm_stream):
+                bucket["work"] = dist.all_reduce(flat, group=self.group, async_op=True)
+        else:
+            bucket["work"] = dist.all_reduce(flat, group=self.group, async_op=True)
+
+    def _on_grad(self, p):
+        b, slot = self._where[id(p)]
+        bucket = self.buckets[b]
+        if p.grad is None or p.grad.data_ptr() != bucket["views"][slot].data_ptr():
+            raise RuntimeError("GradientReducer: call zero_grad() of the reducer before backward()")
+        bucket["pending"] -= 1
+        if bucket["pending"] == 0 and not bucket["launched"]:
+            self._launch(bucket)
+
+    def finish(self):
+        """Complete every bucket's reduction and scale to the mean; the compute stream waits for the comm stream."""
+        if not self.active:
+            return
+        for bucket in self.buckets:
+            if not bucket["launched"]:
+                self._launch(bucket)
+        for bucket in self.buckets:
+            bucket["work"].wait()
+        if self.comm_stream is not None:
+            torch.cuda.current_stream(self.params[0].device).wait_stream(self.comm_stream)
+        for bucket in self.buckets:
+            bucket["flat"].div_(self.world)
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []

@@ -73,6 +73,27 @@ def main():
         yr = conv(xr)
         (yr * gys).sum().backward()
         res.update(ref_conv_y=yr.detach().numpy(), ref_conv_gx=xr.grad.numpy(), ref_conv_gw=conv.weight.grad.numpy())
+    # 4) data-parallel replicas: bucketed gradient averaging overlapped with backward (hooks), incl. a parameter that
+    #    gets no gradient and a weight used twice (one accumulate, one hook call)
+    torch.manual_seed(2)
+    c1, c2, unused = Conv3dParams(4, 8, 3, padding=1), Conv3dParams(8, 8, 1), Conv3dParams(8, 4, 1)
+    plist = list(c1.parameters()) + list(c2.parameters()) + list(unused.parameters())
+    red = cdist.GradientReducer(plist, bucket_bytes=300)           # several buckets
+    assert len(red.buckets) > 2
+    xr = torch.randn(1, 4, 4, 4, 4, generator=torch.Generator().manual_seed(10 + rank))
+    for it in range(2):                                             # buckets are reusable across steps
+        red.zero_grad()
+        y = c2(c2(c1(xr)))
+        (y * y).sum().backward()
+        red.finish()
+    res["dp_grads"] = np.concatenate([p.grad.reshape(-1).numpy() for p in plist])
+    for p in plist:
+        p.grad = None
+    red.remove()
+    y = c2(c2(c1(xr)))
+    (y * y).sum().backward()
+    res["dp_local"] = np.concatenate([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).numpy()
+                                      for p in plist])
     np.savez(out % rank, **res)
     dist.barrier()
     dist.destroy_process_group()
