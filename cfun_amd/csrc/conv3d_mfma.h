@@ -43,6 +43,26 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
   return base + local;
 }
 
+// Tile raster: consecutive logical ids sweep super-tiles of 4(z) x 4(y) x all(x) output tiles, so that the ~100
+// workgroups an XCD runs at a time share their halos through its 4 MB L2 in z as well as in x / y (a plain x,y,z
+// raster revisits a z-neighbour one whole tile-slab later, after the L2 has turned over).  Bijective for any counts.
+__device__ __forceinline__ void tile_raster(unsigned t, int ntz, int nty, int ntx, int& tz, int& ty, int& tx) {
+  constexpr int SZ = 4, SY = 4;
+  const unsigned band = (unsigned)(SZ * nty * ntx);
+  const int zb = (int)(t / band);
+  unsigned r = t - (unsigned)zb * band;
+  const int bz = ntz - zb * SZ < SZ ? ntz - zb * SZ : SZ;
+  const unsigned sup = (unsigned)(bz * SY * ntx);
+  const int yb = (int)(r / sup);
+  r -= (unsigned)yb * sup;
+  const int by = nty - yb * SY < SY ? nty - yb * SY : SY;
+  const int tzi = (int)(r / (unsigned)(by * ntx));
+  r -= (unsigned)(tzi * by * ntx);
+  tz = zb * SZ + tzi;
+  ty = yb * SY + (int)(r / (unsigned)ntx);
+  tx = (int)(r % (unsigned)ntx);
+}
+
 // Internal launch modes derived by the C entry points (conv3d.hip) from CfunConv3dParams.
 struct ConvMode {
   int flip;      // mirrored taps: the data gradient of a stride-1 conv
@@ -103,10 +123,10 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform
   unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
   const int cot = lid % ncot; lid /= ncot;
-  const int tx = lid % ntx; lid /= ntx;
-  const int ty = lid % nty; lid /= nty;
-  const int tz = lid % ntz;
-  const int n = lid / ntz;
+  const unsigned per_n = (unsigned)(ntz * nty * ntx);
+  const int n = lid / per_n;
+  int tz, ty, tx;
+  tile_raster(lid - (unsigned)n * per_n, ntz, nty, ntx, tz, ty, tx);
   const int z0 = tz * T::TD, y0 = ty * T::TH, x0 = tx * T::TW;
   const int cobase = cot * NT;
   const int sh = p.up2 ? 1 : 0;
