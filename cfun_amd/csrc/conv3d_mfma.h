@@ -468,7 +468,11 @@ wgrad_body(float* smem, const float* __restrict__ x, const float* __restrict__ g
 #pragma unroll
     for (int nn = 0; nn < NSUB; ++nn) acc[t][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Staging of tile t+1 is issued before the MFMA phase of tile t and must not stall it: every load is
+  // UNCONDITIONAL (out-of-range items read offset 0) and the zero padding is applied from the validity bits at
+  // commit time -- exec-masked loads made hipcc wrap each one in nested branches and wait (vmcnt(0)) mid-way.
   float4 xin[T::X_LOADS], gin[G_LOADS];
+  unsigned xvalid = 0, gvalid = 0;
   auto prefetch = [&](int tile) {
     int t = tile;
     const int tx = t % ntx; t /= ntx;
@@ -476,55 +480,60 @@ wgrad_body(float* smem, const float* __restrict__ x, const float* __restrict__ g
     const int tz = t % ntz;
     const int n = t / ntz;
     const int z0 = tz * T::TD, y0 = ty * T::TH, x0 = tx * T::TW;
+    xvalid = 0; gvalid = 0;
 #pragma unroll
     for (int i = 0; i < T::X_LOADS; ++i) {
       const int it = tid + i * 256;
-      xin[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (it < T::IVOX * 4) {
-        const int idx = it >> 2, c = ci0 + (it & 3) * 4;
-        const int ix = idx % T::IX, iy = (idx / T::IX) % T::IY, iz = idx / (T::IX * T::IY);
-        int vz, vy, vx;
-        if (T::COMPACT) { vz = (z0 + iz) * S - p.pd; vy = (y0 + iy) * S - p.ph; vx = (x0 + ix) * S - p.pw; }
-        else { vz = z0 * S - p.pd + iz; vy = y0 * S - p.ph + iy; vx = x0 * S - p.pw + ix; }
-        if (c < p.Ci && vz >= 0 && vz < Dv && vy >= 0 && vy < Hv && vx >= 0 && vx < Wv)
-          xin[i] = *reinterpret_cast<const float4*>(
-              x + ((((int64_t)n * p.Di + (vz >> sh)) * p.Hi + (vy >> sh)) * p.Wi + (vx >> sh)) * p.Ci + c);
-      }
+      const int idx = it >> 2, c = ci0 + (it & 3) * 4;
+      const int ix = idx % T::IX, iy = (idx / T::IX) % T::IY, iz = idx / (T::IX * T::IY);
+      int vz, vy, vx;
+      if (T::COMPACT) { vz = (z0 + iz) * S - p.pd; vy = (y0 + iy) * S - p.ph; vx = (x0 + ix) * S - p.pw; }
+      else { vz = z0 * S - p.pd + iz; vy = y0 * S - p.ph + iy; vx = x0 * S - p.pw + ix; }
+      const bool ok = (it < T::IVOX * 4) & (c < p.Ci) & (vz >= 0) & (vz < Dv) & (vy >= 0) & (vy < Hv) & (vx >= 0) &
+                      (vx < Wv);
+      // 32-bit element offsets (the launcher rejects tensors of 2^31 elements or more): half the address registers
+      const unsigned off = ((((unsigned)n * p.Di + (vz >> sh)) * p.Hi + (vy >> sh)) * p.Wi + (vx >> sh)) * p.Ci + c;
+      xin[i] = *reinterpret_cast<const float4*>(x + (ok ? off : 0u));
+      xvalid |= (ok ? 1u : 0u) << i;
     }
 #pragma unroll
     for (int i = 0; i < G_LOADS; ++i) {
       const int it = tid + i * 256;
-      gin[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (it < G_ITEMS) {
-        const int vox = it / (NT / 4), col = (it % (NT / 4)) * 4;
-        const int lx = vox % T::TW, ly = (vox / T::TW) % T::TH, lz = vox / (T::TW * T::TH);
-        const int oz = z0 + lz, oy = y0 + ly, ox = x0 + lx;
-        if (col < colimit && cobase + col < p.Co && oz < p.Do && oy < p.Ho && ox < p.Wo) {
-          if (p.d2s) {   // g is the hi-res gradient of y [N,2Do,2Ho,2Wo,Cq]: gather parity q, channel o
-            const int CqP = p.Co >> 3, Cq = p.d2s_cq > 0 ? p.d2s_cq : CqP;
-            const int co = cobase + col, q = co / CqP, o = co - q * CqP;
-            if (o < Cq)
-              gin[i] = *reinterpret_cast<const float4*>(
-                  g + ((((int64_t)n * 2 * p.Do + 2 * oz + (q >> 2)) * 2 * p.Ho + 2 * oy + ((q >> 1) & 1)) * 2 * p.Wo +
-                       2 * ox + (q & 1)) * Cq + o);
-          } else {
-            gin[i] = *reinterpret_cast<const float4*>(
-                g + ((((int64_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * p.Co + cobase + col);
-          }
-        }
+      const int vox = it / (NT / 4), col = (it % (NT / 4)) * 4;
+      const int lx = vox % T::TW, ly = (vox / T::TW) % T::TH, lz = vox / (T::TW * T::TH);
+      const int oz = z0 + lz, oy = y0 + ly, ox = x0 + lx;
+      bool ok = (it < G_ITEMS) & (col < colimit) & (cobase + col < p.Co) & (oz < p.Do) & (oy < p.Ho) & (ox < p.Wo);
+      unsigned off;
+      if (p.d2s) {   // g is the hi-res gradient of y [N,2Do,2Ho,2Wo,Cq]: gather parity q, channel o
+        const int CqP = p.Co >> 3, Cq = p.d2s_cq > 0 ? p.d2s_cq : CqP;
+        const int co = cobase + col, q = co / CqP, o = co - q * CqP;
+        ok = ok & (o < Cq);
+        off = ((((unsigned)n * 2 * p.Do + 2 * oz + (q >> 2)) * 2 * p.Ho + 2 * oy + ((q >> 1) & 1)) * 2 * p.Wo + 2 * ox +
+               (q & 1)) * Cq + o;
+      } else {
+        off = ((((unsigned)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * p.Co + cobase + col;
       }
+      gin[i] = *reinterpret_cast<const float4*>(g + (ok ? off : 0u));
+      gvalid |= (ok ? 1u : 0u) << i;
     }
   };
   auto commit = [&]() {
+    // (component-wise select: `cond ? xin[i] : zero` on the struct takes its address and sends the array to scratch)
+    auto keep = [](unsigned bit, const float4& v) {
+      const float m = bit ? 1.f : 0.f;
+      return make_float4(bit ? v.x : m, bit ? v.y : m, bit ? v.z : m, bit ? v.w : m);
+    };
 #pragma unroll
     for (int i = 0; i < T::X_LOADS; ++i) {
       const int it = tid + i * 256;
-      if (it < T::IVOX * 4) *reinterpret_cast<float4*>(Xl + (it >> 2) * T::XS + (it & 3) * 4) = xin[i];
+      if (it < T::IVOX * 4)
+        *reinterpret_cast<float4*>(Xl + (it >> 2) * T::XS + (it & 3) * 4) = keep((xvalid >> i) & 1u, xin[i]);
     }
 #pragma unroll
     for (int i = 0; i < G_LOADS; ++i) {
       const int it = tid + i * 256;
-      if (it < G_ITEMS) *reinterpret_cast<float4*>(Gl + (it / (NT / 4)) * GS + (it % (NT / 4)) * 4) = gin[i];
+      if (it < G_ITEMS)
+        *reinterpret_cast<float4*>(Gl + (it / (NT / 4)) * GS + (it % (NT / 4)) * 4) = keep((gvalid >> i) & 1u, gin[i]);
     }
   };
 
@@ -662,6 +671,9 @@ int launch_wgrad_mfma(const float* x, const float* g, float* partial, const Cfun
   using T = WgTile<KD, KH, KW, S>;
   constexpr int NT = 16 * NSUB, GS = pad_row16(NT);
   const size_t lds = (size_t)(T::IVOX * T::XS + T::TVOX * GS) * sizeof(float);
+  // the kernel addresses x and g with 32-bit element offsets
+  const int64_t lim = (int64_t)1 << 31;
+  if ((int64_t)p.N * p.Di * p.Hi * p.Wi * p.Ci >= lim || (int64_t)p.N * p.Do * p.Ho * p.Wo * p.Co >= lim) return CFUN_EINVAL;
   auto kern = k_wgrad_mfma<KD, KH, KW, S, NSUB, false, 1>;
   if constexpr (KD * KH * KW == 27) {   // C_in <= 8: PACK taps per A fragment
     const int pack = w.ncisub > 1 ? 1 : p.Ci <= 4 ? 4 : p.Ci <= 8 ? 2 : 1;
