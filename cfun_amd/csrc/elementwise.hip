@@ -385,6 +385,53 @@ k_weight_unpack(const float* __restrict__ dwp, float* __restrict__ dw, int Co, i
   }
 }
 
+// ---------------------------------------------------------------------------------------- optimizer tail
+// (model.py:1538-1545, 1641-1645: clip_grad_norm_(5.0) + SGD with momentum and weight decay)
+constexpr int kNormBlocks = 512;   // partial sums of squares per call
+
+__global__ void __launch_bounds__(kBlock)
+k_sumsq_partials(const float* __restrict__ g, int64_t n, double* __restrict__ partials) {
+  __shared__ double red[kBlock / 64];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double v = (double)g[i];
+    acc += v * v;
+  }
+  acc = cfun_wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int w = 0; w < kBlock / 64; ++w) s += red[w];
+    partials[blockIdx.x] = s;
+  }
+}
+
+__global__ void k_norm_finalize(const double* __restrict__ partials, int count, float* __restrict__ norm) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < count; i += 64) s += partials[i];
+  s = cfun_wave_sum_d(s);
+  if (threadIdx.x == 0) norm[0] = (float)sqrt(s);
+}
+
+// g' = g * min(1, max_norm / (norm + 1e-6)); d = g' + wd * p; m = first ? d : momentum * m + d; p -= lr * m
+__global__ void __launch_bounds__(kBlock)
+k_sgd_momentum_step(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, int64_t n, float lr,
+                    float momentum, float wd, float max_norm, const float* __restrict__ norm, int first) {
+  float coef = 1.f;
+  if (max_norm > 0.f) {
+    coef = __fdiv_rn(max_norm, __fadd_rn(norm[0], 1e-6f));
+    coef = coef > 1.f ? 1.f : coef;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    float d = __fmul_rn(g[i], coef);
+    if (wd != 0.f) d = __fadd_rn(d, __fmul_rn(wd, p[i]));
+    const float b = first ? d : __fadd_rn(__fmul_rn(momentum, m[i]), d);
+    m[i] = b;
+    p[i] = __fsub_rn(p[i], __fmul_rn(lr, b));
+  }
+}
+
 }  // namespace
 
 // ====================================================================== C ABI
@@ -548,6 +595,32 @@ int cfun_maxpool2_bwd(const float* dy, const uint8_t* idx, float* dx, int32_t N,
   const int64_t total = (int64_t)N * Do * Ho * Wo * C;
   if (total <= 0) return CFUN_OK;
   hipLaunchKernelGGL(k_maxpool2_bwd, dim3(ew_grid(total)), dim3(kBlock), 0, cfun_st(stream), dy, idx, dx, total, Do, Ho, Wo, C);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+int32_t cfun_sumsq_partials_count(void) { return kNormBlocks; }
+
+int cfun_sumsq_partials(const float* g, int64_t n, double* partials, cfun_stream_t stream) {
+  if (n < 0) return CFUN_EINVAL;
+  hipLaunchKernelGGL(k_sumsq_partials, dim3(kNormBlocks), dim3(kBlock), 0, cfun_st(stream), g, n, partials);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+int cfun_norm_finalize(const double* partials, int32_t count, float* norm, cfun_stream_t stream) {
+  if (count < 0) return CFUN_EINVAL;
+  hipLaunchKernelGGL(k_norm_finalize, dim3(1), dim3(64), 0, cfun_st(stream), partials, count, norm);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+int cfun_sgd_momentum_step(float* p, const float* g, float* m, int64_t n, float lr, float momentum, float weight_decay,
+                           float max_norm, const float* norm, int32_t first_step, cfun_stream_t stream) {
+  if (n <= 0) return CFUN_OK;
+  if (max_norm > 0.f && norm == nullptr) return CFUN_EINVAL;
+  hipLaunchKernelGGL(k_sgd_momentum_step, dim3(ew_grid(n)), dim3(kBlock), 0, cfun_st(stream), p, g, m, n, lr, momentum,
+                     weight_decay, max_norm, norm, first_step);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }

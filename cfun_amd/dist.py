@@ -204,7 +204,7 @@ class GradientReducer:
         order = list(reversed(self.params))
         cur, cur_bytes = [], 0
         for p in order:
-            nbytes = p.numel() * p.element_size()
+            nbytes = self._padded(p.numel()) * p.element_size()
             if cur and cur_bytes + nbytes > bucket_bytes:
                 self._add_bucket(cur)
                 cur, cur_bytes = [], 0
@@ -221,15 +221,23 @@ class GradientReducer:
             self.comm_stream = torch.cuda.Stream(device=self.params[0].device)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if self.active else []
 
+    ALIGN = 64   # elements: every view starts on a 256-byte boundary (the kernels use 16-byte vector accesses)
+
+    @classmethod
+    def _padded(cls, n):
+        return (n + cls.ALIGN - 1) // cls.ALIGN * cls.ALIGN
+
     def _add_bucket(self, plist):
-        n = sum(p.numel() for p in plist)
+        n = sum(self._padded(p.numel()) for p in plist)
         flat = torch.zeros(n, dtype=plist[0].dtype, device=plist[0].device)
         off = 0
-        views = []
+        views, offsets = [], []
         for p in plist:
             views.append(flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
-        self.buckets.append(dict(flat=flat, params=plist, views=views, pending=len(plist), work=None, launched=False))
+            offsets.append(off)
+            off += self._padded(p.numel())      # the padding stays zero: neutral for sums, norms and updates
+        self.buckets.append(dict(flat=flat, params=plist, views=views, offsets=offsets, pending=len(plist), work=None,
+                                 launched=False))
 
     def zero_grad(self):
         """Zero the buckets and (re)attach ``p.grad`` to its bucket view; call instead of ``net.zero_grad()``."""

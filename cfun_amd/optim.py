@@ -1,0 +1,73 @@
+"""The optimizer tail of the reference's ``train_epoch`` (model.py:1538-1545, 1641-1645) as flat-arena HIP kernels:
+
+    torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+    optim.SGD([{params: trainables without 'bn' in the name, weight_decay: WEIGHT_DECAY},
+               {params: trainables with 'bn' in the name}], lr, momentum=LEARNING_MOMENTUM).step()
+
+MI355X-first layout: the trainable parameters, their gradients and the momentum live in a few large flat fp32
+arenas (the gradient arenas are the buckets of ``cfun_amd.dist.GradientReducer``, so data-parallel averaging,
+clipping and the update all work on the same memory); ``p.data`` / ``p.grad`` are views, the ``nn.Module`` and its
+state dict are unchanged.  A step is: one sum-of-squares launch per arena, one finalize (the global gradient norm
+stays on the device -- no ``.item()`` sync as in clip_grad_norm_), one fused clip + weight-decay + momentum +
+update launch per arena, instead of ~8 tiny launches per parameter tensor.
+
+On this path every BatchNorm parameter is frozen (model.py:1297-1304), so the 'bn' group of the reference is empty
+and the weight decay is uniform over the arena; a trainable parameter with 'bn' in its name is rejected rather
+than silently decayed.
+"""
+import torch
+
+from . import _lib
+from . import dist as cdist
+from ._lib import check, ptr, stream
+
+
+class FlatSGD:
+    def __init__(self, named_params, lr, momentum=0.9, weight_decay=1e-4, clip_norm=5.0, bucket_bytes=64 << 20,
+                 group=None):
+        named = [(n, p) for n, p in named_params if p.requires_grad]
+        for n, _ in named:
+            if "bn" in n:
+                raise ValueError("FlatSGD: trainable BatchNorm parameter %r (the reference gives it no weight decay; "
+                                 "this path keeps BatchNorm frozen)" % n)
+        self.lr, self.momentum, self.weight_decay, self.clip_norm = float(lr), float(momentum), float(weight_decay), clip_norm
+        self.reducer = cdist.GradientReducer([p for _, p in named], bucket_bytes=bucket_bytes, group=group)
+        self.param_arenas, self.momentum_arenas = [], []
+        for bucket in self.reducer.buckets:          # parameters move into arenas laid out like the gradient buckets
+            flat = torch.zeros_like(bucket["flat"])
+            with torch.no_grad():
+                for p, off in zip(bucket["params"], bucket["offsets"]):
+                    view = flat[off:off + p.numel()].view_as(p)
+                    view.copy_(p.data)
+                    p.data = view
+            self.param_arenas.append(flat)
+            self.momentum_arenas.append(torch.zeros_like(flat))
+        dev = self.param_arenas[0].device if self.param_arenas else torch.device("cpu")
+        lib = _lib.load()
+        self._npart = int(lib.cfun_sumsq_partials_count())
+        self._partials = torch.zeros(max(1, len(self.param_arenas)) * self._npart, dtype=torch.float64, device=dev)
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)     # total norm of the last step (device)
+        self.steps = 0
+
+    def zero_grad(self):
+        self.reducer.zero_grad()
+
+    @torch.no_grad()
+    def step(self):
+        """Average over data-parallel ranks (if any), clip to ``clip_norm`` by the global L2 norm, SGD update."""
+        self.reducer.finish()
+        lib = _lib.load()
+        clip = float(self.clip_norm) if self.clip_norm else 0.0
+        if clip > 0.0:
+            for i, bucket in enumerate(self.reducer.buckets):
+                g = bucket["flat"]
+                check(lib.cfun_sumsq_partials(ptr(g), g.numel(), ptr(self._partials[i * self._npart:]), stream(g)),
+                      "sumsq_partials")
+            check(lib.cfun_norm_finalize(ptr(self._partials), self._partials.numel(), ptr(self.grad_norm),
+                                         stream(self.grad_norm)), "norm_finalize")
+        for bucket, p, m in zip(self.reducer.buckets, self.param_arenas, self.momentum_arenas):
+            g = bucket["flat"]
+            check(lib.cfun_sgd_momentum_step(ptr(p), ptr(g), ptr(m), p.numel(), self.lr, self.momentum,
+                                             self.weight_decay, clip, ptr(self.grad_norm) if clip > 0.0 else None,
+                                             1 if self.steps == 0 else 0, stream(p)), "sgd_momentum_step")
+        self.steps += 1

@@ -213,6 +213,21 @@ int cfun_weight_pack_transpose(const float* wp, float* wpT, int32_t Co, int32_t 
 int cfun_weight_unpack(const float* dwp, float* dw, int32_t Co, int32_t Ci, int32_t T, cfun_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Optimizer tail of train_epoch (model.py:1538-1545, 1641-1645) over FLAT fp32 buffers (cfun_amd/optim.py keeps
+ * parameters, gradients and momentum in a few large arenas, so a step is 2 + #arenas launches):
+ *   sumsq_partials: partials[0 .. cfun_sumsq_partials_count()) = per-workgroup fp64 sums of g^2 (fixed order)
+ *   norm_finalize:  norm[0] = sqrt(sum of `count` partials)         -- torch.nn.utils.clip_grad_norm_'s total norm
+ *   sgd_momentum_step (torch.optim.SGD, dampening 0, no nesterov), in place on p and m:
+ *       c = max_norm > 0 ? min(1, max_norm / (norm[0] + 1e-6)) : 1 ;  d = c*g + weight_decay*p ;
+ *       m = first_step ? d : momentum*m + d ;  p -= lr*m
+ * ---------------------------------------------------------------------------------------------- */
+int32_t cfun_sumsq_partials_count(void);
+int cfun_sumsq_partials(const float* g, int64_t n, double* partials, cfun_stream_t stream);
+int cfun_norm_finalize(const double* partials, int32_t count, float* norm, cfun_stream_t stream);
+int cfun_sgd_momentum_step(float* p, const float* g, float* m, int64_t n, float lr, float momentum, float weight_decay,
+                           float max_norm, const float* norm, int32_t first_step, cfun_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Depth-sharding helpers: copy `planes` depth planes at z0 of a [N,D,H,W,C]
  * tensor into a dense send buffer / write a received buffer into a padded tensor.
  * ---------------------------------------------------------------------------------------------- */

@@ -395,3 +395,37 @@ def check_detection_target_layer(device, seed=3):
     far = torch.tensor([[0.0, 0.0, 0.0, 0.05, 0.05, 0.05]]).to(device)
     e = model.detection_target_layer(far, gt_ids.to(device), gt.to(device), lab.to(torch.uint8).to(device), cfg)
     assert e[0].shape[0] == 0 and e[1].shape[0] == 0 and e[4].shape[0] == 0
+
+
+def check_flat_sgd(device, seed=5):
+    """cfun_amd.optim.FlatSGD vs the reference's own calls -- torch.nn.utils.clip_grad_norm_(5.0) + torch.optim.SGD
+    (momentum 0.9, weight decay 1e-4) -- over three steps (first-step momentum init, clipping active and inactive)."""
+    from cfun_amd import optim
+    gen = torch.Generator().manual_seed(seed)
+    shapes = [(8, 4, 3, 3, 3), (8,), (16, 8, 1, 1, 1), (5, 7), (1,)]
+    ref = [torch.randn(*s, generator=gen).requires_grad_(True) for s in shapes]
+    mine = [r.detach().clone().to(device).requires_grad_(True) for r in ref]
+    frozen = torch.randn(4, device=device)                      # requires_grad False: must be left alone
+    named = [("w%d" % i, p) for i, p in enumerate(mine)] + [("frozen", frozen)]
+    opt_ref = torch.optim.SGD([{"params": ref, "weight_decay": 1e-4}], lr=0.01, momentum=0.9)
+    opt = optim.FlatSGD(named, lr=0.01, momentum=0.9, weight_decay=1e-4, clip_norm=5.0, bucket_bytes=1024)
+    assert len(opt.param_arenas) > 1
+    for step_i, gscale in enumerate((40.0, 0.01, 3.0)):          # norm >> 5 (clipped), << 5, around
+        grads = [torch.randn(*s, generator=gen) * gscale for s in shapes]
+        opt_ref.zero_grad()
+        opt.zero_grad()
+        for r, m, g in zip(ref, mine, grads):
+            r.grad = g.clone()
+            m.grad.copy_(g)                                       # p.grad is a view of the gradient arena
+        total = torch.nn.utils.clip_grad_norm_(ref, 5.0)
+        opt_ref.step()
+        opt.step()
+        assert abs(float(opt.grad_norm[0]) - float(total)) <= 1e-5 * float(total)
+        for r, m in zip(ref, mine):
+            np.testing.assert_allclose(m.detach().cpu().numpy(), r.detach().numpy(), rtol=2e-6, atol=1e-7)
+    assert torch.equal(frozen.cpu(), named[-1][1].cpu())
+    try:
+        optim.FlatSGD([("fpn.C1.bn.weight", mine[1])], lr=0.1)
+        raise AssertionError("a trainable 'bn' parameter must be rejected")
+    except ValueError:
+        pass

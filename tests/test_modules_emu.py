@@ -76,3 +76,7 @@ def test_inference_vs_oracle(emu_direct):
 
 def test_detection_target_layer(emu):
     mc.check_detection_target_layer(emu)
+
+
+def test_flat_sgd_vs_torch(emu):
+    mc.check_flat_sgd(emu)
