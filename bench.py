@@ -103,13 +103,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    local %= torch.cuda.device_count()    # (several ranks on one GPU only in the gloo smoke test of this script)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+        # "nccl" is RCCL on ROCm; CFUN_BENCH_BACKEND=gloo only to exercise this path on a single-GPU box
+        dist.init_process_group(os.environ.get("CFUN_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
 
     from cfun_amd import config, ops, step
     stage, h, w, d = WORKLOADS[args.workload]

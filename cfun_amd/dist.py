@@ -220,6 +220,12 @@ class GradientReducer:
         if self.params and self.params[0].is_cuda:
             self.comm_stream = torch.cuda.Stream(device=self.params[0].device)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if self.active else []
+        if self.active and self.buckets:
+            # create the communicator here, on the caller's thread, not inside the first backward's autograd hook
+            warm = torch.zeros(1, dtype=self.buckets[0]["flat"].dtype, device=self.buckets[0]["flat"].device)
+            dist.all_reduce(warm, group=self.group)
+            if warm.is_cuda:
+                torch.cuda.current_stream(warm.device).synchronize()
 
     ALIGN = 64   # elements: every view starts on a 256-byte boundary (the kernels use 16-byte vector accesses)
 
