@@ -640,6 +640,202 @@ k_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ g, float* __
                                                tiles_per_chunk, ntiles);
 }
 
+// ---- C_in = 16*NPL + R with R = 16/PACK <= 8 remainder channels and 27 taps (the level-1 U-Net convs: C_in = 20 ->
+// NPL 1, PACK 4; C_in = 40 -> NPL 2, PACK 2): ONE workgroup accumulates all input channels of its tiles -- NPL plain
+// 16-channel subtiles of 27 tap rows each, and the remainder channels as ceil(27/PACK) packed rows of PACK taps x R
+// channels (row i reads tap PACK*q + i/R, channel 16*NPL + i%R) -- instead of NPL+1 workgroups of 27 rows each, the
+// last one mostly zero padding.  34 instead of 54 (68 instead of 81) MFMA rows per tile, G staged once, and all
+// workgroups are equal (packing only the remainder in its own workgroup loses to the round-robin dispatcher).
+template <int KD, int KH, int KW, int S>
+constexpr bool wgrad_fused_shape() { return KD * KH * KW == 27; }
+
+// 0: not applicable; else NPL | PACK << 4
+inline int wgrad_fused_mode(const CfunConv3dParams& p, int nsub) {
+  if (p.kd * p.kh * p.kw != 27 || (p.d2s && p.tap_skip) || nsub > 3) return 0;
+  if (p.Ci > 16 && p.Ci <= 20) return 1 | (4 << 4);
+  if (p.Ci > 32 && p.Ci <= 40 && p.stride == 1) return 2 | (2 << 4);
+  return 0;
+}
+
+template <int KD, int KH, int KW, int S, int NSUB, int NPL, int PACK>
+__global__ void __launch_bounds__(256)
+k_wgrad_fused(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ partial, CfunConv3dParams p,
+              int ntz, int nty, int ntx, int ncot, int tiles_per_chunk, int ntiles) {
+  using T = WgTile<KD, KH, KW, S>;
+  constexpr int TAPS = T::TAPS, NT = 16 * NSUB, GS = pad_row16(NT);
+  constexpr int R = 16 / PACK, CH = 16 * NPL + R, C4 = CH / 4;
+  constexpr int XS = CH == 20 ? 24 : CH;        // floats per staged voxel; fragment reads at most 2-way conflicted
+  constexpr int TPW = cdiv(TAPS, 4);            // 7 plain tap rows per wave and subtile
+  constexpr int NQ = cdiv(TAPS, PACK);          // packed rows
+  constexpr int TPP = cdiv(NQ, 4);              // per wave
+  constexpr int X_ITEMS = T::IVOX * C4, X_LOADS = cdiv(X_ITEMS, 256);
+  constexpr int G_ITEMS = T::TVOX * (NT / 4), G_LOADS = cdiv(G_ITEMS, 256);
+  CFUN_DYN_LDS(float, smem);
+  float* Xl = smem;                      // [IVOX][XS]
+  float* Gl = smem + T::IVOX * XS;       // [TVOX][GS]
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int cot = lid % ncot;
+  const int chunk = lid / ncot;
+  const int cobase = cot * NT;
+  const int sh = p.up2 ? 1 : 0;
+  const int Dv = p.Di << sh, Hv = p.Hi << sh, Wv = p.Wi << sh;
+
+  f32x4 acc[NPL][TPW][NSUB], accp[TPP][NSUB];
+#pragma unroll
+  for (int nn = 0; nn < NSUB; ++nn) {
+#pragma unroll
+    for (int s = 0; s < NPL; ++s)
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) acc[s][t][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < TPP; ++u) accp[u][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  float4 xin[X_LOADS], gin[G_LOADS];
+  unsigned xvalid = 0, gvalid = 0;
+  auto prefetch = [&](int tile) {   // unconditional loads + validity bits, as in wgrad_body
+    int t = tile;
+    const int tx = t % ntx; t /= ntx;
+    const int ty = t % nty; t /= nty;
+    const int tz = t % ntz;
+    const int n = t / ntz;
+    const int z0 = tz * T::TD, y0 = ty * T::TH, x0 = tx * T::TW;
+    xvalid = 0; gvalid = 0;
+#pragma unroll
+    for (int i = 0; i < X_LOADS; ++i) {
+      const int it = tid + i * 256;
+      const int idx = it / C4, c = (it - idx * C4) * 4;
+      const int ix = idx % T::IX, iy = (idx / T::IX) % T::IY, iz = idx / (T::IX * T::IY);
+      const int vz = z0 * S - p.pd + iz, vy = y0 * S - p.ph + iy, vx = x0 * S - p.pw + ix;
+      const bool ok = (it < X_ITEMS) & (c < p.Ci) & (vz >= 0) & (vz < Dv) & (vy >= 0) & (vy < Hv) & (vx >= 0) & (vx < Wv);
+      const unsigned off = ((((unsigned)n * p.Di + (vz >> sh)) * p.Hi + (vy >> sh)) * p.Wi + (vx >> sh)) * p.Ci + c;
+      xin[i] = *reinterpret_cast<const float4*>(x + (ok ? off : 0u));
+      xvalid |= (ok ? 1u : 0u) << i;
+    }
+#pragma unroll
+    for (int i = 0; i < G_LOADS; ++i) {
+      const int it = tid + i * 256;
+      const int vox = it / (NT / 4), col = (it % (NT / 4)) * 4;
+      const int lx = vox % T::TW, ly = (vox / T::TW) % T::TH, lz = vox / (T::TW * T::TH);
+      const int oz = z0 + lz, oy = y0 + ly, ox = x0 + lx;
+      bool ok = (it < G_ITEMS) & (cobase + col < p.Co) & (oz < p.Do) & (oy < p.Ho) & (ox < p.Wo);
+      unsigned off;
+      if (p.d2s) {   // hi-res gradient [N,2Do,2Ho,2Wo,Cq]: gather parity q, channel o
+        const int CqP = p.Co >> 3, Cq = p.d2s_cq > 0 ? p.d2s_cq : CqP;
+        const int co = cobase + col, q = co / CqP, o = co - q * CqP;
+        ok = ok & (o < Cq);
+        off = ((((unsigned)n * 2 * p.Do + 2 * oz + (q >> 2)) * 2 * p.Ho + 2 * oy + ((q >> 1) & 1)) * 2 * p.Wo + 2 * ox +
+               (q & 1)) * Cq + o;
+      } else {
+        off = ((((unsigned)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * p.Co + cobase + col;
+      }
+      gin[i] = *reinterpret_cast<const float4*>(g + (ok ? off : 0u));
+      gvalid |= (ok ? 1u : 0u) << i;
+    }
+  };
+  auto commit = [&]() {
+    auto keep = [](unsigned bit, const float4& v) {
+      const float m = bit ? 1.f : 0.f;
+      return make_float4(bit ? v.x : m, bit ? v.y : m, bit ? v.z : m, bit ? v.w : m);
+    };
+#pragma unroll
+    for (int i = 0; i < X_LOADS; ++i) {
+      const int it = tid + i * 256;
+      if (it < X_ITEMS) {
+        const int idx = it / C4, c = (it - idx * C4) * 4;
+        *reinterpret_cast<float4*>(Xl + idx * XS + c) = keep((xvalid >> i) & 1u, xin[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < G_LOADS; ++i) {
+      const int it = tid + i * 256;
+      if (it < G_ITEMS)
+        *reinterpret_cast<float4*>(Gl + (it / (NT / 4)) * GS + (it % (NT / 4)) * 4) = keep((gvalid >> i) & 1u, gin[i]);
+    }
+  };
+
+  const int t_begin = chunk * tiles_per_chunk;
+  const int t_end = (t_begin + tiles_per_chunk < ntiles) ? t_begin + tiles_per_chunk : ntiles;
+  const float* Xv = Xl + (lane >> 4) * T::RS * XS;   // this lane's voxel k = lane>>4 of a 4-voxel group
+  const float* Gw = Gl + (lane >> 4) * GS + (lane & 15);
+  auto tap_off = [&](int tap) {
+    const int dz = tap / (KH * KW), dy = (tap / KW) % KH, dx = tap % KW;
+    return ((dz * T::IY + dy) * T::IX + dx) * XS;
+  };
+  int toff[TPW], toffp[TPP];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {       // plain rows: tap t*4 + wave, channel lane&15 (surplus slots recompute tap 26)
+    const int tap = t * 4 + wv;
+    toff[t] = tap_off(tap < TAPS ? tap : TAPS - 1) + (lane & 15);
+  }
+#pragma unroll
+  for (int u = 0; u < TPP; ++u) {       // packed rows: q = u*4 + wave; row i -> tap PACK*q + i/R, channel 16*NPL + i%R
+    const int tap = (u * 4 + wv) * PACK + (lane & 15) / R;
+    toffp[u] = tap_off(tap < TAPS ? tap : TAPS - 1) + 16 * NPL + (lane & 15) % R;
+  }
+
+  if (t_begin < t_end) prefetch(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (tile + 1 < t_end) prefetch(tile + 1);
+#pragma unroll 2
+    for (int grp = 0; grp < T::TVOX / 4; ++grp) {
+      const int xq = grp & 3, ly = (grp >> 2) & 3, lz = grp >> 4;
+      float b[NSUB], a[NPL][TPW], ap[TPP];
+#pragma unroll
+      for (int nn = 0; nn < NSUB; ++nn) b[nn] = Gw[(grp * 4) * GS + nn * 16];
+      const float* Xg = Xv + ((lz * T::RS * T::IY + ly * T::RS) * T::IX + xq * 4 * T::RS) * XS;
+#pragma unroll
+      for (int s = 0; s < NPL; ++s)
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) a[s][t] = Xg[toff[t] + 16 * s];
+#pragma unroll
+      for (int u = 0; u < TPP; ++u) ap[u] = Xg[toffp[u]];
+#pragma unroll
+      for (int s = 0; s < NPL; ++s)
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+          for (int nn = 0; nn < NSUB; ++nn)
+            acc[s][t][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][t], b[nn], acc[s][t][nn], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < TPP; ++u)
+#pragma unroll
+        for (int nn = 0; nn < NSUB; ++nn)
+          accp[u][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[u], b[nn], accp[u][nn], 0, 0, 0);
+    }
+  }
+
+  // partial[chunk][tap][ci][CoP]; D[i][j=co]: lane -> co = lane&15, row i = (lane>>4)*4 + r
+  float* out = partial + (int64_t)chunk * TAPS * p.Ci * p.CoP;
+#pragma unroll
+  for (int nn = 0; nn < NSUB; ++nn) {
+    const int co = cobase + nn * 16 + (lane & 15);
+    if (co >= p.CoP) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = (lane >> 4) * 4 + r;
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        const int tap = t * 4 + wv;
+        if (tap < TAPS) {
+#pragma unroll
+          for (int s = 0; s < NPL; ++s) out[((int64_t)tap * p.Ci + 16 * s + i) * p.CoP + co] = acc[s][t][nn][r];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < TPP; ++u) {
+        const int tap = (u * 4 + wv) * PACK + i / R, ci = 16 * NPL + i % R;
+        if (tap < TAPS && ci < p.Ci) out[((int64_t)tap * p.Ci + ci) * p.CoP + co] = accp[u][nn][r];
+      }
+    }
+  }
+}
+
 struct WgPlan {
   int ntz, nty, ntx, ntiles, ncisub, ncot, nchunks, tiles_per_chunk, nsub, kslots;
 };
@@ -651,7 +847,7 @@ WgPlan wgrad_plan(const CfunConv3dParams& p, int nsub) {
   w.nsub = nsub;
   w.ntz = cdiv(p.Do, T::TD); w.nty = cdiv(p.Ho, T::TH); w.ntx = cdiv(p.Wo, T::TW);
   w.ntiles = p.N * w.ntz * w.nty * w.ntx;
-  w.ncisub = cdiv(p.Ci, 16);
+  w.ncisub = (wgrad_fused_shape<KD, KH, KW, S>() && wgrad_fused_mode(p, nsub)) ? 1 : cdiv(p.Ci, 16);
   w.ncot = (p.d2s && p.tap_skip) ? 8 * cdiv(p.Co >> 3, 16 * nsub) : cdiv(p.CoP, 16 * nsub);
   int want = 512 / (w.ncisub * w.ncot);   // ~2 workgroups per CU in total; fewer partials to reduce
   if (want < 1) want = 1;
@@ -674,6 +870,26 @@ int launch_wgrad_mfma(const float* x, const float* g, float* partial, const Cfun
   // the kernel addresses x and g with 32-bit element offsets
   const int64_t lim = (int64_t)1 << 31;
   if ((int64_t)p.N * p.Di * p.Hi * p.Wi * p.Ci >= lim || (int64_t)p.N * p.Do * p.Ho * p.Wo * p.Co >= lim) return CFUN_EINVAL;
+  if constexpr (wgrad_fused_shape<KD, KH, KW, S>() && NSUB <= 3) {
+    const int mode = wgrad_fused_mode(p, NSUB);
+    if (mode) {
+      const int xs = (mode & 15) == 1 ? 24 : 40;
+      const size_t ldsf = (size_t)(T::IVOX * xs + T::TVOX * GS) * sizeof(float);
+      void (*kf)(const float*, const float*, float*, CfunConv3dParams, int, int, int, int, int, int) =
+          k_wgrad_fused<KD, KH, KW, S, NSUB, 1, 4>;
+      if constexpr (S == 1) {
+        if ((mode & 15) == 2) kf = k_wgrad_fused<KD, KH, KW, S, NSUB, 2, 2>;
+      }
+      if (ldsf > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
+        if (e != hipSuccess) return (int)e;
+      }
+      hipLaunchKernelGGL(kf, dim3((unsigned)(w.nchunks * w.ncot)), dim3(256), ldsf, st, x, g, partial, p, w.ntz, w.nty,
+                         w.ntx, w.ncot, w.tiles_per_chunk, w.ntiles);
+      CFUN_LAUNCH_CHECK();
+      return CFUN_OK;
+    }
+  }
   auto kern = k_wgrad_mfma<KD, KH, KW, S, NSUB, false, 1>;
   if constexpr (KD * KH * KW == 27) {   // C_in <= 8: PACK taps per A fragment
     const int pack = w.ncisub > 1 ? 1 : p.Ci <= 4 ? 4 : p.Ci <= 8 ? 2 : 1;
