@@ -351,3 +351,24 @@ def check_mask_target_labels(device, seed=11):
         ref = orc.mask_targets(rois, onehot, shape).argmax(1).to(torch.uint8)
         out = ops.mask_target_labels(lab.to(torch.uint8).to(device), rois.to(device), shape)
         assert torch.equal(out.cpu(), ref), shape
+
+
+def check_weight_layouts(device, seed=13):
+    """cfun_weight_pack / _pack_transpose / _unpack vs permute + pad, bit-exact (C_out not a multiple of 16, 1 and
+    147 taps, tiles that straddle 32)."""
+    gen = _gen(seed)
+    for co, ci, k in ((20, 8, (3, 3, 3)), (3, 40, (1, 1, 1)), (16, 1, (3, 7, 7)), (70, 33, (1, 3, 3)), (8, 8, (5, 5, 5))):
+        w = randn(gen, co, ci, *k)
+        t = k[0] * k[1] * k[2]
+        cop, cip = (co + 15) // 16 * 16, (ci + 15) // 16 * 16
+        ref = torch.zeros(t, ci, cop)
+        ref[:, :, :co] = w.permute(2, 3, 4, 1, 0).reshape(t, ci, co)
+        wd = w.to(device).requires_grad_(True)
+        wp = ops.pack_weight(wd)
+        assert torch.equal(wp.detach().cpu(), ref), (co, ci, k)
+        ref_t = torch.zeros(t, co, cip)
+        ref_t[:, :, :ci] = ref[:, :, :co].transpose(1, 2)
+        assert torch.equal(ops._transpose_pack(wp.detach(), co).cpu(), ref_t), (co, ci, k)
+        g = randn(gen, t, ci, cop)
+        wp.backward(g.to(device))
+        assert torch.equal(wd.grad.cpu(), g[:, :, :co].reshape(*k, ci, co).permute(4, 3, 0, 1, 2)), (co, ci, k)

@@ -78,3 +78,7 @@ def test_mask_losses_3class(emu):
 
 def test_mask_target_labels(emu):
     kc.check_mask_target_labels(emu)
+
+
+def test_weight_layouts(emu):
+    kc.check_weight_layouts(emu)

@@ -132,3 +132,7 @@ def test_mfma_equals_direct_on_device(gpu):
 
 def test_mask_target_labels(gpu):
     kc.check_mask_target_labels(gpu)
+
+
+def test_weight_layouts(gpu):
+    kc.check_weight_layouts(gpu)
