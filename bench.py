@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sharded", action="store_true",
+                    help="N > 1: ONE volume per step over all ranks (depth-sharded FPN/RPN with halo exchange, head "
+                         "RoIs dealt round-robin; strong scaling) instead of one volume per rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -118,7 +121,8 @@ def main():
     cfg = config.heart_config(stage, h, w, d)
     torch.manual_seed(0)                       # identical replicated weights on every rank
     net = step.CFUNHotPath(cfg).to(dev)
-    sample = step.synthetic_inputs(cfg, dev, seed=rank)
+    sharded = args.sharded and world > 1
+    sample = step.synthetic_inputs(cfg, dev, seed=0 if sharded else rank)
     assert sample["p_rois"].shape[0] == 4 and sample["n_rois"].shape[0] == 8   # heads must not be skipped
     timer = ops.LaunchTimer(dominant_kernel_match(cfg))
     # N > 1: data-parallel replicas (one volume per GPU).  Gradients are averaged in 64 MB flat buckets whose RCCL
@@ -133,7 +137,11 @@ def main():
             net.zero_grad(set_to_none=True)
         else:
             reducer.zero_grad()
-        out, losses, total = step.training_step(net, sample)
+        if sharded:     # the ranks' loss shares / gradients add up to the single-GPU step (reducer averages: x world)
+            with cdist.depth_sharded():
+                losses, total, _ = cdist.sharded_training_step(net, sample)
+        else:
+            out, losses, total = step.training_step(net, sample)
         if reducer is not None:
             reducer.finish()
         return losses
@@ -164,27 +172,32 @@ def main():
     if rank == 0:
         b = cfg.UNET_MASK_BRANCH_CHANNEL
         side = cfg.MASK_POOL_SIZE
-        flops = 2.0 * (2 * b) * (2 * b) * 27 * side[0] * side[1] * side[2] * 4      # per launch (4 RoIs)
+        n_roi_launch = len(range(0, 4, world)) if sharded else 4                     # RoIs of rank 0's mask-head launches
+        flops = 2.0 * (2 * b) * (2 * b) * 27 * side[0] * side[1] * side[2] * n_roi_launch   # per launch
         durs = timer.durations_ms()
         t_k = sum(durs) / max(len(durs), 1) * 1e-3
         achieved = flops / t_k / 1e12 if t_k > 0 else 0.0
         result = {
             "metric": "volumes/sec fwd+bwd, 256x256x128 8-class CT" if args.workload == "cfg2"
                       else "volumes/sec fwd+bwd (%s)" % args.workload,
-            "value": world * args.steps / elapsed, "unit": "volumes/s", "n_gpus": world, "steps": args.steps,
+            "value": (1 if sharded else world) * args.steps / elapsed, "unit": "volumes/s", "n_gpus": world,
+            "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %dx%dx%d CT, stage '%s', 4 positive + 8 negative RoIs, U-Net b=%d, "
                                    "96^3 -> %d^3 masks, 6 losses incl. 3-D Sobel edge loss, fwd+bwd"
                                    % (args.workload, h, w, d, stage, b, cfg.MASK_SHAPE[0]),
-                       "parallelism": "1 volume per GPU x %d, bucketed gradient all-reduce (RCCL) overlapped with backward" % world if world > 1
-                                      else "single GPU"},
+                       "parallelism": ("ONE volume over %d GPUs: depth-sharded FPN/RPN with xGMI halo exchange, RPN "
+                                       "all-gather, head RoIs round-robin, gradient all-reduce; losses = rank 0's shares"
+                                       % world) if sharded else
+                                      ("1 volume per GPU x %d, bucketed gradient all-reduce (RCCL) overlapped with backward"
+                                       % world) if world > 1 else "single GPU"},
             "losses": lv,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": pmc_traffic() if args.workload == "cfg2" else None,
                          "kernel": "k_conv_mfma<3,3,3,1,3> (conv_norm_lrelu_l4.0: 3x3x3 %d->%d @ %dx%d^3)"
-                                   % (2 * b, 2 * b, 4, side[0]),
+                                   % (2 * b, 2 * b, n_roi_launch, side[0]),
                          "flops_per_launch": flops, "avg_launch_ms": t_k * 1e3, "launches_timed": len(durs)},
         }
         if world == 1 and not args.no_cpu_baseline:

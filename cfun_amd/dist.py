@@ -53,6 +53,18 @@ def depth_sharded(group=None):
         _CTX = old
 
 
+@contextlib.contextmanager
+def slab_local():
+    """Suspend depth sharding inside a ``depth_sharded`` block: the convolutions executed here work on whole,
+    rank-private tensors (the per-RoI heads: a RoI crop is not a slab of anything)."""
+    global _CTX
+    old, _CTX = _CTX, None
+    try:
+        yield
+    finally:
+        _CTX = old
+
+
 def _exchange(ctx, send_prev, send_next, recv_prev_shape, recv_next_shape, like):
     """Ring-neighbour exchange of packed plane buffers.  Returns (from_prev, from_next); None at the volume
     boundary.  Global ranks are resolved through the group so sub-groups work."""
@@ -173,6 +185,125 @@ def sharded_backbone_rpn(net, image_slab):
     logits, probs, bbox = gather_rpn_outputs(local)
     rois = net.proposals(probs, bbox, "inference" if not net.training else "training")
     return p2, p3, logits, probs, bbox, rois
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# One volume over R ranks: the whole training step (BASELINE.json configs[3])
+# ---------------------------------------------------------------------------------------------------------------
+class _AllGatherDepth(torch.autograd.Function):
+    """Slab [1, d, H, W, C] -> the full [1, d*R, H, W, C] map on every rank (RoIAlign of the classifier head reads
+    boxes that cross slabs; p2 + p3 are 9.4 MB at cfg2).  Backward: every rank holds a gradient for the full map;
+    the owner of a slab needs their sum -> one all-reduce, then the local slice."""
+
+    @staticmethod
+    def forward(ctx, x, shard):
+        ctx.shard = shard
+        x = x.contiguous()
+        parts = [torch.empty_like(x) for _ in range(shard.world)]
+        dist.all_gather(parts, x, group=shard.group)
+        return torch.cat(parts, dim=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        shard = ctx.shard
+        g = g.contiguous()
+        dist.all_reduce(g, group=shard.group)
+        d = g.shape[1] // shard.world
+        return g.narrow(1, shard.rank * d, d).contiguous(), None
+
+
+def gather_depth(x, shard=None):
+    shard = shard or _CTX
+    if shard is None or shard.world == 1:
+        return x
+    return _AllGatherDepth.apply(x, shard)
+
+
+def local_anchor_index(level_counts, shard=None):
+    """Global flat indices of the anchors this rank's slabs produce, in local order (its level-2 block, then its
+    level-3 block): level l's A_l anchors are flattened (z, y, x) (model.py:727-729), so a depth slab owns the
+    contiguous range [off_l + r*A_l/R, off_l + (r+1)*A_l/R)."""
+    shard = shard or _CTX
+    idx, off = [], 0
+    for a in level_counts:
+        per = a // shard.world
+        idx.append(torch.arange(off + shard.rank * per, off + (shard.rank + 1) * per))
+        off += a
+    return torch.cat(idx)
+
+
+def sharded_training_step(net, s, shard=None):
+    """ONE volume on R ranks: forward + the 6 losses + backward of ``cfun_amd.step.training_step`` with
+
+    * FPN / RPN depth-sharded (halo exchange inside the depth-coupled convs), proposals from one all-gather;
+    * RPN losses on the rank's own anchors with the global normalisation (so local gradients are exact);
+    * head RoIs dealt round-robin: rank r classifies rois[r::R] (on the all-gathered p2 / p3) and runs the mask
+      U-Net on p_rois[r::R] (crops of the raw image, which every rank holds);
+    * every loss returned as THIS rank's additive share: sum over ranks = the single-GPU loss, and the sum over
+      ranks of the parameter gradients = the single-GPU gradient (all-reduce them with op=SUM).
+
+    ``s`` is the replicated sample of ``step.synthetic_inputs`` (every rank holds the full image and targets).
+    Returns (local losses list, local total)."""
+    import torch.nn.functional as F
+    from . import model as M
+    shard = shard or _CTX
+    R, r = shard.world, shard.rank
+    cfg = net.config
+    net.train()
+    image = s["image"]
+    p2s, p3s = net.fpn.forward_ndhwc(ops.to_ndhwc(slab(image, dim=2, shard=shard)))
+    local = [net.rpn.forward_ndhwc(p) for p in (p2s, p3s)]
+    with torch.no_grad():
+        _, probs_g, bbox_g = gather_rpn_outputs([[t.detach() for t in lv] for lv in local], shard)
+    rpn_rois = net.proposals(probs_g, bbox_g, "training")           # identical on every rank (unused by the injected heads)
+
+    # ---- RPN losses on the local anchors (model.py:808-860), global normalisation
+    counts = [lv[0].shape[1] * R for lv in local]
+    lidx = local_anchor_index(counts, shard).to(image.device)
+    m = s["rpn_match"].squeeze(2)[0]                                  # [A] global
+    logits_l = torch.cat([lv[0] for lv in local], dim=1)[0]           # [A/R, 2]
+    bbox_l = torch.cat([lv[2] for lv in local], dim=1)[0]             # [A/R, 6]
+    m_l = m[lidx]
+    nz, npos = int((m != 0).sum()), int((m == 1).sum())
+    sel = torch.nonzero(m_l != 0)[:, 0]
+    l_rpn_cls = F.cross_entropy(logits_l[sel], (m_l[sel] == 1).long(), reduction="sum") / max(nz, 1) if sel.numel() \
+        else logits_l.sum() * 0.0
+    pos_rank = torch.cumsum((m == 1).long(), 0) - 1                    # k-th positive <-> target row k
+    psel = torch.nonzero(m_l == 1)[:, 0]
+    l_rpn_box = F.smooth_l1_loss(bbox_l[psel], s["rpn_bbox_t"][0, pos_rank[lidx[psel]]], reduction="sum") / max(npos * 6, 1) \
+        if psel.numel() else bbox_l.sum() * 0.0
+
+    # ---- heads on this rank's share of the RoIs
+    p2, p3 = gather_depth(p2s, shard), gather_depth(p3s, shard)
+    rois = torch.cat([s["p_rois"], s["n_rois"]], dim=0)
+    n_all, n_pos = rois.shape[0], s["p_rois"].shape[0]
+    mine = torch.arange(r, n_all, R, device=rois.device)
+    zero = p2.sum() * 0.0
+    l_cls = l_box = zero
+    if mine.numel():
+        cls_logits, _, cls_bbox = net.classifier.forward_ndhwc([p2[0], p3[0]], rois[mine])
+        tcls = s["target_class_ids"][mine]
+        l_cls = F.cross_entropy(cls_logits, (tcls > 0).long(), reduction="sum") / n_all
+        pos = torch.nonzero(tcls > 0)[:, 0]
+        npos_all = int((s["target_class_ids"] > 0).sum())
+        if pos.numel():
+            l_box = F.smooth_l1_loss(cls_bbox[pos, 1, :], s["target_deltas"][mine][pos], reduction="sum") / (npos_all * 6)
+    pmine = torch.arange(r, n_pos, R, device=rois.device)
+    l_mask = l_edge = zero
+    if pmine.numel():
+        with slab_local():      # the U-Net's 3x3x3 convs see whole RoI crops, not depth slabs
+            mlog, mprob = net.mask.forward_ndhwc(ops.to_ndhwc(image)[0], s["p_rois"][pmine])
+        labels = s["mask_labels"][pmine].contiguous()
+        share = pmine.numel() / float(n_pos)
+        if cfg.STAGE == "finetune":
+            ce, edge = ops.mask_losses(mlog, mprob, labels)
+            l_mask, l_edge = ce * share, edge * share
+        else:
+            l_mask = ops.mask_cross_entropy(mlog, labels) * share
+    losses = [l_rpn_cls, l_rpn_box, l_cls, l_box, l_mask, l_edge]
+    total = net.total_loss(losses)
+    total.backward()
+    return losses, total, rpn_rois
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -94,6 +94,47 @@ def main():
     (y * y).sum().backward()
     res["dp_local"] = np.concatenate([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).numpy()
                                       for p in plist])
+    # 5) ONE volume over 2 ranks: depth-sharded FPN/RPN + round-robin head RoIs; the ranks' loss shares add up to
+    #    the single-process losses and the summed gradients equal the single-process gradients
+    from cfun_amd import config as ccfg
+    cls = type("TinyHeart32", (ccfg.HeartConfig,), dict(
+        IMAGE_MAX_DIM=32, IMAGE_MIN_DIM=32, MASK_POOL_SIZE=[32, 32, 32], POOL_SIZE=[4, 4, 4],
+        UNET_MASK_BRANCH_CHANNEL=4, TOP_DOWN_PYRAMID_SIZE=16, RPN_CONV_CHANNELS=16, FPN_CLASSIFY_FC_LAYERS_SIZE=16,
+        RPN_ANCHOR_SCALES=(16, 32), PRE_NMS_LIMIT=64, POST_NMS_ROIS_TRAINING=16))
+    cfg5 = cls("beginning")
+    cfg5.MASK_SHAPE = cfg5.MINI_MASK_SHAPE = (32, 32, 32)
+    torch.manual_seed(4)
+    net5 = step.CFUNHotPath(cfg5)
+    s5 = step.synthetic_inputs(cfg5, torch.device("cpu"), 0)
+    s5["p_rois"], s5["mask_labels"] = s5["p_rois"][:2], s5["mask_labels"][:2]      # 2 positives + 4 negatives
+    s5["n_rois"] = s5["n_rois"][:4]
+    keep = [0, 1, 4, 5, 6, 7]
+    s5["target_class_ids"], s5["target_deltas"] = s5["target_class_ids"][keep], s5["target_deltas"][keep]
+    b5 = cfg5.UNET_MASK_BRANCH_CHANNEL
+    g5 = torch.Generator().manual_seed(9)
+    masks5 = [torch.empty(2, c).bernoulli_(0.4, generator=g5) / 0.4 for c in (b5, 2 * b5, 4 * b5, 8 * b5, 16 * b5)]
+    net5.mask.modified_u_net.dropout_masks = [mk[rank::world] for mk in masks5]
+    net5.zero_grad(set_to_none=True)
+    with cdist.depth_sharded():
+        losses5, total5, rois5 = cdist.sharded_training_step(net5, s5)
+    lv = torch.stack([l.detach().float() for l in losses5])
+    dist.all_reduce(lv)
+    names5 = [k for k, p in net5.named_parameters() if p.requires_grad]
+    flat5 = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                       for k, p in net5.named_parameters() if p.requires_grad])
+    dist.all_reduce(flat5)
+    res["sh_losses"], res["sh_grads"], res["sh_rois"] = lv.numpy(), flat5.numpy(), rois5.detach().numpy()
+    if rank == 0:
+        net5.mask.modified_u_net.dropout_masks = masks5
+        net5.zero_grad(set_to_none=True)
+        out_r, losses_r, total_r = step.training_step(net5, s5)
+        res["ref_losses"] = np.array([float(l.detach()) for l in losses_r], np.float32)
+        res["ref_grads"] = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                                      for k, p in net5.named_parameters() if p.requires_grad]).numpy()
+        res["ref_rois5"] = out_r["rpn_rois"].detach().numpy()
+        sizes = [int(p.numel()) for k, p in net5.named_parameters() if p.requires_grad]
+        res["grad_sizes"] = np.array(sizes)
+        res["grad_names"] = np.array(names5)
     np.savez(out % rank, **res)
     dist.barrier()
     dist.destroy_process_group()

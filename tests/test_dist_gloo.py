@@ -64,3 +64,15 @@ def test_depth_sharding_world2(emu_lib, tmp_path):
     for k in range(2):
         np.testing.assert_allclose(r[k]["dp_grads"], mean, rtol=1e-5, atol=1e-6)
     assert np.abs(r[0]["dp_local"] - r[1]["dp_local"]).max() > 1e-3      # the ranks really saw different data
+
+    # one volume over 2 ranks (sharded_training_step): loss shares and gradient sums equal the single-process step
+    np.testing.assert_allclose(r[0]["sh_losses"], ref["ref_losses"], rtol=2e-4, atol=1e-6)
+    np.testing.assert_array_equal(r[0]["sh_losses"], r[1]["sh_losses"])
+    assert r[0]["sh_rois"].shape == ref["ref_rois5"].shape
+    np.testing.assert_allclose(r[0]["sh_rois"], ref["ref_rois5"], rtol=0, atol=1e-5)
+    off = 0
+    for name, n in zip(ref["grad_names"], ref["grad_sizes"]):
+        a, b = r[0]["sh_grads"][off:off + n], ref["ref_grads"][off:off + n]
+        off += n
+        den = max(np.linalg.norm(b), 1e-12)
+        assert np.linalg.norm(a - b) / den < 2e-3 or np.abs(a - b).max() < 1e-6, (str(name), np.linalg.norm(a - b) / den)
