@@ -24,6 +24,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PEAK_HBM_GBS = 8000.0           # HBM3E spec (MI355X_MICROARCH.md; ~6.3 TB/s achievable)
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak (= fp32 vector peak)
 
 WORKLOADS = {
@@ -41,8 +42,13 @@ def dominant_kernel_match(cfg):
     side = cfg.MASK_POOL_SIZE
 
     def match(p):
-        return (p.kd, p.kh, p.kw, p.stride, p.up2) == (3, 3, 3, 1, 0) and p.Ci == 2 * b and p.Co == 2 * b \
-            and (p.Do, p.Ho, p.Wo) == tuple(side)
+        if (p.kd, p.kh, p.kw, p.stride, p.up2) != (3, 3, 3, 1, 0) or (p.Do, p.Ho, p.Wo) != tuple(side):
+            return None
+        if p.Ci == 2 * b and p.Co == 2 * b:
+            return "mfma"            # conv_norm_lrelu_l4.0: the dominant, MFMA-bound launch
+        if p.Ci == 1 and p.Co == b:
+            return "hbm"             # conv3d_c1_1: the HBM-bound 3x3x3 conv of the path (C_in = 1, AI 13 flop/B)
+        return None
     return match
 
 
@@ -174,7 +180,8 @@ def main():
         side = cfg.MASK_POOL_SIZE
         n_roi_launch = len(range(0, 4, world)) if sharded else 4                     # RoIs of rank 0's mask-head launches
         flops = 2.0 * (2 * b) * (2 * b) * 27 * side[0] * side[1] * side[2] * n_roi_launch   # per launch
-        durs = timer.durations_ms()
+        durs = timer.durations_ms("mfma")
+        durs_h = timer.durations_ms("hbm")
         t_k = sum(durs) / max(len(durs), 1) * 1e-3
         achieved = flops / t_k / 1e12 if t_k > 0 else 0.0
         result = {
@@ -200,6 +207,15 @@ def main():
                                    % (2 * b, 2 * b, n_roi_launch, side[0]),
                          "flops_per_launch": flops, "avg_launch_ms": t_k * 1e3, "launches_timed": len(durs)},
         }
+        if durs_h:   # north_star's "HBM roofline on the 3x3x3 conv kernel": the C_in = 1 stem, algorithmic bytes / time
+            t_h = sum(durs_h) / len(durs_h) * 1e-3
+            vox = n_roi_launch * side[0] * side[1] * side[2]
+            nbytes = 4.0 * (vox + vox * b + 27 * b)
+            result["roofline_hbm"] = {
+                "bound": "hbm", "achieved": nbytes / t_h / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": nbytes / t_h / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                "kernel": "k_conv_stem<3,3,3,1,%d> (conv3d_c1_1: 3x3x3 1->%d @ %dx%d^3)" % (b, b, n_roi_launch, side[0]),
+                "bytes_per_launch": nbytes, "avg_launch_ms": t_h * 1e3, "launches_timed": len(durs_h)}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, threads=min(os.cpu_count() or 1, 32))
         print(json.dumps(result), flush=True)

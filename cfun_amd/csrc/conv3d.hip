@@ -11,6 +11,9 @@ int cfun_conv_bwd_data_direct(const float*, const float*, float*, const CfunConv
 int cfun_conv_bwd_weight_direct(const float*, const float*, float*, const CfunConv3dParams*, void*, size_t, hipStream_t);
 size_t cfun_direct_wgrad_ws(const CfunConv3dParams*);
 int cfun_reduce_partials(const float*, float*, int64_t, int, hipStream_t);
+// conv3d_stem.hip
+int cfun_conv_stem_supported(const CfunConv3dParams*);
+int cfun_conv_stem_fwd(const float*, const float*, const float*, const float*, float*, const CfunConv3dParams*, hipStream_t);
 // conv3d_wgrad_c1.hip
 int cfun_wgrad_c1_supported(const CfunConv3dParams*);
 size_t cfun_wgrad_c1_ws(const CfunConv3dParams*);
@@ -305,6 +308,8 @@ int cfun_conv3d_fwd(const float* x, const float* wp, const float* scale, const f
     return s->fwd(nsub, x, wp, scale, shift, res, y, *p, md, ws, ws ? ws_bytes : 0, cfun_st(stream));
   }
   if (p->algo == CFUN_ALGO_MFMA) return CFUN_EINVAL;
+  if (p->algo != CFUN_ALGO_DIRECT && cfun_conv_stem_supported(p) && cfun_aligned16(y))
+    return cfun_conv_stem_fwd(x, wp, scale, shift, y, p, cfun_st(stream));    // C_in = 1: LDS-tiled, write-bound
   return cfun_conv_fwd_direct(x, wp, scale, shift, res, y, p, cfun_st(stream));
 }
 

@@ -1,0 +1,118 @@
+// C_in = 1 stem convolutions (conv3d_c1_1 of the U-Net, mask_branch.py:23; the P3D stem backbone.py:123-126 and its
+// LiTS variant): the HBM-bound 3-D convs of the path (AI 13-49 flop/B) -- the output is 16-24x
+// larger than the input, so the kernel is a coalesced streaming WRITE fed from an LDS-staged input tile:
+//   * a 256-thread workgroup owns 2(z) x 4(y) x 32(x) output voxels; the input halo tile (C = 1) is loaded once,
+//     coalesced along x, zero padding = the bounds check;
+//   * every thread keeps all C_out accumulators of ONE voxel in registers; taps are LDS reads at compile-time
+//     offsets (conflict-free along x), weights are wave-uniform scalar loads (SGPR operands of v_fmac);
+//   * fused epilogue: folded-BN / dropout scale, shift, ReLU / LeakyReLU; each lane stores its voxel's C_out
+//     contiguous floats as float4s, so a wave writes one contiguous 64*C_out*4-byte span.
+// The generic direct kernel computed 8 channels per thread in 3 passes over the input with 32-byte scattered
+// stores (0.35 ms per stem = 0.85 TB/s); this one is write-bound.
+#include "common.h"
+
+namespace {
+
+template <int KD, int KH, int KW, int S, int CO>
+struct StemTile {
+  static constexpr int TZ = 2, TY = 4, TX = 32;
+  static constexpr int IZ = (TZ - 1) * S + KD, IY = (TY - 1) * S + KH, IX = (TX - 1) * S + KW;
+  static constexpr int IVOX = IZ * IY * IX;
+};
+
+template <int KD, int KH, int KW, int S, int CO>
+__global__ void __launch_bounds__(256)
+k_conv_stem(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale,
+            const float* __restrict__ shift, float* __restrict__ y, CfunConv3dParams p, int ntz, int nty, int ntx) {
+  using T = StemTile<KD, KH, KW, S, CO>;
+  __shared__ float tile[T::IVOX];
+  unsigned b = blockIdx.x;
+  const int tx = b % ntx; b /= ntx;
+  const int ty = b % nty; b /= nty;
+  const int tz = b % ntz;
+  const int n = b / ntz;
+  const int z0 = tz * T::TZ, y0 = ty * T::TY, x0 = tx * T::TX;
+  const int iz0 = z0 * S - p.pd, iy0 = y0 * S - p.ph, ix0 = x0 * S - p.pw;
+  const float* xn = x + (int64_t)n * p.Di * p.Hi * p.Wi;
+  for (int i = threadIdx.x; i < T::IVOX; i += 256) {
+    const int lx = i % T::IX, ly = (i / T::IX) % T::IY, lz = i / (T::IX * T::IY);
+    const int gz = iz0 + lz, gy = iy0 + ly, gx = ix0 + lx;
+    float v = 0.f;
+    if (gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi) v = xn[((int64_t)gz * p.Hi + gy) * p.Wi + gx];
+    tile[i] = v;
+  }
+  __syncthreads();
+  const int lx = threadIdx.x % T::TX, ly = (threadIdx.x / T::TX) % T::TY, lz = threadIdx.x / (T::TX * T::TY);
+  const float* t0 = tile + ((lz * S) * T::IY + ly * S) * T::IX + lx * S;
+  float acc[CO];
+#pragma unroll
+  for (int j = 0; j < CO; ++j) acc[j] = 0.f;
+  // one (dz, dy) tap row per iteration, NOT unrolled: fully unrolled, hipcc hoists all KD*KH*KW*CO scalar weight loads
+  // to the top and spills them through v_writelane / v_readlane (12 extra instructions per FMA)
+#pragma unroll 1
+  for (int r = 0; r < KD * KH; ++r) {
+    const int dz = r / KH, dy = r - dz * KH;
+    const float* trow = t0 + (dz * T::IY + dy) * T::IX;
+    const float* wrow = wp + (int64_t)r * KW * p.CoP;               // wave-uniform: scalar loads
+#pragma unroll
+    for (int dx = 0; dx < KW; ++dx) {
+      const float xv = trow[dx];
+      const float* w = wrow + dx * p.CoP;
+#pragma unroll
+      for (int j = 0; j < CO; ++j) acc[j] = fmaf(xv, w[j], acc[j]);
+    }
+  }
+  // epilogue in registers, then through LDS so that the stores are fully coalesced: an output row of the tile is
+  // TX*CO contiguous floats; lanes write consecutive float4s of it instead of CO floats at a CO*4-byte lane stride
+  __shared__ float outt[T::TZ * T::TY * T::TX * CO];
+#pragma unroll
+  for (int j = 0; j < CO; ++j) {
+    float v = acc[j];
+    if (p.scale_mode == 1) v *= scale[j];
+    else if (p.scale_mode == 2) v *= scale[n * CO + j];
+    if (p.has_shift) v += shift[j];
+    outt[threadIdx.x * CO + j] = cfun_apply_act(v, p.act, p.slope);
+  }
+  __syncthreads();
+  constexpr int ROW4 = T::TX * CO / 4;                      // float4s per (z, y) output row of the tile
+  for (int i = threadIdx.x; i < T::TZ * T::TY * ROW4; i += 256) {
+    const int row = i / ROW4, q = i - row * ROW4;
+    const int oz = z0 + row / T::TY, oy = y0 + row % T::TY;
+    const int ox = x0 + (q * 4) / CO;                       // CO % 4 == 0: a float4 never straddles two voxels
+    if (oz < p.Do && oy < p.Ho && ox < p.Wo)
+      *reinterpret_cast<float4*>(y + ((((int64_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + x0) * CO + q * 4) =
+          *reinterpret_cast<const float4*>(outt + row * T::TX * CO + q * 4);
+  }
+}
+
+template <int KD, int KH, int KW, int S, int CO>
+int launch_stem(const float* x, const float* wp, const float* scale, const float* shift, float* y,
+                const CfunConv3dParams& p, hipStream_t st) {
+  using T = StemTile<KD, KH, KW, S, CO>;
+  const int ntz = (p.Do + T::TZ - 1) / T::TZ, nty = (p.Ho + T::TY - 1) / T::TY, ntx = (p.Wo + T::TX - 1) / T::TX;
+  const int64_t blocks = (int64_t)p.N * ntz * nty * ntx;
+  if (blocks <= 0) return CFUN_OK;
+  if (blocks > 0x7fffffffLL) return CFUN_EINVAL;
+  hipLaunchKernelGGL((k_conv_stem<KD, KH, KW, S, CO>), dim3((unsigned)blocks), dim3(256), 0, st, x, wp, scale, shift, y, p,
+                     ntz, nty, ntx);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+}  // namespace
+
+// 1 when the stem kernel covers this forward call (conv3d.hip asks before falling back to the generic direct kernel)
+int cfun_conv_stem_supported(const CfunConv3dParams* p) {
+  if (p->Ci != 1 || p->up2 || p->d2s || p->res_mode) return 0;
+  const int k = p->kd * 100 + p->kh * 10 + p->kw;
+  return (k == 333 && p->stride == 1 && p->Co == 20) || (k == 377 && p->stride == 2 && p->Co == 16) ||
+         (k == 577 && p->stride == 2 && p->Co == 24);
+}
+
+int cfun_conv_stem_fwd(const float* x, const float* wp, const float* scale, const float* shift, float* y,
+                       const CfunConv3dParams* p, hipStream_t st) {
+  const int k = p->kd * 100 + p->kh * 10 + p->kw;
+  if (k == 333) return launch_stem<3, 3, 3, 1, 20>(x, wp, scale, shift, y, *p, st);
+  if (k == 377) return launch_stem<3, 7, 7, 2, 16>(x, wp, scale, shift, y, *p, st);
+  return launch_stem<5, 7, 7, 2, 24>(x, wp, scale, shift, y, *p, st);
+}

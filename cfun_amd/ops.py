@@ -125,15 +125,19 @@ def _c(t):
 
 
 class LaunchTimer:
-    """Times forward conv launches with HIP events on the launch stream (bench.py roofline leg).
-    ``match(p)`` selects the launches; durations are read after a synchronise with ``durations_ms()``."""
+    """Times forward conv launches with HIP events on the launch stream (bench.py roofline legs).
+    ``match(p)`` returns a key (or None) for a launch's CfunConv3dParams; durations are read per key after a
+    synchronise with ``durations_ms(key)``."""
 
     def __init__(self, match):
         self.match = match
-        self.events = []
+        self.events = {}
 
-    def durations_ms(self):
-        return [a.elapsed_time(b) for a, b in self.events]
+    def add(self, key, ev0, ev1):
+        self.events.setdefault(key, []).append((ev0, ev1))
+
+    def durations_ms(self, key):
+        return [a.elapsed_time(b) for a, b in self.events.get(key, [])]
 
 
 _TIMER = None
@@ -161,7 +165,7 @@ class _Conv3d(torch.autograd.Function):
             y = torch.empty((p.N, 2 * p.Do, 2 * p.Ho, 2 * p.Wo, cq), dtype=torch.float32, device=x.device)
         else:
             y = torch.empty((p.N, p.Do, p.Ho, p.Wo, p.Co), dtype=torch.float32, device=x.device)
-        timed = _TIMER is not None and x.is_cuda and _TIMER.match(p)
+        timed = _TIMER.match(p) if (_TIMER is not None and x.is_cuda) else None
         if timed:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
@@ -170,7 +174,7 @@ class _Conv3d(torch.autograd.Function):
                                   ws.numel(), stream(x)), "conv3d_fwd")
         if timed:
             ev1.record()
-            _TIMER.events.append((ev0, ev1))
+            _TIMER.add(timed, ev0, ev1)
         ctx.spec = spec
         ctx.p = p
         ctx.res_shape = None if res is None else res.shape

@@ -103,6 +103,8 @@ CONV_CASES_LARGE = {
     "mfma_111_160_80": (2, (24, 24, 24), 160, 80, (1, 1, 1), dict(algo=ALGO_MFMA)),
     "mfma_555_8_8_up2": (1, (24, 24, 24), 8, 8, (5, 5, 5), dict(algo=ALGO_MFMA, up2=True, res=True, res_up2=True)),
     "direct_stem_96": (2, (48, 48, 48), 1, 20, (3, 3, 3), dict(algo=ALGO_DIRECT)),
+    "auto_stem_c1_48cube": (2, (48, 48, 50), 1, 20, (3, 3, 3), dict(algo=ALGO_AUTO, scale=True, per_n=True)),
+    "auto_p3d_stem_64": (1, (32, 64, 66), 1, 16, (3, 7, 7), dict(stride=2, pad=(1, 3, 3), act=ACT_RELU, scale=True, shift=True, algo=ALGO_AUTO)),
     "auto_333_20_20_48cube": (2, (48, 48, 48), 20, 20, (3, 3, 3), dict(algo=ALGO_AUTO, scale=True, per_n=True)),
 }
 

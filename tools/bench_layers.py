@@ -19,6 +19,7 @@ from cfun_amd._lib import ACT_NONE, check, ptr  # noqa: E402
 # name, N, (D,H,W) of the stored input, Ci, Co, k, stride, mode   (mode: "", "up2", "fold3", "fold5")
 B = 20
 LAYERS = [
+    ("c1_1 stem 1->20 @96", 4, (96, 96, 96), 1, B, 3, 1, ""),
     ("c1_2 / lrelu_conv_c1 20->20 @96", 4, (96, 96, 96), B, B, 3, 1, ""),
     ("l4.0 40->40 @96", 4, (96, 96, 96), 2 * B, 2 * B, 3, 1, ""),
     ("l3.3 up2 40->20 @48->96 (unfolded)", 4, (48, 48, 48), 2 * B, B, 3, 1, "up2"),
