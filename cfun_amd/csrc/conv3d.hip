@@ -365,10 +365,17 @@ int cfun_conv3d_bwd_data(const float* g, const float* wpT, float* dx, const Cfun
   return cfun_conv_bwd_data_direct(g, wpT, dx, p, cfun_st(stream));
 }
 
+// the MFMA weight-gradient kernels address x and g with 32-bit element offsets
+static bool wgrad_mfma_fits(const CfunConv3dParams* p) {
+  const int64_t lim = (int64_t)1 << 31;
+  const int64_t go = (int64_t)p->N * p->Do * p->Ho * p->Wo * p->Co;
+  return (int64_t)p->N * p->Di * p->Hi * p->Wi * p->Ci < lim && go < lim;
+}
+
 size_t cfun_conv3d_bwd_weight_workspace_bytes(const CfunConv3dParams* p) {
   if (!valid_params(p)) return 0;
   if (p->algo != CFUN_ALGO_DIRECT && cfun_wgrad_c1_supported(p)) return cfun_align_up(cfun_wgrad_c1_ws(p), 256);
-  const Shape* s = p->algo == CFUN_ALGO_DIRECT ? nullptr : mfma_shape(p);
+  const Shape* s = (p->algo == CFUN_ALGO_DIRECT || !wgrad_mfma_fits(p)) ? nullptr : mfma_shape(p);
   if (s) {
     cfun_mfma::WgPlan w;
     s->plan(*p, wgrad_nsub(p, s), &w);
@@ -384,7 +391,7 @@ int cfun_conv3d_bwd_weight(const float* x, const float* g, float* dwp, const Cfu
     if (!cfun_aligned16(g) || !cfun_aligned16(ws)) return CFUN_EALIGN;
     return cfun_wgrad_c1(x, g, dwp, p, ws, ws_bytes, cfun_st(stream));
   }
-  const Shape* s = p->algo == CFUN_ALGO_DIRECT ? nullptr : mfma_shape(p);
+  const Shape* s = (p->algo == CFUN_ALGO_DIRECT || !wgrad_mfma_fits(p)) ? nullptr : mfma_shape(p);
   if (s) {
     if (!cfun_aligned16(x) || !cfun_aligned16(g)) return CFUN_EALIGN;
     if (ws_bytes < cfun_conv3d_bwd_weight_workspace_bytes(p)) return CFUN_EWORKSPACE;

@@ -209,3 +209,23 @@ def test_train_loop_flat_sgd(gpu):
         assert float(opt.grad_norm[0]) > 0
     assert all(t == t for t in totals) and totals[-1] < totals[0], totals
     assert set(net.state_dict()) == sd_keys                 # parameters moved into arenas, the module is unchanged
+
+
+def test_cfg3_volume_forward_properties(gpu):
+    """BASELINE.json configs[3] size on ONE GPU (512x512x256, 268 MB input): FPN + RPN + proposals run, shapes follow
+    SURVEY.md section 8(a) (147 456 anchors), outputs are finite, RPN probabilities are distributions and the
+    proposals are inside the unit cube -- size-independent properties, the oracle would need minutes here."""
+    from cfun_amd import config, step
+    cfg = config.heart_config("beginning", 512, 512, 256)
+    torch.manual_seed(0)
+    net = step.CFUNHotPath(cfg).to(gpu).eval()
+    image = torch.randn(1, 1, 256, 512, 512, device=gpu)
+    with torch.no_grad():
+        p2, p3, logits, probs, bbox = net.backbone_rpn(image)
+        rois = net.proposals(probs, bbox, "inference")
+    assert tuple(p2.shape) == (1, 32, 64, 64, 128) and tuple(p3.shape) == (1, 16, 32, 32, 128)
+    assert logits.shape[1] == 147456 == net.anchors.shape[0]
+    assert bool(torch.isfinite(p2).all()) and bool(torch.isfinite(bbox).all())
+    assert float((probs.sum(-1) - 1).abs().max()) < 1e-5
+    assert 1 <= rois.shape[1] <= cfg.POST_NMS_ROIS_INFERENCE
+    assert float(rois.min()) >= 0.0 and float(rois.max()) <= 1.0
