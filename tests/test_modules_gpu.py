@@ -229,3 +229,23 @@ def test_cfg3_volume_forward_properties(gpu):
     assert float((probs.sum(-1) - 1).abs().max()) < 1e-5
     assert 1 <= rois.shape[1] <= cfg.POST_NMS_ROIS_INFERENCE
     assert float(rois.min()) >= 0.0 and float(rois.max()) <= 1.0
+
+
+def test_lits_full_size_step_properties(gpu):
+    """BASELINE.json configs[4] at the fork's real sizes (320x320x256 volume, P3D35, (5,7,7) stem, b = 32, 3 classes,
+    32x80x80 crops): one training step runs, the 6 losses are finite, every trainable tensor receives a finite
+    gradient.  (Value parity for these shapes: test_training_step_lits_shapes and the unet_lits_eval golden.)"""
+    from cfun_amd import config, step
+    cfg = config.LiTSConfig("beginning")
+    torch.manual_seed(0)
+    net = step.CFUNHotPath(cfg).to(gpu)
+    s = step.synthetic_inputs(cfg, gpu, 0)
+    assert tuple(s["image"].shape) == (1, 1, 256, 320, 320)
+    net.zero_grad(set_to_none=True)
+    out, losses, total = step.training_step(net, s)
+    assert tuple(out["mrcnn_mask_logits"].shape) == (4, 32, 80, 80, 3)
+    assert all(bool(torch.isfinite(l)) for l in losses)
+    for k, p in net.named_parameters():
+        if p.requires_grad and "bn" not in k and "downsample.1" not in k and "C1.1" not in k \
+                and "out_upscale_conv" not in k:        # ('finetune'-only conv, mask_branch.py:118-122)
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
