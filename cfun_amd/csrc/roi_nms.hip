@@ -258,6 +258,58 @@ k_mask_target_labels(const uint8_t* __restrict__ labels, const int32_t* __restri
   }
 }
 
+// Inference tail (utils.unmold_mask + the argmax of unmold_detections, utils.py:443-460, model.py:1853-1858): the
+// detection's class probabilities [d,h,w,C] are resized to its box with F.interpolate(mode='trilinear',
+// align_corners=False) semantics, pasted into a zero volume and arg-maxed over the classes.  Fused here: one thread
+// per voxel of the FULL volume interpolates the C channels in registers and writes the class id -- the
+// [D,H,W,C] fp32 tensor the reference builds on the host (268 MB at 256x256x128) is never materialised.
+__device__ __forceinline__ void lin_src(int dst, int in, int out, int& i0, int& i1, float& l1) {
+  const float scale = (float)in / (float)out;
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = (int)src;
+  i0 = i0 > in - 1 ? in - 1 : i0;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+}
+
+template <int CT>
+__global__ void __launch_bounds__(256)
+k_unmold_argmax(const float* __restrict__ probs, uint8_t* __restrict__ out, int64_t total, int D, int H, int W, int md,
+                int mh, int mw, int Crt, int z1, int y1, int x1, int z2, int y2, int x2) {
+  const int C = CT > 0 ? CT : Crt;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t t = i;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const int z = (int)(t / H);
+    uint8_t best = 0;
+    if (z >= z1 && z < z2 && y >= y1 && y < y2 && x >= x1 && x < x2) {
+      int za, zb, ya, yb, xa, xb;
+      float lz, ly, lx;
+      lin_src(z - z1, md, z2 - z1, za, zb, lz);
+      lin_src(y - y1, mh, y2 - y1, ya, yb, ly);
+      lin_src(x - x1, mw, x2 - x1, xa, xb, lx);
+      const float wz0 = 1.f - lz, wy0 = 1.f - ly, wx0 = 1.f - lx;
+      const float* p000 = probs + (((int64_t)za * mh + ya) * mw + xa) * C;
+      const float* p001 = probs + (((int64_t)za * mh + ya) * mw + xb) * C;
+      const float* p010 = probs + (((int64_t)za * mh + yb) * mw + xa) * C;
+      const float* p011 = probs + (((int64_t)za * mh + yb) * mw + xb) * C;
+      const float* p100 = probs + (((int64_t)zb * mh + ya) * mw + xa) * C;
+      const float* p101 = probs + (((int64_t)zb * mh + ya) * mw + xb) * C;
+      const float* p110 = probs + (((int64_t)zb * mh + yb) * mw + xa) * C;
+      const float* p111 = probs + (((int64_t)zb * mh + yb) * mw + xb) * C;
+      float vmax = -INFINITY;
+      for (int c = 0; c < C; ++c) {
+        const float v = wz0 * (wy0 * (wx0 * p000[c] + lx * p001[c]) + ly * (wx0 * p010[c] + lx * p011[c])) +
+                        lz * (wy0 * (wx0 * p100[c] + lx * p101[c]) + ly * (wx0 * p110[c] + lx * p111[c]));
+        if (v > vmax) { vmax = v; best = (uint8_t)c; }      // first maximum wins, as np.argmax
+      }
+    }
+    out[i] = best;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -282,6 +334,24 @@ int cfun_roi_align3d_bwd(const float* dout, const int32_t* bounds, float* dfm, i
   int64_t blocks = (total + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(k_roi_align_bwd, dim3((unsigned)blocks), dim3(256), 0, cfun_st(stream), dout, bounds, dfm, total, D, H, W, C, pd, ph, pw);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+int cfun_unmold_argmax(const float* probs, uint8_t* out, int32_t D, int32_t H, int32_t W, int32_t md, int32_t mh,
+                       int32_t mw, int32_t C, const int32_t* box, cfun_stream_t stream) {
+  const int64_t total = (int64_t)D * H * W;
+  if (total <= 0) return CFUN_OK;
+  if (md <= 0 || mh <= 0 || mw <= 0 || C <= 0 || C > 255 || !box) return CFUN_EINVAL;
+  if (box[0] < 0 || box[1] < 0 || box[2] < 0 || box[3] > D || box[4] > H || box[5] > W) return CFUN_EINVAL;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  if (C == 8)
+    hipLaunchKernelGGL(k_unmold_argmax<8>, dim3((unsigned)blocks), dim3(256), 0, cfun_st(stream), probs, out, total, D, H, W,
+                       md, mh, mw, C, box[0], box[1], box[2], box[3], box[4], box[5]);
+  else
+    hipLaunchKernelGGL(k_unmold_argmax<0>, dim3((unsigned)blocks), dim3(256), 0, cfun_st(stream), probs, out, total, D, H, W,
+                       md, mh, mw, C, box[0], box[1], box[2], box[3], box[4], box[5]);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }

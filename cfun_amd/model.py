@@ -207,6 +207,32 @@ def detection_layer(config, rois, mrcnn_class, mrcnn_bbox, window):
     return refine_detections(rois.squeeze(0) if rois.dim() == 3 else rois, mrcnn_class, mrcnn_bbox, window, config)
 
 
+def unmold_detections(detections, mrcnn_mask, image_shape, window):
+    """model.py:1812-1864 + utils.unmold_mask (utils.py:443-460) with the mask resize and the class arg-max fused on
+    the device (``cfun_unmold_argmax``).  detections [N,8] (z1,y1,x1,z2,y2,x2,class,score) device tensor or numpy,
+    mrcnn_mask [N,d,h,w,C] class probabilities (device tensor, NDHWC per detection), image_shape [c,D,H,W], window
+    (z1,y1,x1,z2,y2,x2).  Returns the reference's tuple: boxes (y1,x1,z1,y2,x2,z2) int32 numpy, class ids
+    ``np.arange(1, 8)`` (sic, model.py:1864), scores, class map [H,W,D] (int64 numpy, = argmax over classes of the
+    FIRST detection's un-molded mask, 0 outside its box)."""
+    det = detections.detach().cpu().numpy() if torch.is_tensor(detections) else np.asarray(detections)
+    zero_ix = np.where(det[:, 6] == 0)[0]
+    n = zero_ix[0] if zero_ix.shape[0] > 0 else det.shape[0]
+    boxes = det[:n, :6].astype(np.int32)
+    scores = det[:n, 7]
+    window = np.asarray(window, dtype=np.float64)
+    scales = np.array([image_shape[1] / (window[3] - window[0]), image_shape[2] / (window[4] - window[1]),
+                       image_shape[3] / (window[5] - window[2])] * 2)
+    shifts = np.array([window[0], window[1], window[2]] * 2)
+    boxes = np.multiply(boxes - shifts, scales).astype(np.int32)
+    keep = np.where((boxes[:, 3] - boxes[:, 0]) * (boxes[:, 4] - boxes[:, 1]) * (boxes[:, 5] - boxes[:, 2]) > 0)[0]
+    if keep.shape[0] == 0:
+        raise ValueError("unmold_detections: no detection with a non-empty box (the reference indexes masks[0] here)")
+    boxes, scores = boxes[keep], scores[keep]
+    cmap = ops.unmold_argmax(mrcnn_mask[int(keep[0])], boxes[0], image_shape[1:4])
+    boxes[:, [0, 1, 2, 3, 4, 5]] = boxes[:, [1, 2, 0, 4, 5, 3]]
+    return boxes, np.arange(1, 8), scores, cmap.permute(1, 2, 0).cpu().numpy().astype(np.int64)
+
+
 # ------------------------------------------------------------------------------------------ RoIAlign
 def roi_levels(boxes):
     """model.py:322-332: clamp(round(4 + log2(h*w*d)/3), 2, 3) on normalised boxes (fp32, half-to-even)."""

@@ -418,6 +418,19 @@ def mask_target_labels(labels, rois, mask_shape):
     return out
 
 
+def unmold_argmax(probs, box, image_dhw):
+    """utils.unmold_mask + argmax (utils.py:443-460, model.py:1853-1858): probs [md,mh,mw,C] (NDHWC of ONE
+    detection), box (z1,y1,x1,z2,y2,x2) voxel ints inside the volume -> uint8 class map [D,H,W]."""
+    lib = _lib.load()
+    probs = _c(probs.detach().float())
+    md, mh, mw, c = probs.shape
+    d, h, w = [int(v) for v in image_dhw]
+    out = torch.empty((d, h, w), dtype=torch.uint8, device=probs.device)
+    hbox = (C.c_int32 * 6)(*[int(v) for v in box])
+    check(lib.cfun_unmold_argmax(ptr(probs), ptr(out), d, h, w, md, mh, mw, c, hbox, stream(probs)), "unmold_argmax")
+    return out
+
+
 def nms3d(boxes, scores, threshold, max_num):
     """Greedy 3-D NMS on device; returns (keep int32 [n], count int32 [1]) -- keep[:count] is the pick order."""
     lib = _lib.load()

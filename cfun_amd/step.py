@@ -136,6 +136,20 @@ class CFUNHotPath(nn.Module):
         _, mask_probs = self.mask.forward_ndhwc(ops.to_ndhwc(image)[0], det[:, :6] / scale)
         return [det.unsqueeze(0), ops.to_ncdhw(mask_probs).unsqueeze(0)]
 
+    def detect(self, image, window=None):
+        """``MaskRCNN.detect`` for one already molded volume [1,1,D,H,W] (model.py:1341-1389 without the host-side
+        resize / z-score of ``mold_inputs``): inference forward, then ``unmold_detections``.  Returns the
+        reference's result dict (rois (y1,x1,z1,y2,x2,z2), class_ids, scores, mask [H,W,D])."""
+        det, masks = self.predict_inference(image, window)
+        if det.shape[1] == 0:
+            return dict(rois=np.zeros((0, 6), np.int32), class_ids=np.zeros((0,), np.int32),
+                        scores=np.zeros((0,), np.float32), mask=None)
+        height, width, depth = [int(v) for v in self.config.IMAGE_SHAPE[:3]]
+        win = (0, 0, 0, depth, height, width) if window is None else window
+        probs = masks[0].permute(0, 2, 3, 4, 1).contiguous()          # [N, d, h, w, C]
+        rois, class_ids, scores, mask = model.unmold_detections(det[0], probs, [1, depth, height, width], win)
+        return dict(rois=rois, class_ids=class_ids, scores=scores, mask=mask)
+
     def compute_losses(self, out, rpn_match, rpn_bbox_t, target_class_ids, target_deltas, mask_labels):
         """The 6 losses of model.py:984-1000 (mask labels: uint8 [n_pos,d,h,w])."""
         losses = [model.compute_rpn_class_loss(rpn_match, out["rpn_class_logits"]),

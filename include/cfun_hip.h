@@ -142,6 +142,13 @@ int cfun_maxpool2_fwd(const float* x, float* y, uint8_t* idx, int32_t N, int32_t
 int cfun_maxpool2_bwd(const float* dy, const uint8_t* idx, float* dx, int32_t N, int32_t Do, int32_t Ho, int32_t Wo,
                       int32_t C, cfun_stream_t stream);
 
+/* Inference tail: utils.unmold_mask (utils.py:443-460: F.interpolate(mode='trilinear', align_corners=False) of the
+ * detection's class probabilities to its box, pasted into a zero volume) fused with the class arg-max of
+ * unmold_detections (model.py:1853-1858).  probs [md,mh,mw,C] fp32 (device), box = HOST int32[6] (z1,y1,x1,z2,y2,x2)
+ * inside the volume, out [D,H,W] uint8 class ids (0 outside the box). */
+int cfun_unmold_argmax(const float* probs, uint8_t* out, int32_t D, int32_t H, int32_t W, int32_t md, int32_t mh,
+                       int32_t mw, int32_t C, const int32_t* box, cfun_stream_t stream);
+
 /* GT mask targets of detection_target_layer (model.py:481-493, utils.py:318-339) as uint8 class labels:
  * labels [D,H,W] (class id per voxel = argmax of the one-hot GT), bounds [R,6] int32 voxel crop
  * (z1,y1,x1,z2,y2,x2) = int(shape * normalised coordinate), out [R,md,mh,mw] = nearest-resized crop. */

@@ -237,6 +237,41 @@ def refine_detections(rois, probs, deltas, window, image_dhw, min_confidence=0.7
     return torch.cat([refined[keep], class_ids[keep].unsqueeze(1).float(), class_scores[keep].unsqueeze(1)], dim=1)
 
 
+def unmold_mask(mask, bbox, image_shape):
+    """utils.py:443-460: mask [d,h,w,C] (one detection's class probabilities) -> float32 [D,H,W,C], resized to the
+    box with F.interpolate(mode='trilinear', align_corners=False) (the reference's own call) and pasted into zeros.
+    image_shape = [channels, depth, height, width]."""
+    z1, y1, x1, z2, y2, x2 = [int(v) for v in bbox]
+    m = torch.as_tensor(mask).float().permute(3, 0, 1, 2).unsqueeze(0)
+    m = F.interpolate(m, size=(z2 - z1, y2 - y1, x2 - x1), mode="trilinear", align_corners=False)
+    m = m.squeeze(0).permute(1, 2, 3, 0).numpy()
+    full = np.zeros((image_shape[1], image_shape[2], image_shape[3], m.shape[-1]), dtype=np.float32)
+    full[z1:z2, y1:y2, x1:x2, :] = m
+    return full
+
+
+def unmold_detections(detections, mrcnn_mask, image_shape, window):
+    """model.py:1812-1864: detections [N,8] (numpy), mrcnn_mask [N,d,h,w,C], image_shape [c,D,H,W], window
+    (z1,y1,x1,z2,y2,x2) -> (boxes (y1,x1,z1,y2,x2,z2) int32, class ids = arange(1,8) (sic), scores, class map
+    [H,W,D] = argmax of the FIRST detection's un-molded mask)."""
+    detections = np.asarray(detections)
+    zero_ix = np.where(detections[:, 6] == 0)[0]
+    n = zero_ix[0] if zero_ix.shape[0] > 0 else detections.shape[0]
+    boxes = detections[:n, :6].astype(np.int32)
+    scores = detections[:n, 7]
+    masks = np.asarray(mrcnn_mask)[np.arange(n)]
+    window = np.asarray(window, dtype=np.float64)
+    scales = np.array([image_shape[1] / (window[3] - window[0]), image_shape[2] / (window[4] - window[1]),
+                       image_shape[3] / (window[5] - window[2])] * 2)
+    shifts = np.array([window[0], window[1], window[2]] * 2)
+    boxes = np.multiply(boxes - shifts, scales).astype(np.int32)
+    keep = np.where((boxes[:, 3] - boxes[:, 0]) * (boxes[:, 4] - boxes[:, 1]) * (boxes[:, 5] - boxes[:, 2]) > 0)[0]
+    boxes, scores, masks = boxes[keep], scores[keep], masks[keep]
+    full = np.argmax(unmold_mask(masks[0], boxes[0], image_shape), axis=3)
+    boxes[:, [0, 1, 2, 3, 4, 5]] = boxes[:, [1, 2, 0, 4, 5, 3]]
+    return boxes, np.arange(1, 8), scores, full.transpose((1, 2, 0))
+
+
 def roi_bounds(boxes, dhw):
     """model.py:271-278 / utils.py:160-174: fp32 product, floor lo / ceil hi, int64."""
     scale = torch.tensor([dhw[0], dhw[1], dhw[2]] * 2, dtype=torch.float32)

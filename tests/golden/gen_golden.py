@@ -459,7 +459,24 @@ def case_refine():
          image_dhw=np.array([d, h, w]), std_dev=np.asarray(cfg.RPN_BBOX_STD_DEV, dtype=np.float32), **out)
 
 
-CASES = dict(refine=case_refine, nms=case_nms, anchors=case_anchors, roi_align=case_roi_align, fpn_rpn=case_fpn_rpn, unet=case_unet,
+def case_unmold():
+    """utils.unmold_mask + MaskRCNN.unmold_detections (utils.py:443-460, model.py:1812-1864): 3 detections (one of
+    zero volume, dropped), class probabilities on a 12x10x8 grid, window == whole image."""
+    d, h, w, c = 20, 24, 28, 8
+    probs = torch.softmax(torch.from_numpy(formula.uniform("unm.logits", (3, 12, 10, 8, c), -3, 3)), dim=-1).numpy()
+    det = np.array([[2, 3, 4, 17, 21, 25, 3, 0.95], [5, 5, 5, 5, 9, 9, 2, 0.9], [0, 0, 0, 10, 12, 14, 1, 0.8],
+                    [0, 0, 0, 0, 0, 0, 0, 0]], np.float32)
+    image_shape = [1, d, h, w]
+    window = np.array([0, 0, 0, d, h, w], np.float32)
+    full = ref_utils.unmold_mask(probs[0], det[0, :6].astype(np.int32), image_shape)
+    pad = np.concatenate([probs, np.zeros((1,) + probs.shape[1:], np.float32)], axis=0)
+    boxes, ids, scores, cmap = ref_model.MaskRCNN.unmold_detections(None, det.copy(), pad, image_shape, window)
+    save("unmold", probs=probs, detections=det, image_shape=np.array(image_shape), window=window,
+         full_mask_sub=full[::3, ::3, ::3].copy(), full_mask_sum=np.array(full.astype(np.float64).sum()),
+         boxes=boxes, class_ids=ids, scores=scores, class_map=cmap.astype(np.uint8))
+
+
+CASES = dict(unmold=case_unmold, refine=case_refine, nms=case_nms, anchors=case_anchors, roi_align=case_roi_align, fpn_rpn=case_fpn_rpn, unet=case_unet,
              losses=case_losses, proposal=case_proposal, classifier=case_classifier, predict=case_predict)
 
 if __name__ == "__main__":

@@ -299,10 +299,20 @@ def check_inference_vs_oracle(device, cfg, seed=0, max_instances=2):
     mp = masks[0].cpu().numpy()
     assert mp.shape == tuple(ref["mask_probs"].shape)
     assert np.abs(mp - ref["mask_probs"].numpy()).max() < 5e-4
+    # detect(): + unmold_detections (boxes to (y,x,z) order, class map of the first detection, fused on device)
+    res = net.detect(s["image"])
+    dd, hh, ww = [int(v) for v in s["image"].shape[2:]]
+    rb, rids, rsc, rmap = orc.unmold_detections(rd, ref["mask_probs"].permute(0, 2, 3, 4, 1).numpy(), [1, dd, hh, ww],
+                                                [0, 0, 0, dd, hh, ww])
+    np.testing.assert_array_equal(res["rois"], rb)
+    np.testing.assert_allclose(res["scores"], rsc, rtol=1e-4, atol=1e-6)
+    assert res["mask"].shape == rmap.shape == (hh, ww, dd)
+    assert (res["mask"] != rmap).mean() <= 2e-3          # arg-max of interpolated fp32 probabilities: near-tie flips
     # the empty-detection guard (the reference raises UnboundLocalError there)
     cfg.DETECTION_MIN_CONFIDENCE = 1.5
     det0, masks0 = net.predict_inference(s["image"])
     assert tuple(det0.shape) == (1, 0, 8) and masks0.shape[1] == 0
+    assert net.detect(s["image"])["mask"] is None
     return dict(n_det=int(d.shape[0]))
 
 
@@ -429,3 +439,25 @@ def check_flat_sgd(device, seed=5):
         raise AssertionError("a trainable 'bn' parameter must be rejected")
     except ValueError:
         pass
+
+
+def check_unmold_golden(device):
+    """cfun_amd.model.unmold_detections (fused resize + argmax kernel) vs the reference's own outputs.  The class map
+    is an arg-max of interpolated probabilities: the fp32 evaluation order differs from torch's CPU kernel, so a few
+    near-tie voxels may flip -- at most 1e-3 of the voxels inside the box."""
+    from cfun_amd import model
+    g = load_golden("unmold")
+    shape = [int(v) for v in g["image_shape"]]
+    probs = torch.from_numpy(np.concatenate([g["probs"], np.zeros((1,) + g["probs"].shape[1:], np.float32)], axis=0))
+    boxes, ids, scores, cmap = model.unmold_detections(torch.from_numpy(g["detections"]).to(device), probs.to(device),
+                                                       shape, g["window"])
+    np.testing.assert_array_equal(boxes, g["boxes"])
+    np.testing.assert_array_equal(ids, g["class_ids"])
+    np.testing.assert_array_equal(scores, g["scores"])
+    assert cmap.shape == g["class_map"].shape and cmap.dtype == np.int64
+    z1, y1, x1, z2, y2, x2 = g["detections"][0, :6].astype(int)
+    inside = np.zeros(cmap.shape, bool)
+    inside[y1:y2, x1:x2, z1:z2] = True
+    assert np.all(cmap[~inside] == 0)
+    assert (cmap != g["class_map"]).sum() <= 1e-3 * inside.sum()
+    assert (cmap != 0).any()

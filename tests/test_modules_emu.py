@@ -80,3 +80,7 @@ def test_detection_target_layer(emu):
 
 def test_flat_sgd_vs_torch(emu):
     mc.check_flat_sgd(emu)
+
+
+def test_unmold_golden(emu):
+    mc.check_unmold_golden(emu)

@@ -249,3 +249,7 @@ def test_lits_full_size_step_properties(gpu):
         if p.requires_grad and "bn" not in k and "downsample.1" not in k and "C1.1" not in k \
                 and "out_upscale_conv" not in k:        # ('finetune'-only conv, mask_branch.py:118-122)
             assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
+
+
+def test_unmold_golden(gpu):
+    mc.check_unmold_golden(gpu)

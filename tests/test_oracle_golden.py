@@ -223,3 +223,20 @@ def test_predict_cfg0_full_dataflow():
         a, r = params[k].grad.numpy(), g["grad:" + k]
         e = np.linalg.norm((a - r).ravel()) / max(np.linalg.norm(r.ravel()), 1e-30)
         assert e < 2e-2, "%s: rel L2 %.3e" % (k, e)   # LeakyReLU mask flips, see tests/module_cases.UNET_GRAD_L2_TOL
+
+
+def test_unmold_golden():
+    """utils.unmold_mask / MaskRCNN.unmold_detections (inference tail) vs the
+    reference's own outputs."""
+    g = load_golden("unmold")
+    shape = [int(v) for v in g["image_shape"]]
+    full = orc.unmold_mask(g["probs"][0], g["detections"][0, :6].astype(np.int32), shape)
+    np.testing.assert_array_equal(full[::3, ::3, ::3], g["full_mask_sub"])
+    assert abs(full.astype(np.float64).sum() - float(g["full_mask_sum"])) < 1e-9 * float(g["full_mask_sum"])
+    pad = np.concatenate([g["probs"], np.zeros((1,) + g["probs"].shape[1:], np.float32)], axis=0)
+    boxes, ids, scores, cmap = orc.unmold_detections(g["detections"], pad, shape, g["window"])
+    np.testing.assert_array_equal(boxes, g["boxes"])
+    np.testing.assert_array_equal(ids, g["class_ids"])
+    np.testing.assert_array_equal(scores, g["scores"])
+    np.testing.assert_array_equal(cmap.astype(np.uint8), g["class_map"])
+    assert boxes.shape[0] == 2                      # the zero-volume detection was dropped
