@@ -81,3 +81,22 @@ def box_refinement(box, gt_box):
     gz = gt_box[:, 0] + 0.5 * gd; gy = gt_box[:, 1] + 0.5 * gh; gx = gt_box[:, 2] + 0.5 * gw
     return torch.stack([(gz - cz) / d, (gy - cy) / h, (gx - cx) / w,
                         torch.log(gd / d), torch.log(gh / h), torch.log(gw / w)], dim=1)
+
+
+# ---- input formatting (model.py:1870-1904) --------------------------------------------------------------------
+def mold_image(images):
+    """model.py:1902-1904: z-score with the whole-volume mean and POPULATION std (numpy's default ddof = 0); works
+    on numpy arrays and on (device) tensors."""
+    if torch.is_tensor(images):
+        return (images - images.mean()) / images.std(unbiased=False)
+    return (images - images.mean()) / images.std()
+
+
+def compose_image_meta(image_id, image_shape, window, active_class_ids):
+    """model.py:1870-1887."""
+    return np.array([image_id] + list(image_shape) + list(window) + list(active_class_ids))
+
+
+def parse_image_meta(meta):
+    """model.py:1890-1899."""
+    return meta[:, 0], meta[:, 1:5], meta[:, 5:11], meta[:, 11:]

@@ -72,3 +72,18 @@ def test_c_restatement_of_nms(tag):
     cnt = lib.cfun_ref_nms(boxes.ctypes.data_as(fp), order.ctypes.data_as(ip), n, ctypes.c_float(thr), int(mx),
                            keep.ctypes.data_as(ip))
     np.testing.assert_array_equal(keep[:cnt], g[tag + "_keep"])
+
+
+def test_input_formatting_helpers():
+    """utils.mold_image / compose_image_meta / parse_image_meta (model.py:1870-1904) -- host-side, no kernel."""
+    import numpy as np
+    import torch
+    from cfun_amd import utils
+    x = np.random.default_rng(0).normal(3.0, 7.0, (4, 5, 6)).astype(np.float32)
+    m = utils.mold_image(x)
+    assert abs(float(m.mean())) < 1e-5 and abs(float(m.std()) - 1.0) < 1e-5
+    np.testing.assert_allclose(utils.mold_image(torch.from_numpy(x)).numpy(), m, rtol=1e-5, atol=1e-6)
+    meta = utils.compose_image_meta(7, [1, 32, 64, 64], (0, 0, 0, 32, 64, 64), np.zeros(8, np.int32))[None]
+    iid, shape, window, active = utils.parse_image_meta(meta)
+    assert int(iid[0]) == 7 and list(shape[0]) == [1, 32, 64, 64] and list(window[0]) == [0, 0, 0, 32, 64, 64]
+    assert active.shape == (1, 8)
