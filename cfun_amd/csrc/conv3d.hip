@@ -14,6 +14,9 @@ int cfun_reduce_partials(const float*, float*, int64_t, int, hipStream_t);
 // conv3d_stem.hip
 int cfun_conv_stem_supported(const CfunConv3dParams*);
 int cfun_conv_stem_fwd(const float*, const float*, const float*, const float*, float*, const CfunConv3dParams*, hipStream_t);
+int cfun_conv_pointwise_supported(const CfunConv3dParams*);
+int cfun_conv_pointwise_fwd(const float*, const float*, const float*, const float*, const float*, float*,
+                            const CfunConv3dParams*, hipStream_t);
 // conv3d_wgrad_c1.hip
 int cfun_wgrad_c1_supported(const CfunConv3dParams*);
 size_t cfun_wgrad_c1_ws(const CfunConv3dParams*);
@@ -296,6 +299,8 @@ int cfun_conv3d_fwd(const float* x, const float* wp, const float* scale, const f
   if (!valid_params(p)) return CFUN_EINVAL;
   if ((p->scale_mode && !scale) || (p->has_shift && !shift) || (p->res_mode && !res)) return CFUN_EINVAL;
   if (p->scale_mode < 0 || p->scale_mode > 2 || p->res_mode < 0 || p->res_mode > 1) return CFUN_EINVAL;
+  if (p->algo == CFUN_ALGO_AUTO && cfun_conv_pointwise_supported(p) && cfun_aligned16(x) && cfun_aligned16(y))
+    return cfun_conv_pointwise_fwd(x, wp, scale, shift, res, y, p, cfun_st(stream));   // 1x1x1 -> 8: streaming
   const Shape* s = p->algo == CFUN_ALGO_DIRECT ? nullptr : mfma_shape(p);
   if (s) {
     if (!cfun_aligned16(x) || !cfun_aligned16(wp) || !cfun_aligned16(y) || (scale && !cfun_aligned16(scale)) ||

@@ -116,3 +116,78 @@ int cfun_conv_stem_fwd(const float* x, const float* wp, const float* scale, cons
   if (k == 377) return launch_stem<3, 7, 7, 2, 16>(x, wp, scale, shift, y, *p, st);
   return launch_stem<5, 7, 7, 2, 24>(x, wp, scale, shift, y, *p, st);
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// 1x1x1 convs with 8 output channels on large volumes (conv3d_l4 40->8 @ 4x96^3, ds3 80->8, the fused RPN heads
+// 256->8): pure streaming -- read C_in floats per voxel, write 8.  One thread per voxel keeps its 8 accumulators,
+// reads its row as float4s and takes the weights as wave-uniform scalar loads; the MFMA tile kernel spends a
+// barrier per 4-channel chunk on 4 KB of input here and runs at 1.5 TB/s.
+namespace {
+
+template <int CO>
+__global__ void __launch_bounds__(256)
+k_conv_pointwise(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale,
+                 const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
+                 CfunConv3dParams p, int64_t total) {
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
+    const float4* xr = reinterpret_cast<const float4*>(x + v * p.Ci);
+    float acc[CO];
+#pragma unroll
+    for (int j = 0; j < CO; ++j) acc[j] = 0.f;
+#pragma unroll 2
+    for (int c = 0; c < p.Ci; c += 4) {
+      const float4 xv = xr[c >> 2];
+      const float* w = wp + (int64_t)c * p.CoP;          // wave-uniform: scalar loads
+#pragma unroll
+      for (int j = 0; j < CO; ++j) {
+        acc[j] = fmaf(xv.x, w[j], acc[j]);
+        acc[j] = fmaf(xv.y, w[p.CoP + j], acc[j]);
+        acc[j] = fmaf(xv.z, w[2 * p.CoP + j], acc[j]);
+        acc[j] = fmaf(xv.w, w[3 * p.CoP + j], acc[j]);
+      }
+    }
+    const int64_t per_n = (int64_t)p.Do * p.Ho * p.Wo;
+    const int n = (int)(v / per_n);
+    int64_t ridx = v;
+    if (p.res_mode && p.res_up2) {
+      int64_t t = v - n * per_n;
+      const int xo = (int)(t % p.Wo); t /= p.Wo;
+      const int yo = (int)(t % p.Ho);
+      const int zo = (int)(t / p.Ho);
+      ridx = (((int64_t)n * (p.Do >> 1) + (zo >> 1)) * (p.Ho >> 1) + (yo >> 1)) * (p.Wo >> 1) + (xo >> 1);
+    }
+#pragma unroll
+    for (int j = 0; j < CO; j += 4) {
+      float r[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float a = acc[j + k];
+        if (p.scale_mode == 1) a *= scale[j + k];
+        else if (p.scale_mode == 2) a *= scale[n * CO + j + k];
+        if (p.has_shift) a += shift[j + k];
+        if (p.res_mode) a += res[ridx * CO + j + k];
+        r[k] = cfun_apply_act(a, p.act, p.slope);
+      }
+      *reinterpret_cast<float4*>(y + v * CO + j) = make_float4(r[0], r[1], r[2], r[3]);
+    }
+  }
+}
+
+}  // namespace
+
+int cfun_conv_pointwise_supported(const CfunConv3dParams* p) {
+  if (p->kd != 1 || p->kh != 1 || p->kw != 1 || p->stride != 1 || p->up2 || p->d2s) return 0;
+  if (p->Co != 8 || (p->Ci & 3)) return 0;
+  return (int64_t)p->N * p->Do * p->Ho * p->Wo >= 32768;      // small volumes: the split-K MFMA path
+}
+
+int cfun_conv_pointwise_fwd(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
+                            float* y, const CfunConv3dParams* p, hipStream_t st) {
+  const int64_t total = (int64_t)p->N * p->Do * p->Ho * p->Wo;
+  if (total <= 0) return CFUN_OK;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(k_conv_pointwise<8>, dim3((unsigned)blocks), dim3(256), 0, st, x, wp, scale, shift, res, y, *p, total);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}

@@ -92,6 +92,7 @@ CONV_CASES = {
     "mfma_111_rem_40_8_res_up2": (1, (4, 6, 18), 40, 8, (1, 1, 1), dict(algo=ALGO_MFMA, res=True, res_up2=True)),
     "mfma_333_s2_rem_20_40": (1, (8, 8, 10), 20, 40, (3, 3, 3), dict(algo=ALGO_MFMA, stride=2)),
     "mfma_333_d2s_res": (2, (3, 4, 5), 8, 64, (3, 3, 3), dict(algo=ALGO_MFMA, d2s=True, res=True)),
+    "auto_111_8_8_pointwise": (1, (16, 32, 64), 8, 8, (1, 1, 1), dict(algo=ALGO_AUTO, res=True, res_up2=True, shift=True, act=ACT_RELU, scale=True)),
     "direct_333_d2s_res_cq3": (1, (3, 4, 5), 3, 24, (3, 3, 3), dict(algo=ALGO_DIRECT, d2s=True, res=True, act=ACT_LRELU)),
 }
 # bigger shapes: many workgroups, several chunks per wgrad block, channel counts of the real nets (GPU tier)
@@ -103,6 +104,8 @@ CONV_CASES_LARGE = {
     "mfma_111_160_80": (2, (24, 24, 24), 160, 80, (1, 1, 1), dict(algo=ALGO_MFMA)),
     "mfma_555_8_8_up2": (1, (24, 24, 24), 8, 8, (5, 5, 5), dict(algo=ALGO_MFMA, up2=True, res=True, res_up2=True)),
     "direct_stem_96": (2, (48, 48, 48), 1, 20, (3, 3, 3), dict(algo=ALGO_DIRECT)),
+    "auto_111_40_8_pointwise_res_up2": (2, (24, 32, 34), 40, 8, (1, 1, 1), dict(algo=ALGO_AUTO, res=True, res_up2=True, shift=True)),
+    "auto_111_256_8_pointwise": (1, (16, 32, 64), 256, 8, (1, 1, 1), dict(algo=ALGO_AUTO, shift=True, act=ACT_LRELU)),
     "auto_stem_c1_48cube": (2, (48, 48, 50), 1, 20, (3, 3, 3), dict(algo=ALGO_AUTO, scale=True, per_n=True)),
     "auto_p3d_stem_64": (1, (32, 64, 66), 1, 16, (3, 7, 7), dict(stride=2, pad=(1, 3, 3), act=ACT_RELU, scale=True, shift=True, algo=ALGO_AUTO)),
     "auto_333_20_20_48cube": (2, (48, 48, 48), 20, 20, (3, 3, 3), dict(algo=ALGO_AUTO, scale=True, per_n=True)),
