@@ -66,6 +66,8 @@ _SIGNATURES = {
     "cfun_edge_loss_bwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "cfun_edge_loss_bwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "cfun_mask_losses_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "cfun_edge_loss_fwd_save": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "cfun_mask_losses_bwd_saved": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cfun_mask_target_labels": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "cfun_unmold_argmax": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "cfun_sumsq_partials_count": (C.c_int32, []),

@@ -167,7 +167,9 @@ __device__ __forceinline__ void plane_sums(const float* __restrict__ probs, cons
     }
 }
 
-// MODE 0: accumulate sum (|grad p| - |grad t|)^2 ; MODE 1: write dc[o][c-1][0..1] = dL/d(c0), dL/d(c1)
+// MODE 0: accumulate sum (|grad p| - |grad t|)^2 ; MODE 1: write dc[o][c-1][0..1] = dL/d(c0), dL/d(c1) scaled by gscale;
+// MODE 2: both in one pass -- the loss, and dc for an upstream gradient of 1 (the training forward saves it, so the
+// backward needs no second march over the probabilities)
 template <int CT, int MODE>
 __global__ void __launch_bounds__(kBlock)
 k_edge_march(const float* __restrict__ probs, const uint8_t* __restrict__ labels, const float* __restrict__ gscale,
@@ -175,7 +177,7 @@ k_edge_march(const float* __restrict__ probs, const uint8_t* __restrict__ labels
   const int Do = D - 2, Ho = H - 2, Wo = W - 2;
   const int nseg = (Do + kZSeg - 1) / kZSeg;
   const int64_t total = (int64_t)n * nseg * Ho * Wo;
-  const float gs = MODE == 1 ? gscale[0] * 2.f / ((float)Do * (float)Ho * (float)Wo * (float)n) : 0.f;
+  const float gs = MODE == 0 ? 0.f : (MODE == 1 ? gscale[0] : 1.f) * 2.f / ((float)Do * (float)Ho * (float)Wo * (float)n);
   double acc = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
     int64_t t = i;
@@ -191,17 +193,18 @@ k_edge_march(const float* __restrict__ probs, const uint8_t* __restrict__ labels
     plane_sums<CT>(probs, labels, nbase, z0 + 1, y, x, H, W, P[1], T[1]);
     for (int zo = z0; zo < z1; ++zo) {
       plane_sums<CT>(probs, labels, nbase, zo + 2, y, x, H, W, P[2], T[2]);
-      float* o = MODE == 1 ? dc + ((((r * Do + zo) * Ho + y) * Wo + x)) * (2 * (CT - 1)) : nullptr;
+      float* o = MODE != 0 ? dc + ((((r * Do + zo) * Ho + y) * Wo + x)) * (2 * (CT - 1)) : nullptr;
 #pragma unroll
       for (int c = 0; c < CT - 1; ++c) {
         const float p0 = P[0].dy[c] + 2.f * P[1].dy[c] + P[2].dy[c], p1 = P[0].sm[c] - P[2].sm[c];
         const float t0 = T[0].dy[c] + 2.f * T[1].dy[c] + T[2].dy[c], t1 = T[0].sm[c] - T[2].sm[c];
         const float pm = sqrtf(p0 * p0 + p1 * p1 + p0 * p0);   // channel 0 twice (model.py:969-972)
         const float tm = sqrtf(t0 * t0 + t1 * t1 + t0 * t0);
-        if (MODE == 0) {
+        if (MODE != 1) {
           const float d = pm - tm;
           acc += (double)(d * d);
-        } else {
+        }
+        if (MODE != 0) {
           const float k = gs * (pm - tm) / pm;      // 0/0 -> NaN exactly like torch's sqrt backward (App. A-13)
           o[c * 2] = k * 2.f * p0;
           o[c * 2 + 1] = k * p1;
@@ -210,7 +213,7 @@ k_edge_march(const float* __restrict__ probs, const uint8_t* __restrict__ labels
       P[0] = P[1]; P[1] = P[2]; T[0] = T[1]; T[1] = T[2];
     }
   }
-  if (MODE == 0) {
+  if (MODE != 1) {
     const double s = block_sum(acc);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
   }
@@ -247,7 +250,8 @@ __device__ __forceinline__ void plane_adj(const float* __restrict__ dc, int64_t 
 template <int CT, bool FUSE>
 __global__ void __launch_bounds__(kBlock)
 k_edge_bwd_gather(const float* __restrict__ dc, float* __restrict__ dprobs, int n, int D, int H, int W,
-                  const float* __restrict__ probs, const uint8_t* __restrict__ labels, const float* __restrict__ gce) {
+                  const float* __restrict__ probs, const uint8_t* __restrict__ labels, const float* __restrict__ gce,
+                  const float* __restrict__ gedge) {
   const int Do = D - 2, Ho = H - 2, Wo = W - 2;
   const int nseg = (D + kZSeg - 1) / kZSeg;
   const int64_t total = (int64_t)n * nseg * H * W;
@@ -269,9 +273,10 @@ k_edge_bwd_gather(const float* __restrict__ dc, float* __restrict__ dprobs, int 
       float* o = dprobs + vox * CT;
       float g[CT];
       g[0] = 0.f;
+      const float ge = gedge ? gedge[0] : 1.f;     // dc saved by the forward is for an upstream gradient of 1
 #pragma unroll
       for (int c = 0; c < CT - 1; ++c)   // A[dz]: dz=0 -> zo=z, dz=1 -> z-1, dz=2 -> z-2 ; B[dz] = (1,0,-1)
-        g[c + 1] = (q0[2][c] + 2.f * q0[1][c] + q0[0][c]) + (q1[2][c] - q1[0][c]);
+        g[c + 1] = ge * ((q0[2][c] + 2.f * q0[1][c] + q0[0][c]) + (q1[2][c] - q1[0][c]));
       if (FUSE) {
         const float gs = gce[0] / (float)((int64_t)n * D * H * W);
         const int lab = labels[vox];
@@ -380,11 +385,43 @@ int cfun_edge_loss_bwd(const float* probs, const uint8_t* labels, const float* g
   const int64_t cols_i = (int64_t)n * ((D + kZSeg - 1) / kZSeg) * H * W;
   if (C == 8) {
     hipLaunchKernelGGL((k_edge_march<8, 1>), dim3(vox_grid(cols_o)), dim3(kBlock), 0, cfun_st(stream), probs, labels, gscale, (double*)nullptr, (float*)ws, n, D, H, W);
-    hipLaunchKernelGGL((k_edge_bwd_gather<8, false>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dprobs, n, D, H, W, (const float*)nullptr, (const uint8_t*)nullptr, (const float*)nullptr);
+    hipLaunchKernelGGL((k_edge_bwd_gather<8, false>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dprobs, n, D, H, W, (const float*)nullptr, (const uint8_t*)nullptr, (const float*)nullptr, (const float*)nullptr);
   } else {
     hipLaunchKernelGGL((k_edge_march<3, 1>), dim3(vox_grid(cols_o)), dim3(kBlock), 0, cfun_st(stream), probs, labels, gscale, (double*)nullptr, (float*)ws, n, D, H, W);
-    hipLaunchKernelGGL((k_edge_bwd_gather<3, false>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dprobs, n, D, H, W, (const float*)nullptr, (const uint8_t*)nullptr, (const float*)nullptr);
+    hipLaunchKernelGGL((k_edge_bwd_gather<3, false>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dprobs, n, D, H, W, (const float*)nullptr, (const uint8_t*)nullptr, (const float*)nullptr, (const float*)nullptr);
   }
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+// training forward: the loss AND the unit-gradient coefficient field dc (cfun_edge_loss_bwd_workspace_bytes bytes)
+int cfun_edge_loss_fwd_save(const float* probs, const uint8_t* labels, float* loss, float* dc, int32_t n, int32_t D,
+                            int32_t H, int32_t W, int32_t C, void* ws, size_t ws_bytes, cfun_stream_t stream) {
+  if (C != 8 && C != 3) return CFUN_EINVAL;
+  if (n <= 0 || D < 3 || H < 3 || W < 3) return CFUN_EINVAL;
+  if (ws_bytes < kMaxBlocks * sizeof(double)) return CFUN_EWORKSPACE;
+  const int64_t per = (int64_t)(D - 2) * (H - 2) * (W - 2);
+  const int64_t cols = (int64_t)n * ((D - 2 + kZSeg - 1) / kZSeg) * (H - 2) * (W - 2);
+  const unsigned blocks = vox_grid(cols);
+  if (C == 8) hipLaunchKernelGGL((k_edge_march<8, 2>), dim3(blocks), dim3(kBlock), 0, cfun_st(stream), probs, labels, (const float*)nullptr, (double*)ws, dc, n, D, H, W);
+  else hipLaunchKernelGGL((k_edge_march<3, 2>), dim3(blocks), dim3(kBlock), 0, cfun_st(stream), probs, labels, (const float*)nullptr, (double*)ws, dc, n, D, H, W);
+  hipLaunchKernelGGL(k_finalize_sum, dim3(1), dim3(64), 0, cfun_st(stream), (const double*)ws, (int)blocks,
+                     1.0 / ((double)per * (double)n), loss);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+// backward of both mask losses from the dc saved by cfun_edge_loss_fwd_save: ONE pass (no second march)
+int cfun_mask_losses_bwd_saved(const float* probs, const uint8_t* labels, const float* g_ce, const float* g_edge,
+                               const float* dc, float* dlogits, int32_t n, int32_t D, int32_t H, int32_t W, int32_t C,
+                               cfun_stream_t stream) {
+  if (C != 8 && C != 3) return CFUN_EINVAL;
+  const int64_t total = (int64_t)n * D * H * W;
+  if (total <= 0) return CFUN_OK;
+  if (D < 3 || H < 3 || W < 3 || !dc || !g_edge) return CFUN_EINVAL;
+  const int64_t cols_i = (int64_t)n * ((D + kZSeg - 1) / kZSeg) * H * W;
+  if (C == 8) hipLaunchKernelGGL((k_edge_bwd_gather<8, true>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), dc, dlogits, n, D, H, W, probs, labels, g_ce, g_edge);
+  else hipLaunchKernelGGL((k_edge_bwd_gather<3, true>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), dc, dlogits, n, D, H, W, probs, labels, g_ce, g_edge);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }
@@ -401,10 +438,10 @@ int cfun_mask_losses_bwd(const float* probs, const uint8_t* labels, const float*
   const int64_t cols_i = (int64_t)n * ((D + kZSeg - 1) / kZSeg) * H * W;
   if (C == 8) {
     hipLaunchKernelGGL((k_edge_march<8, 1>), dim3(vox_grid(cols_o)), dim3(kBlock), 0, cfun_st(stream), probs, labels, g_edge, (double*)nullptr, (float*)ws, n, D, H, W);
-    hipLaunchKernelGGL((k_edge_bwd_gather<8, true>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dlogits, n, D, H, W, probs, labels, g_ce);
+    hipLaunchKernelGGL((k_edge_bwd_gather<8, true>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dlogits, n, D, H, W, probs, labels, g_ce, (const float*)nullptr);
   } else {
     hipLaunchKernelGGL((k_edge_march<3, 1>), dim3(vox_grid(cols_o)), dim3(kBlock), 0, cfun_st(stream), probs, labels, g_edge, (double*)nullptr, (float*)ws, n, D, H, W);
-    hipLaunchKernelGGL((k_edge_bwd_gather<3, true>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dlogits, n, D, H, W, probs, labels, g_ce);
+    hipLaunchKernelGGL((k_edge_bwd_gather<3, true>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dlogits, n, D, H, W, probs, labels, g_ce, (const float*)nullptr);
   }
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;

@@ -556,21 +556,32 @@ class _MaskLosses(torch.autograd.Function):
         st = stream(logits)
         check(lib.cfun_softmax_ce_fwd(ptr(logits), ptr(labels), ptr(out), nvox, c, ptr(ws), ws.numel(), st),
               "softmax_ce_fwd")
-        check(lib.cfun_edge_loss_fwd(ptr(probs), ptr(labels), ptr(out[1:]), n, d, h, w, c, ptr(ws), ws.numel(), st),
-              "edge_loss_fwd")
-        ctx.save_for_backward(probs, labels)
+        dc = None
+        if ctx.needs_input_grad[0] and min(d, h, w) >= 3:   # training: keep the edge coefficients, one-pass backward
+            dc = torch.empty(lib.cfun_edge_loss_bwd_workspace_bytes(n, d, h, w, c) // 4, dtype=torch.float32,
+                             device=logits.device)
+            check(lib.cfun_edge_loss_fwd_save(ptr(probs), ptr(labels), ptr(out[1:]), ptr(dc), n, d, h, w, c, ptr(ws),
+                                              ws.numel(), st), "edge_loss_fwd_save")
+        else:
+            check(lib.cfun_edge_loss_fwd(ptr(probs), ptr(labels), ptr(out[1:]), n, d, h, w, c, ptr(ws), ws.numel(), st),
+                  "edge_loss_fwd")
+        ctx.save_for_backward(probs, labels, dc)
         return out[0], out[1]
 
     @staticmethod
     def backward(ctx, g_ce, g_edge):
         lib = _lib.load()
-        probs, labels = ctx.saved_tensors
+        probs, labels, dc = ctx.saved_tensors
         n, d, h, w, c = probs.shape
         g = torch.stack([g_ce.reshape(()).float(), g_edge.reshape(()).float()])
         dl = torch.empty_like(probs)
-        ws = workspace(lib.cfun_edge_loss_bwd_workspace_bytes(n, d, h, w, c), probs)
-        check(lib.cfun_mask_losses_bwd(ptr(probs), ptr(labels), ptr(g), ptr(g[1:]), ptr(dl), n, d, h, w, c, ptr(ws),
-                                       ws.numel(), stream(probs)), "mask_losses_bwd")
+        if dc is not None:
+            check(lib.cfun_mask_losses_bwd_saved(ptr(probs), ptr(labels), ptr(g), ptr(g[1:]), ptr(dc), ptr(dl), n, d, h,
+                                                 w, c, stream(probs)), "mask_losses_bwd_saved")
+        else:
+            ws = workspace(lib.cfun_edge_loss_bwd_workspace_bytes(n, d, h, w, c), probs)
+            check(lib.cfun_mask_losses_bwd(ptr(probs), ptr(labels), ptr(g), ptr(g[1:]), ptr(dl), n, d, h, w, c, ptr(ws),
+                                           ws.numel(), stream(probs)), "mask_losses_bwd")
         return dl, None, None
 
 

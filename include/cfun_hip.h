@@ -207,6 +207,15 @@ int cfun_mask_losses_bwd(const float* probs, const uint8_t* labels, const float*
                          float* dlogits, int32_t n, int32_t D, int32_t H, int32_t W, int32_t C, void* ws,
                          size_t ws_bytes, cfun_stream_t stream);
 
+/* Training variant: the forward also stores the unit-gradient coefficient field dc
+ * (cfun_edge_loss_bwd_workspace_bytes(n,D,H,W,C) bytes, 2*(C-1) floats per valid voxel), and the backward of both
+ * mask losses is then ONE pass (no second Sobel march over the probabilities). */
+int cfun_edge_loss_fwd_save(const float* probs, const uint8_t* labels, float* loss, float* dc, int32_t n, int32_t D,
+                            int32_t H, int32_t W, int32_t C, void* ws, size_t ws_bytes, cfun_stream_t stream);
+int cfun_mask_losses_bwd_saved(const float* probs, const uint8_t* labels, const float* g_ce, const float* g_edge,
+                               const float* dc, float* dlogits, int32_t n, int32_t D, int32_t H, int32_t W, int32_t C,
+                               cfun_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Weight layout conversion between the reference's state-dict layout and the kernels' packs (one launch
  * each; replaces the permute / pad / transpose glue around nn.Conv3d.weight):
