@@ -136,14 +136,14 @@ def main():
     reducer = None
     if world > 1:
         from cfun_amd import dist as cdist
-        reducer = cdist.GradientReducer(net.parameters())
+        reducer = cdist.GradientReducer(net.parameters(), average=not (args.sharded))   # sharded: additive shares -> sum
 
     def one_step():
         if reducer is None:
             net.zero_grad(set_to_none=True)
         else:
             reducer.zero_grad()
-        if sharded:     # the ranks' loss shares / gradients add up to the single-GPU step (reducer averages: x world)
+        if sharded:     # the ranks' loss shares / gradients add up to the single-GPU step (the reducer sums)
             with cdist.depth_sharded():
                 losses, total, _ = cdist.sharded_training_step(net, sample)
         else:

@@ -320,14 +320,16 @@ class GradientReducer:
 
         red = GradientReducer(net.parameters())
         per step:  red.zero_grad(); loss.backward(); red.finish()      # then p.grad holds the mean over ranks
+                                                                       # (average=False: the sum, for sharded_training_step)
 
     Buckets are filled in reverse parameter order (heads first), the order autograd produces them in.  A parameter
     that gets no gradient in a step still takes part in its bucket's reduction (its slice stays zero); ``finish``
     launches whatever bucket did not complete through the hooks.  With world size 1 it is a no-op container
     (``always_reduce`` keeps the collectives for single-rank tests of the stream logic)."""
 
-    def __init__(self, params, bucket_bytes=64 << 20, group=None, always_reduce=False):
+    def __init__(self, params, bucket_bytes=64 << 20, group=None, always_reduce=False, average=True):
         self.group = group
+        self.average = average      # False: plain sum (the ranks hold additive shares of ONE sample's gradient)
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.active = self.world > 1 or (always_reduce and dist.is_available() and dist.is_initialized())
         self.params = [p for p in params if p.requires_grad]
@@ -416,8 +418,9 @@ class GradientReducer:
             bucket["work"].wait()
         if self.comm_stream is not None:
             torch.cuda.current_stream(self.params[0].device).wait_stream(self.comm_stream)
-        for bucket in self.buckets:
-            bucket["flat"].div_(self.world)
+        if self.average:
+            for bucket in self.buckets:
+                bucket["flat"].div_(self.world)
 
     def remove(self):
         for h in self._hooks:
