@@ -68,9 +68,87 @@ class Modified3DUNet(nn.Module):
         if not self.training or self.dropout_p <= 0:
             return [None] * 5
         if self.dropout_masks is not None:
-            return [m.to(device=device, dtype=torch.float32).contiguous() for m in self.dropout_masks]
+            return [m.detach().to(device="cpu", dtype=torch.float32).contiguous() for m in self.dropout_masks]
         b, keep = self.base_n_filter, 1.0 - self.dropout_p
-        return [torch.empty((n, c), device=device).bernoulli_(keep).div_(keep) for c in (b, 2 * b, 4 * b, 8 * b, 16 * b)]
+        # drawn on the host: the kept-channel index lists of _dropout_pair must not cost a device sync
+        return [torch.empty((n, c)).bernoulli_(keep).div_(keep) for c in (b, 2 * b, 4 * b, 8 * b, 16 * b)]
+
+    # Dropout3d zeroes whole channels per sample, and InstanceNorm + LeakyReLU keep an all-zero channel at exactly
+    # zero.  So in "conv1 -> Dropout3d -> norm/act -> conv2" (every level's pair, mask_branch.py:129-176) conv1 only
+    # has to produce the kept channels and conv2 only has to read them: with p = 0.6 that is 40 % of conv1's output
+    # rows and 40 % of conv2's reduction -- identical values and gradients (the dropped channels contribute exact
+    # zeros), ~55 % of the pair's FLOPs gone in forward, data-gradient and weight-gradient.  The kept sets differ per
+    # RoI, so the pair runs per sample on weights gathered by ``index_select`` (differentiable: the weight gradient
+    # scatters back); only where a single RoI still fills the GPU (>= SPARSE_MIN_VOX voxels, levels 1-3 at 96^3).
+    SPARSE_MIN_VOX = 24 * 24 * 24
+
+    @staticmethod
+    def _kept_channels(drop_cpu):
+        """Per sample: the kept channel indices of a host mask [N,C], padded with dropped ones (scale 0) to a multiple
+        of 4 (host lists)."""
+        lists = []
+        for row in drop_cpu.tolist():                      # plain Python lists: per-element tensor indexing is ~10 us each
+            kept = [j for j, v in enumerate(row) if v > 0]
+            dropped = [j for j, v in enumerate(row) if v <= 0]
+            kept += dropped[:(-len(kept)) % 4 or (4 if not kept else 0)]
+            lists.append(sorted(kept))
+        return lists
+
+    def _upload_dropout(self, drops, device):
+        """All five masks and all kept-channel lists go to the device in TWO transfers at the start of the forward
+        pass: a pageable host-to-device copy in the middle of the pass waits for the stream and leaves the GPU idle
+        until the host has caught up (10 such stalls cost ~1 ms per step; pinning the staging buffers per step costs
+        more than it saves)."""
+        if drops[0] is None:
+            return [None] * 5
+        lists = [self._kept_channels(m) for m in drops]
+        flat_idx = torch.tensor([j for lv in lists for l in lv for j in l], dtype=torch.long).to(device)
+        pad = [(-m.numel()) % 4 for m in drops]                       # every mask starts 16-byte aligned
+        flat_m = torch.cat([torch.nn.functional.pad(m.reshape(-1), (0, p)) for m, p in zip(drops, pad)]).to(device)
+        out, oi, om = [], 0, 0
+        for m, lv, p in zip(drops, lists, pad):
+            idxs = []
+            for l in lv:
+                idxs.append(flat_idx[oi:oi + len(l)])
+                oi += len(l)
+            out.append((flat_m[om:om + m.numel()].view(m.shape), idxs))
+            om += m.numel() + p
+        return out
+
+    def _dropout_pair(self, src, head, conv1, conv2, drop_cpu, pre2):
+        """One level's ``(a, res) = head(src); out = conv2(pre2(Dropout3d(conv1(a)))) + res``: conv1 / conv2 are the
+        level's 3x3x3 Conv3dParams (conv1: Ci -> C, conv2: C -> Co), drop_cpu = (device mask [N,C] (keep / (1-p)),
+        per-sample kept-channel index tensors) from ``_upload_dropout`` or None, ``head`` the ops that produce the
+        pair's input and residual from ``src`` [N,...]."""
+        n = src.shape[0]
+        c = conv1.out_channels
+        if drop_cpu is None:
+            a, res = head(src)
+            return conv2(pre2(conv1(a)), res=res)
+        drop, idxs = drop_cpu
+        s2 = getattr(head, "stride", 1)
+        vox = (src.shape[1] // s2) * (src.shape[2] // s2) * (src.shape[3] // s2)
+        sparse = (vox >= self.SPARSE_MIN_VOX and c % 4 == 0 and conv2.out_channels % 4 == 0
+                  and conv1.in_channels % 4 == 0 and conv1.bias is None and conv2.bias is None)
+        if not sparse:
+            a, res = head(src)
+            return conv2(pre2(conv1(a, scale=drop)), res=res)
+        algo = default_algo()
+        # the level's head ops stay batched (per-sample heads measured no better); unbind, not t[i:i+1]: its backward is
+        # ONE stack, n slices would each zero-fill a full-size gradient
+        a_all, res_all = head(src)
+        a_parts, res_parts = a_all.unbind(0), res_all.unbind(0)
+        outs = []
+        for i in range(n):
+            a, res = a_parts[i].unsqueeze(0), res_parts[i].unsqueeze(0)
+            idx = idxs[i]
+            w1 = conv1.weight.index_select(0, idx)
+            spec1 = ops.ConvSpec(k=conv1.kernel_size, co=idx.numel(), pad=conv1.padding, scale_per_n=True, algo=algo)
+            t = ops.conv3d(a, ops.pack_weight(w1), spec1, scale=drop[i:i + 1].index_select(1, idx).contiguous())
+            w2 = conv2.weight.index_select(1, idx)
+            spec2 = ops.ConvSpec(k=conv2.kernel_size, co=conv2.out_channels, pad=conv2.padding, algo=algo)
+            outs.append(ops.conv3d(pre2(t), ops.pack_weight(w2), spec2, res=res))
+        return torch.cat(outs, dim=0)
 
     @staticmethod
     def _up_conv(h, conv):
@@ -88,23 +166,28 @@ class Modified3DUNet(nn.Module):
 
     def forward_ndhwc(self, x):
         nl = ops.instnorm_lrelu
-        drop = self._drop_masks(x.shape[0], x.device)
+        drop = self._upload_dropout(self._drop_masks(x.shape[0], x.device), x.device)
 
         def nluc(h, holder):   # norm -> lrelu -> nearest x2 -> 3x3x3 conv -> norm -> lrelu  (mask_branch.py:108-116)
             return nl(self._up_conv(nl(h), holder[3]))
 
         # level 1: residual is the pre-activation stem output, context_1 is taken before the norm
-        res = self.conv3d_c1_1(x)
-        h = self.conv3d_c1_2(ops.lrelu(res), scale=drop[0])
-        out = self.lrelu_conv_c1[1](ops.lrelu(h), res=res)
+        def head1(xp):
+            res = self.conv3d_c1_1(xp)
+            return ops.lrelu(res), res
+        out = self._dropout_pair(x, head1, self.conv3d_c1_2, self.lrelu_conv_c1[1], drop[0], ops.lrelu)
         ctx = [ops.lrelu(out)]
         h = nl(out)
         # levels 2..5: stride-2 conv, then the SAME norm_lrelu_conv weights twice around the dropout
         for lvl in (2, 3, 4, 5):
-            res = getattr(self, "conv3d_c%d" % lvl)(h)
+            down = getattr(self, "conv3d_c%d" % lvl)
+
+            def head(hp, down=down):
+                res = down(hp)
+                return nl(res), res
+            head.stride = 2
             conv = getattr(self, "norm_lrelu_conv_c%d" % lvl)[2]
-            t = conv(nl(res), scale=drop[lvl - 1])
-            out = conv(nl(t), res=res)
+            out = self._dropout_pair(h, head, conv, conv, drop[lvl - 1], nl)
             if lvl < 5:
                 h = nl(out)
                 ctx.append(h)

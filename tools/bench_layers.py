@@ -38,6 +38,14 @@ LAYERS = [
     ("nlc_c5 320->320 @6", 4, (6, 6, 6), 16 * B, 16 * B, 3, 1, ""),
     ("out_upscale 5^3 8->8 @96->192 (folded)", 4, (96, 96, 96), 8, 8, 5, 1, "fold5"),
     ("conv3d_l4 1x1 40->8 @96", 4, (96, 96, 96), 2 * B, 8, 1, 1, ""),
+    ("sparse-dropout 20->8 @96 (1 RoI)", 1, (96, 96, 96), B, 8, 3, 1, ""),
+    ("sparse-dropout 8->20 @96 (1 RoI)", 1, (96, 96, 96), 8, B, 3, 1, ""),
+    ("sparse-dropout 20->12 @96 (1 RoI)", 1, (96, 96, 96), B, 12, 3, 1, ""),
+    ("sparse-dropout 12->20 @96 (1 RoI)", 1, (96, 96, 96), 12, B, 3, 1, ""),
+    ("sparse-dropout 40->16 @48 (1 RoI)", 1, (48, 48, 48), 2 * B, 16, 3, 1, ""),
+    ("sparse-dropout 16->40 @48 (1 RoI)", 1, (48, 48, 48), 16, 2 * B, 3, 1, ""),
+    ("sparse-dropout 80->32 @24 (1 RoI)", 1, (24, 24, 24), 4 * B, 32, 3, 1, ""),
+    ("sparse-dropout 32->80 @24 (1 RoI)", 1, (24, 24, 24), 32, 4 * B, 3, 1, ""),
     ("P2_conv2 128->128 @16x32x32", 1, (16, 32, 32), 128, 128, 3, 1, ""),
     ("rpn.conv_shared 128->256 @16x32x32", 1, (16, 32, 32), 128, 256, 3, 1, ""),
 ]
