@@ -15,6 +15,14 @@ inline unsigned ew_grid(int64_t work_items) {
 }
 
 // ------------------------------------------------------------------ simple elementwise
+// launch of the per-sample apply kernels: (blocks, N) with >= 4 voxels per thread
+inline unsigned apply_blocks(int64_t V, int lanes) {
+  int64_t b = (V + (int64_t)lanes * 4 - 1) / ((int64_t)lanes * 4);
+  if (b < 1) b = 1;
+  if (b > 16384) b = 16384;
+  return (unsigned)b;
+}
+
 __global__ void __launch_bounds__(kBlock) k_lrelu_fwd(const float4* x, float4* y, int64_t n4, float slope) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
     float4 v = x[i];
@@ -40,6 +48,33 @@ k_lrelu_bwd(const float4* x, const float4* dy, float4* dx, int64_t n4, float slo
 __global__ void k_lrelu_bwd_tail(const float* x, const float* dy, float* dx, int64_t from, int64_t n, float slope) {
   int64_t i = from + threadIdx.x;
   if (i < n) dx[i] = x[i] > 0.f ? dy[i] : dy[i] * slope;
+}
+// channel-strided variants (C % 4 == 0): rows of C floats inside a wider NDHWC buffer (zero-copy concat, section 3.5);
+// cg = C/4 float4 groups per voxel, xg / yg = row strides in float4s
+__global__ void __launch_bounds__(kBlock)
+k_lrelu_fwd_s(const float4* x, float4* y, int64_t nvox, int cg, int64_t xg, int64_t yg, float slope) {
+  // thread = (voxel lane, group): consecutive threads walk a voxel's row, then the next voxel -- coalesced on both
+  // sides, and no per-element 64-bit division (a flat index / cg costs 5x the kernel time)
+  const int lanes = kBlock / cg, c = threadIdx.x % cg, vl = threadIdx.x / cg;
+  if (vl >= lanes) return;
+  for (int64_t v = (int64_t)blockIdx.x * lanes + vl; v < nvox; v += (int64_t)gridDim.x * lanes) {
+    float4 a = x[v * xg + c];
+    a.x = a.x > 0.f ? a.x : a.x * slope; a.y = a.y > 0.f ? a.y : a.y * slope;
+    a.z = a.z > 0.f ? a.z : a.z * slope; a.w = a.w > 0.f ? a.w : a.w * slope;
+    y[v * yg + c] = a;
+  }
+}
+__global__ void __launch_bounds__(kBlock)
+k_lrelu_bwd_s(const float4* x, const float4* dy, float4* dx, int64_t nvox, int cg, int64_t dyg, float slope) {
+  const int lanes = kBlock / cg, c = threadIdx.x % cg, vl = threadIdx.x / cg;
+  if (vl >= lanes) return;
+  for (int64_t v = (int64_t)blockIdx.x * lanes + vl; v < nvox; v += (int64_t)gridDim.x * lanes) {
+    const float4 a = x[v * cg + c];
+    float4 g = dy[v * dyg + c];
+    g.x = a.x > 0.f ? g.x : g.x * slope; g.y = a.y > 0.f ? g.y : g.y * slope;
+    g.z = a.z > 0.f ? g.z : g.z * slope; g.w = a.w > 0.f ? g.w : g.w * slope;
+    dx[v * cg + c] = g;
+  }
 }
 __global__ void __launch_bounds__(kBlock) k_add(const float4* a, const float4* b, float4* o, int64_t n4) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
@@ -95,7 +130,7 @@ template <int VEC>
 struct StatSumSq {  // sum x, sum x^2
   static constexpr int NQ = 2;
   const float* x;
-  __device__ void operator()(int64_t e, int, int, double (&acc)[2][VEC]) const {
+  __device__ void operator()(int64_t e, int, int, double (&acc)[2][VEC], int64_t, int) const {
     float a[VEC];
     Vec<VEC>::load(x, e, a);
 #pragma unroll
@@ -106,7 +141,7 @@ template <int VEC>
 struct StatSum {  // sum g
   static constexpr int NQ = 1;
   const float* x;
-  __device__ void operator()(int64_t e, int, int, double (&acc)[1][VEC]) const {
+  __device__ void operator()(int64_t e, int, int, double (&acc)[1][VEC], int64_t, int) const {
     float a[VEC];
     Vec<VEC>::load(x, e, a);
 #pragma unroll
@@ -121,10 +156,11 @@ struct StatNormBwd {  // sum gn, sum gn*xhat with gn = dy*lrelu'(xhat)
   const float* stats;  // [N,C,2]
   int C;
   float slope;
-  __device__ void operator()(int64_t e, int n, int c0, double (&acc)[2][VEC]) const {
+  int64_t dyg;         // dy row stride in VEC groups (C / VEC when dense)
+  __device__ void operator()(int64_t e, int n, int c0, double (&acc)[2][VEC], int64_t vox, int cg) const {
     float a[VEC], b[VEC];
     Vec<VEC>::load(x, e, a);
-    Vec<VEC>::load(dy, e, b);
+    Vec<VEC>::load(dy, vox * dyg + cg, b);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       const float mean = stats[((int64_t)n * C + c0 + j) * 2], rstd = stats[((int64_t)n * C + c0 + j) * 2 + 1];
@@ -152,7 +188,7 @@ k_channel_reduce(F f, double* __restrict__ partial, int64_t V, int C, int lanes)
     for (int j = 0; j < VEC; ++j) acc[q][j] = 0.0;
   if (vl < lanes) {
     for (int64_t v = (int64_t)blockIdx.x * lanes + vl; v < V; v += (int64_t)gridDim.x * lanes)
-      f(((int64_t)n * V + v) * CG + cg, n, cg * VEC, acc);
+      f(((int64_t)n * V + v) * CG + cg, n, cg * VEC, acc, (int64_t)n * V + v, cg);
   }
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
@@ -223,23 +259,32 @@ inline size_t reduce_ws(int N, int64_t V, int C, int NQ) {
   return cfun_align_up((size_t)N * r.blocks * NQ * C * sizeof(double), 256);
 }
 
+// thread = (voxel lane, channel group) of sample blockIdx.y: the group and its statistics are fixed per thread, the
+// voxel index advances by a constant -- no per-element 64-bit division; y may be channel-strided (yg groups per row)
 template <int VEC>
 __global__ void __launch_bounds__(kBlock)
-k_instnorm_lrelu_fwd(const float* __restrict__ x, const float* __restrict__ stats, float* __restrict__ y,
-                     int64_t total, int64_t V, int C, float slope) {
+k_instnorm_lrelu_fwd(const float* __restrict__ x, const float* __restrict__ stats, float* __restrict__ y, int64_t V, int C,
+                     float slope, int64_t yg, int lanes) {
   const int CG = C / VEC;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
-    const int cg = (int)(i % CG);
-    const int64_t n = i / (V * CG);
-    const float* st = stats + ((int64_t)n * C + cg * VEC) * 2;
+  const int cg = threadIdx.x % CG, vl = threadIdx.x / CG;
+  const int n = blockIdx.y;
+  if (vl >= lanes) return;
+  float mean[VEC], rstd[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    mean[j] = stats[((int64_t)n * C + cg * VEC + j) * 2];
+    rstd[j] = stats[((int64_t)n * C + cg * VEC + j) * 2 + 1];
+  }
+  for (int64_t v = (int64_t)blockIdx.x * lanes + vl; v < V; v += (int64_t)gridDim.x * lanes) {
+    const int64_t vox = (int64_t)n * V + v;
     float a[VEC];
-    Vec<VEC>::load(x, i, a);
+    Vec<VEC>::load(x, vox * CG + cg, a);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      const float xh = (a[j] - st[2 * j]) * st[2 * j + 1];
+      const float xh = (a[j] - mean[j]) * rstd[j];
       a[j] = xh > 0.f ? xh : xh * slope;
     }
-    Vec<VEC>::store(y, i, a);
+    Vec<VEC>::store(y, vox * yg + cg, a);
   }
 }
 
@@ -247,25 +292,30 @@ k_instnorm_lrelu_fwd(const float* __restrict__ x, const float* __restrict__ stat
 template <int VEC>
 __global__ void __launch_bounds__(kBlock)
 k_instnorm_lrelu_bwd(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ means,
-                     const float* __restrict__ dy, float* __restrict__ dx, int64_t total, int64_t V, int C,
-                     float slope) {
+                     const float* __restrict__ dy, float* __restrict__ dx, int64_t V, int C, float slope, int64_t dyg,
+                     int lanes) {
   const int CG = C / VEC;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
-    const int cg = (int)(i % CG);
-    const int64_t n = i / (V * CG);
-    const float* st = stats + ((int64_t)n * C + cg * VEC) * 2;
-    const float* mm = means + ((int64_t)n * C + cg * VEC) * 2;
+  const int cg = threadIdx.x % CG, vl = threadIdx.x / CG;
+  const int n = blockIdx.y;
+  if (vl >= lanes) return;
+  float mean[VEC], rstd[VEC], m0[VEC], m1[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const int64_t k = ((int64_t)n * C + cg * VEC + j) * 2;
+    mean[j] = stats[k]; rstd[j] = stats[k + 1]; m0[j] = means[k]; m1[j] = means[k + 1];
+  }
+  for (int64_t v = (int64_t)blockIdx.x * lanes + vl; v < V; v += (int64_t)gridDim.x * lanes) {
+    const int64_t vox = (int64_t)n * V + v;
     float a[VEC], b[VEC], r[VEC];
-    Vec<VEC>::load(x, i, a);
-    Vec<VEC>::load(dy, i, b);
+    Vec<VEC>::load(x, vox * CG + cg, a);
+    Vec<VEC>::load(dy, vox * dyg + cg, b);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      const float rstd = st[2 * j + 1];
-      const float xh = (a[j] - st[2 * j]) * rstd;
+      const float xh = (a[j] - mean[j]) * rstd[j];
       const float gn = xh > 0.f ? b[j] : b[j] * slope;
-      r[j] = rstd * (gn - mm[2 * j] - xh * mm[2 * j + 1]);
+      r[j] = rstd[j] * (gn - m0[j] - xh * m1[j]);
     }
-    Vec<VEC>::store(dx, i, r);
+    Vec<VEC>::store(dx, vox * CG + cg, r);
   }
 }
 
@@ -461,6 +511,30 @@ int cfun_lrelu_bwd(const float* x, const float* dy, float* dx, int64_t n, float 
   return CFUN_OK;
 }
 
+int cfun_lrelu_fwd_strided(const float* x, float* y, int64_t nvox, int32_t C, int64_t x_stride, int64_t y_stride,
+                           float slope, cfun_stream_t stream) {
+  if (nvox <= 0) return CFUN_OK;
+  if (C <= 0 || (C & 3) || (x_stride & 3) || (y_stride & 3) || x_stride < C || y_stride < C) return CFUN_EINVAL;
+  if (!cfun_aligned16(x) || !cfun_aligned16(y)) return CFUN_EALIGN;
+  if (C / 4 > kBlock) return CFUN_EINVAL;
+  hipLaunchKernelGGL(k_lrelu_fwd_s, dim3(apply_blocks(nvox, kBlock / (C / 4))), dim3(kBlock), 0, cfun_st(stream),
+                     (const float4*)x, (float4*)y, nvox, C / 4, x_stride / 4, y_stride / 4, slope);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+int cfun_lrelu_bwd_strided(const float* x, const float* dy, float* dx, int64_t nvox, int32_t C, int64_t dy_stride,
+                           float slope, cfun_stream_t stream) {
+  if (nvox <= 0) return CFUN_OK;
+  if (C <= 0 || (C & 3) || (dy_stride & 3) || dy_stride < C) return CFUN_EINVAL;
+  if (!cfun_aligned16(x) || !cfun_aligned16(dy) || !cfun_aligned16(dx)) return CFUN_EALIGN;
+  if (C / 4 > kBlock) return CFUN_EINVAL;
+  hipLaunchKernelGGL(k_lrelu_bwd_s, dim3(apply_blocks(nvox, kBlock / (C / 4))), dim3(kBlock), 0, cfun_st(stream),
+                     (const float4*)x, (const float4*)dy, (float4*)dx, nvox, C / 4, dy_stride / 4, slope);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
 int cfun_add(const float* a, const float* b, float* out, int64_t n, cfun_stream_t stream) {
   if (n <= 0) return CFUN_OK;
   const int64_t n4 = (cfun_aligned16(a) && cfun_aligned16(b) && cfun_aligned16(out)) ? n / 4 : 0;
@@ -533,24 +607,39 @@ int cfun_instnorm_stats(const float* x, float* stats, int32_t N, int64_t V, int3
   return CFUN_OK;
 }
 
-int cfun_instnorm_lrelu_fwd(const float* x, const float* stats, float* y, int32_t N, int64_t V, int32_t C,
-                            float slope, cfun_stream_t stream) {
+int cfun_instnorm_lrelu_fwd_strided(const float* x, const float* stats, float* y, int32_t N, int64_t V, int32_t C,
+                                    int64_t y_stride, float slope, cfun_stream_t stream) {
   if (N <= 0 || V <= 0) return CFUN_OK;
-  if (C <= 0) return CFUN_EINVAL;
+  if (C <= 0 || y_stride < C || C / vec_of(C) > kBlock) return CFUN_EINVAL;
   const int vec = vec_of(C);
+  if (y_stride != C && (vec != 4 || (y_stride & 3))) return CFUN_EINVAL;
   if (vec == 4 && (!cfun_aligned16(x) || !cfun_aligned16(y))) return CFUN_EALIGN;
-  const int64_t total = (int64_t)N * V * (C / vec);
-  if (vec == 4) hipLaunchKernelGGL(k_instnorm_lrelu_fwd<4>, dim3(ew_grid(total)), dim3(kBlock), 0, cfun_st(stream), x, stats, y, total, V, C, slope);
-  else hipLaunchKernelGGL(k_instnorm_lrelu_fwd<1>, dim3(ew_grid(total)), dim3(kBlock), 0, cfun_st(stream), x, stats, y, total, V, C, slope);
+  const int lanes = kBlock / (C / vec);
+  const dim3 grid(apply_blocks(V, lanes), (unsigned)N);
+  if (vec == 4) hipLaunchKernelGGL(k_instnorm_lrelu_fwd<4>, grid, dim3(kBlock), 0, cfun_st(stream), x, stats, y, V, C, slope, y_stride / 4, lanes);
+  else hipLaunchKernelGGL(k_instnorm_lrelu_fwd<1>, grid, dim3(kBlock), 0, cfun_st(stream), x, stats, y, V, C, slope, (int64_t)C, lanes);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }
 
+int cfun_instnorm_lrelu_fwd(const float* x, const float* stats, float* y, int32_t N, int64_t V, int32_t C,
+                            float slope, cfun_stream_t stream) {
+  return cfun_instnorm_lrelu_fwd_strided(x, stats, y, N, V, C, C, slope, stream);
+}
+
 int cfun_instnorm_lrelu_bwd(const float* x, const float* stats, const float* dy, float* dx, int32_t N, int64_t V,
                             int32_t C, float slope, void* ws, size_t ws_bytes, cfun_stream_t stream) {
+  return cfun_instnorm_lrelu_bwd_strided(x, stats, dy, dx, N, V, C, C, slope, ws, ws_bytes, stream);
+}
+
+int cfun_instnorm_lrelu_bwd_strided(const float* x, const float* stats, const float* dy, float* dx, int32_t N, int64_t V,
+                                    int32_t C, int64_t dy_stride, float slope, void* ws, size_t ws_bytes,
+                                    cfun_stream_t stream) {
   if (N <= 0 || V <= 0) return CFUN_OK;
-  if (C <= 0 || C / vec_of(C) > kBlock) return CFUN_EINVAL;
+  if (C <= 0 || C / vec_of(C) > kBlock || dy_stride < C) return CFUN_EINVAL;
   const int vec = vec_of(C);
+  if (dy_stride != C && (vec != 4 || (dy_stride & 3))) return CFUN_EINVAL;
+  const int64_t dyg = dy_stride / vec;
   if (vec == 4 && (!cfun_aligned16(x) || !cfun_aligned16(dy) || !cfun_aligned16(dx))) return CFUN_EALIGN;
   if (ws_bytes < cfun_instnorm_workspace_bytes(N, V, C)) return CFUN_EWORKSPACE;
   const ReducePlan r = reduce_plan(N, V, C);
@@ -558,16 +647,16 @@ int cfun_instnorm_lrelu_bwd(const float* x, const float* stats, const float* dy,
   float* means = (float*)((char*)ws + reduce_ws(N, V, C, 2));
   if (vec == 4) {
     auto kern = k_channel_reduce<StatNormBwd<4>, 4>;
-    hipLaunchKernelGGL(kern, dim3(r.blocks, N), dim3(kBlock), 0, cfun_st(stream), StatNormBwd<4>{x, dy, stats, C, slope}, partial, V, C, r.lanes);
+    hipLaunchKernelGGL(kern, dim3(r.blocks, N), dim3(kBlock), 0, cfun_st(stream), StatNormBwd<4>{x, dy, stats, C, slope, dyg}, partial, V, C, r.lanes);
   } else {
     auto kern = k_channel_reduce<StatNormBwd<1>, 1>;
-    hipLaunchKernelGGL(kern, dim3(r.blocks, N), dim3(kBlock), 0, cfun_st(stream), StatNormBwd<1>{x, dy, stats, C, slope}, partial, V, C, r.lanes);
+    hipLaunchKernelGGL(kern, dim3(r.blocks, N), dim3(kBlock), 0, cfun_st(stream), StatNormBwd<1>{x, dy, stats, C, slope, dyg}, partial, V, C, r.lanes);
   }
   hipLaunchKernelGGL(k_channel_finalize, dim3((N * C * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, cfun_st(stream),
                      (const double*)partial, means, N * C, C, r.blocks, 2, V, 0.f, 2);
-  const int64_t total = (int64_t)N * V * (C / vec);
-  if (vec == 4) hipLaunchKernelGGL(k_instnorm_lrelu_bwd<4>, dim3(ew_grid(total)), dim3(kBlock), 0, cfun_st(stream), x, stats, (const float*)means, dy, dx, total, V, C, slope);
-  else hipLaunchKernelGGL(k_instnorm_lrelu_bwd<1>, dim3(ew_grid(total)), dim3(kBlock), 0, cfun_st(stream), x, stats, (const float*)means, dy, dx, total, V, C, slope);
+  const dim3 grid(apply_blocks(V, r.lanes), (unsigned)N);
+  if (vec == 4) hipLaunchKernelGGL(k_instnorm_lrelu_bwd<4>, grid, dim3(kBlock), 0, cfun_st(stream), x, stats, (const float*)means, dy, dx, V, C, slope, dyg, r.lanes);
+  else hipLaunchKernelGGL(k_instnorm_lrelu_bwd<1>, grid, dim3(kBlock), 0, cfun_st(stream), x, stats, (const float*)means, dy, dx, V, C, slope, dyg, r.lanes);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }

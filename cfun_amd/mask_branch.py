@@ -168,15 +168,19 @@ class Modified3DUNet(nn.Module):
         nl = ops.instnorm_lrelu
         drop = self._upload_dropout(self._drop_masks(x.shape[0], x.device), x.device)
 
-        def nluc(h, holder):   # norm -> lrelu -> nearest x2 -> 3x3x3 conv -> norm -> lrelu  (mask_branch.py:108-116)
-            return nl(self._up_conv(nl(h), holder[3]))
+        def nluc(h, holder, out=None):   # norm -> lrelu -> nearest x2 -> 3x3x3 conv -> norm -> lrelu  (mask_branch.py:108-116)
+            return nl(self._up_conv(nl(h), holder[3]), out=out)
 
         # level 1: residual is the pre-activation stem output, context_1 is taken before the norm
         def head1(xp):
             res = self.conv3d_c1_1(xp)
             return ops.lrelu(res), res
         out = self._dropout_pair(x, head1, self.conv3d_c1_2, self.lrelu_conv_c1[1], drop[0], ops.lrelu)
-        ctx = [ops.lrelu(out)]
+        # context_1 is only ever read by the level-1 concat (mask_branch.py:203): it is written straight into the second
+        # half of that concat's buffer, the decoder later writes the first half -- no torch.cat, no gradient slices copied
+        b1 = self.base_n_filter
+        cat1 = ops.ConcatBuffer(out, 2 * b1) if b1 % 4 == 0 else None
+        ctx = [ops.lrelu(out, out=None if cat1 is None else cat1.slot(b1, 2 * b1))]
         h = nl(out)
         # levels 2..5: stride-2 conv, then the SAME norm_lrelu_conv weights twice around the dropout
         for lvl in (2, 3, 4, 5):
@@ -198,8 +202,13 @@ class Modified3DUNet(nn.Module):
         ds2 = nl(self.conv_norm_lrelu_l2[0](torch.cat([h, ctx[2]], dim=-1)))
         h = nluc(self.conv3d_l2(ds2), self.norm_lrelu_upscale_conv_norm_lrelu_l2)
         ds3 = nl(self.conv_norm_lrelu_l3[0](torch.cat([h, ctx[1]], dim=-1)))
-        h = nluc(self.conv3d_l3(ds3), self.norm_lrelu_upscale_conv_norm_lrelu_l3)
-        h = nl(self.conv_norm_lrelu_l4[0](torch.cat([h, ctx[0]], dim=-1)))
+        if cat1 is None:
+            h = nluc(self.conv3d_l3(ds3), self.norm_lrelu_upscale_conv_norm_lrelu_l3)
+            joined = torch.cat([h, ctx[0]], dim=-1)
+        else:
+            h = nluc(self.conv3d_l3(ds3), self.norm_lrelu_upscale_conv_norm_lrelu_l3, out=cat1.slot(0, b1))
+            joined = cat1.join(h, ctx[0])
+        h = nl(self.conv_norm_lrelu_l4[0](joined))
         # deep supervision: up(up(ds2_1x1) + ds3_1x1) + out_pred, each add is a conv epilogue
         s = self.ds3_1x1_conv3d(ds3, res=self.ds2_1x1_conv3d(ds2), res_up2=True)
         out = self.conv3d_l4(h, res=s, res_up2=True)

@@ -251,9 +251,77 @@ def channel_sum(g2d):
     return out
 
 
+# ---- zero-copy channel concatenation ------------------------------------------------------------------------------
+class ConcatBuffer:
+    """A [N,D,H,W,C_total] NDHWC buffer whose channel ranges are filled IN PLACE by the ops that produce the operands
+    of a ``torch.cat(..., dim=-1)`` (``lrelu(x, out=buf.slot(c0, c1))``, ``instnorm_lrelu(x, out=...)``) and handed to
+    the consumer by ``join()`` without a copy; the backward hands the gradient's channel ranges back as strided views
+    that the strided backward kernels read in place.  All ranges and C_total must be multiples of 4."""
+
+    def __init__(self, like, c_total):
+        self.data = torch.empty(tuple(like.shape[:-1]) + (c_total,), dtype=torch.float32, device=like.device)
+        self.c_total = c_total
+
+    def slot(self, c0, c1):
+        if c0 % 4 or c1 % 4 or self.c_total % 4:
+            raise ValueError("ConcatBuffer slots must be multiples of 4 channels")
+        return (self, c0, c1)
+
+    def join(self, *parts):
+        """parts: the tensors returned by the ops that filled the slots, in channel order."""
+        return _JoinChannels.apply(self, *parts)
+
+
+def _slot_view(out):
+    buf, c0, c1 = out
+    return buf.data[..., c0:c1]
+
+
+def _row_stride(t):
+    """Channel-row stride (floats) of an NDHWC tensor that is dense or a channel slice of a dense buffer; None if the
+    layout is anything else (then the caller makes it contiguous)."""
+    c = t.shape[-1]
+    if t.is_contiguous():
+        return c
+    st, shp = t.stride(), t.shape
+    if st[-1] != 1:
+        return None
+    rs = st[-2]
+    exp = rs
+    for d in range(t.dim() - 2, -1, -1):          # every outer stride must be the dense one for row stride rs
+        if st[d] != exp and shp[d] != 1:
+            return None
+        exp *= shp[d]
+    return rs if rs % 4 == 0 and c % 4 == 0 and t.data_ptr() % 16 == 0 else None
+
+
+def ptr_raw(t):
+    """Device pointer of a tensor that may be a channel slice (checked by the caller with _row_stride)."""
+    if not t.is_cuda and not _lib.is_emulator():
+        raise RuntimeError("cfun_amd: CPU tensor passed to a HIP kernel (there is no CPU fallback)")
+    return t.data_ptr()
+
+
+class _JoinChannels(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, buf, *parts):
+        ctx.widths = [p.shape[-1] for p in parts]
+        if sum(ctx.widths) != buf.c_total:
+            raise RuntimeError("ConcatBuffer.join: the parts do not cover the buffer")
+        return buf.data.view(buf.data.shape)        # a fresh alias of the filled buffer: no copy
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, c0 = [], 0
+        for w in ctx.widths:
+            outs.append(g[..., c0:c0 + w])            # strided views; the strided backward kernels read them in place
+            c0 += w
+        return (None,) + tuple(outs)
+
+
 class _InstNormLReLU(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, eps):
+    def forward(ctx, x, eps, out=None):
         lib = _lib.load()
         x = _c(x)
         n, c = x.shape[0], x.shape[-1]
@@ -265,8 +333,15 @@ class _InstNormLReLU(torch.autograd.Function):
         ws = workspace(lib.cfun_instnorm_workspace_bytes(n, v, c), x)
         st = stream(x)
         check(lib.cfun_instnorm_stats(ptr(x), ptr(stats), n, v, c, eps, ptr(ws), ws.numel(), st), "instnorm_stats")
-        y = torch.empty_like(x)
-        check(lib.cfun_instnorm_lrelu_fwd(ptr(x), ptr(stats), ptr(y), n, v, c, LRELU_SLOPE, st), "instnorm_lrelu_fwd")
+        if out is None:
+            y = torch.empty_like(x)
+            check(lib.cfun_instnorm_lrelu_fwd(ptr(x), ptr(stats), ptr(y), n, v, c, LRELU_SLOPE, st), "instnorm_lrelu_fwd")
+        else:                                        # write into a channel range of a ConcatBuffer
+            y = _slot_view(out)
+            if y.shape != x.shape:
+                raise RuntimeError("instnorm_lrelu: out slot %s does not match %s" % (tuple(y.shape), tuple(x.shape)))
+            check(lib.cfun_instnorm_lrelu_fwd_strided(ptr(x), ptr(stats), ptr_raw(y), n, v, c, out[0].c_total,
+                                                      LRELU_SLOPE, st), "instnorm_lrelu_fwd_strided")
         ctx.save_for_backward(x, stats)
         return y
 
@@ -274,28 +349,39 @@ class _InstNormLReLU(torch.autograd.Function):
     def backward(ctx, dy):
         lib = _lib.load()
         x, stats = ctx.saved_tensors
-        dy = _c(dy)
         n, c = x.shape[0], x.shape[-1]
         v = x.numel() // (n * c)
+        rs = _row_stride(dy)
+        if rs is None:
+            dy, rs = dy.contiguous(), c
         dx = torch.empty_like(x)
         ws = workspace(lib.cfun_instnorm_workspace_bytes(n, v, c), x)
-        check(lib.cfun_instnorm_lrelu_bwd(ptr(x), ptr(stats), ptr(dy), ptr(dx), n, v, c, LRELU_SLOPE, ptr(ws),
-                                          ws.numel(), stream(x)), "instnorm_lrelu_bwd")
-        return dx, None
+        check(lib.cfun_instnorm_lrelu_bwd_strided(ptr(x), ptr(stats), ptr_raw(dy), ptr(dx), n, v, c, rs, LRELU_SLOPE,
+                                                  ptr(ws), ws.numel(), stream(x)), "instnorm_lrelu_bwd")
+        return dx, None, None
 
 
-def instnorm_lrelu(x, eps=1e-5):
-    """LeakyReLU(InstanceNorm3d(x)) (affine=False, biased variance), mask_branch.py:28-116."""
-    return _InstNormLReLU.apply(x, eps)
+def instnorm_lrelu(x, eps=1e-5, out=None):
+    """LeakyReLU(InstanceNorm3d(x)) (affine=False, biased variance), mask_branch.py:28-116.  ``out``: a
+    ``ConcatBuffer.slot`` to write the result into (zero-copy concat)."""
+    return _InstNormLReLU.apply(x, eps, out)
 
 
 class _LReLU(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, out=None):
         lib = _lib.load()
         x = _c(x)
-        y = torch.empty_like(x)
-        check(lib.cfun_lrelu_fwd(ptr(x), ptr(y), x.numel(), LRELU_SLOPE, stream(x)), "lrelu_fwd")
+        if out is None:
+            y = torch.empty_like(x)
+            check(lib.cfun_lrelu_fwd(ptr(x), ptr(y), x.numel(), LRELU_SLOPE, stream(x)), "lrelu_fwd")
+        else:
+            y = _slot_view(out)
+            c = x.shape[-1]
+            if y.shape != x.shape:
+                raise RuntimeError("lrelu: out slot %s does not match %s" % (tuple(y.shape), tuple(x.shape)))
+            check(lib.cfun_lrelu_fwd_strided(ptr(x), ptr_raw(y), x.numel() // c, c, c, out[0].c_total, LRELU_SLOPE,
+                                             stream(x)), "lrelu_fwd_strided")
         ctx.save_for_backward(x)
         return y
 
@@ -303,14 +389,20 @@ class _LReLU(torch.autograd.Function):
     def backward(ctx, dy):
         lib = _lib.load()
         (x,) = ctx.saved_tensors
-        dy = _c(dy)
+        c = x.shape[-1]
+        rs = _row_stride(dy)
         dx = torch.empty_like(x)
-        check(lib.cfun_lrelu_bwd(ptr(x), ptr(dy), ptr(dx), x.numel(), LRELU_SLOPE, stream(x)), "lrelu_bwd")
-        return dx
+        if rs is None or rs == c or c % 4:          # dense (or odd) gradient: the flat kernel
+            dy = _c(dy)
+            check(lib.cfun_lrelu_bwd(ptr(x), ptr(dy), ptr(dx), x.numel(), LRELU_SLOPE, stream(x)), "lrelu_bwd")
+        else:
+            check(lib.cfun_lrelu_bwd_strided(ptr(x), ptr_raw(dy), ptr(dx), x.numel() // c, c, rs, LRELU_SLOPE,
+                                             stream(x)), "lrelu_bwd_strided")
+        return dx, None
 
 
-def lrelu(x):
-    return _LReLU.apply(x)
+def lrelu(x, out=None):
+    return _LReLU.apply(x, out)
 
 
 class _Add(torch.autograd.Function):

@@ -121,6 +121,13 @@ int cfun_channel_sum(const float* g, float* out, int64_t nvox, int32_t C, void* 
  * ---------------------------------------------------------------------------------------------- */
 int cfun_lrelu_fwd(const float* x, float* y, int64_t n, float slope, cfun_stream_t stream);
 int cfun_lrelu_bwd(const float* x, const float* dy, float* dx, int64_t n, float slope, cfun_stream_t stream);
+/* Channel-strided forms (C % 4 == 0, strides in floats, % 4 == 0): the rows of C channels live inside a wider NDHWC
+ * buffer -- the producers of a concatenation write straight into its halves and the consumers of its gradient read
+ * straight out of them (zero-copy torch.cat, mask_branch.py:184-206).  x / dx dense unless a stride is given. */
+int cfun_lrelu_fwd_strided(const float* x, float* y, int64_t nvox, int32_t C, int64_t x_stride, int64_t y_stride,
+                           float slope, cfun_stream_t stream);
+int cfun_lrelu_bwd_strided(const float* x, const float* dy, float* dx, int64_t nvox, int32_t C, int64_t dy_stride,
+                           float slope, cfun_stream_t stream);
 int cfun_add(const float* a, const float* b, float* out, int64_t n, cfun_stream_t stream);
 /* lo[n,z,y,x,c] = sum of the 8 children of hi (backward of nearest x2 upsampling). lo dims D,H,W. */
 int cfun_upsample2_bwd(const float* hi, float* lo, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C,
@@ -135,6 +142,11 @@ int cfun_instnorm_lrelu_fwd(const float* x, const float* stats, float* y, int32_
                             float slope, cfun_stream_t stream);
 int cfun_instnorm_lrelu_bwd(const float* x, const float* stats, const float* dy, float* dx, int32_t N, int64_t V,
                             int32_t C, float slope, void* ws, size_t ws_bytes, cfun_stream_t stream);
+int cfun_instnorm_lrelu_fwd_strided(const float* x, const float* stats, float* y, int32_t N, int64_t V, int32_t C,
+                                    int64_t y_stride, float slope, cfun_stream_t stream);
+int cfun_instnorm_lrelu_bwd_strided(const float* x, const float* stats, const float* dy, float* dx, int32_t N, int64_t V,
+                                    int32_t C, int64_t dy_stride, float slope, void* ws, size_t ws_bytes,
+                                    cfun_stream_t stream);
 
 /* MaxPool3d(kernel 2, stride 2) (backbone.py:127).  idx[v,c] = argmax child 0..7 (uint8). */
 int cfun_maxpool2_fwd(const float* x, float* y, uint8_t* idx, int32_t N, int32_t Do, int32_t Ho, int32_t Wo,
