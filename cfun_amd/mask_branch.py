@@ -134,21 +134,23 @@ class Modified3DUNet(nn.Module):
             a, res = head(src)
             return conv2(pre2(conv1(a, scale=drop)), res=res)
         algo = default_algo()
-        # the level's head ops stay batched (per-sample heads measured no better); unbind, not t[i:i+1]: its backward is
-        # ONE stack, n slices would each zero-fill a full-size gradient
+        # the level's head ops stay batched (per-sample heads measured no better); batched <-> per-sample hand-overs are
+        # zero-copy in both directions (ops.split_batch / join_batch: results and gradients are written in place)
         a_all, res_all = head(src)
-        a_parts, res_parts = a_all.unbind(0), res_all.unbind(0)
+        a_parts, res_parts = ops.split_batch(a_all), ops.split_batch(res_all)
+        ybuf, gbuf = ops.BatchBuffer(n), ops.BatchBuffer(n)     # outputs / conv1 input gradients, written in place
         outs = []
         for i in range(n):
-            a, res = a_parts[i].unsqueeze(0), res_parts[i].unsqueeze(0)
+            a, res = a_parts[i], res_parts[i]
             idx = idxs[i]
             w1 = conv1.weight.index_select(0, idx)
             spec1 = ops.ConvSpec(k=conv1.kernel_size, co=idx.numel(), pad=conv1.padding, scale_per_n=True, algo=algo)
-            t = ops.conv3d(a, ops.pack_weight(w1), spec1, scale=drop[i:i + 1].index_select(1, idx).contiguous())
+            t = ops.conv3d(a, ops.pack_weight(w1), spec1, scale=drop[i:i + 1].index_select(1, idx).contiguous(),
+                           dx_slot=(gbuf, i))
             w2 = conv2.weight.index_select(1, idx)
             spec2 = ops.ConvSpec(k=conv2.kernel_size, co=conv2.out_channels, pad=conv2.padding, algo=algo)
-            outs.append(ops.conv3d(pre2(t), ops.pack_weight(w2), spec2, res=res))
-        return torch.cat(outs, dim=0)
+            outs.append(ops.conv3d(pre2(t), ops.pack_weight(w2), spec2, res=res, out=(ybuf, i)))
+        return ops.join_batch(ybuf, outs)
 
     @staticmethod
     def _up_conv(h, conv):

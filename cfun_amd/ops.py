@@ -150,7 +150,7 @@ def set_launch_timer(timer):
 
 class _Conv3d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, wp, scale, shift, res, spec):
+    def forward(ctx, x, wp, scale, shift, res, spec, out=None, dx_slot=None):
         lib = _lib.load()
         x = _c(x)
         wp = _c(wp)
@@ -163,6 +163,8 @@ class _Conv3d(torch.autograd.Function):
         if spec.d2s:
             cq = spec.d2s_cq or p.Co // 8
             y = torch.empty((p.N, 2 * p.Do, 2 * p.Ho, 2 * p.Wo, cq), dtype=torch.float32, device=x.device)
+        elif out is not None:        # write into sample `i` of a BatchBuffer (zero-copy batch join)
+            y = out[0].sample(out[1], (p.N, p.Do, p.Ho, p.Wo, p.Co), x)
         else:
             y = torch.empty((p.N, p.Do, p.Ho, p.Wo, p.Co), dtype=torch.float32, device=x.device)
         timed = _TIMER.match(p) if (_TIMER is not None and x.is_cuda) else None
@@ -178,6 +180,7 @@ class _Conv3d(torch.autograd.Function):
         ctx.spec = spec
         ctx.p = p
         ctx.res_shape = None if res is None else res.shape
+        ctx.dx_slot = dx_slot
         ctx.save_for_backward(x, wp, scale, y if spec.act != ACT_NONE else None)
         return y
 
@@ -208,7 +211,8 @@ class _Conv3d(torch.autograd.Function):
         dx = dwp = dshift = dres = None
         if need_x:
             wpT = _transpose_pack(wp, p.Co)
-            dx = torch.empty_like(x)
+            # dx of a per-sample conv goes straight into its sample of the batch's gradient (zero-copy batch split)
+            dx = torch.empty_like(x) if ctx.dx_slot is None else ctx.dx_slot[0].sample(ctx.dx_slot[1], x.shape, x)
             nb = lib.cfun_conv3d_bwd_data_workspace_bytes(C.byref(p))
             ws = workspace(nb, x)
             check(lib.cfun_conv3d_bwd_data(ptr(g), ptr(wpT), ptr(dx), C.byref(p), ptr(ws), ws.numel(), st),
@@ -232,12 +236,84 @@ class _Conv3d(torch.autograd.Function):
                       "upsample2_bwd")
             else:
                 dres = gp
-        return dx, dwp, None, dshift, dres, None
+        return dx, dwp, None, dshift, dres, None, None, None
 
 
-def conv3d(x, wp, spec, scale=None, shift=None, res=None):
-    """y = act(scale * conv(x) + shift + res); see include/cfun_hip.h (cfun_conv3d_fwd)."""
-    return _Conv3d.apply(x, wp, scale, shift, res, spec)
+def conv3d(x, wp, spec, scale=None, shift=None, res=None, out=None, dx_slot=None):
+    """y = act(scale * conv(x) + shift + res); see include/cfun_hip.h (cfun_conv3d_fwd).  ``out`` / ``dx_slot``:
+    (BatchBuffer, i) -- write y / the input gradient into sample i of a shared batch buffer (per-sample convs)."""
+    return _Conv3d.apply(x, wp, scale, shift, res, spec, out, dx_slot)
+
+
+# ---- zero-copy batch split / join (per-sample convs inside a batched graph) ------------------------------------
+class BatchBuffer:
+    """[N, ...] storage allocated on first use whose samples are written in place by per-sample ops."""
+
+    def __init__(self, n):
+        self.n, self.data = n, None
+
+    def sample(self, i, shape1, like):
+        if self.data is None:
+            self.data = torch.empty((self.n,) + tuple(shape1[1:]), dtype=torch.float32, device=like.device)
+        if tuple(self.data.shape[1:]) != tuple(shape1[1:]) or shape1[0] != 1:
+            raise RuntimeError("BatchBuffer: sample shape %s does not fit %s" % (tuple(shape1), tuple(self.data.shape)))
+        return self.data[i:i + 1]
+
+
+def _consecutive_samples(parts):
+    """The [N,...] tensor whose samples the contiguous [1,...] tensors ``parts`` are, if they lie back to back in one
+    storage (then no copy is needed to stack them); else None."""
+    p0 = parts[0]
+    if p0 is None:
+        return None
+    step = p0.numel()
+    for i, t in enumerate(parts):
+        if (t is None or not t.is_contiguous() or t.shape != p0.shape or t.dtype != p0.dtype
+                or t.untyped_storage().data_ptr() != p0.untyped_storage().data_ptr()
+                or t.storage_offset() != p0.storage_offset() + i * step):
+            return None
+    return torch.as_strided(p0, (len(parts),) + tuple(p0.shape[1:]), (step,) + tuple(p0.stride()[1:]), p0.storage_offset())
+
+
+class _SplitBatch(torch.autograd.Function):
+    """x [N,...] -> N views [1,...].  Backward: if the N gradients already are the samples of one buffer (the per-sample
+    convs wrote them there, ``dx_slot``; or they are slices of one upstream gradient) it is returned as is -- the
+    plain ``unbind`` would stack them (a full-size copy), ``x[i:i+1]`` would zero-fill N full-size tensors."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return tuple(x.narrow(0, i, 1) for i in range(x.shape[0]))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        full = _consecutive_samples(grads)
+        if full is not None:
+            return full
+        ref = next(g for g in grads if g is not None)
+        return torch.cat([g if g is not None else torch.zeros_like(ref) for g in grads], dim=0)
+
+
+def split_batch(x):
+    return _SplitBatch.apply(x)
+
+
+class _JoinBatch(torch.autograd.Function):
+    """The per-sample results written into ``buf`` (conv3d(out=(buf, i))) as one [N,...] tensor, without a copy."""
+
+    @staticmethod
+    def forward(ctx, buf, *parts):
+        if _consecutive_samples(parts) is None:
+            raise RuntimeError("join_batch: the parts are not the samples of the BatchBuffer")
+        return buf.data.view(buf.data.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        return (None,) + tuple(g[i:i + 1] for i in range(g.shape[0]))
+
+
+def join_batch(buf, parts):
+    return _JoinBatch.apply(buf, *parts)
 
 
 def channel_sum(g2d):
