@@ -32,6 +32,7 @@ WORKLOADS = {
     "cfg2": ("finetune", 256, 256, 128),   # the configuration BASELINE.json's metric is quoted on
     "cfg1": ("beginning", 128, 128, 64),
     "cfg0": ("beginning", 64, 64, 32),
+    "cfg3": ("finetune", 512, 512, 256),   # configs[3]'s volume on however many GPUs are given (--sharded: one volume)
 }
 
 
