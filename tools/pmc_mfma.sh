@@ -1,0 +1,37 @@
+#!/bin/bash
+# MFMA-pipe utilisation of the dominant conv launch (conv_norm_lrelu_l4.0) from the SQ / GRBM counters
+# (MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (busy cycles * 256 CUs * 4 SIMDs); GRBM_GUI_ACTIVE comes back summed over
+# the 8 XCDs, so busy cycles = GRBM_GUI_ACTIVE / 8 -- it then equals kernel time x 2.4 GHz), one rocprofv3 --pmc pass
+# with --kernel-trace only.  Prints the JSON committed as profiles/round1_pmc_mfma_conv_l4_0.json.
+#   usage (on the GPU box, from the repo root):  bash tools/pmc_mfma.sh
+set -u
+REPO=$(cd "$(dirname "$0")/.." && pwd)
+export TMPDIR=/tmp
+mkdir -p "$REPO/gpurun_out"
+cd /tmp
+rm -rf /tmp/pmc_mfma
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d /tmp/pmc_mfma -o p -- \
+    python "$REPO/tools/bench_layers.py" --filter l4.0 --iters 1 > "$REPO/gpurun_out/pmc_mfma.log" 2>&1
+cp "$(find /tmp/pmc_mfma -name '*counter_collection.csv' | head -1)" "$REPO/gpurun_out/pmc_mfma.csv"
+python - "$REPO/gpurun_out/pmc_mfma.csv" <<'PY'
+import csv, json, sys
+K = "k_conv_mfma<3, 3, 3, 1, 3, false, 0>"
+acc = {}
+for row in csv.DictReader(open(sys.argv[1])):
+    if K in row["Kernel_Name"]:
+        acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+avg = {k: sum(v) / len(v) for k, v in acc.items()}
+cus = 256
+rec = {"what": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES (one pass, --kernel-trace only) "
+               "around tools/bench_layers.py --filter l4.0 --iters 1 on MI355X (tools/pmc_mfma.sh)",
+       "kernel": "cfun_mfma::k_conv_mfma<3,3,3,1,3,false,0> (3x3x3 40->40 @ 4x96^3, forward / data gradient)",
+       "dispatches": len(next(iter(acc.values()))) if acc else 0, "counters_avg": avg}
+if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and "GRBM_GUI_ACTIVE" in avg and avg["GRBM_GUI_ACTIVE"] > 0:
+    busy = avg["GRBM_GUI_ACTIVE"] / 8.0            # the counter is reported summed over the 8 XCDs
+    rec["busy_cycles_per_xcd"] = busy
+    rec["mfma_util"] = avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (busy * cus * 4)
+    rec["formula"] = "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 256 CUs * 4 SIMDs)"
+    rec["check"] = ("SQ_VALU_MFMA_BUSY_CYCLES = 32 cycles x 179.2 M v_mfma_f32_16x16x4_f32 issued (13 824 tiles x 4 waves x "
+                    "3 240); busy cycles / 2.4 GHz = the kernel's 2.68 ms")
+print(json.dumps(rec, indent=2))
+PY
