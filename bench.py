@@ -64,6 +64,16 @@ def pmc_traffic():
         return None
 
 
+def pmc_mfma_util():
+    """MFMA-pipe busy fraction of the dominant kernel from the committed counter pass (tools/pmc_mfma.sh)."""
+    path = os.path.join(ROOT, "profiles", "round1_pmc_mfma_conv_l4_0.json")
+    try:
+        with open(path) as f:
+            return float(json.load(f)["mfma_util"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(cfg, threads):
     """The oracle (plain fp32 torch-CPU restatement of the reference path) on the host cores: bounded sample =
     FPN+RPN forward+backward on the full volume + U-Net mask head forward+backward on ONE 96^3 RoI;
@@ -204,6 +214,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": pmc_traffic() if args.workload == "cfg2" else None,
+                         "mfma_util_pmc": pmc_mfma_util() if args.workload == "cfg2" else None,
                          "kernel": "k_conv_mfma<3,3,3,1,3> (conv_norm_lrelu_l4.0: 3x3x3 %d->%d @ %dx%d^3)"
                                    % (2 * b, 2 * b, n_roi_launch, side[0]),
                          "flops_per_launch": flops, "avg_launch_ms": t_k * 1e3, "launches_timed": len(durs)},
