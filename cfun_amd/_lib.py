@@ -74,6 +74,7 @@ _SIGNATURES = {
     "cfun_mask_losses_bwd_saved": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cfun_mask_target_labels": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "cfun_unmold_argmax": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "cfun_unmold_overlap": (C.c_int, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "cfun_sumsq_partials_count": (C.c_int32, []),
     "cfun_sumsq_partials": (C.c_int, [_P, C.c_int64, _P, _P]),
     "cfun_norm_finalize": (C.c_int, [_P, _I, _P, _P]),

@@ -101,6 +101,7 @@ class LiTSConfig(Config):
     IMAGE_MIN_DIM = 256
     MASK_POOL_SIZE = [32, 80, 80]
     UNET_DROPOUT = 0.0
+    UNMOLD_OVERLAP_TILE = True          # utils.unmold_mask averages ALL detections (LiTS_2017/utils.py:383-408)
 
     def __init__(self, stage="beginning"):
         super().__init__(stage)

@@ -310,6 +310,68 @@ k_unmold_argmax(const float* __restrict__ probs, uint8_t* __restrict__ out, int6
   }
 }
 
+// LiTS fork: overlap-tile un-molding (LiTS_2017/utils.py:383-408 + the argmax of LiTS_2017/model.py:1828-1829).  Every
+// detection's class probabilities [md,mh,mw,C] are resized to its own box (trilinear, align_corners=False), ADDED into
+// the full volume in detection order, divided by (hit count + 1e-6) and clipped to [0,1]; the class map is the
+// arg-max.  One thread per voxel keeps the C running sums in registers, walks the (<= 64, kernel-argument) boxes in
+// the reference's order -- same fp32 additions, same order -- and writes the class id and/or the averaged
+// probabilities; the two [D,H,W,C] fp32 host arrays of the reference are never built.
+constexpr int kMaxOverlapBoxes = 64;
+struct OverlapBoxes { int32_t n; int32_t b[kMaxOverlapBoxes][6]; };
+
+template <int CT>
+__global__ void __launch_bounds__(256)
+k_unmold_overlap(const float* __restrict__ probs, uint8_t* __restrict__ labels, float* __restrict__ full, int64_t total,
+                 int D, int H, int W, int md, int mh, int mw, OverlapBoxes bx) {
+  constexpr int C = CT;
+  const int64_t mstride = (int64_t)md * mh * mw * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t t = i;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const int z = (int)(t / H);
+    float sum[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) sum[c] = 0.f;
+    float count = 0.f;
+    for (int k = 0; k < bx.n; ++k) {                        // uniform trip count; containment is per lane
+      const int z1 = bx.b[k][0], y1 = bx.b[k][1], x1 = bx.b[k][2], z2 = bx.b[k][3], y2 = bx.b[k][4], x2 = bx.b[k][5];
+      if (z < z1 || z >= z2 || y < y1 || y >= y2 || x < x1 || x >= x2) continue;
+      int za, zb, ya, yb, xa, xb;
+      float lz, ly, lx;
+      lin_src(z - z1, md, z2 - z1, za, zb, lz);
+      lin_src(y - y1, mh, y2 - y1, ya, yb, ly);
+      lin_src(x - x1, mw, x2 - x1, xa, xb, lx);
+      const float wz0 = 1.f - lz, wy0 = 1.f - ly, wx0 = 1.f - lx;
+      const float* pk = probs + (int64_t)k * mstride;
+      const float* p000 = pk + (((int64_t)za * mh + ya) * mw + xa) * C;
+      const float* p001 = pk + (((int64_t)za * mh + ya) * mw + xb) * C;
+      const float* p010 = pk + (((int64_t)za * mh + yb) * mw + xa) * C;
+      const float* p011 = pk + (((int64_t)za * mh + yb) * mw + xb) * C;
+      const float* p100 = pk + (((int64_t)zb * mh + ya) * mw + xa) * C;
+      const float* p101 = pk + (((int64_t)zb * mh + ya) * mw + xb) * C;
+      const float* p110 = pk + (((int64_t)zb * mh + yb) * mw + xa) * C;
+      const float* p111 = pk + (((int64_t)zb * mh + yb) * mw + xb) * C;
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+        sum[c] += wz0 * (wy0 * (wx0 * p000[c] + lx * p001[c]) + ly * (wx0 * p010[c] + lx * p011[c])) +
+                  lz * (wy0 * (wx0 * p100[c] + lx * p101[c]) + ly * (wx0 * p110[c] + lx * p111[c]));
+      count += 1.f;
+    }
+    const float den = count + 1e-6f;
+    uint8_t best = 0;
+    float vmax = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      float v = sum[c] / den;
+      v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
+      if (full) full[i * C + c] = v;
+      if (v > vmax) { vmax = v; best = (uint8_t)c; }        // first maximum wins, as np.argmax
+    }
+    if (labels) labels[i] = best;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -352,6 +414,34 @@ int cfun_unmold_argmax(const float* probs, uint8_t* out, int32_t D, int32_t H, i
   else
     hipLaunchKernelGGL(k_unmold_argmax<0>, dim3((unsigned)blocks), dim3(256), 0, cfun_st(stream), probs, out, total, D, H, W,
                        md, mh, mw, C, box[0], box[1], box[2], box[3], box[4], box[5]);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+int cfun_unmold_overlap(const float* probs, const int32_t* boxes, int32_t n, uint8_t* labels, float* full, int32_t D,
+                        int32_t H, int32_t W, int32_t md, int32_t mh, int32_t mw, int32_t C, cfun_stream_t stream) {
+  const int64_t total = (int64_t)D * H * W;
+  if (total <= 0 || (!labels && !full)) return CFUN_OK;
+  if (n < 0 || n > kMaxOverlapBoxes || md <= 0 || mh <= 0 || mw <= 0 || (n > 0 && (!boxes || !probs))) return CFUN_EINVAL;
+  OverlapBoxes bx;
+  bx.n = n;
+  for (int k = 0; k < n; ++k) {
+    const int32_t* b = boxes + 6 * k;
+    if (b[0] < 0 || b[1] < 0 || b[2] < 0 || b[3] > D || b[4] > H || b[5] > W) return CFUN_EINVAL;
+    for (int j = 0; j < 6; ++j) bx.b[k][j] = b[j];
+  }
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+#define CFUN_UNMOLD_OVERLAP(CT)                                                                                       \
+  hipLaunchKernelGGL(k_unmold_overlap<CT>, dim3((unsigned)blocks), dim3(256), 0, cfun_st(stream), probs, labels, full, \
+                     total, D, H, W, md, mh, mw, bx)
+  switch (C) {
+    case 2: CFUN_UNMOLD_OVERLAP(2); break;
+    case 3: CFUN_UNMOLD_OVERLAP(3); break;
+    case 8: CFUN_UNMOLD_OVERLAP(8); break;
+    default: return CFUN_EINVAL;
+  }
+#undef CFUN_UNMOLD_OVERLAP
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }

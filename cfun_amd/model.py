@@ -233,6 +233,29 @@ def unmold_detections(detections, mrcnn_mask, image_shape, window):
     return boxes, np.arange(1, 8), scores, cmap.permute(1, 2, 0).cpu().numpy().astype(np.int64)
 
 
+def unmold_detections_overlap(detections, mrcnn_mask, image_shape, window):
+    """LiTS fork (LiTS_2017/model.py:1777-1835 + the overlap-tile utils.unmold_mask, LiTS_2017/utils.py:383-408):
+    ALL detections' masks are resized to their boxes, averaged where they overlap and arg-maxed -- one fused pass on
+    the device (``cfun_unmold_overlap``).  Arguments as ``unmold_detections``.  Returns the reference's tuple: boxes
+    (y1,x1,z1,y2,x2,z2) int32, class ids ``np.arange(1, 3)`` (sic, :1835), scores, class map [H,W,D] int64."""
+    det = detections.detach().cpu().numpy() if torch.is_tensor(detections) else np.asarray(detections)
+    zero_ix = np.where(det[:, 6] == 0)[0]
+    n = zero_ix[0] if zero_ix.shape[0] > 0 else det.shape[0]
+    boxes = det[:n, :6].astype(np.int32)
+    scores = det[:n, 7]
+    window = np.asarray(window, dtype=np.float64)
+    scales = np.array([image_shape[1] / (window[3] - window[0]), image_shape[2] / (window[4] - window[1]),
+                       image_shape[3] / (window[5] - window[2])] * 2)
+    shifts = np.array([window[0], window[1], window[2]] * 2)
+    boxes = np.multiply(boxes - shifts, scales).astype(np.int32)
+    keep = np.where((boxes[:, 3] - boxes[:, 0]) * (boxes[:, 4] - boxes[:, 1]) * (boxes[:, 5] - boxes[:, 2]) > 0)[0]
+    boxes, scores = boxes[keep], scores[keep]
+    masks = mrcnn_mask[torch.as_tensor(keep, dtype=torch.long, device=mrcnn_mask.device)]
+    cmap = ops.unmold_overlap(masks, boxes, image_shape[1:4])
+    boxes[:, [0, 1, 2, 3, 4, 5]] = boxes[:, [1, 2, 0, 4, 5, 3]]
+    return boxes, np.arange(1, 3), scores, cmap.permute(1, 2, 0).cpu().numpy().astype(np.int64)
+
+
 # ------------------------------------------------------------------------------------------ RoIAlign
 def roi_levels(boxes):
     """model.py:322-332: clamp(round(4 + log2(h*w*d)/3), 2, 3) on normalised boxes (fp32, half-to-even)."""

@@ -599,6 +599,25 @@ def unmold_argmax(probs, box, image_dhw):
     return out
 
 
+def unmold_overlap(probs, boxes, image_dhw, want_full=False):
+    """LiTS overlap-tile utils.unmold_mask + argmax (LiTS_2017/utils.py:383-408, LiTS_2017/model.py:1828-1829):
+    probs [n,md,mh,mw,C] (NDHWC per detection), boxes [n,6] voxel ints inside the volume -> uint8 class map [D,H,W]
+    (and, with ``want_full``, the averaged + clipped probabilities [D,H,W,C] the reference's function returns)."""
+    lib = _lib.load()
+    probs = _c(probs.detach().float())
+    n, md, mh, mw, c = probs.shape
+    d, h, w = [int(v) for v in image_dhw]
+    boxes = [int(v) for row in boxes for v in row]
+    if len(boxes) != 6 * n:
+        raise ValueError("unmold_overlap: %d masks but %d box coordinates" % (n, len(boxes)))
+    labels = torch.empty((d, h, w), dtype=torch.uint8, device=probs.device)
+    full = torch.empty((d, h, w, c), dtype=torch.float32, device=probs.device) if want_full else None
+    hbox = (C.c_int32 * max(6 * n, 1))(*boxes)
+    check(lib.cfun_unmold_overlap(ptr(probs) if n else None, hbox, n, ptr(labels), ptr(full) if want_full else None,
+                                  d, h, w, md, mh, mw, c, stream(probs)), "unmold_overlap")
+    return (labels, full) if want_full else labels
+
+
 def nms3d(boxes, scores, threshold, max_num):
     """Greedy 3-D NMS on device; returns (keep int32 [n], count int32 [1]) -- keep[:count] is the pick order."""
     lib = _lib.load()

@@ -147,7 +147,9 @@ class CFUNHotPath(nn.Module):
         height, width, depth = [int(v) for v in self.config.IMAGE_SHAPE[:3]]
         win = (0, 0, 0, depth, height, width) if window is None else window
         probs = masks[0].permute(0, 2, 3, 4, 1).contiguous()          # [N, d, h, w, C]
-        rois, class_ids, scores, mask = model.unmold_detections(det[0], probs, [1, depth, height, width], win)
+        unmold = model.unmold_detections_overlap if getattr(self.config, "UNMOLD_OVERLAP_TILE", False) \
+            else model.unmold_detections
+        rois, class_ids, scores, mask = unmold(det[0], probs, [1, depth, height, width], win)
         return dict(rois=rois, class_ids=class_ids, scores=scores, mask=mask)
 
     def compute_losses(self, out, rpn_match, rpn_bbox_t, target_class_ids, target_deltas, mask_labels):

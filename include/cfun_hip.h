@@ -161,6 +161,15 @@ int cfun_maxpool2_bwd(const float* dy, const uint8_t* idx, float* dx, int32_t N,
 int cfun_unmold_argmax(const float* probs, uint8_t* out, int32_t D, int32_t H, int32_t W, int32_t md, int32_t mh,
                        int32_t mw, int32_t C, const int32_t* box, cfun_stream_t stream);
 
+/* LiTS fork inference tail: the overlap-tile utils.unmold_mask (LiTS_2017/utils.py:383-408) -- every detection's
+ * class probabilities resized (trilinear, align_corners=False) to its own box, summed into the volume in detection
+ * order, divided by (hit count + 1e-6), clipped to [0,1] -- fused with the class arg-max of unmold_detections
+ * (LiTS_2017/model.py:1828-1829).  probs [n,md,mh,mw,C] fp32 (device; C in {2,3,8}), boxes = HOST int32[n*6]
+ * (z1,y1,x1,z2,y2,x2) inside the volume, n <= 64.  labels [D,H,W] uint8 and/or full [D,H,W,C] fp32 (either may be
+ * NULL).  n == 0 yields zeros. */
+int cfun_unmold_overlap(const float* probs, const int32_t* boxes, int32_t n, uint8_t* labels, float* full, int32_t D,
+                        int32_t H, int32_t W, int32_t md, int32_t mh, int32_t mw, int32_t C, cfun_stream_t stream);
+
 /* GT mask targets of detection_target_layer (model.py:481-493, utils.py:318-339) as uint8 class labels:
  * labels [D,H,W] (class id per voxel = argmax of the one-hot GT), bounds [R,6] int32 voxel crop
  * (z1,y1,x1,z2,y2,x2) = int(shape * normalised coordinate), out [R,md,mh,mw] = nearest-resized crop. */

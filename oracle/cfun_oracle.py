@@ -272,6 +272,45 @@ def unmold_detections(detections, mrcnn_mask, image_shape, window):
     return boxes, np.arange(1, 8), scores, full.transpose((1, 2, 0))
 
 
+def unmold_mask_overlap(masks, bboxes, image_shape):
+    """LiTS_2017/utils.py:383-408 (overlap-tile): masks [n,d,h,w,C], bboxes [n,6] ints, image_shape [c,D,H,W] ->
+    float32 [D,H,W,C]: per-detection trilinear (align_corners=False) resize, fp32 add + count in detection order,
+    add / (count + 1e-6), clip to [0,1]."""
+    masks = np.asarray(masks)
+    assert masks.shape[0] == len(bboxes)
+    shape = (image_shape[1], image_shape[2], image_shape[3], masks.shape[-1])
+    add = np.zeros(shape, dtype=np.float32)
+    cnt = np.zeros(shape, dtype=np.float32)
+    for i in range(masks.shape[0]):
+        z1, y1, x1, z2, y2, x2 = [int(v) for v in bboxes[i]]
+        m = torch.from_numpy(masks[i]).float().permute(3, 0, 1, 2).unsqueeze(0)
+        m = F.interpolate(m, size=(z2 - z1, y2 - y1, x2 - x1), mode="trilinear", align_corners=False)
+        add[z1:z2, y1:y2, x1:x2, :] += m.squeeze(0).numpy().transpose(1, 2, 3, 0)
+        cnt[z1:z2, y1:y2, x1:x2, :] += 1.0
+    return (add / (cnt + np.float32(1e-6))).clip(min=0.0, max=1.0)
+
+
+def unmold_detections_overlap(detections, mrcnn_mask, image_shape, window):
+    """LiTS_2017/model.py:1777-1835: as ``unmold_detections`` but ALL kept detections are un-molded together
+    (overlap-tile) before the arg-max, and the class ids are ``arange(1, 3)`` (sic)."""
+    detections = np.asarray(detections)
+    zero_ix = np.where(detections[:, 6] == 0)[0]
+    n = zero_ix[0] if zero_ix.shape[0] > 0 else detections.shape[0]
+    boxes = detections[:n, :6].astype(np.int32)
+    scores = detections[:n, 7]
+    masks = np.asarray(mrcnn_mask)[np.arange(n)]
+    window = np.asarray(window, dtype=np.float64)
+    scales = np.array([image_shape[1] / (window[3] - window[0]), image_shape[2] / (window[4] - window[1]),
+                       image_shape[3] / (window[5] - window[2])] * 2)
+    shifts = np.array([window[0], window[1], window[2]] * 2)
+    boxes = np.multiply(boxes - shifts, scales).astype(np.int32)
+    keep = np.where((boxes[:, 3] - boxes[:, 0]) * (boxes[:, 4] - boxes[:, 1]) * (boxes[:, 5] - boxes[:, 2]) > 0)[0]
+    boxes, scores, masks = boxes[keep], scores[keep], masks[keep]
+    full = np.argmax(unmold_mask_overlap(masks, boxes, image_shape), axis=3)
+    boxes[:, [0, 1, 2, 3, 4, 5]] = boxes[:, [1, 2, 0, 4, 5, 3]]
+    return boxes, np.arange(1, 3), scores, full.transpose((1, 2, 0))
+
+
 def roi_bounds(boxes, dhw):
     """model.py:271-278 / utils.py:160-174: fp32 product, floor lo / ceil hi, int64."""
     scale = torch.tensor([dhw[0], dhw[1], dhw[2]] * 2, dtype=torch.float32)

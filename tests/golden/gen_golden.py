@@ -476,7 +476,42 @@ def case_unmold():
          boxes=boxes, class_ids=ids, scores=scores, class_map=cmap.astype(np.uint8))
 
 
-CASES = dict(unmold=case_unmold, refine=case_refine, nms=case_nms, anchors=case_anchors, roi_align=case_roi_align, fpn_rpn=case_fpn_rpn, unet=case_unet,
+def import_lits():
+    """The LiTS fork's model/utils under their own names (its files shadow the heart modules' names)."""
+    saved = {k: sys.modules.pop(k) for k in ("utils", "model", "backbone", "mask_branch", "config") if k in sys.modules}
+    sys.path.insert(0, os.path.join(REF, "LiTS_2017"))
+    try:
+        import model as lits_model
+        import utils as lits_utils
+    finally:
+        sys.path.pop(0)
+        for k in ("utils", "model", "backbone", "mask_branch", "config"):
+            sys.modules.pop(k, None)
+        sys.modules.update(saved)
+    return lits_model, lits_utils
+
+
+def case_unmold_lits():
+    """LiTS overlap-tile utils.unmold_mask + MaskRCNN.unmold_detections (LiTS_2017/utils.py:383-408,
+    LiTS_2017/model.py:1777-1835): 5 detections (one of zero volume, dropped; the other four overlap, up to four deep), 3 class probabilities on an 8x10x12 grid, window == whole image."""
+    lits_model, lits_utils = import_lits()
+    d, h, w, c = 20, 24, 28, 3
+    probs = torch.softmax(torch.from_numpy(formula.uniform("unl.logits", (5, 8, 10, 12, c), -3, 3)), dim=-1).numpy()
+    det = np.array([[2, 3, 4, 17, 21, 25, 1, 0.95], [5, 5, 5, 5, 9, 9, 2, 0.9], [0, 0, 0, 10, 12, 14, 1, 0.8],
+                    [8, 10, 12, 20, 24, 28, 2, 0.75], [6, 2, 9, 12, 20, 16, 2, 0.72], [0, 0, 0, 0, 0, 0, 0, 0]],
+                   np.float32)
+    image_shape = [1, d, h, w]
+    window = np.array([0, 0, 0, d, h, w], np.float32)
+    keep = [0, 2, 3, 4]
+    full = lits_utils.unmold_mask(probs[keep], det[keep, :6].astype(np.int32), image_shape)
+    pad = np.concatenate([probs, np.zeros((1,) + probs.shape[1:], np.float32)], axis=0)
+    boxes, ids, scores, cmap = lits_model.MaskRCNN.unmold_detections(None, det.copy(), pad, image_shape, window)
+    save("unmold_lits", probs=probs, detections=det, image_shape=np.array(image_shape), window=window,
+         full_mask_sub=full[::3, ::3, ::3].copy(), full_mask_sum=np.array(full.astype(np.float64).sum()),
+         boxes=boxes, class_ids=ids, scores=scores, class_map=cmap.astype(np.uint8))
+
+
+CASES = dict(unmold_lits=case_unmold_lits, unmold=case_unmold, refine=case_refine, nms=case_nms, anchors=case_anchors, roi_align=case_roi_align, fpn_rpn=case_fpn_rpn, unet=case_unet,
              losses=case_losses, proposal=case_proposal, classifier=case_classifier, predict=case_predict)
 
 if __name__ == "__main__":

@@ -191,12 +191,13 @@ def tiny_config(stage="finetune"):
     return cfg
 
 
-def tiny_lits_config(stage="beginning"):
+def tiny_lits_config(stage="beginning", max_dim=32, min_dim=16):
     """The LiTS fork's shapes (BASELINE.json configs[4]) shrunk: P3D35 ([4,5] blocks, 5x7x7 stem), 3 classes,
     channel counts in the fork's 3:6 ratios, no dropout, non-cubic mask crops."""
     from cfun_amd import config
     cls = type("TinyLiTS", (config.LiTSConfig,), dict(
-        IMAGE_MAX_DIM=32, IMAGE_MIN_DIM=16, MASK_POOL_SIZE=[32, 48, 32], POOL_SIZE=[4, 4, 4], BACKBONE_CHANNELS=[12, 24],
+        IMAGE_MAX_DIM=max_dim, IMAGE_MIN_DIM=min_dim, MASK_POOL_SIZE=[32, 48, 32], POOL_SIZE=[4, 4, 4],
+        BACKBONE_CHANNELS=[12, 24],
         UNET_MASK_BRANCH_CHANNEL=4, TOP_DOWN_PYRAMID_SIZE=20, RPN_CONV_CHANNELS=40, FPN_CLASSIFY_FC_LAYERS_SIZE=16,
         RPN_ANCHOR_SCALES=(16, 32), PRE_NMS_LIMIT=64, POST_NMS_ROIS_TRAINING=16))
     cfg = cls(stage)
@@ -302,9 +303,12 @@ def check_inference_vs_oracle(device, cfg, seed=0, max_instances=2):
     # detect(): + unmold_detections (boxes to (y,x,z) order, class map of the first detection, fused on device)
     res = net.detect(s["image"])
     dd, hh, ww = [int(v) for v in s["image"].shape[2:]]
-    rb, rids, rsc, rmap = orc.unmold_detections(rd, ref["mask_probs"].permute(0, 2, 3, 4, 1).numpy(), [1, dd, hh, ww],
-                                                [0, 0, 0, dd, hh, ww])
+    # (LiTS fork: all detections, overlap-tile averaged)
+    ref_unmold = orc.unmold_detections_overlap if getattr(cfg, "UNMOLD_OVERLAP_TILE", False) else orc.unmold_detections
+    rb, rids, rsc, rmap = ref_unmold(rd, ref["mask_probs"].permute(0, 2, 3, 4, 1).numpy(), [1, dd, hh, ww],
+                                     [0, 0, 0, dd, hh, ww])
     np.testing.assert_array_equal(res["rois"], rb)
+    np.testing.assert_array_equal(res["class_ids"], rids)
     np.testing.assert_allclose(res["scores"], rsc, rtol=1e-4, atol=1e-6)
     assert res["mask"].shape == rmap.shape == (hh, ww, dd)
     assert (res["mask"] != rmap).mean() <= 2e-3          # arg-max of interpolated fp32 probabilities: near-tie flips
@@ -461,3 +465,40 @@ def check_unmold_golden(device):
     assert np.all(cmap[~inside] == 0)
     assert (cmap != g["class_map"]).sum() <= 1e-3 * inside.sum()
     assert (cmap != 0).any()
+
+
+def check_unmold_lits_golden(device):
+    """LiTS overlap-tile un-molding: cfun_amd.model.unmold_detections_overlap / ops.unmold_overlap (one fused pass)
+    vs the fork's own outputs.  Averaged probabilities to 2e-6 (fp32 evaluation order of the interpolation differs from
+    torch's CPU kernel); the class map may flip only where the top two averaged probabilities tie to that precision."""
+    from cfun_amd import model, ops
+    g = load_golden("unmold_lits")
+    shape = [int(v) for v in g["image_shape"]]
+    det = g["detections"]
+    probs = torch.from_numpy(np.concatenate([g["probs"], np.zeros((1,) + g["probs"].shape[1:], np.float32)], axis=0))
+    boxes, ids, scores, cmap = model.unmold_detections_overlap(torch.from_numpy(det).to(device), probs.to(device),
+                                                               shape, g["window"])
+    np.testing.assert_array_equal(boxes, g["boxes"])
+    np.testing.assert_array_equal(ids, g["class_ids"])
+    np.testing.assert_array_equal(scores, g["scores"])
+    assert cmap.shape == g["class_map"].shape and cmap.dtype == np.int64
+    keep = [0, 2, 3, 4]
+    kb = det[keep, :6].astype(np.int32)
+    labels, full = ops.unmold_overlap(probs[keep].to(device), kb, shape[1:], want_full=True)
+    full = full.cpu().numpy()
+    ref_full = orc.unmold_mask_overlap(g["probs"][keep], kb, shape)
+    np.testing.assert_array_equal(ref_full[::3, ::3, ::3], g["full_mask_sub"])       # the oracle is the fork's function
+    np.testing.assert_allclose(full, ref_full, rtol=0, atol=2e-6)
+    top2 = np.sort(ref_full, axis=3)[..., -2:]
+    tie = (top2[..., 1] - top2[..., 0]) < 1e-5
+    ref_map = g["class_map"].transpose(2, 0, 1)                                        # [H,W,D] -> [D,H,W]
+    got = labels.cpu().numpy()
+    assert np.array_equal(got[~tie], ref_map[~tie])
+    assert np.array_equal(cmap.transpose(2, 0, 1), got)
+    covered = np.zeros(shape[1:], np.int32)
+    for b in kb:
+        covered[b[0]:b[3], b[1]:b[4], b[2]:b[5]] += 1
+    assert covered.max() == 4 and np.all(got[covered == 0] == 0) and (got != 0).any()
+    # no detection at all: zeros
+    empty = ops.unmold_overlap(probs[:0].to(device), np.zeros((0, 6), np.int32), shape[1:])
+    assert int(empty.sum()) == 0

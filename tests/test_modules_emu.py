@@ -68,6 +68,13 @@ def test_refine_detections_golden(emu):
     mc.check_refine_detections_golden(emu)
 
 
+def test_inference_lits_overlap_tile(emu_direct):
+    """LiTS fork inference: P3D35 + 3-class heads, two overlapping detections un-molded with the overlap-tile average
+    (64x64x32: on the 32x32x16 volume the clipped proposals coincide and their class scores tie exactly)."""
+    r = mc.check_inference_vs_oracle(emu_direct, mc.tiny_lits_config(max_dim=64, min_dim=32), max_instances=2)
+    assert r["n_det"] == 2
+
+
 def test_inference_vs_oracle(emu_direct):
     """predict('inference') + refine_detections on the tiny config, 1 detection through the U-Net."""
     r = mc.check_inference_vs_oracle(emu_direct, mc.tiny_config("beginning"), max_instances=1)
@@ -84,3 +91,7 @@ def test_flat_sgd_vs_torch(emu):
 
 def test_unmold_golden(emu):
     mc.check_unmold_golden(emu)
+
+
+def test_unmold_lits_golden(emu):
+    mc.check_unmold_lits_golden(emu)

@@ -127,6 +127,13 @@ def test_inference_vs_oracle(gpu, stage):
     assert r["n_det"] >= 1
 
 
+def test_inference_lits_overlap_tile(gpu):
+    """LiTS fork inference: P3D35 + 3-class heads, several detections un-molded with the overlap-tile average."""
+    # 64x64x32: on the 32x32x16 volume the clipped proposals coincide and their class scores tie exactly
+    r = mc.check_inference_vs_oracle(gpu, mc.tiny_lits_config(max_dim=64, min_dim=32), max_instances=3)
+    assert r["n_det"] >= 2
+
+
 def test_inference_cfg0(gpu):
     """predict('inference') at BASELINE configs[0] size (64x64x32, real channel counts) vs the oracle."""
     from cfun_amd import config
@@ -253,3 +260,7 @@ def test_lits_full_size_step_properties(gpu):
 
 def test_unmold_golden(gpu):
     mc.check_unmold_golden(gpu)
+
+
+def test_unmold_lits_golden(gpu):
+    mc.check_unmold_lits_golden(gpu)

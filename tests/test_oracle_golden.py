@@ -240,3 +240,21 @@ def test_unmold_golden():
     np.testing.assert_array_equal(scores, g["scores"])
     np.testing.assert_array_equal(cmap.astype(np.uint8), g["class_map"])
     assert boxes.shape[0] == 2                      # the zero-volume detection was dropped
+
+
+def test_unmold_lits_golden():
+    """LiTS fork: overlap-tile utils.unmold_mask / MaskRCNN.unmold_detections (LiTS_2017/utils.py:383-408,
+    LiTS_2017/model.py:1777-1835) vs the fork's own outputs."""
+    g = load_golden("unmold_lits")
+    shape = [int(v) for v in g["image_shape"]]
+    keep = [0, 2, 3, 4]
+    full = orc.unmold_mask_overlap(g["probs"][keep], g["detections"][keep, :6].astype(np.int32), shape)
+    np.testing.assert_array_equal(full[::3, ::3, ::3], g["full_mask_sub"])
+    assert abs(full.astype(np.float64).sum() - float(g["full_mask_sum"])) < 1e-9 * float(g["full_mask_sum"])
+    pad = np.concatenate([g["probs"], np.zeros((1,) + g["probs"].shape[1:], np.float32)], axis=0)
+    boxes, ids, scores, cmap = orc.unmold_detections_overlap(g["detections"], pad, shape, g["window"])
+    np.testing.assert_array_equal(boxes, g["boxes"])
+    np.testing.assert_array_equal(ids, g["class_ids"])
+    np.testing.assert_array_equal(scores, g["scores"])
+    np.testing.assert_array_equal(cmap.astype(np.uint8), g["class_map"])
+    assert boxes.shape[0] == 4                      # the zero-volume detection was dropped
