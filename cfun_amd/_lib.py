@@ -40,6 +40,7 @@ _SIGNATURES = {
     "cfun_conv3d_bwd_data": (C.c_int, [_P, _P, _P, _PP, _P, _Z, _P]),
     "cfun_conv3d_bwd_weight_workspace_bytes": (_Z, [_PP]),
     "cfun_conv3d_bwd_weight": (C.c_int, [_P, _P, _P, _PP, _P, _Z, _P]),
+    "cfun_conv3d_bwd_weight_oidhw": (C.c_int, [_P, _P, _P, _PP, _P, _Z, _P]),
     "cfun_act_bwd": (C.c_int, [_P, _P, _P, _P, _L, _I, _L, _I, _F, _I, _P]),
     "cfun_channel_sum_workspace_bytes": (_Z, [_L, _I]),
     "cfun_channel_sum": (C.c_int, [_P, _P, _L, _I, _P, _Z, _P]),

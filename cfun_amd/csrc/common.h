@@ -27,6 +27,10 @@ static inline size_t cfun_align_up(size_t v, size_t a) { return (v + a - 1) / a 
 
 static inline bool cfun_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// where a weight gradient goes: the packed layout [taps][Ci][CoP] (oidhw = 0) or torch's OIDHW [Co][Ci][taps]
+// (oidhw = 1; the chunk reduction and the layout change are then one kernel, conv3d_direct.hip)
+struct CfunWgradDst { float* ptr; int oidhw; };
+
 __device__ __forceinline__ float cfun_apply_act(float v, int act, float slope) {
   if (act == CFUN_ACT_RELU) return v > 0.f ? v : 0.f;
   if (act == CFUN_ACT_LRELU) return v > 0.f ? v : v * slope;

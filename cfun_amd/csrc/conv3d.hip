@@ -8,9 +8,10 @@
 int cfun_conv_fwd_direct(const float*, const float*, const float*, const float*, const float*, float*,
                          const CfunConv3dParams*, hipStream_t);
 int cfun_conv_bwd_data_direct(const float*, const float*, float*, const CfunConv3dParams*, hipStream_t);
-int cfun_conv_bwd_weight_direct(const float*, const float*, float*, const CfunConv3dParams*, void*, size_t, hipStream_t);
+int cfun_conv_bwd_weight_direct(const float*, const float*, CfunWgradDst, const CfunConv3dParams*, void*, size_t, hipStream_t);
 size_t cfun_direct_wgrad_ws(const CfunConv3dParams*);
-int cfun_reduce_partials(const float*, float*, int64_t, int, hipStream_t);
+int cfun_wgrad_finish(const float*, CfunWgradDst, const CfunConv3dParams*, int, hipStream_t);
+int cfun_wgrad_zero(CfunWgradDst, const CfunConv3dParams*, hipStream_t);
 // conv3d_stem.hip
 int cfun_conv_stem_supported(const CfunConv3dParams*);
 int cfun_conv_stem_fwd(const float*, const float*, const float*, const float*, float*, const CfunConv3dParams*, hipStream_t);
@@ -20,7 +21,7 @@ int cfun_conv_pointwise_fwd(const float*, const float*, const float*, const floa
 // conv3d_wgrad_c1.hip
 int cfun_wgrad_c1_supported(const CfunConv3dParams*);
 size_t cfun_wgrad_c1_ws(const CfunConv3dParams*);
-int cfun_wgrad_c1(const float*, const float*, float*, const CfunConv3dParams*, void*, size_t, hipStream_t);
+int cfun_wgrad_c1(const float*, const float*, CfunWgradDst, const CfunConv3dParams*, void*, size_t, hipStream_t);
 
 namespace {
 
@@ -389,27 +390,36 @@ size_t cfun_conv3d_bwd_weight_workspace_bytes(const CfunConv3dParams* p) {
   return cfun_align_up(cfun_direct_wgrad_ws(p), 256);
 }
 
-int cfun_conv3d_bwd_weight(const float* x, const float* g, float* dwp, const CfunConv3dParams* p, void* ws,
-                           size_t ws_bytes, cfun_stream_t stream) {
+static int bwd_weight_any(const float* x, const float* g, CfunWgradDst dst, const CfunConv3dParams* p, void* ws,
+                          size_t ws_bytes, cfun_stream_t stream) {
   if (!valid_params(p)) return CFUN_EINVAL;
   if (p->algo != CFUN_ALGO_DIRECT && cfun_wgrad_c1_supported(p) && (int64_t)p->N * p->Do * p->Ho * p->Wo > 0) {
     if (!cfun_aligned16(g) || !cfun_aligned16(ws)) return CFUN_EALIGN;
-    return cfun_wgrad_c1(x, g, dwp, p, ws, ws_bytes, cfun_st(stream));
+    return cfun_wgrad_c1(x, g, dst, p, ws, ws_bytes, cfun_st(stream));
   }
   const Shape* s = (p->algo == CFUN_ALGO_DIRECT || !wgrad_mfma_fits(p)) ? nullptr : mfma_shape(p);
   if (s) {
     if (!cfun_aligned16(x) || !cfun_aligned16(g)) return CFUN_EALIGN;
     if (ws_bytes < cfun_conv3d_bwd_weight_workspace_bytes(p)) return CFUN_EWORKSPACE;
-    const int64_t nout = (int64_t)p->kd * p->kh * p->kw * p->Ci * p->CoP;
     cfun_mfma::WgPlan w;
     s->plan(*p, wgrad_nsub(p, s), &w);
-    if (w.ntiles == 0) return (int)hipMemsetAsync(dwp, 0, nout * sizeof(float), cfun_st(stream));
+    if (w.ntiles == 0) return cfun_wgrad_zero(dst, p, cfun_st(stream));
     const int rc = s->wgrad(x, g, (float*)ws, *p, w, cfun_st(stream));
     if (rc) return rc;
-    return cfun_reduce_partials((const float*)ws, dwp, nout, w.nchunks * w.kslots, cfun_st(stream));
+    return cfun_wgrad_finish((const float*)ws, dst, p, w.nchunks * w.kslots, cfun_st(stream));
   }
   if (p->algo == CFUN_ALGO_MFMA) return CFUN_EINVAL;
-  return cfun_conv_bwd_weight_direct(x, g, dwp, p, ws, ws_bytes, cfun_st(stream));
+  return cfun_conv_bwd_weight_direct(x, g, dst, p, ws, ws_bytes, cfun_st(stream));
+}
+
+int cfun_conv3d_bwd_weight(const float* x, const float* g, float* dwp, const CfunConv3dParams* p, void* ws,
+                           size_t ws_bytes, cfun_stream_t stream) {
+  return bwd_weight_any(x, g, CfunWgradDst{dwp, 0}, p, ws, ws_bytes, stream);
+}
+
+int cfun_conv3d_bwd_weight_oidhw(const float* x, const float* g, float* dw, const CfunConv3dParams* p, void* ws,
+                                 size_t ws_bytes, cfun_stream_t stream) {
+  return bwd_weight_any(x, g, CfunWgradDst{dw, 1}, p, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

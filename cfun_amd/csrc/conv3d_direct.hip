@@ -209,8 +209,12 @@ k_conv_bwd_weight_direct(const float* __restrict__ x, const float* __restrict__ 
 // sum partial[chunk][i] over chunks -> out[i]; shared with the MFMA wgrads through cfun_reduce_partials().
 // block = 64 consecutive outputs x 4 chunk lanes (coalesced 256-byte rows, 4 loads in flight per thread),
 // fixed summation order => deterministic.
+// OIDHW = true: out is torch's [Co][Ci][T] weight layout instead of the packed [T][Ci][CoP] (padding columns dropped);
+// the 4-byte stores scatter, which is immaterial while the chunk reads dominate (chunks >> 1).
+template <bool OIDHW>
 static __global__ void __launch_bounds__(256)
-cfun_k_reduce_partials(const float* __restrict__ partial, float* __restrict__ out, int64_t n, int chunks) {
+cfun_k_reduce_partials(const float* __restrict__ partial, float* __restrict__ out, int64_t n, int chunks, int T, int Ci,
+                       int Co, int CoP) {
   __shared__ float sm[256];
   const int tid = threadIdx.x;
   const int64_t i = (int64_t)blockIdx.x * 64 + (tid & 63);
@@ -228,14 +232,100 @@ cfun_k_reduce_partials(const float* __restrict__ partial, float* __restrict__ ou
   }
   sm[tid] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (cl == 0 && i < n) out[i] = (sm[tid] + sm[tid + 64]) + (sm[tid + 128] + sm[tid + 192]);
+  if (cl == 0 && i < n) {
+    const float v = (sm[tid] + sm[tid + 64]) + (sm[tid + 128] + sm[tid + 192]);
+    if (OIDHW) {
+      const int co = (int)(i % CoP);
+      const int64_t r = i / CoP;            // t * Ci + ci
+      const int ci = (int)(r % Ci), t = (int)(r / Ci);
+      if (co < Co) out[((int64_t)co * Ci + ci) * T + t] = v;
+    } else {
+      out[i] = v;
+    }
+  }
 }
 
 int cfun_reduce_partials(const float* partial, float* out, int64_t n, int chunks, hipStream_t st) {
   if (n <= 0) return CFUN_OK;
-  hipLaunchKernelGGL(cfun_k_reduce_partials, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, partial, out, n, chunks);
+  hipLaunchKernelGGL(cfun_k_reduce_partials<false>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, partial, out, n, chunks,
+                     0, 0, 0, 0);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
+}
+
+// The same sum -- identical association, so identical bits -- for ONE element, in one thread.
+static __device__ __forceinline__ float reduce_chunks_at(const float* __restrict__ partial, int64_t n, int chunks, int64_t i) {
+  float lane[4];
+#pragma unroll
+  for (int cl = 0; cl < 4; ++cl) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int c = cl;
+    for (; c + 12 < chunks; c += 16) {
+      s0 += partial[(int64_t)c * n + i];
+      s1 += partial[(int64_t)(c + 4) * n + i];
+      s2 += partial[(int64_t)(c + 8) * n + i];
+      s3 += partial[(int64_t)(c + 12) * n + i];
+    }
+    for (; c < chunks; c += 4) s0 += partial[(int64_t)c * n + i];
+    lane[cl] = (s0 + s1) + (s2 + s3);
+  }
+  return (lane[0] + lane[1]) + (lane[2] + lane[3]);
+}
+
+// chunk reduction fused with the packed -> OIDHW layout change (elementwise.hip's cfun_weight_unpack):
+// dw[co][ci][t] = sum_chunks partial[chunk][t][ci][co]: one launch and one pass instead of reduce + unpack (80 weight
+// gradients per training step).  Two shapes of the same sum:
+//   * many chunks, small weight (high-resolution layers): cfun_k_reduce_partials<true> -- 4 chunk lanes per output,
+//     coalesced chunk reads, scattered 4-byte stores;
+//   * few chunks, large weight (low-resolution layers): this kernel -- 32(t) x 32(co) tiles per ci, read along co,
+//     turned in LDS, written along t (coalesced both ways; one thread walks all chunks of its element).
+static __global__ void __launch_bounds__(256)
+cfun_k_reduce_unpack(const float* __restrict__ partial, float* __restrict__ dw, int64_t n, int chunks, int T, int Ci, int Co,
+                     int CoP, int tiles_t, int tiles_c) {
+  __shared__ float tile[32][33];
+  int b = blockIdx.x;
+  const int tc = b % tiles_c; b /= tiles_c;
+  const int tt = b % tiles_t;
+  const int ci = b / tiles_t;
+  const int t0 = tt * 32, c0 = tc * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int t = t0 + ty + 8 * k, co = c0 + tx;
+    tile[ty + 8 * k][tx] = (t < T && co < Co) ? reduce_chunks_at(partial, n, chunks, ((int64_t)t * Ci + ci) * CoP + co) : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int co = c0 + ty + 8 * k, t = t0 + tx;
+    if (t < T && co < Co) dw[((int64_t)co * Ci + ci) * T + t] = tile[tx][ty + 8 * k];
+  }
+}
+
+int cfun_wgrad_finish(const float* partial, CfunWgradDst dst, const CfunConv3dParams* p, int chunks, hipStream_t st) {
+  const int T = p->kd * p->kh * p->kw;
+  const int64_t n = (int64_t)T * p->Ci * p->CoP;
+  if (!dst.oidhw) return cfun_reduce_partials(partial, dst.ptr, n, chunks, st);
+  if (n <= 0) return CFUN_OK;
+  if (chunks > 8) {
+    hipLaunchKernelGGL(cfun_k_reduce_partials<true>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, partial, dst.ptr, n,
+                       chunks, T, p->Ci, p->Co, p->CoP);
+    CFUN_LAUNCH_CHECK();
+    return CFUN_OK;
+  }
+  const int tiles_t = (T + 31) / 32, tiles_c = (p->Co + 31) / 32;
+  const int64_t blocks = (int64_t)p->Ci * tiles_t * tiles_c;
+  if (blocks <= 0) return CFUN_OK;
+  if (blocks > 0x7fffffffLL) return CFUN_EINVAL;
+  hipLaunchKernelGGL(cfun_k_reduce_unpack, dim3((unsigned)blocks), dim3(256), 0, st, partial, dst.ptr, n, chunks, T, p->Ci,
+                     p->Co, p->CoP, tiles_t, tiles_c);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+int cfun_wgrad_zero(CfunWgradDst dst, const CfunConv3dParams* p, hipStream_t st) {
+  const int64_t T = (int64_t)p->kd * p->kh * p->kw;
+  return (int)hipMemsetAsync(dst.ptr, 0, (size_t)(T * p->Ci * (dst.oidhw ? p->Co : p->CoP)) * sizeof(float), st);
 }
 
 int64_t cfun_direct_wgrad_chunks(const CfunConv3dParams* p, int64_t* vox_per_chunk) {
@@ -271,12 +361,11 @@ int cfun_conv_bwd_data_direct(const float* g, const float* wpT, float* dx, const
   return CFUN_OK;
 }
 
-int cfun_conv_bwd_weight_direct(const float* x, const float* g, float* dwp, const CfunConv3dParams* p, void* ws,
+int cfun_conv_bwd_weight_direct(const float* x, const float* g, CfunWgradDst dst, const CfunConv3dParams* p, void* ws,
                                 size_t ws_bytes, hipStream_t st) {
   const int taps = p->kd * p->kh * p->kw;
-  const int64_t nout = (int64_t)taps * p->Ci * p->CoP;
   const int64_t total = (int64_t)p->N * p->Do * p->Ho * p->Wo;
-  if (total == 0) return (int)hipMemsetAsync(dwp, 0, nout * sizeof(float), st);
+  if (total == 0) return cfun_wgrad_zero(dst, p, st);
   if (ws_bytes < cfun_direct_wgrad_ws(p)) return CFUN_EWORKSPACE;
   int64_t vpc;
   const int64_t chunks = cfun_direct_wgrad_chunks(p, &vpc);
@@ -284,5 +373,5 @@ int cfun_conv_bwd_weight_direct(const float* x, const float* g, float* dwp, cons
   dim3 grid((unsigned)chunks, (unsigned)p->Ci, (unsigned)((pairs + 255) / 256));
   hipLaunchKernelGGL(k_conv_bwd_weight_direct, grid, dim3(256), 0, st, x, g, (float*)ws, *p, total, vpc);
   CFUN_LAUNCH_CHECK();
-  return cfun_reduce_partials((const float*)ws, dwp, nout, (int)chunks, st);
+  return cfun_wgrad_finish((const float*)ws, dst, p, (int)chunks, st);
 }

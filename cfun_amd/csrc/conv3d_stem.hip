@@ -10,8 +10,15 @@
 // The generic direct kernel computed 8 channels per thread in 3 passes over the input with 32-byte scattered
 // stores (0.35 ms per stem = 0.85 TB/s); this one is write-bound.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store4(float4* dst, const float4& v) {
+  __builtin_nontemporal_store(f32x4n{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4n*>(dst));
+}
 
 template <int KD, int KH, int KW, int S, int CO>
 struct StemTile {
@@ -20,7 +27,7 @@ struct StemTile {
   static constexpr int IVOX = IZ * IY * IX;
 };
 
-template <int KD, int KH, int KW, int S, int CO>
+template <int KD, int KH, int KW, int S, int CO, int VAR = 0>
 __global__ void __launch_bounds__(256)
 k_conv_stem(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale,
             const float* __restrict__ shift, float* __restrict__ y, CfunConv3dParams p, int ntz, int nty, int ntx) {
@@ -34,44 +41,80 @@ k_conv_stem(const float* __restrict__ x, const float* __restrict__ wp, const flo
   const int z0 = tz * T::TZ, y0 = ty * T::TY, x0 = tx * T::TX;
   const int iz0 = z0 * S - p.pd, iy0 = y0 * S - p.ph, ix0 = x0 * S - p.pw;
   const float* xn = x + (int64_t)n * p.Di * p.Hi * p.Wi;
-  for (int i = threadIdx.x; i < T::IVOX; i += 256) {
+  // all of the thread's halo loads are issued before the first LDS write (a rolled loop serialises one HBM round trip
+  // per iteration: 4 x ~1.5 us per workgroup was half of the kernel's time)
+  constexpr int NL = (T::IVOX + 255) / 256;
+  float stage[NL];
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const int i = threadIdx.x + k * 256;
     const int lx = i % T::IX, ly = (i / T::IX) % T::IY, lz = i / (T::IX * T::IY);
     const int gz = iz0 + lz, gy = iy0 + ly, gx = ix0 + lx;
-    float v = 0.f;
-    if (gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi) v = xn[((int64_t)gz * p.Hi + gy) * p.Wi + gx];
-    tile[i] = v;
+    stage[k] = 0.f;
+    if (i < T::IVOX && gz >= 0 && gz < p.Di && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi)
+      stage[k] = xn[((int64_t)gz * p.Hi + gy) * p.Wi + gx];
+  }
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const int i = threadIdx.x + k * 256;
+    if (i < T::IVOX) tile[i] = stage[k];
   }
   __syncthreads();
   const int lx = threadIdx.x % T::TX, ly = (threadIdx.x / T::TX) % T::TY, lz = threadIdx.x / (T::TX * T::TY);
   const float* t0 = tile + ((lz * S) * T::IY + ly * S) * T::IX + lx * S;
-  float acc[CO];
+  // accumulators as float2 pairs: v_pk_fma_f32 (2 FMAs per lane per issue -- the only way to the 157 TFLOP/s fp32 VALU
+  // rate; plain v_fmac tops out at half of it, which made this kernel VALU- rather than write-bound)
+  f32x2 acc[CO / 2];
 #pragma unroll
-  for (int j = 0; j < CO; ++j) acc[j] = 0.f;
+  for (int j = 0; j < CO / 2; ++j) acc[j] = f32x2{0.f, 0.f};
   // one (dz, dy) tap row per iteration, NOT unrolled: fully unrolled, hipcc hoists all KD*KH*KW*CO scalar weight loads
   // to the top and spills them through v_writelane / v_readlane (12 extra instructions per FMA)
 #pragma unroll 1
-  for (int r = 0; r < KD * KH; ++r) {
+  for (int r = 0; r < ((VAR & 8) ? 1 : KD * KH); ++r) {
     const int dz = r / KH, dy = r - dz * KH;
     const float* trow = t0 + (dz * T::IY + dy) * T::IX;
     const float* wrow = wp + (int64_t)r * KW * p.CoP;               // wave-uniform: scalar loads
 #pragma unroll
     for (int dx = 0; dx < KW; ++dx) {
-      const float xv = trow[dx];
-      const float* w = wrow + dx * p.CoP;
+      const float xs = trow[dx];
+      const f32x2 xv = {xs, xs};
+      const f32x2* w = reinterpret_cast<const f32x2*>(wrow + dx * p.CoP);   // CoP % 4 == 0: 8-byte aligned pairs
 #pragma unroll
-      for (int j = 0; j < CO; ++j) acc[j] = fmaf(xv, w[j], acc[j]);
+      for (int j = 0; j < CO / 2; ++j) acc[j] = __builtin_elementwise_fma(xv, w[j], acc[j]);
     }
   }
   // epilogue in registers, then through LDS so that the stores are fully coalesced: an output row of the tile is
   // TX*CO contiguous floats; lanes write consecutive float4s of it instead of CO floats at a CO*4-byte lane stride
-  __shared__ float outt[T::TZ * T::TY * T::TX * CO];
+  constexpr bool DIRECT = VAR & 1, W128 = VAR & 2, NT = VAR & 4;
+  __shared__ float outt[DIRECT ? 4 : T::TZ * T::TY * T::TX * CO];
+  float o[CO];
 #pragma unroll
   for (int j = 0; j < CO; ++j) {
-    float v = acc[j];
+    float v = acc[j >> 1][j & 1];
     if (p.scale_mode == 1) v *= scale[j];
     else if (p.scale_mode == 2) v *= scale[n * CO + j];
     if (p.has_shift) v += shift[j];
-    outt[threadIdx.x * CO + j] = cfun_apply_act(v, p.act, p.slope);
+    o[j] = cfun_apply_act(v, p.act, p.slope);
+  }
+  if (DIRECT) {
+    const int oz = z0 + lz, oy = y0 + ly, ox = x0 + lx;
+    if (oz < p.Do && oy < p.Ho && ox < p.Wo) {
+      float4* dst = reinterpret_cast<float4*>(y + ((((int64_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * CO);
+#pragma unroll
+      for (int q = 0; q < CO / 4; ++q) {
+        const float4 v4 = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+        if (NT) nt_store4(dst + q, v4); else dst[q] = v4;
+      }
+    }
+    return;
+  }
+  if (W128) {
+#pragma unroll
+    for (int q = 0; q < CO / 4; ++q)
+      *reinterpret_cast<float4*>(outt + threadIdx.x * CO + 4 * q) = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < CO; ++j) outt[threadIdx.x * CO + j] = o[j];
   }
   __syncthreads();
   constexpr int ROW4 = T::TX * CO / 4;                      // float4s per (z, y) output row of the tile
@@ -79,13 +122,16 @@ k_conv_stem(const float* __restrict__ x, const float* __restrict__ wp, const flo
     const int row = i / ROW4, q = i - row * ROW4;
     const int oz = z0 + row / T::TY, oy = y0 + row % T::TY;
     const int ox = x0 + (q * 4) / CO;                       // CO % 4 == 0: a float4 never straddles two voxels
-    if (oz < p.Do && oy < p.Ho && ox < p.Wo)
-      *reinterpret_cast<float4*>(y + ((((int64_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + x0) * CO + q * 4) =
-          *reinterpret_cast<const float4*>(outt + row * T::TX * CO + q * 4);
+    if (oz < p.Do && oy < p.Ho && ox < p.Wo) {
+      float4* dst = reinterpret_cast<float4*>(y + ((((int64_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + x0) * CO + q * 4);
+      const float4 v4 = *reinterpret_cast<const float4*>(outt + row * T::TX * CO + q * 4);
+      if ((VAR & 16) && v4.x != 123.f) continue;
+      if (NT) nt_store4(dst, v4); else *dst = v4;
+    }
   }
 }
 
-template <int KD, int KH, int KW, int S, int CO>
+template <int KD, int KH, int KW, int S, int CO, int VAR = 0>
 int launch_stem(const float* x, const float* wp, const float* scale, const float* shift, float* y,
                 const CfunConv3dParams& p, hipStream_t st) {
   using T = StemTile<KD, KH, KW, S, CO>;
@@ -93,7 +139,7 @@ int launch_stem(const float* x, const float* wp, const float* scale, const float
   const int64_t blocks = (int64_t)p.N * ntz * nty * ntx;
   if (blocks <= 0) return CFUN_OK;
   if (blocks > 0x7fffffffLL) return CFUN_EINVAL;
-  hipLaunchKernelGGL((k_conv_stem<KD, KH, KW, S, CO>), dim3((unsigned)blocks), dim3(256), 0, st, x, wp, scale, shift, y, p,
+  hipLaunchKernelGGL((k_conv_stem<KD, KH, KW, S, CO, VAR>), dim3((unsigned)blocks), dim3(256), 0, st, x, wp, scale, shift, y, p,
                      ntz, nty, ntx);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
@@ -112,7 +158,21 @@ int cfun_conv_stem_supported(const CfunConv3dParams* p) {
 int cfun_conv_stem_fwd(const float* x, const float* wp, const float* scale, const float* shift, float* y,
                        const CfunConv3dParams* p, hipStream_t st) {
   const int k = p->kd * 100 + p->kh * 10 + p->kw;
-  if (k == 333) return launch_stem<3, 3, 3, 1, 20>(x, wp, scale, shift, y, *p, st);
+  if (k == 333) {
+    static const int var = getenv("CFUN_STEM_VAR") ? atoi(getenv("CFUN_STEM_VAR")) : 0;   // EXPERIMENT
+    switch (var) {
+      case 1: return launch_stem<3, 3, 3, 1, 20, 1>(x, wp, scale, shift, y, *p, st);
+      case 2: return launch_stem<3, 3, 3, 1, 20, 2>(x, wp, scale, shift, y, *p, st);
+      case 4: return launch_stem<3, 3, 3, 1, 20, 4>(x, wp, scale, shift, y, *p, st);
+      case 5: return launch_stem<3, 3, 3, 1, 20, 5>(x, wp, scale, shift, y, *p, st);
+      case 6: return launch_stem<3, 3, 3, 1, 20, 6>(x, wp, scale, shift, y, *p, st);
+      case 8: return launch_stem<3, 3, 3, 1, 20, 8>(x, wp, scale, shift, y, *p, st);
+      case 16: return launch_stem<3, 3, 3, 1, 20, 16>(x, wp, scale, shift, y, *p, st);
+      case 24: return launch_stem<3, 3, 3, 1, 20, 24>(x, wp, scale, shift, y, *p, st);
+      default: break;
+    }
+    return launch_stem<3, 3, 3, 1, 20>(x, wp, scale, shift, y, *p, st);
+  }
   if (k == 377) return launch_stem<3, 7, 7, 2, 16>(x, wp, scale, shift, y, *p, st);
   return launch_stem<5, 7, 7, 2, 24>(x, wp, scale, shift, y, *p, st);
 }

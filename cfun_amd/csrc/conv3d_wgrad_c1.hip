@@ -8,7 +8,7 @@
 //   cfun_reduce_partials, deterministic).  HBM-bound: one pass over G and X.
 #include "conv3d_mfma.h"
 
-int cfun_reduce_partials(const float*, float*, int64_t, int, hipStream_t);
+int cfun_wgrad_finish(const float*, CfunWgradDst, const CfunConv3dParams*, int, hipStream_t);
 
 namespace {
 
@@ -170,7 +170,7 @@ C1Plan c1_plan(const CfunConv3dParams& p) {
 }
 
 template <int KD, int KH, int KW, int S, int NSUB>
-int launch_c1(const float* x, const float* g, float* dwp, const CfunConv3dParams& p, void* ws, size_t ws_bytes,
+int launch_c1(const float* x, const float* g, CfunWgradDst dst, const CfunConv3dParams& p, void* ws, size_t ws_bytes,
               hipStream_t st) {
   using T = C1Tile<KD, KH, KW, S>;
   constexpr int NT = 16 * NSUB, GS = pad_row16(NT);
@@ -188,14 +188,14 @@ int launch_c1(const float* x, const float* g, float* dwp, const CfunConv3dParams
   hipLaunchKernelGGL(kern, dim3((unsigned)w.nchunks), dim3(256), lds, st, x, g, (float*)ws, p, w.ntz, w.nty, w.ntx,
                      w.tiles_per_chunk, w.ntiles);
   CFUN_LAUNCH_CHECK();
-  return cfun_reduce_partials((const float*)ws, dwp, nout, w.nchunks, st);
+  return cfun_wgrad_finish((const float*)ws, dst, &p, w.nchunks, st);
 }
 
 template <int KD, int KH, int KW, int S>
-int dispatch_c1(const float* x, const float* g, float* dwp, const CfunConv3dParams& p, void* ws, size_t ws_bytes,
+int dispatch_c1(const float* x, const float* g, CfunWgradDst dst, const CfunConv3dParams& p, void* ws, size_t ws_bytes,
                 hipStream_t st) {
-  if (p.CoP <= 16) return launch_c1<KD, KH, KW, S, 1>(x, g, dwp, p, ws, ws_bytes, st);
-  return launch_c1<KD, KH, KW, S, 2>(x, g, dwp, p, ws, ws_bytes, st);
+  if (p.CoP <= 16) return launch_c1<KD, KH, KW, S, 1>(x, g, dst, p, ws, ws_bytes, st);
+  return launch_c1<KD, KH, KW, S, 2>(x, g, dst, p, ws, ws_bytes, st);
 }
 
 }  // namespace
@@ -221,12 +221,12 @@ size_t cfun_wgrad_c1_ws(const CfunConv3dParams* p) {
   return (size_t)w.nchunks * taps * p->CoP * sizeof(float);
 }
 
-int cfun_wgrad_c1(const float* x, const float* g, float* dwp, const CfunConv3dParams* p, void* ws, size_t ws_bytes,
+int cfun_wgrad_c1(const float* x, const float* g, CfunWgradDst dst, const CfunConv3dParams* p, void* ws, size_t ws_bytes,
                   hipStream_t st) {
   switch (cfun_wgrad_c1_supported(p)) {
-    case 1: return dispatch_c1<3, 3, 3, 1>(x, g, dwp, *p, ws, ws_bytes, st);
-    case 2: return dispatch_c1<3, 7, 7, 2>(x, g, dwp, *p, ws, ws_bytes, st);
-    case 3: return dispatch_c1<5, 7, 7, 2>(x, g, dwp, *p, ws, ws_bytes, st);
+    case 1: return dispatch_c1<3, 3, 3, 1>(x, g, dst, *p, ws, ws_bytes, st);
+    case 2: return dispatch_c1<3, 7, 7, 2>(x, g, dst, *p, ws, ws_bytes, st);
+    case 3: return dispatch_c1<5, 7, 7, 2>(x, g, dst, *p, ws, ws_bytes, st);
     default: return CFUN_EINVAL;
   }
 }

@@ -62,7 +62,7 @@ class Conv3dParams(nn.Module):
             shift = t if self.bias is None else torch.addcmul(t, self.bias, scale)   # (b - mean) * s + beta
         elif scale is not None:
             per_n = True
-        return ops.conv3d(x, self.packed(), self.spec(act, up2, res_up2, per_n, pad), scale=scale, shift=shift, res=res)
+        return ops.conv3d_w(x, self.weight, self.spec(act, up2, res_up2, per_n, pad), scale=scale, shift=shift, res=res)
 
     def extra_repr(self):
         return "%d, %d, kernel_size=%s, stride=%d, padding=%s, bias=%s" % (

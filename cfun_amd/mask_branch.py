@@ -145,11 +145,11 @@ class Modified3DUNet(nn.Module):
             idx = idxs[i]
             w1 = conv1.weight.index_select(0, idx)
             spec1 = ops.ConvSpec(k=conv1.kernel_size, co=idx.numel(), pad=conv1.padding, scale_per_n=True, algo=algo)
-            t = ops.conv3d(a, ops.pack_weight(w1), spec1, scale=drop[i:i + 1].index_select(1, idx).contiguous(),
+            t = ops.conv3d_w(a, w1, spec1, scale=drop[i:i + 1].index_select(1, idx).contiguous(),
                            dx_slot=(gbuf, i))
             w2 = conv2.weight.index_select(1, idx)
             spec2 = ops.ConvSpec(k=conv2.kernel_size, co=conv2.out_channels, pad=conv2.padding, algo=algo)
-            outs.append(ops.conv3d(pre2(t), ops.pack_weight(w2), spec2, res=res, out=(ybuf, i)))
+            outs.append(ops.conv3d_w(pre2(t), w2, spec2, res=res, out=(ybuf, i)))
         return ops.join_batch(ybuf, outs)
 
     @staticmethod
@@ -164,7 +164,7 @@ class Modified3DUNet(nn.Module):
         cqp = (co + 15) // 16 * 16
         spec = ops.ConvSpec(k=(3, 3, 3), co=8 * cqp, pad=(1, 1, 1), d2s=True, d2s_cq=co, tap_skip=True,
                             algo=default_algo())
-        return ops.conv3d(h, ops.pack_weight(ops.fold_up2_weight(conv.weight, cqp)), spec)
+        return ops.conv3d_w(h, ops.fold_up2_weight(conv.weight, cqp), spec)
 
     def forward_ndhwc(self, x):
         nl = ops.instnorm_lrelu
@@ -223,7 +223,7 @@ class Modified3DUNet(nn.Module):
             wf = ops.fold_up2_weight(conv.weight)
             spec = ops.ConvSpec(k=(3, 3, 3), co=8 * self.n_classes, pad=(1, 1, 1), d2s=True, res_up2=True,
                                 algo=default_algo())
-            out = ops.conv3d(out, ops.pack_weight(wf), spec, res=out)
+            out = ops.conv3d_w(out, wf, spec, res=out)
         return out
 
     def forward(self, x):

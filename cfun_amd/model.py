@@ -58,7 +58,7 @@ class RPN(nn.Module):
         w = torch.cat([self.conv_class.weight, self.conv_bbox.weight], dim=0)
         b = torch.cat([self.conv_class.bias, self.conv_bbox.bias], dim=0)
         spec = ops.ConvSpec(k=(1, 1, 1), co=w.shape[0], algo=default_algo())
-        out = ops.conv3d(h, ops.pack_weight(w), spec, shift=b)
+        out = ops.conv3d_w(h, w, spec, shift=b)
         a2 = 2 * self.anchors_per_location
         logits = out[..., :a2].reshape(n, -1, 2)
         bbox = out[..., a2:].reshape(n, -1, 6)

@@ -25,11 +25,8 @@ class _PackWeight(torch.autograd.Function):
     def forward(ctx, w):
         co, ci = w.shape[0], w.shape[1]
         t = w.shape[2] * w.shape[3] * w.shape[4]
-        w = w.contiguous()
-        wp = torch.empty((t, ci, _round16(co)), dtype=torch.float32, device=w.device)
-        check(_lib.load().cfun_weight_pack(ptr(w), ptr(wp), co, ci, t, stream(w)), "weight_pack")
         ctx.wshape = tuple(w.shape)
-        return wp
+        return _pack(w)
 
     @staticmethod
     def backward(ctx, dwp):
@@ -38,6 +35,15 @@ class _PackWeight(torch.autograd.Function):
         dw = torch.empty(ctx.wshape, dtype=torch.float32, device=dwp.device)
         check(_lib.load().cfun_weight_unpack(ptr(dwp), ptr(dw), co, ci, dwp.shape[0], stream(dwp)), "weight_unpack")
         return dw
+
+
+def _pack(w):
+    co, ci = w.shape[0], w.shape[1]
+    t = w.shape[2] * w.shape[3] * w.shape[4]
+    w = w.detach().contiguous()
+    wp = torch.empty((t, ci, _round16(co)), dtype=torch.float32, device=w.device)
+    check(_lib.load().cfun_weight_pack(ptr(w), ptr(wp), co, ci, t, stream(w)), "weight_pack")
+    return wp
 
 
 def pack_weight(w):
@@ -150,9 +156,11 @@ def set_launch_timer(timer):
 
 class _Conv3d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, wp, scale, shift, res, spec, out=None, dx_slot=None):
+    def forward(ctx, x, wp, scale, shift, res, spec, out=None, dx_slot=None, w_src=None):
         lib = _lib.load()
         x = _c(x)
+        if w_src is not None:        # OIDHW weight: packed here, its gradient comes back in OIDHW (one fused pass)
+            wp = _pack(w_src)
         wp = _c(wp)
         scale = None if scale is None else _c(scale)
         shift = None if shift is None else _c(shift)
@@ -181,6 +189,7 @@ class _Conv3d(torch.autograd.Function):
         ctx.p = p
         ctx.res_shape = None if res is None else res.shape
         ctx.dx_slot = dx_slot
+        ctx.wshape = None if w_src is None else tuple(w_src.shape)
         ctx.save_for_backward(x, wp, scale, y if spec.act != ACT_NONE else None)
         return y
 
@@ -190,6 +199,7 @@ class _Conv3d(torch.autograd.Function):
         x, wp, scale, y = ctx.saved_tensors
         spec, p = ctx.spec, ctx.p
         need_x, need_w, need_scale, need_shift, need_res = ctx.needs_input_grad[:5]
+        need_wsrc = ctx.needs_input_grad[8]
         if need_scale:
             raise RuntimeError("cfun_amd conv3d: gradient w.r.t. the epilogue scale is not implemented "
                                "(BatchNorm is frozen on this path, model.py:1297-1304)")
@@ -208,7 +218,7 @@ class _Conv3d(torch.autograd.Function):
             g = torch.empty_like(dy)
             check(lib.cfun_act_bwd(None, ptr(gp), ptr(scale), ptr(g), nvox, p.Co, p.Do * p.Ho * p.Wo, ACT_NONE,
                                    LRELU_SLOPE, p.scale_mode, st), "act_bwd(scale)")
-        dx = dwp = dshift = dres = None
+        dx = dwp = dshift = dres = dw = None
         if need_x:
             wpT = _transpose_pack(wp, p.Co)
             # dx of a per-sample conv goes straight into its sample of the batch's gradient (zero-copy batch split)
@@ -223,6 +233,12 @@ class _Conv3d(torch.autograd.Function):
             ws = workspace(nb, x)
             check(lib.cfun_conv3d_bwd_weight(ptr(x), ptr(g), ptr(dwp), C.byref(p), ptr(ws), ws.numel(), st),
                   "conv3d_bwd_weight")
+        if need_wsrc:
+            dw = torch.empty(ctx.wshape, dtype=torch.float32, device=dy.device)
+            nb = lib.cfun_conv3d_bwd_weight_workspace_bytes(C.byref(p))
+            ws = workspace(nb, x)
+            check(lib.cfun_conv3d_bwd_weight_oidhw(ptr(x), ptr(g), ptr(dw), C.byref(p), ptr(ws), ws.numel(), st),
+                  "conv3d_bwd_weight_oidhw")
         if need_shift:
             dshift = channel_sum(gp.view(-1, p.Co))
         if need_res:
@@ -236,13 +252,21 @@ class _Conv3d(torch.autograd.Function):
                       "upsample2_bwd")
             else:
                 dres = gp
-        return dx, dwp, None, dshift, dres, None, None, None
+        return dx, dwp, None, dshift, dres, None, None, None, dw
 
 
 def conv3d(x, wp, spec, scale=None, shift=None, res=None, out=None, dx_slot=None):
     """y = act(scale * conv(x) + shift + res); see include/cfun_hip.h (cfun_conv3d_fwd).  ``out`` / ``dx_slot``:
     (BatchBuffer, i) -- write y / the input gradient into sample i of a shared batch buffer (per-sample convs)."""
-    return _Conv3d.apply(x, wp, scale, shift, res, spec, out, dx_slot)
+    return _Conv3d.apply(x, wp, scale, shift, res, spec, out, dx_slot, None)
+
+
+def conv3d_w(x, w, spec, scale=None, shift=None, res=None, out=None, dx_slot=None):
+    """``conv3d`` on an OIDHW weight [Co,Ci,kd,kh,kw] (a parameter, a gathered slice of one, a folded up-conv
+    weight): packed inside the op, and the weight gradient is produced directly in OIDHW -- the reduction of the
+    wgrad kernel's per-chunk partial sums and the un-packing are one kernel (cfun_conv3d_bwd_weight_oidhw) instead
+    of conv3d(x, pack_weight(w))'s reduce + un-pack launches.  Same values bit for bit."""
+    return _Conv3d.apply(x, None, scale, shift, res, spec, out, dx_slot, w)
 
 
 # ---- zero-copy batch split / join (per-sample convs inside a batched graph) ------------------------------------

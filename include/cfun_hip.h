@@ -106,6 +106,11 @@ int cfun_conv3d_bwd_data(const float* g, const float* wpT, float* dx, const Cfun
 size_t cfun_conv3d_bwd_weight_workspace_bytes(const CfunConv3dParams* p);
 int cfun_conv3d_bwd_weight(const float* x, const float* g, float* dwp, const CfunConv3dParams* p, void* ws,
                            size_t ws_bytes, cfun_stream_t stream);
+/* Same gradient (same kernels, same workspace, bit-identical sums) delivered in torch's OIDHW layout
+ * dw [Co, Ci, kd, kh, kw] -- what `nn.Conv3d.weight.grad` holds (backbone.py:14-23, mask_branch.py:23-89): the
+ * reduction of the per-chunk partial sums and the packed -> OIDHW transposition are one pass. */
+int cfun_conv3d_bwd_weight_oidhw(const float* x, const float* g, float* dw, const CfunConv3dParams* p, void* ws,
+                                 size_t ws_bytes, cfun_stream_t stream);
 
 /* g = dy * act'(y) * s  -- the epilogue's derivative (y is the saved conv output); also the gradient of `res`.
  * `vox_per_n` = Do*Ho*Wo (only used by scale_mode 2). */

@@ -147,6 +147,12 @@ def check_conv(device, n, dhw, ci, co, k, stride=1, pad=None, up2=False, act=ACT
         assert_close(sfd.grad, sfr.grad, "dshift", tol)
     if res:
         assert_close(rsd.grad, rsr.grad, "dres", tol)
+    # the product path: OIDHW weight in, OIDHW gradient out (chunk reduction + un-packing fused) -- same bits
+    xw, ww, sfw, rsw = leafs(device)
+    yw = ops.conv3d_w(xw, ww, spec, None if sc is None else sc.to(device), sfw, rsw)
+    yw.backward(gy.to(device))
+    assert torch.equal(yw, y) and torch.equal(xw.grad, xd.grad), "conv3d_w: y / dx differ from the packed path"
+    assert torch.equal(ww.grad, wd.grad), "conv3d_w: fused OIDHW weight gradient differs from reduce + unpack"
 
 
 # ------------------------------------------------------------------------------------------ norm / act / pool
