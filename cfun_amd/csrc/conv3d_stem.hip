@@ -10,15 +10,11 @@
 // The generic direct kernel computed 8 channels per thread in 3 passes over the input with 32-byte scattered
 // stores (0.35 ms per stem = 0.85 TB/s); this one is write-bound.
 #include "common.h"
-#include <cstdlib>
 
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4n __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void nt_store4(float4* dst, const float4& v) {
-  __builtin_nontemporal_store(f32x4n{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4n*>(dst));
-}
+
 
 template <int KD, int KH, int KW, int S, int CO>
 struct StemTile {
@@ -27,7 +23,7 @@ struct StemTile {
   static constexpr int IVOX = IZ * IY * IX;
 };
 
-template <int KD, int KH, int KW, int S, int CO, int VAR = 0>
+template <int KD, int KH, int KW, int S, int CO>
 __global__ void __launch_bounds__(256)
 k_conv_stem(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale,
             const float* __restrict__ shift, float* __restrict__ y, CfunConv3dParams p, int ntz, int nty, int ntx) {
@@ -70,7 +66,7 @@ k_conv_stem(const float* __restrict__ x, const float* __restrict__ wp, const flo
   // one (dz, dy) tap row per iteration, NOT unrolled: fully unrolled, hipcc hoists all KD*KH*KW*CO scalar weight loads
   // to the top and spills them through v_writelane / v_readlane (12 extra instructions per FMA)
 #pragma unroll 1
-  for (int r = 0; r < ((VAR & 8) ? 1 : KD * KH); ++r) {
+  for (int r = 0; r < KD * KH; ++r) {
     const int dz = r / KH, dy = r - dz * KH;
     const float* trow = t0 + (dz * T::IY + dy) * T::IX;
     const float* wrow = wp + (int64_t)r * KW * p.CoP;               // wave-uniform: scalar loads
@@ -85,53 +81,42 @@ k_conv_stem(const float* __restrict__ x, const float* __restrict__ wp, const flo
   }
   // epilogue in registers, then through LDS so that the stores are fully coalesced: an output row of the tile is
   // TX*CO contiguous floats; lanes write consecutive float4s of it instead of CO floats at a CO*4-byte lane stride
-  constexpr bool DIRECT = VAR & 1, W128 = VAR & 2, NT = VAR & 4;
-  __shared__ float outt[DIRECT ? 4 : T::TZ * T::TY * T::TX * CO];
-  float o[CO];
+  __shared__ float outt[T::TZ * T::TY * T::TX * CO];
 #pragma unroll
-  for (int j = 0; j < CO; ++j) {
-    float v = acc[j >> 1][j & 1];
-    if (p.scale_mode == 1) v *= scale[j];
-    else if (p.scale_mode == 2) v *= scale[n * CO + j];
-    if (p.has_shift) v += shift[j];
-    o[j] = cfun_apply_act(v, p.act, p.slope);
-  }
-  if (DIRECT) {
-    const int oz = z0 + lz, oy = y0 + ly, ox = x0 + lx;
-    if (oz < p.Do && oy < p.Ho && ox < p.Wo) {
-      float4* dst = reinterpret_cast<float4*>(y + ((((int64_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * CO);
+  for (int q = 0; q < CO / 4; ++q) {
+    float o[4];
 #pragma unroll
-      for (int q = 0; q < CO / 4; ++q) {
-        const float4 v4 = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
-        if (NT) nt_store4(dst + q, v4); else dst[q] = v4;
-      }
+    for (int e = 0; e < 4; ++e) {
+      const int j = 4 * q + e;
+      float v = acc[j >> 1][j & 1];
+      if (p.scale_mode == 1) v *= scale[j];
+      else if (p.scale_mode == 2) v *= scale[n * CO + j];
+      if (p.has_shift) v += shift[j];
+      o[e] = cfun_apply_act(v, p.act, p.slope);
     }
-    return;
-  }
-  if (W128) {
-#pragma unroll
-    for (int q = 0; q < CO / 4; ++q)
-      *reinterpret_cast<float4*>(outt + threadIdx.x * CO + 4 * q) = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
-  } else {
-#pragma unroll
-    for (int j = 0; j < CO; ++j) outt[threadIdx.x * CO + j] = o[j];
+    *reinterpret_cast<float4*>(outt + threadIdx.x * CO + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);   // conflict-free
   }
   __syncthreads();
+  // wave w stores the (z, y) rows 2w and 2w+1 of the tile: ROW4 consecutive float4s each, 64 per instruction --
+  // row-uniform index arithmetic (the flat "i / ROW4, i % ROW4" loop cost as many VALU cycles as a third of the FMAs)
   constexpr int ROW4 = T::TX * CO / 4;                      // float4s per (z, y) output row of the tile
-  for (int i = threadIdx.x; i < T::TZ * T::TY * ROW4; i += 256) {
-    const int row = i / ROW4, q = i - row * ROW4;
+  constexpr int RPW = T::TZ * T::TY / 4;                    // rows per wave
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int row = wave * RPW + rr;
     const int oz = z0 + row / T::TY, oy = y0 + row % T::TY;
-    const int ox = x0 + (q * 4) / CO;                       // CO % 4 == 0: a float4 never straddles two voxels
-    if (oz < p.Do && oy < p.Ho && ox < p.Wo) {
-      float4* dst = reinterpret_cast<float4*>(y + ((((int64_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + x0) * CO + q * 4);
-      const float4 v4 = *reinterpret_cast<const float4*>(outt + row * T::TX * CO + q * 4);
-      if ((VAR & 16) && v4.x != 123.f) continue;
-      if (NT) nt_store4(dst, v4); else *dst = v4;
-    }
+    if (oz >= p.Do || oy >= p.Ho) continue;                 // wave-uniform
+    float* yrow = y + ((((int64_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + x0) * CO;
+    const float* orow = outt + row * T::TX * CO;
+    const int nq = (p.Wo - x0 < T::TX ? p.Wo - x0 : T::TX) * (CO / 4);     // float4s of the row inside the volume
+#pragma unroll
+    for (int q = lane; q < ROW4; q += 64)
+      if (q < nq) *reinterpret_cast<float4*>(yrow + q * 4) = *reinterpret_cast<const float4*>(orow + q * 4);
   }
 }
 
-template <int KD, int KH, int KW, int S, int CO, int VAR = 0>
+template <int KD, int KH, int KW, int S, int CO>
 int launch_stem(const float* x, const float* wp, const float* scale, const float* shift, float* y,
                 const CfunConv3dParams& p, hipStream_t st) {
   using T = StemTile<KD, KH, KW, S, CO>;
@@ -139,7 +124,7 @@ int launch_stem(const float* x, const float* wp, const float* scale, const float
   const int64_t blocks = (int64_t)p.N * ntz * nty * ntx;
   if (blocks <= 0) return CFUN_OK;
   if (blocks > 0x7fffffffLL) return CFUN_EINVAL;
-  hipLaunchKernelGGL((k_conv_stem<KD, KH, KW, S, CO, VAR>), dim3((unsigned)blocks), dim3(256), 0, st, x, wp, scale, shift, y, p,
+  hipLaunchKernelGGL((k_conv_stem<KD, KH, KW, S, CO>), dim3((unsigned)blocks), dim3(256), 0, st, x, wp, scale, shift, y, p,
                      ntz, nty, ntx);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
@@ -158,21 +143,7 @@ int cfun_conv_stem_supported(const CfunConv3dParams* p) {
 int cfun_conv_stem_fwd(const float* x, const float* wp, const float* scale, const float* shift, float* y,
                        const CfunConv3dParams* p, hipStream_t st) {
   const int k = p->kd * 100 + p->kh * 10 + p->kw;
-  if (k == 333) {
-    static const int var = getenv("CFUN_STEM_VAR") ? atoi(getenv("CFUN_STEM_VAR")) : 0;   // EXPERIMENT
-    switch (var) {
-      case 1: return launch_stem<3, 3, 3, 1, 20, 1>(x, wp, scale, shift, y, *p, st);
-      case 2: return launch_stem<3, 3, 3, 1, 20, 2>(x, wp, scale, shift, y, *p, st);
-      case 4: return launch_stem<3, 3, 3, 1, 20, 4>(x, wp, scale, shift, y, *p, st);
-      case 5: return launch_stem<3, 3, 3, 1, 20, 5>(x, wp, scale, shift, y, *p, st);
-      case 6: return launch_stem<3, 3, 3, 1, 20, 6>(x, wp, scale, shift, y, *p, st);
-      case 8: return launch_stem<3, 3, 3, 1, 20, 8>(x, wp, scale, shift, y, *p, st);
-      case 16: return launch_stem<3, 3, 3, 1, 20, 16>(x, wp, scale, shift, y, *p, st);
-      case 24: return launch_stem<3, 3, 3, 1, 20, 24>(x, wp, scale, shift, y, *p, st);
-      default: break;
-    }
-    return launch_stem<3, 3, 3, 1, 20>(x, wp, scale, shift, y, *p, st);
-  }
+  if (k == 333) return launch_stem<3, 3, 3, 1, 20>(x, wp, scale, shift, y, *p, st);
   if (k == 377) return launch_stem<3, 7, 7, 2, 16>(x, wp, scale, shift, y, *p, st);
   return launch_stem<5, 7, 7, 2, 24>(x, wp, scale, shift, y, *p, st);
 }
