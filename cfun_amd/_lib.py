@@ -82,6 +82,7 @@ _SIGNATURES = {
     "cfun_sgd_momentum_step": (C.c_int, [_P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, _P, _I, _P]),
     "cfun_weight_pack": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "cfun_weight_pack_transpose": (C.c_int, [_P, _P, _I, _I, _I, _P]),
+    "cfun_weight_pack_both": (C.c_int, [_P, _P, _P, _I, _I, _I, _P]),
     "cfun_weight_unpack": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "cfun_halo_pack": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "cfun_halo_unpack": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

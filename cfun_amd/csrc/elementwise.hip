@@ -404,6 +404,46 @@ k_halo_copy(const float* __restrict__ src, float* __restrict__ dst, int64_t per_
 //   dst[b*d_b + r*d_r + c*d_c] = r < R ? src[b*s_b + r*s_r + c*s_c] : 0      for r < Rpad, c < C
 // with s_c == 1 and d_r == 1, so a 32x32 tile is read contiguously along c, turned in LDS and written contiguously
 // along r (a thread-per-element gather ran at a tenth of the bandwidth: 1.4 ms per step for 48 MB of weights).
+struct TransposeJob {
+  float* dst;
+  int R, Rpad, C;
+  int64_t s_b, s_r, d_b, d_c;
+  int tiles_r, tiles_c;
+  unsigned blocks;
+};
+
+__device__ __forceinline__ void transpose_pad_tile(const float* __restrict__ src, float* __restrict__ dst, int R, int Rpad,
+                                                   int C, int64_t s_b, int64_t s_r, int64_t d_b, int64_t d_c, int tiles_r,
+                                                   int tiles_c, int t, float (*tile)[33]) {
+  const int tc = t % tiles_c; t /= tiles_c;
+  const int tr = t % tiles_r;
+  const int b = t / tiles_r;
+  const int r0 = tr * 32, c0 = tc * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 8 * k, c = c0 + tx;
+    tile[ty + 8 * k][tx] = (r < R && c < C) ? src[(int64_t)b * s_b + (int64_t)r * s_r + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + 8 * k, r = r0 + tx;
+    if (r < Rpad && c < C) dst[(int64_t)b * d_b + (int64_t)c * d_c + r] = tile[tx][ty + 8 * k];
+  }
+}
+
+// two transposes of the same source in one launch (forward + data-gradient weight layouts): blocks [0, a.blocks) run
+// job a, the rest job b
+__global__ void __launch_bounds__(kBlock)
+k_transpose_pad2(const float* __restrict__ src, TransposeJob a, TransposeJob b) {
+  __shared__ float tile[32][33];
+  const bool first = blockIdx.x < a.blocks;
+  const TransposeJob& j = first ? a : b;
+  transpose_pad_tile(src, j.dst, j.R, j.Rpad, j.C, j.s_b, j.s_r, j.d_b, j.d_c, j.tiles_r, j.tiles_c,
+                     (int)(first ? blockIdx.x : blockIdx.x - a.blocks), tile);
+}
+
 __global__ void __launch_bounds__(kBlock)
 k_transpose_pad(const float* __restrict__ src, float* __restrict__ dst, int R, int Rpad, int C, int64_t s_b, int64_t s_r,
                 int64_t d_b, int64_t d_c, int tiles_r, int tiles_c) {
@@ -724,6 +764,24 @@ int cfun_weight_pack(const float* w, float* wp, int32_t Co, int32_t Ci, int32_t 
   // batch = ci, r = co (padded to CoP), c = tap:  w[co][ci][t] -> wp[t][ci][co]
   return transpose_pad(w, wp, Ci, Co, CoP, T, /*s_b*/ T, /*s_r*/ (int64_t)Ci * T, /*d_b*/ CoP, /*d_c*/ (int64_t)Ci * CoP,
                        cfun_st(stream));
+}
+
+int cfun_weight_pack_both(const float* w, float* wp, float* wpT, int32_t Co, int32_t Ci, int32_t T, cfun_stream_t stream) {
+  if (Co <= 0 || Ci <= 0 || T <= 0) return CFUN_EINVAL;
+  const int CoP = (Co + 15) / 16 * 16, CiP = (Ci + 15) / 16 * 16;
+  TransposeJob a, b;
+  // a: batch = ci, r = co (padded to CoP), c = tap:  w[co][ci][t] -> wp[t][ci][co]   (= cfun_weight_pack)
+  a.dst = wp; a.R = Co; a.Rpad = CoP; a.C = T; a.s_b = T; a.s_r = (int64_t)Ci * T; a.d_b = CoP; a.d_c = (int64_t)Ci * CoP;
+  a.tiles_r = (CoP + 31) / 32; a.tiles_c = (T + 31) / 32;
+  // b: batch = co, r = ci (padded to CiP), c = tap:  w[co][ci][t] -> wpT[t][co][ci]  (= pack + pack_transpose)
+  b.dst = wpT; b.R = Ci; b.Rpad = CiP; b.C = T; b.s_b = (int64_t)Ci * T; b.s_r = T; b.d_b = CiP; b.d_c = (int64_t)Co * CiP;
+  b.tiles_r = (CiP + 31) / 32; b.tiles_c = (T + 31) / 32;
+  const int64_t na = (int64_t)Ci * a.tiles_r * a.tiles_c, nb = (int64_t)Co * b.tiles_r * b.tiles_c;
+  if (na + nb > 0x7fffffffLL) return CFUN_EINVAL;
+  a.blocks = (unsigned)na; b.blocks = (unsigned)nb;
+  hipLaunchKernelGGL(k_transpose_pad2, dim3((unsigned)(na + nb)), dim3(kBlock), 0, cfun_st(stream), w, a, b);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
 }
 
 int cfun_weight_pack_transpose(const float* wp, float* wpT, int32_t Co, int32_t Ci, int32_t T, cfun_stream_t stream) {

@@ -37,13 +37,18 @@ class _PackWeight(torch.autograd.Function):
         return dw
 
 
-def _pack(w):
+def _pack(w, both=False):
+    """OIDHW -> packed wp [T,Ci,CoP]; with ``both`` also the data-gradient layout wpT [T,Co,CiP], same launch."""
     co, ci = w.shape[0], w.shape[1]
     t = w.shape[2] * w.shape[3] * w.shape[4]
     w = w.detach().contiguous()
     wp = torch.empty((t, ci, _round16(co)), dtype=torch.float32, device=w.device)
-    check(_lib.load().cfun_weight_pack(ptr(w), ptr(wp), co, ci, t, stream(w)), "weight_pack")
-    return wp
+    if not both:
+        check(_lib.load().cfun_weight_pack(ptr(w), ptr(wp), co, ci, t, stream(w)), "weight_pack")
+        return wp
+    wpT = torch.empty((t, co, _round16(ci)), dtype=torch.float32, device=w.device)
+    check(_lib.load().cfun_weight_pack_both(ptr(w), ptr(wp), ptr(wpT), co, ci, t, stream(w)), "weight_pack_both")
+    return wp, wpT
 
 
 def pack_weight(w):
@@ -159,8 +164,12 @@ class _Conv3d(torch.autograd.Function):
     def forward(ctx, x, wp, scale, shift, res, spec, out=None, dx_slot=None, w_src=None):
         lib = _lib.load()
         x = _c(x)
+        wpT = None
         if w_src is not None:        # OIDHW weight: packed here, its gradient comes back in OIDHW (one fused pass)
-            wp = _pack(w_src)
+            if ctx.needs_input_grad[0]:      # the data gradient's layout in the same launch, kept for backward
+                wp, wpT = _pack(w_src, both=True)
+            else:
+                wp = _pack(w_src)
         wp = _c(wp)
         scale = None if scale is None else _c(scale)
         shift = None if shift is None else _c(shift)
@@ -190,13 +199,13 @@ class _Conv3d(torch.autograd.Function):
         ctx.res_shape = None if res is None else res.shape
         ctx.dx_slot = dx_slot
         ctx.wshape = None if w_src is None else tuple(w_src.shape)
-        ctx.save_for_backward(x, wp, scale, y if spec.act != ACT_NONE else None)
+        ctx.save_for_backward(x, wp, scale, y if spec.act != ACT_NONE else None, wpT)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        x, wp, scale, y = ctx.saved_tensors
+        x, wp, scale, y, wpT = ctx.saved_tensors
         spec, p = ctx.spec, ctx.p
         need_x, need_w, need_scale, need_shift, need_res = ctx.needs_input_grad[:5]
         need_wsrc = ctx.needs_input_grad[8]
@@ -220,7 +229,8 @@ class _Conv3d(torch.autograd.Function):
                                    LRELU_SLOPE, p.scale_mode, st), "act_bwd(scale)")
         dx = dwp = dshift = dres = dw = None
         if need_x:
-            wpT = _transpose_pack(wp, p.Co)
+            if wpT is None:
+                wpT = _transpose_pack(wp, p.Co)
             # dx of a per-sample conv goes straight into its sample of the batch's gradient (zero-copy batch split)
             dx = torch.empty_like(x) if ctx.dx_slot is None else ctx.dx_slot[0].sample(ctx.dx_slot[1], x.shape, x)
             nb = lib.cfun_conv3d_bwd_data_workspace_bytes(C.byref(p))

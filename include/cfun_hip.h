@@ -252,6 +252,9 @@ int cfun_mask_losses_bwd_saved(const float* probs, const uint8_t* labels, const 
  * ---------------------------------------------------------------------------------------------- */
 int cfun_weight_pack(const float* w, float* wp, int32_t Co, int32_t Ci, int32_t T, cfun_stream_t stream);
 int cfun_weight_pack_transpose(const float* wp, float* wpT, int32_t Co, int32_t Ci, int32_t T, cfun_stream_t stream);
+/* cfun_weight_pack and cfun_weight_pack_transpose of the same OIDHW weight in ONE launch (a training step needs both
+ * layouts of every conv weight: wp for the forward / weight-gradient kernels, wpT for the data gradient). */
+int cfun_weight_pack_both(const float* w, float* wp, float* wpT, int32_t Co, int32_t Ci, int32_t T, cfun_stream_t stream);
 int cfun_weight_unpack(const float* dwp, float* dw, int32_t Co, int32_t Ci, int32_t T, cfun_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------

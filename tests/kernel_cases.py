@@ -381,6 +381,8 @@ def check_weight_layouts(device, seed=13):
         ref_t = torch.zeros(t, co, cip)
         ref_t[:, :, :ci] = ref[:, :, :co].transpose(1, 2)
         assert torch.equal(ops._transpose_pack(wp.detach(), co).cpu(), ref_t), (co, ci, k)
+        wp2, wpt2 = ops._pack(wd, both=True)                      # both layouts in one launch
+        assert torch.equal(wp2.cpu(), ref) and torch.equal(wpt2.cpu(), ref_t), (co, ci, k)
         g = randn(gen, t, ci, cop)
         wp.backward(g.to(device))
         assert torch.equal(wd.grad.cpu(), g[:, :, :co].reshape(*k, ci, co).permute(4, 3, 0, 1, 2)), (co, ci, k)
