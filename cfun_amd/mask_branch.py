@@ -140,14 +140,15 @@ class Modified3DUNet(nn.Module):
         a_parts, res_parts = ops.split_batch(a_all), ops.split_batch(res_all)
         ybuf, gbuf = ops.BatchBuffer(n), ops.BatchBuffer(n)     # outputs / conv1 input gradients, written in place
         outs = []
+        w1s, w2s = ops.gather_slices(conv1.weight, 0, idxs), ops.gather_slices(conv2.weight, 1, idxs)
         for i in range(n):
             a, res = a_parts[i], res_parts[i]
             idx = idxs[i]
-            w1 = conv1.weight.index_select(0, idx)
+            w1 = w1s[i]
             spec1 = ops.ConvSpec(k=conv1.kernel_size, co=idx.numel(), pad=conv1.padding, scale_per_n=True, algo=algo)
             t = ops.conv3d_w(a, w1, spec1, scale=drop[i:i + 1].index_select(1, idx).contiguous(),
                            dx_slot=(gbuf, i))
-            w2 = conv2.weight.index_select(1, idx)
+            w2 = w2s[i]
             spec2 = ops.ConvSpec(k=conv2.kernel_size, co=conv2.out_channels, pad=conv2.padding, algo=algo)
             outs.append(ops.conv3d_w(pre2(t), w2, spec2, res=res, out=(ybuf, i)))
         return ops.join_batch(ybuf, outs)

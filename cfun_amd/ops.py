@@ -76,6 +76,35 @@ def fold_up2_weight(w, cqp=None):
     return wf.reshape(8 * o, i, 3, 3, 3)
 
 
+class _GatherSlices(torch.autograd.Function):
+    """w -> tuple(w.index_select(dim, idx) for idx in idxs) with ONE gradient: zeros + one index_add_ per slice.
+    n separate index_select nodes each build a full-size zero-filled gradient and autograd then adds the n of them
+    (per-RoI Dropout3d weight slices: 3n - 1 launches per weight instead of n + 1)."""
+
+    @staticmethod
+    def forward(ctx, w, dim, *idxs):
+        ctx.dim, ctx.wshape = dim, tuple(w.shape)
+        ctx.save_for_backward(*idxs)
+        return tuple(w.index_select(dim, idx) for idx in idxs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        idxs = ctx.saved_tensors
+        dw = None
+        for idx, g in zip(idxs, grads):
+            if g is None:
+                continue
+            if dw is None:
+                dw = torch.zeros(ctx.wshape, dtype=g.dtype, device=g.device)
+            dw.index_add_(ctx.dim, idx, g)
+        return (dw, None) + (None,) * len(idxs)
+
+
+def gather_slices(w, dim, idxs):
+    """[w.index_select(dim, idx) for idx in idxs], differentiable w.r.t. w with a single accumulated gradient."""
+    return _GatherSlices.apply(w, dim, *idxs)
+
+
 def _transpose_pack(wp, co):
     """wp [T,Ci,CoP] -> wpT [T,Co,CiP] (no grad; used by bwd_data)."""
     t, ci, _ = wp.shape
