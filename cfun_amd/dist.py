@@ -393,6 +393,8 @@ class GradientReducer:
         flat = bucket["flat"]
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream(flat.device))   # the gradients are complete
+            for s in ops.side_streams(flat.device):      # ... including those a branch produced on its own stream
+                self.comm_stream.wait_stream(s)
             with torch.cuda.stream(self.comm_stream):
                 bucket["work"] = dist.all_reduce(flat, group=self.group, async_op=True)
         else:

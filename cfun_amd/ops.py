@@ -859,6 +859,26 @@ def halo_unpack(buf, x, z0):
 
 
 # ---- layout helpers (module boundary only; NCDHW <-> NDHWC) -------------------------------------------
+# ---- side streams (independent branches of one step on concurrent HIP streams) ---------------------------------------
+_SIDE_STREAMS = {}
+
+
+def side_stream(device, name):
+    """The process-wide side HIP stream ``name`` of ``device`` (created on first use)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, name)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=idx)
+    return _SIDE_STREAMS[key]
+
+
+def side_streams(device):
+    """Every side stream handed out for ``device`` -- whoever consumes results off-stream (the gradient reducer's
+    communication stream) has to wait for all of them, not only for the current stream."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return [s for (d, _), s in _SIDE_STREAMS.items() if d == idx]
+
+
 def to_ndhwc(x):
     """[N,C,D,H,W] (any memory format) -> contiguous [N,D,H,W,C]; free for channels_last_3d / C == 1."""
     return x.permute(0, 2, 3, 4, 1).contiguous()

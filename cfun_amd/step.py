@@ -6,11 +6,18 @@
 Out of scope here: sampling of detection targets.  The head RoI sets (positives
 first, then negatives), their class ids / box deltas and the uint8 mask labels are inputs.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
 
 from . import backbone, model, ops, utils
+
+# CFUN_OVERLAP_MASK_HEAD=1 runs the mask head on its own HIP stream beside FPN / RPN / classifier (see _mask_head).
+# Off by default: measured on one MI355X at cfg2 it is 1.2 ms per step SLOWER (56.8 vs 55.6 ms) -- the U-Net's convs
+# already fill the chip, and the small kernels they now share it with cost them more than the overlap hides.
+OVERLAP_MASK_HEAD = os.environ.get("CFUN_OVERLAP_MASK_HEAD", "0") == "1"
 
 
 class CFUNHotPath(nn.Module):
@@ -76,16 +83,38 @@ class CFUNHotPath(nn.Module):
         return model.proposal_layer([rpn_probs, rpn_bbox], proposal_count=count, nms_threshold=cfg.RPN_NMS_THRESHOLD,
                                     anchors=self.anchors, config=cfg)
 
+    def _mask_head(self, image, p_rois):
+        """The mask head (RoIAlign of the raw image + U-Net + softmax) on its own HIP stream: it reads only the image
+        and the positive RoIs, so FPN / RPN / proposals / classifier -- a few hundred small, low-occupancy launches --
+        run beside the U-Net's chip-filling convs instead of in front of them; autograd replays every node on its
+        forward stream, so the two backward passes overlap the same way.  Returns (logits, probs, join): ``join()``
+        makes the current stream wait for the head (call it before the outputs are consumed)."""
+        img = ops.to_ndhwc(image)[0]
+        if not (image.is_cuda and OVERLAP_MASK_HEAD):
+            logits, probs = self.mask.forward_ndhwc(img, p_rois)
+            return logits, probs, (lambda: None)
+        main = torch.cuda.current_stream(image.device)
+        side = ops.side_stream(image.device, "mask_head")
+        side.wait_stream(main)                  # image / RoIs / this step's weights are ready
+        with torch.cuda.stream(side):
+            logits, probs = self.mask.forward_ndhwc(img, p_rois)
+
+        def join():
+            main.wait_stream(side)
+            for t in (logits, probs):           # allocated on `side`, consumed (and possibly freed) on `main`
+                t.record_stream(main)
+        return logits, probs, join
+
     def predict_training(self, image, p_rois, n_rois):
         """BatchNorm stays in eval mode while the rest trains (model.py:1397-1406): folded BN needs no switch.
         p_rois [n_pos,6] / n_rois [n_neg,6] normalised.  Returns a dict of the path's outputs."""
         self.train()
+        mask_logits, mask_probs, join = self._mask_head(image, p_rois)      # enqueued first, on its own stream
         p2, p3, rpn_logits, rpn_probs, rpn_bbox = self.backbone_rpn(image)
         rpn_rois = self.proposals(rpn_probs, rpn_bbox, "training")
         rois = torch.cat([p_rois, n_rois], dim=0)
         cls_logits, cls_probs, cls_bbox = self.classifier.forward_ndhwc([p2[0], p3[0]], rois)
-        img = ops.to_ndhwc(image)[0]
-        mask_logits, mask_probs = self.mask.forward_ndhwc(img, p_rois)
+        join()
         return dict(rpn_class_logits=rpn_logits, rpn_probs=rpn_probs, rpn_bbox=rpn_bbox, rpn_rois=rpn_rois,
                     mrcnn_class_logits=cls_logits, mrcnn_class=cls_probs, mrcnn_bbox=cls_bbox,
                     mrcnn_mask_logits=mask_logits, mrcnn_mask=mask_probs, p2=p2, p3=p3)
@@ -108,9 +137,12 @@ class CFUNHotPath(nn.Module):
                    mrcnn_class_logits=None, mrcnn_class=None, mrcnn_bbox=None, mrcnn_mask_logits=None,
                    mrcnn_mask=None)
         if rois.shape[0]:
+            # the mask head waits for this step's targets, then runs beside the classifier head; in backward it
+            # overlaps the FPN / RPN gradients (see _mask_head)
+            out["mrcnn_mask_logits"], out["mrcnn_mask"], join = self._mask_head(image, p_rois)
             out["mrcnn_class_logits"], out["mrcnn_class"], out["mrcnn_bbox"] = self.classifier.forward_ndhwc(
                 [p2[0], p3[0]], rois)
-            out["mrcnn_mask_logits"], out["mrcnn_mask"] = self.mask.forward_ndhwc(ops.to_ndhwc(image)[0], p_rois)
+            join()
         return out
 
     @torch.no_grad()

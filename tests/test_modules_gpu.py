@@ -264,3 +264,35 @@ def test_unmold_golden(gpu):
 
 def test_unmold_lits_golden(gpu):
     mc.check_unmold_lits_golden(gpu)
+
+
+def test_mask_head_side_stream(gpu):
+    """The optional two-stream step (mask head beside FPN / RPN / classifier, step.OVERLAP_MASK_HEAD) runs the same
+    kernels on the same data: losses and the U-Net's gradients equal the single-stream step bit for bit (the FPN /
+    RPN / classifier gradients pass through RoIAlign's atomic scatter-add, whose order varies run to run anyway)."""
+    from cfun_amd import step
+    cfg = mc.tiny_config("finetune")
+    torch.manual_seed(0)
+    net = step.CFUNHotPath(cfg).to(gpu)
+    s = step.synthetic_inputs(cfg, gpu, 0)
+    results = []
+    old = step.OVERLAP_MASK_HEAD
+    try:
+        for flag in (False, True, True):
+            step.OVERLAP_MASK_HEAD = flag
+            torch.manual_seed(5)                      # the same host-drawn Dropout3d masks every time
+            net.zero_grad(set_to_none=True)
+            _, losses, total = step.training_step(net, s)
+            torch.cuda.synchronize()
+            results.append(([float(l) for l in losses],
+                            {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))
+    finally:
+        step.OVERLAP_MASK_HEAD = old
+    for losses, grads in results[1:]:
+        assert losses == results[0][0]
+        assert grads.keys() == results[0][1].keys()
+        for k, g in grads.items():
+            if k.startswith("mask."):
+                assert torch.equal(g, results[0][1][k]), k
+            else:
+                torch.testing.assert_close(g, results[0][1][k], rtol=1e-4, atol=1e-6, msg=k)
