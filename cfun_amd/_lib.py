@@ -15,6 +15,7 @@ DEFAULT_LIB = os.path.join(_HERE, "libcfun_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = 0, 1, 2
+ALGO_B3 = 3      # host-side only (opt-in): eligible 3x3x3 convs on the experimental 3xBF16 kernels, the rest as AUTO
 
 
 class ConvParams(C.Structure):
@@ -83,6 +84,10 @@ _SIGNATURES = {
     "cfun_weight_pack": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "cfun_weight_pack_transpose": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "cfun_weight_pack_both": (C.c_int, [_P, _P, _P, _I, _I, _I, _P]),
+    "cfun_conv3d_b3_supported": (C.c_int, [_PP]),
+    "cfun_weight_pack_b3_bytes": (_Z, [_I, _I]),
+    "cfun_weight_pack_b3": (C.c_int, [_P, _P, _I, _I, _I, _P]),
+    "cfun_conv3d_b3_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _PP, _P]),
     "cfun_weight_unpack": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "cfun_halo_pack": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "cfun_halo_unpack": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -1,0 +1,312 @@
+// EXPERIMENTAL (opt-in, not on the default path): 3x3x3 stride-1 convolution with fp32 operands emulated on the bf16
+// matrix cores ("3xBF16": every fp32 value is the exact sum of three bf16 values hi + mid + lo; of the nine cross
+// products the six with weight >= 2^-16 are kept, each exact in fp32, accumulated in fp32 by the MFMA).  The dropped
+// terms are <= 2^-25 |x w| per product -- below the rounding of an fp32 FMA -- so the result is fp32-accurate, while
+// v_mfma_f32_16x16x32_bf16 retires 16x the MACs per cycle of v_mfma_f32_16x16x4_f32: 6 instructions of 16 cycles
+// replace 8 of 32 for the same K = 32, a 2.67x higher MFMA ceiling (~420 effective TFLOP/s instead of 157).
+//
+// Layout.  A workgroup (4 waves) owns a 4(z) x 4(y) x 16(x) output tile x NT = 16*NSUB output channels, like
+// k_conv_mfma.  K runs over (tap, channel): one MFMA K-step of 32 = 4 taps x 8 channels (lane group kb = lane>>4 takes
+// tap 4s+kb of the 27, the 28th slot carries zero weights), so an 8-channel input chunk is staged per barrier pair:
+// the fp32 halo tile is split into its three bf16 planes on the way into LDS ([plane][voxel][8 ch] = 16 B per voxel,
+// one ds_read_b128 per B operand, at a per-lane tap offset).  The weights are pre-split and pre-swizzled on the device
+// (cfun_weight_pack_b3) into exactly the per-lane A-operand order, [chunk][step][subtile][plane][lane][8 bf16], and are
+// read straight from global memory / L2 with coalesced 16-byte loads, double-buffered one K-step ahead.
+#include "conv3d_mfma.h"
+
+namespace {
+
+using cfun_mfma::tile_raster;
+using cfun_mfma::xcd_remap;
+
+typedef float b3_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned b3_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned b3_u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kB3Steps = 7;            // ceil(27 taps / 4 taps per K-step)
+constexpr int kB3IZ = 6, kB3IY = 6, kB3IX = 18, kB3Vox = kB3IZ * kB3IY * kB3IX;   // halo tile of the 4x4x16 outputs
+constexpr int kB3Plane = kB3Vox * 16;  // bytes of one bf16 plane of an 8-channel chunk
+
+__host__ __device__ inline unsigned b3_bf16_rne(float x) {      // fp32 -> bf16 bits, round to nearest even
+  unsigned u;
+  memcpy(&u, &x, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__host__ __device__ inline float b3_bf16_to_f32(unsigned h) {
+  const unsigned u = h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+// x = hi + mid + lo exactly (to 2^-27 |x|): the two residuals are exact fp32 subtractions
+__host__ __device__ inline void b3_split(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
+  hi = b3_bf16_rne(x);
+  const float r1 = x - b3_bf16_to_f32(hi);
+  mid = b3_bf16_rne(r1);
+  const float r2 = r1 - b3_bf16_to_f32(mid);
+  lo = b3_bf16_rne(r2);
+}
+
+#ifdef CFUN_HIP_EMULATION
+inline b3_f32x4 b3_mfma(b3_u32x4 a, b3_u32x4 b, b3_f32x4 c) { return hipemu_mfma_16x16x32_bf16(a, b, c); }
+#else
+typedef __bf16 b3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b3_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float b3_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ b3_f32x4 b3_mfma(b3_u32x4 a, b3_u32x4 b, b3_f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b3_bf16x8, a), __builtin_bit_cast(b3_bf16x8, b), c, 0, 0, 0);
+}
+#endif
+
+// two fp32 -> the three packed bf16 pairs (element 0 in the low half): v_cvt_pk_bf16_f32 on the GPU
+__device__ __forceinline__ void b3_split_pair(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+#ifdef CFUN_HIP_EMULATION
+  unsigned h0, m0, l0, h1, m1, l1;
+  b3_split(x0, h0, m0, l0);
+  b3_split(x1, h1, m1, l1);
+  hi = h0 | (h1 << 16); mid = m0 | (m1 << 16); lo = l0 | (l1 << 16);
+#else
+  const b3_f32x2 v = {x0, x1};
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, b3_bf16x2));
+  const b3_f32x2 r1 = v - b3_f32x2{__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+  mid = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, b3_bf16x2));
+  const b3_f32x2 r2 = r1 - b3_f32x2{__uint_as_float(mid << 16), __uint_as_float(mid & 0xffff0000u)};
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, b3_bf16x2));
+#endif
+}
+
+// w OIDHW [Co][Ci][27] -> wb3[chunk = ci/8][step][subtile = co/16][plane][lane][8 bf16].  lane = (co & 15) + 16*kb holds
+// tap 4*step + kb, channels 8*chunk .. +7.  transpose_flip: the data-gradient's weights (roles of Co / Ci swapped,
+// taps mirrored) from the same OIDHW tensor: A row = ci, K = co.
+__global__ void __launch_bounds__(256)
+k_pack_b3(const float* __restrict__ w, unsigned short* __restrict__ wb3, int Co, int Ci, int rows, int kch, int nsub,
+          int transpose_flip, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t t = i;
+    const int e = (int)(t & 7); t >>= 3;
+    const int lane = (int)(t & 63); t >>= 6;
+    const int nn = (int)(t % nsub); t /= nsub;
+    const int s = (int)(t % kB3Steps);
+    const int c = (int)(t / kB3Steps);
+    const int row = nn * 16 + (lane & 15), tap = 4 * s + (lane >> 4), k = 8 * c + e;
+    float v = 0.f;
+    if (tap < 27 && row < rows && k < kch)
+      v = transpose_flip ? w[((int64_t)k * Ci + row) * 27 + (26 - tap)] : w[((int64_t)row * Ci + k) * 27 + tap];
+    unsigned hi, mid, lo;
+    b3_split(v, hi, mid, lo);
+    const int64_t base = ((((int64_t)c * kB3Steps + s) * nsub + nn) * 3) * 512 + lane * 8 + e;
+    wb3[base] = (unsigned short)hi;
+    wb3[base + 512] = (unsigned short)mid;
+    wb3[base + 1024] = (unsigned short)lo;
+  }
+}
+
+template <int NSUB>
+__global__ void __launch_bounds__(256)
+k_conv_b3(const float* __restrict__ x, const b3_u32x4* __restrict__ wb3, const float* __restrict__ scale,
+          const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y, CfunConv3dParams p,
+          int ntz, int nty, int ntx, int ncot, int nsub_total) {
+  constexpr int NT = 16 * NSUB;
+  constexpr int ITEMS = kB3Vox * 2, IN_LOADS = (ITEMS + 255) / 256;     // float4 (4 channels) items per chunk
+  CFUN_DYN_LDS(unsigned char, smem);                                     // [3 planes][kB3Vox][16 B]
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int cot = lid % ncot; lid /= ncot;
+  const unsigned per_n = (unsigned)(ntz * nty * ntx);
+  const int n = lid / per_n;
+  int tz, ty, tx;
+  tile_raster(lid - (unsigned)n * per_n, ntz, nty, ntx, tz, ty, tx);
+  const int z0 = tz * 4, y0 = ty * 4, x0 = tx * 16;
+  const int cobase = cot * NT;
+
+  // ---- halo staging descriptors: item = (voxel, 4-channel half); element offset of channel 0 or -1 (zero padding)
+  int64_t in_off[IN_LOADS];
+#pragma unroll
+  for (int i = 0; i < IN_LOADS; ++i) {
+    const int idx = tid + i * 256, vox = idx >> 1;
+    in_off[i] = -1;
+    if (idx < ITEMS) {
+      const int ix = vox % kB3IX, iy = (vox / kB3IX) % kB3IY, iz = vox / (kB3IX * kB3IY);
+      const int vz = z0 - 1 + iz, vy = y0 - 1 + iy, vx = x0 - 1 + ix;
+      if (vz >= 0 && vz < p.Di && vy >= 0 && vy < p.Hi && vx >= 0 && vx < p.Wi)
+        in_off[i] = ((((int64_t)n * p.Di + vz) * p.Hi + vy) * p.Wi + vx) * p.Ci + (idx & 1) * 4;
+    }
+  }
+  float4 xin[IN_LOADS];
+  auto prefetch_x = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < IN_LOADS; ++i)
+      xin[i] = in_off[i] >= 0 ? *reinterpret_cast<const float4*>(x + in_off[i] + c * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto commit_x = [&]() {
+#pragma unroll
+    for (int i = 0; i < IN_LOADS; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < ITEMS) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        b3_split_pair(xin[i].x, xin[i].y, h0, m0, l0);
+        b3_split_pair(xin[i].z, xin[i].w, h1, m1, l1);
+        unsigned char* dst = smem + (idx >> 1) * 16 + (idx & 1) * 8;
+        *reinterpret_cast<b3_u32x2*>(dst) = b3_u32x2{h0, h1};
+        *reinterpret_cast<b3_u32x2*>(dst + kB3Plane) = b3_u32x2{m0, m1};
+        *reinterpret_cast<b3_u32x2*>(dst + 2 * kB3Plane) = b3_u32x2{l0, l1};
+      }
+    }
+  };
+
+  // ---- B operand: lane (v = lane & 15, kb = lane >> 4) reads voxel (wv + dz, m + dy, v + dx) of tap 4s + kb
+  const int kb = lane >> 4;
+  int boff[kB3Steps];
+#pragma unroll
+  for (int s = 0; s < kB3Steps; ++s) {
+    int t = 4 * s + kb;
+    t = t > 26 ? 26 : t;                                  // slot 27: any valid address, its weights are zero
+    const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
+    boff[s] = ((((wv + dz) * kB3IY + dy) * kB3IX) + (lane & 15) + dx) * 16;
+  }
+  // ---- A operand: [chunk][step][subtile][plane][lane] 16-byte entries
+  const b3_u32x4* wl = wb3 + (int64_t)(cot * NSUB) * 3 * 64 + lane;
+  const int64_t wstep = (int64_t)nsub_total * 3 * 64;
+  b3_u32x4 a_cur[NSUB][3], a_nxt[NSUB][3];
+  auto load_a = [&](b3_u32x4 (&a)[NSUB][3], int g) {       // g = chunk * 7 + step
+    const b3_u32x4* src = wl + (int64_t)g * wstep;
+#pragma unroll
+    for (int nn = 0; nn < NSUB; ++nn)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) a[nn][pl] = src[(nn * 3 + pl) * 64];
+  };
+
+  b3_f32x4 acc[4][NSUB];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int nn = 0; nn < NSUB; ++nn) acc[m][nn] = b3_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nchunks = p.Ci >> 3, nsteps = nchunks * kB3Steps;
+  prefetch_x(0);
+  load_a(a_cur, 0);
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();           // every wave is done reading the previous chunk
+    commit_x();
+    __syncthreads();
+    if (c + 1 < nchunks) prefetch_x(c + 1);
+#pragma unroll
+    for (int s = 0; s < kB3Steps; ++s) {
+      const int g = c * kB3Steps + s;
+      if (g + 1 < nsteps) load_a(a_nxt, g + 1);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const unsigned char* bp = smem + boff[s] + m * (kB3IX * 16);
+        const b3_u32x4 b0 = *reinterpret_cast<const b3_u32x4*>(bp);
+        const b3_u32x4 b1 = *reinterpret_cast<const b3_u32x4*>(bp + kB3Plane);
+        const b3_u32x4 b2 = *reinterpret_cast<const b3_u32x4*>(bp + 2 * kB3Plane);
+        // six cross terms, smallest first; consecutive MFMAs go to different accumulators
+#pragma unroll
+        for (int nn = 0; nn < NSUB; ++nn) acc[m][nn] = b3_mfma(a_cur[nn][2], b0, acc[m][nn]);
+#pragma unroll
+        for (int nn = 0; nn < NSUB; ++nn) acc[m][nn] = b3_mfma(a_cur[nn][1], b1, acc[m][nn]);
+#pragma unroll
+        for (int nn = 0; nn < NSUB; ++nn) acc[m][nn] = b3_mfma(a_cur[nn][0], b2, acc[m][nn]);
+#pragma unroll
+        for (int nn = 0; nn < NSUB; ++nn) acc[m][nn] = b3_mfma(a_cur[nn][1], b0, acc[m][nn]);
+#pragma unroll
+        for (int nn = 0; nn < NSUB; ++nn) acc[m][nn] = b3_mfma(a_cur[nn][0], b1, acc[m][nn]);
+#pragma unroll
+        for (int nn = 0; nn < NSUB; ++nn) acc[m][nn] = b3_mfma(a_cur[nn][0], b0, acc[m][nn]);
+      }
+#pragma unroll
+      for (int nn = 0; nn < NSUB; ++nn)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) a_cur[nn][pl] = a_nxt[nn][pl];
+    }
+  }
+
+  // ---- epilogue: lane owns voxel (z0+wv, y0+m, x0+(lane&15)), channels nn*16 + (lane>>4)*4 .. +3
+  const int oz = z0 + wv, ox = x0 + (lane & 15);
+  if (oz >= p.Do || ox >= p.Wo) return;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int oy = y0 + m;
+    if (oy >= p.Ho) continue;
+    const int64_t v = (((int64_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox;
+#pragma unroll
+    for (int nn = 0; nn < NSUB; ++nn) {
+      const int co = cobase + nn * 16 + kb * 4;
+      if (co >= p.Co) continue;
+      float4 r = make_float4(acc[m][nn][0], acc[m][nn][1], acc[m][nn][2], acc[m][nn][3]);
+      if (p.scale_mode) {
+        const float4 s4 = *reinterpret_cast<const float4*>(scale + (p.scale_mode == 2 ? n * p.Co : 0) + co);
+        r.x *= s4.x; r.y *= s4.y; r.z *= s4.z; r.w *= s4.w;
+      }
+      if (p.has_shift) {
+        const float4 t = *reinterpret_cast<const float4*>(shift + co);
+        r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+      }
+      if (p.res_mode) {
+        const float4 t = *reinterpret_cast<const float4*>(res + v * p.Co + co);
+        r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+      }
+      r.x = cfun_apply_act(r.x, p.act, p.slope); r.y = cfun_apply_act(r.y, p.act, p.slope);
+      r.z = cfun_apply_act(r.z, p.act, p.slope); r.w = cfun_apply_act(r.w, p.act, p.slope);
+      *reinterpret_cast<float4*>(y + v * p.Co + co) = r;
+    }
+  }
+}
+
+template <int NSUB>
+int launch_b3(const float* x, const void* wb3, const float* scale, const float* shift, const float* res, float* y,
+              const CfunConv3dParams& p, int nsub_total, hipStream_t st) {
+  const int ntz = (p.Do + 3) / 4, nty = (p.Ho + 3) / 4, ntx = (p.Wo + 15) / 16, ncot = nsub_total / NSUB;
+  const int64_t nblk = (int64_t)p.N * ntz * nty * ntx * ncot;
+  if (nblk == 0) return CFUN_OK;
+  if (nblk > 0x7fffffffLL) return CFUN_EINVAL;
+  hipLaunchKernelGGL((k_conv_b3<NSUB>), dim3((unsigned)nblk), dim3(256), (size_t)3 * kB3Plane, st, x,
+                     (const b3_u32x4*)wb3, scale, shift, res, y, p, ntz, nty, ntx, ncot, nsub_total);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+inline bool b3_shape_ok(const CfunConv3dParams* p) {
+  return p->kd == 3 && p->kh == 3 && p->kw == 3 && p->stride == 1 && p->pd == 1 && p->ph == 1 && p->pw == 1 && !p->up2 &&
+         !p->d2s && !p->res_up2 && !p->tap_skip && (p->Ci & 7) == 0 && (p->Co & 3) == 0 && p->Ci >= 8 &&
+         p->Do == p->Di && p->Ho == p->Hi && p->Wo == p->Wi;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cfun_conv3d_b3_supported(const CfunConv3dParams* p) { return p && b3_shape_ok(p) ? 1 : 0; }
+
+size_t cfun_weight_pack_b3_bytes(int32_t rows, int32_t kch) {
+  if (rows <= 0 || kch <= 0 || (kch & 7)) return 0;
+  return (size_t)(kch / 8) * kB3Steps * ((rows + 15) / 16) * 3 * 64 * 16;
+}
+
+int cfun_weight_pack_b3(const float* w, void* wb3, int32_t Co, int32_t Ci, int32_t transpose_flip, cfun_stream_t stream) {
+  const int rows = transpose_flip ? Ci : Co, kch = transpose_flip ? Co : Ci;
+  if (rows <= 0 || kch <= 0 || (kch & 7)) return CFUN_EINVAL;
+  const int nsub = (rows + 15) / 16;
+  const int64_t total = (int64_t)(kch / 8) * kB3Steps * nsub * 64 * 8;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(k_pack_b3, dim3((unsigned)blocks), dim3(256), 0, cfun_st(stream), w, (unsigned short*)wb3, Co, Ci, rows,
+                     kch, nsub, transpose_flip, total);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+int cfun_conv3d_b3_fwd(const float* x, const void* wb3, const float* scale, const float* shift, const float* res, float* y,
+                       const CfunConv3dParams* p, cfun_stream_t stream) {
+  if (!p || !b3_shape_ok(p)) return CFUN_EINVAL;
+  if (!cfun_aligned16(x) || !cfun_aligned16(wb3) || !cfun_aligned16(y)) return CFUN_EALIGN;
+  const int nsub = (p->Co + 15) / 16;
+  hipStream_t st = cfun_st(stream);
+  if (nsub % 3 == 0) return launch_b3<3>(x, wb3, scale, shift, res, y, *p, nsub, st);
+  if (nsub % 5 == 0) return launch_b3<5>(x, wb3, scale, shift, res, y, *p, nsub, st);
+  if (nsub % 2 == 0) return launch_b3<2>(x, wb3, scale, shift, res, y, *p, nsub, st);
+  return launch_b3<1>(x, wb3, scale, shift, res, y, *p, nsub, st);
+}
+
+}  // extern "C"

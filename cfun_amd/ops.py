@@ -11,7 +11,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib
-from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ALGO_AUTO, ConvParams, check, ptr, stream, workspace
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ALGO_AUTO, ALGO_B3, ConvParams, check, ptr, stream, workspace
 
 LRELU_SLOPE = 0.01  # nn.LeakyReLU() default, mask_branch.py:18
 
@@ -156,7 +156,7 @@ def _params(spec, x_shape, has_scale, has_shift, has_res):
     p.d2s = int(spec.d2s)
     p.d2s_cq = int(spec.d2s_cq)
     p.tap_skip = int(spec.tap_skip)
-    p.algo = spec.algo
+    p.algo = ALGO_AUTO if spec.algo == ALGO_B3 else spec.algo      # ALGO_B3 is resolved on the host (_Conv3d)
     return p
 
 
@@ -194,18 +194,23 @@ class _Conv3d(torch.autograd.Function):
         lib = _lib.load()
         x = _c(x)
         wpT = None
-        if w_src is not None:        # OIDHW weight: packed here, its gradient comes back in OIDHW (one fused pass)
-            if ctx.needs_input_grad[0]:      # the data gradient's layout in the same launch, kept for backward
-                wp, wpT = _pack(w_src, both=True)
-            else:
-                wp = _pack(w_src)
-        wp = _c(wp)
         scale = None if scale is None else _c(scale)
         shift = None if shift is None else _c(shift)
         res = None if res is None else _c(res)
         p = _params(spec, x.shape, scale is not None, shift is not None, res is not None)
-        if wp.shape != (p.kd * p.kh * p.kw, p.Ci, p.CoP):
-            raise RuntimeError("packed weight %s does not match conv %s" % (tuple(wp.shape), spec))
+        # opt-in 3xBF16 kernels (CFUN_CONV_ALGO=b3): forward here, data gradient in backward; wgrad stays exact fp32
+        b3 = bool(spec.algo == ALGO_B3 and w_src is not None and lib.cfun_conv3d_b3_supported(C.byref(p)))
+        if b3:
+            wp, wb3 = None, pack_weight_b3(w_src)
+        elif w_src is not None:      # OIDHW weight: packed here, its gradient comes back in OIDHW (one fused pass)
+            if ctx.needs_input_grad[0]:      # the data gradient's layout in the same launch, kept for backward
+                wp, wpT = _pack(w_src, both=True)
+            else:
+                wp = _pack(w_src)
+        if not b3:
+            wp = _c(wp)
+            if wp.shape != (p.kd * p.kh * p.kw, p.Ci, p.CoP):
+                raise RuntimeError("packed weight %s does not match conv %s" % (tuple(wp.shape), spec))
         if spec.d2s:
             cq = spec.d2s_cq or p.Co // 8
             y = torch.empty((p.N, 2 * p.Do, 2 * p.Ho, 2 * p.Wo, cq), dtype=torch.float32, device=x.device)
@@ -217,9 +222,13 @@ class _Conv3d(torch.autograd.Function):
         if timed:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        ws = workspace(lib.cfun_conv3d_fwd_workspace_bytes(C.byref(p)), x)
-        check(lib.cfun_conv3d_fwd(ptr(x), ptr(wp), ptr(scale), ptr(shift), ptr(res), ptr(y), C.byref(p), ptr(ws),
-                                  ws.numel(), stream(x)), "conv3d_fwd")
+        if b3:
+            check(lib.cfun_conv3d_b3_fwd(ptr(x), ptr(wb3), ptr(scale), ptr(shift), ptr(res), ptr(y), C.byref(p),
+                                         stream(x)), "conv3d_b3_fwd")
+        else:
+            ws = workspace(lib.cfun_conv3d_fwd_workspace_bytes(C.byref(p)), x)
+            check(lib.cfun_conv3d_fwd(ptr(x), ptr(wp), ptr(scale), ptr(shift), ptr(res), ptr(y), C.byref(p), ptr(ws),
+                                      ws.numel(), stream(x)), "conv3d_fwd")
         if timed:
             ev1.record()
             _TIMER.add(timed, ev0, ev1)
@@ -228,13 +237,15 @@ class _Conv3d(torch.autograd.Function):
         ctx.res_shape = None if res is None else res.shape
         ctx.dx_slot = dx_slot
         ctx.wshape = None if w_src is None else tuple(w_src.shape)
-        ctx.save_for_backward(x, wp, scale, y if spec.act != ACT_NONE else None, wpT)
+        ctx.b3 = b3
+        ctx.save_for_backward(x, wp, scale, y if spec.act != ACT_NONE else None, wpT,
+                              w_src.detach() if b3 and ctx.needs_input_grad[0] else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        x, wp, scale, y, wpT = ctx.saved_tensors
+        x, wp, scale, y, wpT, w_b3 = ctx.saved_tensors
         spec, p = ctx.spec, ctx.p
         need_x, need_w, need_scale, need_shift, need_res = ctx.needs_input_grad[:5]
         need_wsrc = ctx.needs_input_grad[8]
@@ -258,14 +269,24 @@ class _Conv3d(torch.autograd.Function):
                                    LRELU_SLOPE, p.scale_mode, st), "act_bwd(scale)")
         dx = dwp = dshift = dres = dw = None
         if need_x:
-            if wpT is None:
-                wpT = _transpose_pack(wp, p.Co)
             # dx of a per-sample conv goes straight into its sample of the batch's gradient (zero-copy batch split)
             dx = torch.empty_like(x) if ctx.dx_slot is None else ctx.dx_slot[0].sample(ctx.dx_slot[1], x.shape, x)
-            nb = lib.cfun_conv3d_bwd_data_workspace_bytes(C.byref(p))
-            ws = workspace(nb, x)
-            check(lib.cfun_conv3d_bwd_data(ptr(g), ptr(wpT), ptr(dx), C.byref(p), ptr(ws), ws.numel(), st),
-                  "conv3d_bwd_data")
+            pd = None
+            if ctx.b3:       # the data gradient is the same 3x3x3 conv on g with transposed, mirrored weights
+                pd = _params(ConvSpec(k=(3, 3, 3), co=p.Ci, pad=(1, 1, 1)), g.shape, False, False, False)
+                if not lib.cfun_conv3d_b3_supported(C.byref(pd)):
+                    pd = None
+            if pd is not None:
+                wb3t = pack_weight_b3(w_b3, transpose_flip=True)     # (held until the launch is enqueued)
+                check(lib.cfun_conv3d_b3_fwd(ptr(g), ptr(wb3t), None, None, None, ptr(dx), C.byref(pd), st),
+                      "conv3d_b3_fwd(dgrad)")
+            else:
+                if wpT is None:
+                    wpT = _transpose_pack(wp if wp is not None else _pack(w_b3), p.Co)
+                nb = lib.cfun_conv3d_bwd_data_workspace_bytes(C.byref(p))
+                ws = workspace(nb, x)
+                check(lib.cfun_conv3d_bwd_data(ptr(g), ptr(wpT), ptr(dx), C.byref(p), ptr(ws), ws.numel(), st),
+                      "conv3d_bwd_data")
         if need_w:
             dwp = torch.empty_like(wp)
             nb = lib.cfun_conv3d_bwd_weight_workspace_bytes(C.byref(p))
@@ -306,6 +327,36 @@ def conv3d_w(x, w, spec, scale=None, shift=None, res=None, out=None, dx_slot=Non
     wgrad kernel's per-chunk partial sums and the un-packing are one kernel (cfun_conv3d_bwd_weight_oidhw) instead
     of conv3d(x, pack_weight(w))'s reduce + un-pack launches.  Same values bit for bit."""
     return _Conv3d.apply(x, None, scale, shift, res, spec, out, dx_slot, w)
+
+
+# ---- EXPERIMENTAL: 3x3x3 conv with fp32 emulated on the bf16 matrix cores (conv3d_b3.hip; not used by the modules) ----
+def pack_weight_b3(w, transpose_flip=False):
+    """OIDHW [Co,Ci,3,3,3] -> the 3xBF16 kernel's pre-split A-operand buffer (transpose_flip: the data gradient's)."""
+    lib = _lib.load()
+    w = _c(w.detach().float())
+    co, ci = w.shape[0], w.shape[1]
+    rows, kch = (ci, co) if transpose_flip else (co, ci)
+    nb = lib.cfun_weight_pack_b3_bytes(rows, kch)
+    if nb == 0:
+        raise ValueError("pack_weight_b3: K = %d channels is not a multiple of 8" % kch)
+    wb3 = torch.empty(nb, dtype=torch.uint8, device=w.device)
+    check(lib.cfun_weight_pack_b3(ptr(w), ptr(wb3), co, ci, int(transpose_flip), stream(w)), "weight_pack_b3")
+    return wb3
+
+
+def conv3d_b3(x, wb3, co, scale=None, shift=None, res=None, act=ACT_NONE, scale_per_n=False):
+    """y = act(scale * conv3x3x3(x) + shift + res), stride 1, pad 1, NDHWC, forward only (no autograd)."""
+    lib = _lib.load()
+    x = _c(x.detach())
+    spec = ConvSpec(k=(3, 3, 3), co=co, pad=(1, 1, 1), act=act, scale_per_n=scale_per_n)
+    p = _params(spec, x.shape, scale is not None, shift is not None, res is not None)
+    if not lib.cfun_conv3d_b3_supported(C.byref(p)):
+        raise ValueError("conv3d_b3: unsupported shape (needs C_in % 8 == 0, C_out % 4 == 0)")
+    y = torch.empty((p.N, p.Do, p.Ho, p.Wo, p.Co), dtype=torch.float32, device=x.device)
+    scale, shift, res = [None if t is None else _c(t) for t in (scale, shift, res)]      # held across the launch
+    check(lib.cfun_conv3d_b3_fwd(ptr(x), ptr(wb3), ptr(scale), ptr(shift), ptr(res), ptr(y), C.byref(p), stream(x)),
+          "conv3d_b3_fwd")
+    return y
 
 
 # ---- zero-copy batch split / join (per-sample convs inside a batched graph) ------------------------------------
@@ -854,7 +905,8 @@ def halo_unpack(buf, x, z0):
     lib = _lib.load()
     n, d, h, w, c = x.shape
     planes = buf.shape[1]
-    check(lib.cfun_halo_unpack(ptr(_c(buf)), ptr(x), n, d, h, w, c, z0, planes, stream(x)), "halo_unpack")
+    buf = _c(buf)                  # held across the launch (a temporary could be recycled before the kernel reads it)
+    check(lib.cfun_halo_unpack(ptr(buf), ptr(x), n, d, h, w, c, z0, planes, stream(x)), "halo_unpack")
     return x
 
 

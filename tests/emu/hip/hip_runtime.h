@@ -55,7 +55,7 @@ void block_sync();
 // one rendezvous of the calling thread's wave; returns a pointer to the wave's 64 x 16-byte exchange slots of
 // the current collective (double buffered, see hip_emu.cpp)
 struct alignas(16) Slot {
-  unsigned char b[16];
+  unsigned char b[32];
 };
 Slot* wave_exchange(const void* mine, size_t bytes);
 int lane_id();
@@ -120,6 +120,36 @@ inline hipemu_f32x4 hipemu_mfma_16x16x4f32(float a, float b, hipemu_f32x4 c, int
   return d;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_16x16x4f32
+
+// v_mfma_f32_16x16x32_bf16: lane l holds 8 bf16 of A row l&15 and of B column l&15 for the K-block l>>4 (as raw bits in
+// a 16-byte vector); D[i][j] = C[i][j] + sum over the 4 K-blocks x 8 elements of A[i][k] * B[k][j].  The hardware's
+// internal summation order is not specified; fp32 fma in ascending (block, element) order here, tests use tolerances.
+typedef unsigned hipemu_u32x4 __attribute__((ext_vector_type(4)));
+inline float hipemu_bf16_bits(const unsigned char* p, int e) {
+  unsigned short h;
+  memcpy(&h, p + 2 * e, 2);
+  const unsigned u = (unsigned)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+inline hipemu_f32x4 hipemu_mfma_16x16x32_bf16(hipemu_u32x4 a, hipemu_u32x4 b, hipemu_f32x4 c) {
+  unsigned char ab[32];
+  memcpy(ab, &a, 16);
+  memcpy(ab + 16, &b, 16);
+  hipemu::Slot* s = hipemu::wave_exchange(ab, sizeof(ab));
+  const int l = hipemu::lane_id(), j = l & 15;
+  hipemu_f32x4 d = c;
+  for (int r = 0; r < 4; ++r) {
+    const int i = (l >> 4) * 4 + r;
+    float acc = c[r];
+    for (int kb = 0; kb < 4; ++kb)
+      for (int e = 0; e < 8; ++e)
+        acc = fmaf(hipemu_bf16_bits(s[i + 16 * kb].b, e), hipemu_bf16_bits(s[j + 16 * kb].b + 16, e), acc);
+    d[r] = acc;
+  }
+  return d;
+}
 
 // v_mfma_f32_4x4x1_16b_f32: 16 independent blocks b = lane>>2; D_b[i][j] = C + A_b[i]*B_b[j] with A_b[i] from lane
 // 4b+i, B_b[j] from lane 4b+j; result lane 4b+j, register i  (layout measured on MI355X: tools/probe_mfma.py)

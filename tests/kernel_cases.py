@@ -386,3 +386,46 @@ def check_weight_layouts(device, seed=13):
         g = randn(gen, t, ci, cop)
         wp.backward(g.to(device))
         assert torch.equal(wd.grad.cpu(), g[:, :, :co].reshape(*k, ci, co).permute(4, 3, 0, 1, 2)), (co, ci, k)
+
+
+def check_conv_b3(device, n, dhw, ci, co, seed=21, act=ACT_NONE, scale=False, shift=False, res=False):
+    """EXPERIMENTAL 3xBF16 conv (conv3d_b3.hip): forward and data gradient against an fp64 reference -- the error must be
+    at the level of an fp32 convolution (the exact-fp32 MFMA path's own error vs fp64 is the yardstick), not bf16's."""
+    gen = _gen(seed)
+    x = randn(gen, n, *dhw, ci)
+    w = randn(gen, co, ci, 3, 3, 3) / float(ci * 27) ** 0.5
+    sc = (torch.rand(co, generator=gen) + 0.5) if scale else None
+    sf = randn(gen, co) if shift else None
+    rs = randn(gen, n, *dhw, co) if res else None
+    spec = ops.ConvSpec(k=(3, 3, 3), co=co, pad=(1, 1, 1), act=act)
+
+    def ref64(xx, ww):
+        y = F.conv3d(xx.double().permute(0, 4, 1, 2, 3), ww.double(), padding=1).permute(0, 2, 3, 4, 1)
+        if sc is not None:
+            y = y * sc.double()
+        if sf is not None:
+            y = y + sf.double()
+        if rs is not None:
+            y = y + rs.double()
+        if act == ACT_LRELU:
+            y = F.leaky_relu(y, 0.01)
+        elif act == ACT_RELU:
+            y = F.relu(y)
+        return y
+
+    y64 = ref64(x, w)
+    dev = lambda t: None if t is None else t.to(device)
+    y_b3 = ops.conv3d_b3(dev(x), ops.pack_weight_b3(dev(w)), co, dev(sc), dev(sf), dev(rs), act).cpu()
+    y_f32 = ops.conv3d(dev(x), ops.pack_weight(dev(w)), spec, dev(sc), dev(sf), dev(rs)).detach().cpu()
+    scale64 = float(y64.abs().max())
+    e_b3 = float((y_b3.double() - y64).abs().max()) / scale64
+    e_f32 = float((y_f32.double() - y64).abs().max()) / scale64
+    assert e_b3 < 2e-6 and e_b3 < 4 * e_f32 + 5e-7, "3xBF16 forward error %.2e (exact fp32 MFMA: %.2e)" % (e_b3, e_f32)
+    # data gradient = the same kernel on the transposed, mirrored weights
+    g = randn(gen, n, *dhw, co)
+    dx64 = F.conv_transpose3d(g.double().permute(0, 4, 1, 2, 3), w.double(), padding=1).permute(0, 2, 3, 4, 1)
+    if ci % 4 == 0 and co % 8 == 0:
+        dx_b3 = ops.conv3d_b3(dev(g), ops.pack_weight_b3(dev(w), transpose_flip=True), ci).cpu()
+        e_dx = float((dx_b3.double() - dx64).abs().max()) / float(dx64.abs().max())
+        assert e_dx < 2e-6, "3xBF16 data-gradient error %.2e" % e_dx
+    return e_b3, e_f32

@@ -82,3 +82,9 @@ def test_mask_target_labels(emu):
 
 def test_weight_layouts(emu):
     kc.check_weight_layouts(emu)
+
+
+def test_conv_b3_experimental(emu):
+    """3xBF16 conv prototype on the emulator (the emulated bf16 MFMA sums in its own order: tolerances only)."""
+    kc.check_conv_b3(emu, 1, (5, 6, 17), 8, 20, act=kc.ACT_LRELU, shift=True)
+    kc.check_conv_b3(emu, 2, (4, 4, 16), 24, 40, scale=True, res=True)
