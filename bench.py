@@ -26,6 +26,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0           # HBM3E spec (MI355X_MICROARCH.md; ~6.3 TB/s achievable)
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak (= fp32 vector peak)
+PEAK_BF16_MFMA_TFLOPS = 2516.6    # dense bf16 matrix peak (256 CUs x 4 SIMDs x 1024 flop/clk x 2.4 GHz; "~2.5 PF")
+B3_PRODUCTS = 6                   # bf16 MFMA products per fp32 multiply-add on the opt-in 3xBF16 path
 
 WORKLOADS = {
     # name: (stage, H, W, D)
@@ -113,6 +115,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true",
+                    help="skip the extra, separately reported leg on the opt-in 3xBF16 conv kernels (CFUN_CONV_ALGO=b3)")
     ap.add_argument("--sharded", action="store_true",
                     help="N > 1: ONE volume per step over all ranks (depth-sharded FPN/RPN with halo exchange, head "
                          "RoIs dealt round-robin; strong scaling) instead of one volume per rank")
@@ -169,6 +173,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    b3 = os.environ.get("CFUN_CONV_ALGO", "auto") == "b3"     # the whole run on the opt-in 3xBF16 kernels: labelled below
     for _ in range(args.warmup):
         losses = one_step()
     fence()
@@ -179,6 +184,27 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     ops.set_launch_timer(None)
+    alt = None
+    if world == 1 and not b3 and not args.no_alt and args.workload == "cfg2":
+        # NOT part of `value`: the same step with the eligible 3x3x3 convs (forward + data gradient) on the
+        # experimental 3xBF16 kernels, timed the same way, reported beside the exact-fp32 result
+        os.environ["CFUN_CONV_ALGO"] = "b3"
+        try:
+            for _ in range(2):
+                alt_losses = one_step()
+            fence()
+            ta = time.perf_counter()
+            for _ in range(args.steps):
+                alt_losses = one_step()
+            fence()
+            ta = time.perf_counter() - ta
+        finally:
+            os.environ["CFUN_CONV_ALGO"] = "auto"
+        alt = {"what": "same step, eligible 3x3x3 convs (forward + data gradient) on the opt-in 3xBF16 kernels "
+                       "(conv3d_b3.hip: fp32 operands split into 3 bf16, 6 cross terms, fp32 accumulate; "
+                       "weight gradients stay on the exact fp32 MFMA path); not used for `value`",
+               "value": args.steps / ta, "unit": "volumes/s", "ms_per_step": 1e3 * ta / args.steps,
+               "losses": [float(l.detach()) for l in alt_losses]}
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -201,7 +227,9 @@ def main():
             "value": (1 if sharded else world) * args.steps / elapsed, "unit": "volumes/s", "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if sharded else "weak", "vs_baseline": None,
+            "dtype": "f32 (conv forward/dgrad operands as 3 x bf16 on the bf16 MFMA, fp32 accumulate)" if b3 else "f32",
+            "data": "synthetic",
             "config": {"workload": "%s: %dx%dx%d CT, stage '%s', 4 positive + 8 negative RoIs, U-Net b=%d, "
                                    "96^3 -> %d^3 masks, 6 losses incl. 3-D Sobel edge loss, fwd+bwd"
                                    % (args.workload, h, w, d, stage, b, cfg.MASK_SHAPE[0]),
@@ -219,6 +247,14 @@ def main():
                                    % (2 * b, 2 * b, n_roi_launch, side[0]),
                          "flops_per_launch": flops, "avg_launch_ms": t_k * 1e3, "launches_timed": len(durs)},
         }
+        if b3:   # algorithmic (fp32) flops against the bf16 matrix peak divided by the 6 products each one costs
+            peak = PEAK_BF16_MFMA_TFLOPS / B3_PRODUCTS
+            result["roofline"].update(peak=peak, frac=achieved / peak, traffic=None, mfma_util_pmc=None,
+                                      kernel="k_conv_b3<3> (conv_norm_lrelu_l4.0: 3x3x3 %d->%d @ %dx%d^3; peak = bf16 "
+                                             "dense %.1f / %d products per fp32 MAC)"
+                                             % (2 * b, 2 * b, n_roi_launch, side[0], PEAK_BF16_MFMA_TFLOPS, B3_PRODUCTS))
+        if alt is not None:
+            result["alt_3xbf16"] = alt
         if durs_h:   # north_star's "HBM roofline on the 3x3x3 conv kernel": the C_in = 1 stem, algorithmic bytes / time
             t_h = sum(durs_h) / len(durs_h) * 1e-3
             vox = n_roi_launch * side[0] * side[1] * side[2]

@@ -85,6 +85,7 @@ _SIGNATURES = {
     "cfun_weight_pack_transpose": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "cfun_weight_pack_both": (C.c_int, [_P, _P, _P, _I, _I, _I, _P]),
     "cfun_conv3d_b3_supported": (C.c_int, [_PP]),
+    "cfun_conv3d_b3_preferred": (C.c_int, [_PP]),
     "cfun_weight_pack_b3_bytes": (_Z, [_I, _I]),
     "cfun_weight_pack_b3": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "cfun_conv3d_b3_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _PP, _P]),

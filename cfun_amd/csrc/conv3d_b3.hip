@@ -10,8 +10,9 @@
 // tap 4s+kb of the 27, the 28th slot carries zero weights), so an 8-channel input chunk is staged per barrier pair:
 // the fp32 halo tile is split into its three bf16 planes on the way into LDS ([plane][voxel][8 ch] = 16 B per voxel,
 // one ds_read_b128 per B operand, at a per-lane tap offset).  The weights are pre-split and pre-swizzled on the device
-// (cfun_weight_pack_b3) into exactly the per-lane A-operand order, [chunk][step][subtile][plane][lane][8 bf16], and are
-// read straight from global memory / L2 with coalesced 16-byte loads, double-buffered one K-step ahead.
+// (cfun_weight_pack_b3; K padded with zero weights to a multiple of 8 channels) into exactly the per-lane A-operand
+// order, [chunk][step][subtile][plane][lane][8 bf16], and are read straight from global memory / L2 with coalesced
+// 16-byte loads, double-buffered one K-step ahead.
 #include "conv3d_mfma.h"
 
 namespace {
@@ -137,7 +138,8 @@ k_conv_b3(const float* __restrict__ x, const b3_u32x4* __restrict__ wb3, const f
   auto prefetch_x = [&](int c) {
 #pragma unroll
     for (int i = 0; i < IN_LOADS; ++i)
-      xin[i] = in_off[i] >= 0 ? *reinterpret_cast<const float4*>(x + in_off[i] + c * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+      xin[i] = (in_off[i] >= 0 && c * 8 + ((tid + i * 256) & 1) * 4 < p.Ci)      // C_in % 8 == 4: the last half is zero
+                   ? *reinterpret_cast<const float4*>(x + in_off[i] + c * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
   auto commit_x = [&]() {
 #pragma unroll
@@ -183,7 +185,7 @@ k_conv_b3(const float* __restrict__ x, const b3_u32x4* __restrict__ wb3, const f
 #pragma unroll
     for (int nn = 0; nn < NSUB; ++nn) acc[m][nn] = b3_f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nchunks = p.Ci >> 3, nsteps = nchunks * kB3Steps;
+  const int nchunks = (p.Ci + 7) >> 3, nsteps = nchunks * kB3Steps;
   prefetch_x(0);
   load_a(a_cur, 0);
   for (int c = 0; c < nchunks; ++c) {
@@ -269,9 +271,11 @@ int launch_b3(const float* x, const void* wb3, const float* scale, const float* 
 
 inline bool b3_shape_ok(const CfunConv3dParams* p) {
   return p->kd == 3 && p->kh == 3 && p->kw == 3 && p->stride == 1 && p->pd == 1 && p->ph == 1 && p->pw == 1 && !p->up2 &&
-         !p->d2s && !p->res_up2 && !p->tap_skip && (p->Ci & 7) == 0 && (p->Co & 3) == 0 && p->Ci >= 8 &&
+         !p->d2s && !p->res_up2 && !p->tap_skip && (p->Ci & 3) == 0 && (p->Co & 3) == 0 && p->Ci >= 8 &&
          p->Do == p->Di && p->Ho == p->Hi && p->Wo == p->Wi;
 }
+
+inline int b3_nsub_per_block(int nsub) { return nsub % 3 == 0 ? 3 : nsub % 5 == 0 ? 5 : nsub % 4 == 0 ? 4 : nsub % 2 == 0 ? 2 : 1; }
 
 }  // namespace
 
@@ -279,16 +283,25 @@ extern "C" {
 
 int cfun_conv3d_b3_supported(const CfunConv3dParams* p) { return p && b3_shape_ok(p) ? 1 : 0; }
 
+// supported AND expected to beat the exact-fp32 MFMA kernel: with fewer workgroups than ~half the CUs the fp32 path's
+// split-K wins (measured: 64-72 workgroups 0.5-0.8x, 144 1.24x, >= 288 1.3-2.3x; tools/bench_b3.py)
+int cfun_conv3d_b3_preferred(const CfunConv3dParams* p) {
+  if (!p || !b3_shape_ok(p)) return 0;
+  const int nsub = (p->Co + 15) / 16;
+  const int64_t nblk = (int64_t)p->N * ((p->Do + 3) / 4) * ((p->Ho + 3) / 4) * ((p->Wo + 15) / 16) * (nsub / b3_nsub_per_block(nsub));
+  return nblk >= 120 ? 1 : 0;
+}
+
 size_t cfun_weight_pack_b3_bytes(int32_t rows, int32_t kch) {
-  if (rows <= 0 || kch <= 0 || (kch & 7)) return 0;
-  return (size_t)(kch / 8) * kB3Steps * ((rows + 15) / 16) * 3 * 64 * 16;
+  if (rows <= 0 || kch <= 0) return 0;
+  return (size_t)((kch + 7) / 8) * kB3Steps * ((rows + 15) / 16) * 3 * 64 * 16;
 }
 
 int cfun_weight_pack_b3(const float* w, void* wb3, int32_t Co, int32_t Ci, int32_t transpose_flip, cfun_stream_t stream) {
   const int rows = transpose_flip ? Ci : Co, kch = transpose_flip ? Co : Ci;
-  if (rows <= 0 || kch <= 0 || (kch & 7)) return CFUN_EINVAL;
+  if (rows <= 0 || kch <= 0) return CFUN_EINVAL;
   const int nsub = (rows + 15) / 16;
-  const int64_t total = (int64_t)(kch / 8) * kB3Steps * nsub * 64 * 8;
+  const int64_t total = (int64_t)((kch + 7) / 8) * kB3Steps * nsub * 64 * 8;
   int64_t blocks = (total + 255) / 256;
   if (blocks > 65536) blocks = 65536;
   hipLaunchKernelGGL(k_pack_b3, dim3((unsigned)blocks), dim3(256), 0, cfun_st(stream), w, (unsigned short*)wb3, Co, Ci, rows,
@@ -303,10 +316,13 @@ int cfun_conv3d_b3_fwd(const float* x, const void* wb3, const float* scale, cons
   if (!cfun_aligned16(x) || !cfun_aligned16(wb3) || !cfun_aligned16(y)) return CFUN_EALIGN;
   const int nsub = (p->Co + 15) / 16;
   hipStream_t st = cfun_st(stream);
-  if (nsub % 3 == 0) return launch_b3<3>(x, wb3, scale, shift, res, y, *p, nsub, st);
-  if (nsub % 5 == 0) return launch_b3<5>(x, wb3, scale, shift, res, y, *p, nsub, st);
-  if (nsub % 2 == 0) return launch_b3<2>(x, wb3, scale, shift, res, y, *p, nsub, st);
-  return launch_b3<1>(x, wb3, scale, shift, res, y, *p, nsub, st);
+  switch (b3_nsub_per_block(nsub)) {
+    case 3: return launch_b3<3>(x, wb3, scale, shift, res, y, *p, nsub, st);
+    case 5: return launch_b3<5>(x, wb3, scale, shift, res, y, *p, nsub, st);
+    case 4: return launch_b3<4>(x, wb3, scale, shift, res, y, *p, nsub, st);
+    case 2: return launch_b3<2>(x, wb3, scale, shift, res, y, *p, nsub, st);
+    default: return launch_b3<1>(x, wb3, scale, shift, res, y, *p, nsub, st);
+  }
 }
 
 }  // extern "C"

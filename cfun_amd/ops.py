@@ -6,6 +6,7 @@ gradients arrive in the reference's OIDHW layout and shared weights (mask_branch
 autograd.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import torch
@@ -188,6 +189,14 @@ def set_launch_timer(timer):
     _TIMER = timer
 
 
+def _b3_wanted(lib, p):
+    """CFUN_CONV_ALGO=b3: the 3xBF16 kernel for this conv?  ``b3!`` (tests) takes every supported shape, ``b3`` only those
+    large enough to beat the exact-fp32 kernel (cfun_conv3d_b3_preferred)."""
+    if os.environ.get("CFUN_CONV_ALGO") == "b3!":
+        return bool(lib.cfun_conv3d_b3_supported(C.byref(p)))
+    return bool(lib.cfun_conv3d_b3_preferred(C.byref(p)))
+
+
 class _Conv3d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, wp, scale, shift, res, spec, out=None, dx_slot=None, w_src=None):
@@ -199,7 +208,7 @@ class _Conv3d(torch.autograd.Function):
         res = None if res is None else _c(res)
         p = _params(spec, x.shape, scale is not None, shift is not None, res is not None)
         # opt-in 3xBF16 kernels (CFUN_CONV_ALGO=b3): forward here, data gradient in backward; wgrad stays exact fp32
-        b3 = bool(spec.algo == ALGO_B3 and w_src is not None and lib.cfun_conv3d_b3_supported(C.byref(p)))
+        b3 = bool(spec.algo == ALGO_B3 and w_src is not None and _b3_wanted(lib, p))
         if b3:
             wp, wb3 = None, pack_weight_b3(w_src)
         elif w_src is not None:      # OIDHW weight: packed here, its gradient comes back in OIDHW (one fused pass)
@@ -274,7 +283,7 @@ class _Conv3d(torch.autograd.Function):
             pd = None
             if ctx.b3:       # the data gradient is the same 3x3x3 conv on g with transposed, mirrored weights
                 pd = _params(ConvSpec(k=(3, 3, 3), co=p.Ci, pad=(1, 1, 1)), g.shape, False, False, False)
-                if not lib.cfun_conv3d_b3_supported(C.byref(pd)):
+                if not _b3_wanted(lib, pd):
                     pd = None
             if pd is not None:
                 wb3t = pack_weight_b3(w_b3, transpose_flip=True)     # (held until the launch is enqueued)
@@ -337,8 +346,6 @@ def pack_weight_b3(w, transpose_flip=False):
     co, ci = w.shape[0], w.shape[1]
     rows, kch = (ci, co) if transpose_flip else (co, ci)
     nb = lib.cfun_weight_pack_b3_bytes(rows, kch)
-    if nb == 0:
-        raise ValueError("pack_weight_b3: K = %d channels is not a multiple of 8" % kch)
     wb3 = torch.empty(nb, dtype=torch.uint8, device=w.device)
     check(lib.cfun_weight_pack_b3(ptr(w), ptr(wb3), co, ci, int(transpose_flip), stream(w)), "weight_pack_b3")
     return wb3
@@ -351,7 +358,7 @@ def conv3d_b3(x, wb3, co, scale=None, shift=None, res=None, act=ACT_NONE, scale_
     spec = ConvSpec(k=(3, 3, 3), co=co, pad=(1, 1, 1), act=act, scale_per_n=scale_per_n)
     p = _params(spec, x.shape, scale is not None, shift is not None, res is not None)
     if not lib.cfun_conv3d_b3_supported(C.byref(p)):
-        raise ValueError("conv3d_b3: unsupported shape (needs C_in % 8 == 0, C_out % 4 == 0)")
+        raise ValueError("conv3d_b3: unsupported shape (needs C_in % 4 == 0, C_in >= 8, C_out % 4 == 0)")
     y = torch.empty((p.N, p.Do, p.Ho, p.Wo, p.Co), dtype=torch.float32, device=x.device)
     scale, shift, res = [None if t is None else _c(t) for t in (scale, shift, res)]      # held across the launch
     check(lib.cfun_conv3d_b3_fwd(ptr(x), ptr(wb3), ptr(scale), ptr(shift), ptr(res), ptr(y), C.byref(p), stream(x)),

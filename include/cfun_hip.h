@@ -253,13 +253,14 @@ int cfun_mask_losses_bwd_saved(const float* probs, const uint8_t* labels, const 
 int cfun_weight_pack(const float* w, float* wp, int32_t Co, int32_t Ci, int32_t T, cfun_stream_t stream);
 int cfun_weight_pack_transpose(const float* wp, float* wpT, int32_t Co, int32_t Ci, int32_t T, cfun_stream_t stream);
 /* EXPERIMENTAL, opt-in (not used by the drop-in modules): 3x3x3 stride-1 pad-1 conv (backbone.py / mask_branch.py
- * 3x3x3 layers with C_in % 8 == 0, C_out % 4 == 0) with the fp32 operands emulated on the bf16 matrix cores: every
+ * 3x3x3 layers with C_in % 4 == 0, C_in >= 8, C_out % 4 == 0) with the fp32 operands emulated on the bf16 matrix cores: every
  * fp32 value is split exactly into three bf16 values and the six significant cross products are accumulated in fp32
  * ("3xBF16"; the neglected terms are below 2^-25 of each product).  cfun_weight_pack_b3 splits and swizzles an OIDHW
  * weight [Co,Ci,3,3,3] into the kernel's A-operand order (cfun_weight_pack_b3_bytes(rows, kch) bytes; rows = Co,
  * kch = Ci -- or, with transpose_flip = 1, the data-gradient's weights: rows = Ci, kch = Co).  Epilogue: scale_mode,
  * shift, plain residual and activation as cfun_conv3d_fwd; no up2 / d2s / tap_skip. */
 int cfun_conv3d_b3_supported(const CfunConv3dParams* p);
+int cfun_conv3d_b3_preferred(const CfunConv3dParams* p);   /* supported and large enough to beat the fp32 MFMA kernel */
 size_t cfun_weight_pack_b3_bytes(int32_t rows, int32_t kch);
 int cfun_weight_pack_b3(const float* w, void* wb3, int32_t Co, int32_t Ci, int32_t transpose_flip, cfun_stream_t stream);
 int cfun_conv3d_b3_fwd(const float* x, const void* wb3, const float* scale, const float* shift, const float* res,

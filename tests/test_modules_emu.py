@@ -99,5 +99,5 @@ def test_unmold_lits_golden(emu):
 
 def test_b3_training_step_vs_oracle(emu, monkeypatch):
     """Opt-in 3xBF16 conv kernels through the module path (CFUN_CONV_ALGO=b3) on the emulator."""
-    monkeypatch.setenv("CFUN_CONV_ALGO", "b3")
+    monkeypatch.setenv("CFUN_CONV_ALGO", "b3!")
     mc.check_training_step_vs_oracle(emu, mc.tiny_config("beginning"), n_pos=1)

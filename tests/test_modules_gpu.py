@@ -300,13 +300,13 @@ def test_mask_head_side_stream(gpu):
 
 # ---- opt-in 3xBF16 conv kernels (CFUN_CONV_ALGO=b3): the same parity gates as the default fp32 MFMA path
 def test_b3_unet_golden(gpu, monkeypatch):
-    monkeypatch.setenv("CFUN_CONV_ALGO", "b3")
+    monkeypatch.setenv("CFUN_CONV_ALGO", "b3!")
     for name in ("unet_beginning_train", "unet_finetune_train"):
         mc.check_unet_golden(gpu, name)
 
 
 def test_b3_training_step_tiny_vs_oracle(gpu, monkeypatch):
-    monkeypatch.setenv("CFUN_CONV_ALGO", "b3")
+    monkeypatch.setenv("CFUN_CONV_ALGO", "b3!")
     mc.check_training_step_vs_oracle(gpu, mc.tiny_config("finetune"))
 
 
@@ -314,10 +314,10 @@ def test_b3_training_step_cfg0_vs_oracle(gpu, monkeypatch):
     """Real channel counts (b = 20: the 40 / 80 / 160 / 320-channel 3x3x3 layers and FPN / RPN run on the 3xBF16
     kernels, forward and data gradient) against the oracle on the host."""
     from cfun_amd import config
-    monkeypatch.setenv("CFUN_CONV_ALGO", "b3")
+    monkeypatch.setenv("CFUN_CONV_ALGO", "b3!")
     mc.check_training_step_vs_oracle(gpu, config.heart_config("beginning", 64, 64, 32), n_pos=2)
 
 
 def test_b3_predict_cfg0_reference_golden(gpu, monkeypatch):
-    monkeypatch.setenv("CFUN_CONV_ALGO", "b3")
+    monkeypatch.setenv("CFUN_CONV_ALGO", "b3!")
     mc.check_predict_cfg0_golden(gpu)

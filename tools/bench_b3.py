@@ -12,7 +12,12 @@ from cfun_amd import ops  # noqa: E402
 
 SHAPES = [("l4.0 40->40 @4x96^3", 4, 96, 40, 40), ("l3.0 80->80 @4x48^3", 4, 48, 80, 80),
           ("l2.0 160->160 @4x24^3", 4, 24, 160, 160), ("l1.0 320->320 @4x12^3", 4, 12, 320, 320),
-          ("nlc_c2 40->40 @4x48^3", 4, 48, 40, 40)]
+          ("nlc_c2 40->40 @4x48^3", 4, 48, 40, 40), ("nlc_c5 320->320 @4x6^3", 4, 6, 320, 320),
+          ("160->160 @4x12^3", 4, 12, 160, 160), ("80->80 @4x24^3", 4, 24, 80, 80), ("c1 20->20 @4x96^3", 4, 96, 20, 20),
+          ("l3.1 80->40 @4x48^3", 4, 48, 80, 40), ("sparse 40->16 @1x96^3", 1, 96, 40, 16),
+          ("sparse 16->40 @1x96^3", 1, 96, 16, 40), ("sparse 8->20 @1x96^3", 1, 96, 8, 20),
+          ("FPN P2 128->128 @1x32^3", 1, 32, 128, 128), ("RPN 128->256 @1x32^3", 1, 32, 128, 256),
+          ("RPN 128->256 @1x16^3", 1, 16, 128, 256)]
 dev = torch.device("cuda")
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 
