@@ -110,7 +110,7 @@ k_conv_b3(const float* __restrict__ x, const b3_u32x4* __restrict__ wb3, const f
           int ntz, int nty, int ntx, int ncot, int nsub_total) {
   constexpr int NT = 16 * NSUB;
   constexpr int ITEMS = kB3Vox * 2, IN_LOADS = (ITEMS + 255) / 256;     // float4 (4 channels) items per chunk
-  CFUN_DYN_LDS(unsigned char, smem);                                     // [3 planes][kB3Vox][16 B]
+  CFUN_DYN_LDS(unsigned char, smem);                                     // [2 buffers][3 planes][kB3Vox][16 B]
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
   const int cot = lid % ncot; lid /= ncot;
@@ -141,7 +141,7 @@ k_conv_b3(const float* __restrict__ x, const b3_u32x4* __restrict__ wb3, const f
       xin[i] = (in_off[i] >= 0 && c * 8 + ((tid + i * 256) & 1) * 4 < p.Ci)      // C_in % 8 == 4: the last half is zero
                    ? *reinterpret_cast<const float4*>(x + in_off[i] + c * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
-  auto commit_x = [&]() {
+  auto commit_x = [&](int buf) {          // split the prefetched fp32 halo into its three bf16 planes of LDS buffer `buf`
 #pragma unroll
     for (int i = 0; i < IN_LOADS; ++i) {
       const int idx = tid + i * 256;
@@ -149,7 +149,7 @@ k_conv_b3(const float* __restrict__ x, const b3_u32x4* __restrict__ wb3, const f
         unsigned h0, m0, l0, h1, m1, l1;
         b3_split_pair(xin[i].x, xin[i].y, h0, m0, l0);
         b3_split_pair(xin[i].z, xin[i].w, h1, m1, l1);
-        unsigned char* dst = smem + (idx >> 1) * 16 + (idx & 1) * 8;
+        unsigned char* dst = smem + buf * (3 * kB3Plane) + (idx >> 1) * 16 + (idx & 1) * 8;
         *reinterpret_cast<b3_u32x2*>(dst) = b3_u32x2{h0, h1};
         *reinterpret_cast<b3_u32x2*>(dst + kB3Plane) = b3_u32x2{m0, m1};
         *reinterpret_cast<b3_u32x2*>(dst + 2 * kB3Plane) = b3_u32x2{l0, l1};
@@ -185,21 +185,27 @@ k_conv_b3(const float* __restrict__ x, const b3_u32x4* __restrict__ wb3, const f
 #pragma unroll
     for (int nn = 0; nn < NSUB; ++nn) acc[m][nn] = b3_f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Two LDS buffers: chunk c+1 is split and written (VALU + ds_write, in the middle of chunk c's MFMA stream) while
+  // chunk c is being read, so a chunk costs ONE barrier and the conversion work hides behind the matrix pipe.
   const int nchunks = (p.Ci + 7) >> 3, nsteps = nchunks * kB3Steps;
   prefetch_x(0);
   load_a(a_cur, 0);
+  commit_x(0);
+  if (nchunks > 1) prefetch_x(1);
+  __syncthreads();
   for (int c = 0; c < nchunks; ++c) {
-    __syncthreads();           // every wave is done reading the previous chunk
-    commit_x();
-    __syncthreads();
-    if (c + 1 < nchunks) prefetch_x(c + 1);
+    const unsigned char* xb = smem + (c & 1) * (3 * kB3Plane);
 #pragma unroll
     for (int s = 0; s < kB3Steps; ++s) {
       const int g = c * kB3Steps + s;
       if (g + 1 < nsteps) load_a(a_nxt, g + 1);
+      if (s == 3 && c + 1 < nchunks) {       // every wave left buffer (c+1)&1 at the barrier that ended chunk c-1
+        commit_x((c + 1) & 1);
+        if (c + 2 < nchunks) prefetch_x(c + 2);
+      }
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        const unsigned char* bp = smem + boff[s] + m * (kB3IX * 16);
+        const unsigned char* bp = xb + boff[s] + m * (kB3IX * 16);
         const b3_u32x4 b0 = *reinterpret_cast<const b3_u32x4*>(bp);
         const b3_u32x4 b1 = *reinterpret_cast<const b3_u32x4*>(bp + kB3Plane);
         const b3_u32x4 b2 = *reinterpret_cast<const b3_u32x4*>(bp + 2 * kB3Plane);
@@ -222,6 +228,7 @@ k_conv_b3(const float* __restrict__ x, const b3_u32x4* __restrict__ wb3, const f
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) a_cur[nn][pl] = a_nxt[nn][pl];
     }
+    __syncthreads();           // chunk c+1 is complete in its buffer; chunk c's buffer is free
   }
 
   // ---- epilogue: lane owns voxel (z0+wv, y0+m, x0+(lane&15)), channels nn*16 + (lane>>4)*4 .. +3
@@ -263,7 +270,7 @@ int launch_b3(const float* x, const void* wb3, const float* scale, const float* 
   const int64_t nblk = (int64_t)p.N * ntz * nty * ntx * ncot;
   if (nblk == 0) return CFUN_OK;
   if (nblk > 0x7fffffffLL) return CFUN_EINVAL;
-  hipLaunchKernelGGL((k_conv_b3<NSUB>), dim3((unsigned)nblk), dim3(256), (size_t)3 * kB3Plane, st, x,
+  hipLaunchKernelGGL((k_conv_b3<NSUB>), dim3((unsigned)nblk), dim3(256), (size_t)2 * 3 * kB3Plane, st, x,
                      (const b3_u32x4*)wb3, scale, shift, res, y, p, ntz, nty, ntx, ncot, nsub_total);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
