@@ -89,6 +89,10 @@ _SIGNATURES = {
     "cfun_weight_pack_b3_bytes": (_Z, [_I, _I]),
     "cfun_weight_pack_b3": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "cfun_conv3d_b3_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _PP, _P]),
+    "cfun_conv3d_b3_wgrad_supported": (C.c_int, [_PP]),
+    "cfun_conv3d_b3_wgrad_preferred": (C.c_int, [_PP]),
+    "cfun_conv3d_b3_wgrad_workspace_bytes": (_Z, [_PP]),
+    "cfun_conv3d_b3_wgrad_oidhw": (C.c_int, [_P, _P, _P, _PP, _P, _Z, _P]),
     "cfun_weight_unpack": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "cfun_halo_pack": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "cfun_halo_unpack": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

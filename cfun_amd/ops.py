@@ -197,6 +197,12 @@ def _b3_wanted(lib, p):
     return bool(lib.cfun_conv3d_b3_preferred(C.byref(p)))
 
 
+def _b3_wgrad_wanted(lib, p):
+    if os.environ.get("CFUN_CONV_ALGO") == "b3!":
+        return bool(lib.cfun_conv3d_b3_wgrad_supported(C.byref(p)))
+    return bool(lib.cfun_conv3d_b3_wgrad_preferred(C.byref(p)))
+
+
 class _Conv3d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, wp, scale, shift, res, spec, out=None, dx_slot=None, w_src=None):
@@ -304,10 +310,15 @@ class _Conv3d(torch.autograd.Function):
                   "conv3d_bwd_weight")
         if need_wsrc:
             dw = torch.empty(ctx.wshape, dtype=torch.float32, device=dy.device)
-            nb = lib.cfun_conv3d_bwd_weight_workspace_bytes(C.byref(p))
-            ws = workspace(nb, x)
-            check(lib.cfun_conv3d_bwd_weight_oidhw(ptr(x), ptr(g), ptr(dw), C.byref(p), ptr(ws), ws.numel(), st),
-                  "conv3d_bwd_weight_oidhw")
+            if spec.algo == ALGO_B3 and _b3_wgrad_wanted(lib, p):      # opt-in 3xBF16 weight gradient
+                ws = workspace(lib.cfun_conv3d_b3_wgrad_workspace_bytes(C.byref(p)), x)
+                check(lib.cfun_conv3d_b3_wgrad_oidhw(ptr(x), ptr(g), ptr(dw), C.byref(p), ptr(ws), ws.numel(), st),
+                      "conv3d_b3_wgrad_oidhw")
+            else:
+                nb = lib.cfun_conv3d_bwd_weight_workspace_bytes(C.byref(p))
+                ws = workspace(nb, x)
+                check(lib.cfun_conv3d_bwd_weight_oidhw(ptr(x), ptr(g), ptr(dw), C.byref(p), ptr(ws), ws.numel(), st),
+                      "conv3d_bwd_weight_oidhw")
         if need_shift:
             dshift = channel_sum(gp.view(-1, p.Co))
         if need_res:
@@ -364,6 +375,20 @@ def conv3d_b3(x, wb3, co, scale=None, shift=None, res=None, act=ACT_NONE, scale_
     check(lib.cfun_conv3d_b3_fwd(ptr(x), ptr(wb3), ptr(scale), ptr(shift), ptr(res), ptr(y), C.byref(p), stream(x)),
           "conv3d_b3_fwd")
     return y
+
+
+def conv3d_b3_wgrad(x, g, co):
+    """dW [Co,Ci,3,3,3] of y = conv3x3x3(x, W) (stride 1, pad 1) from x [N,D,H,W,Ci] and g = dL/dy [N,D,H,W,Co]."""
+    lib = _lib.load()
+    x, g = _c(x.detach()), _c(g.detach())
+    p = _params(ConvSpec(k=(3, 3, 3), co=co, pad=(1, 1, 1)), x.shape, False, False, False)
+    if not lib.cfun_conv3d_b3_wgrad_supported(C.byref(p)):
+        raise ValueError("conv3d_b3_wgrad: unsupported shape")
+    dw = torch.empty((co, x.shape[-1], 3, 3, 3), dtype=torch.float32, device=x.device)
+    ws = workspace(lib.cfun_conv3d_b3_wgrad_workspace_bytes(C.byref(p)), x)
+    check(lib.cfun_conv3d_b3_wgrad_oidhw(ptr(x), ptr(g), ptr(dw), C.byref(p), ptr(ws), ws.numel(), stream(x)),
+          "conv3d_b3_wgrad")
+    return dw
 
 
 # ---- zero-copy batch split / join (per-sample convs inside a batched graph) ------------------------------------

@@ -266,6 +266,14 @@ int cfun_weight_pack_b3(const float* w, void* wb3, int32_t Co, int32_t Ci, int32
 int cfun_conv3d_b3_fwd(const float* x, const void* wb3, const float* scale, const float* shift, const float* res,
                        float* y, const CfunConv3dParams* p, cfun_stream_t stream);
 
+/* EXPERIMENTAL, opt-in: the weight gradient of the same convs on the bf16 matrix cores (conv3d_b3_wgrad.hip; same
+ * operand split).  dw = torch OIDHW [Co,Ci,3,3,3] as cfun_conv3d_bwd_weight_oidhw; ws: _workspace_bytes(p). */
+int cfun_conv3d_b3_wgrad_supported(const CfunConv3dParams* p);
+int cfun_conv3d_b3_wgrad_preferred(const CfunConv3dParams* p);
+size_t cfun_conv3d_b3_wgrad_workspace_bytes(const CfunConv3dParams* p);
+int cfun_conv3d_b3_wgrad_oidhw(const float* x, const float* g, float* dw, const CfunConv3dParams* p, void* ws,
+                               size_t ws_bytes, cfun_stream_t stream);
+
 /* cfun_weight_pack and cfun_weight_pack_transpose of the same OIDHW weight in ONE launch (a training step needs both
  * layouts of every conv weight: wp for the forward / weight-gradient kernels, wpT for the data gradient). */
 int cfun_weight_pack_both(const float* w, float* wp, float* wpT, int32_t Co, int32_t Ci, int32_t T, cfun_stream_t stream);

@@ -428,4 +428,10 @@ def check_conv_b3(device, n, dhw, ci, co, seed=21, act=ACT_NONE, scale=False, sh
         dx_b3 = ops.conv3d_b3(dev(g), ops.pack_weight_b3(dev(w), transpose_flip=True), ci).cpu()
         e_dx = float((dx_b3.double() - dx64).abs().max()) / float(dx64.abs().max())
         assert e_dx < 2e-6, "3xBF16 data-gradient error %.2e" % e_dx
+    # weight gradient (conv3d_b3_wgrad.hip)
+    dw64 = torch.nn.grad.conv3d_weight(x.double().permute(0, 4, 1, 2, 3), (co, ci, 3, 3, 3),
+                                       g.double().permute(0, 4, 1, 2, 3), padding=1)
+    dw_b3 = ops.conv3d_b3_wgrad(dev(x), dev(g), co).cpu()
+    e_dw = float((dw_b3.double() - dw64).abs().max()) / float(dw64.abs().max())
+    assert e_dw < 3e-6, "3xBF16 weight-gradient error %.2e" % e_dw
     return e_b3, e_f32

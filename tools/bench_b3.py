@@ -35,6 +35,20 @@ def timed(fn):
     return e0.elapsed_time(e1) / iters
 
 
+import ctypes as C  # noqa: E402
+from cfun_amd import _lib  # noqa: E402
+from cfun_amd._lib import check, ptr, stream, workspace  # noqa: E402
+
+
+def wgrad_fp32(x, g, co):
+    lib = _lib.load()
+    p = ops._params(ops.ConvSpec(k=(3, 3, 3), co=co, pad=(1, 1, 1)), x.shape, False, False, False)
+    dw = torch.empty((co, x.shape[-1], 3, 3, 3), dtype=torch.float32, device=x.device)
+    ws = workspace(lib.cfun_conv3d_bwd_weight_workspace_bytes(C.byref(p)), x)
+    check(lib.cfun_conv3d_bwd_weight_oidhw(ptr(x), ptr(g), ptr(dw), C.byref(p), ptr(ws), ws.numel(), stream(x)), "wgrad")
+    return dw
+
+
 print("%-26s %10s %10s %8s %12s %12s" % ("layer", "fp32 ms", "3xbf16 ms", "speedup", "err fp32", "err 3xbf16"))
 for name, n, s, ci, co in SHAPES:
     g = torch.Generator().manual_seed(0)
@@ -56,3 +70,10 @@ for name, n, s, ci, co in SHAPES:
     fl = 2.0 * ci * co * 27 * n * s ** 3
     print("%-26s %10.3f %10.3f %8.2f %12.2e %12.2e   (%.0f -> %.0f TFLOP/s)" % (name, t32, tb3, t32 / tb3, e32, eb3,
                                                                                fl / t32 / 1e9, fl / tb3 / 1e9))
+    gg = torch.randn(n, s, s, s, co, generator=g).to(dev)
+    w32 = timed(lambda: wgrad_fp32(x, gg, co))
+    wb = timed(lambda: ops.conv3d_b3_wgrad(x, gg, co))
+    d32, db = wgrad_fp32(x, gg, co), ops.conv3d_b3_wgrad(x, gg, co)
+    ed = float((d32 - db).abs().max()) / float(d32.abs().max())
+    print("%-26s %10.3f %10.3f %8.2f %12s %12.2e   (%.0f -> %.0f TFLOP/s)" % ("   wgrad", w32, wb, w32 / wb, "(vs fp32:)", ed,
+                                                                             fl / w32 / 1e9, fl / wb / 1e9))
