@@ -13,6 +13,7 @@
 // (cfun_weight_pack_b3; K padded with zero weights to a multiple of 8 channels) into exactly the per-lane A-operand
 // order, [chunk][step][subtile][plane][lane][8 bf16], and are read straight from global memory / L2 with coalesced
 // 16-byte loads, double-buffered one K-step ahead.
+#include "b3_common.h"
 #include "conv3d_mfma.h"
 
 namespace {
@@ -20,62 +21,9 @@ namespace {
 using cfun_mfma::tile_raster;
 using cfun_mfma::xcd_remap;
 
-typedef float b3_f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned b3_u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned b3_u32x2 __attribute__((ext_vector_type(2)));
-
 constexpr int kB3Steps = 7;            // ceil(27 taps / 4 taps per K-step)
 constexpr int kB3IZ = 6, kB3IY = 6, kB3IX = 18, kB3Vox = kB3IZ * kB3IY * kB3IX;   // halo tile of the 4x4x16 outputs
 constexpr int kB3Plane = kB3Vox * 16;  // bytes of one bf16 plane of an 8-channel chunk
-
-__host__ __device__ inline unsigned b3_bf16_rne(float x) {      // fp32 -> bf16 bits, round to nearest even
-  unsigned u;
-  memcpy(&u, &x, 4);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return u >> 16;
-}
-__host__ __device__ inline float b3_bf16_to_f32(unsigned h) {
-  const unsigned u = h << 16;
-  float f;
-  memcpy(&f, &u, 4);
-  return f;
-}
-// x = hi + mid + lo exactly (to 2^-27 |x|): the two residuals are exact fp32 subtractions
-__host__ __device__ inline void b3_split(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
-  hi = b3_bf16_rne(x);
-  const float r1 = x - b3_bf16_to_f32(hi);
-  mid = b3_bf16_rne(r1);
-  const float r2 = r1 - b3_bf16_to_f32(mid);
-  lo = b3_bf16_rne(r2);
-}
-
-#ifdef CFUN_HIP_EMULATION
-inline b3_f32x4 b3_mfma(b3_u32x4 a, b3_u32x4 b, b3_f32x4 c) { return hipemu_mfma_16x16x32_bf16(a, b, c); }
-#else
-typedef __bf16 b3_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 b3_bf16x2 __attribute__((ext_vector_type(2)));
-typedef float b3_f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ b3_f32x4 b3_mfma(b3_u32x4 a, b3_u32x4 b, b3_f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b3_bf16x8, a), __builtin_bit_cast(b3_bf16x8, b), c, 0, 0, 0);
-}
-#endif
-
-// two fp32 -> the three packed bf16 pairs (element 0 in the low half): v_cvt_pk_bf16_f32 on the GPU
-__device__ __forceinline__ void b3_split_pair(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
-#ifdef CFUN_HIP_EMULATION
-  unsigned h0, m0, l0, h1, m1, l1;
-  b3_split(x0, h0, m0, l0);
-  b3_split(x1, h1, m1, l1);
-  hi = h0 | (h1 << 16); mid = m0 | (m1 << 16); lo = l0 | (l1 << 16);
-#else
-  const b3_f32x2 v = {x0, x1};
-  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, b3_bf16x2));
-  const b3_f32x2 r1 = v - b3_f32x2{__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
-  mid = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, b3_bf16x2));
-  const b3_f32x2 r2 = r1 - b3_f32x2{__uint_as_float(mid << 16), __uint_as_float(mid & 0xffff0000u)};
-  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, b3_bf16x2));
-#endif
-}
 
 // w OIDHW [Co][Ci][27] -> wb3[chunk = ci/8][step][subtile = co/16][plane][lane][8 bf16].  lane = (co & 15) + 16*kb holds
 // tap 4*step + kb, channels 8*chunk .. +7.  transpose_flip: the data-gradient's weights (roles of Co / Ci swapped,

@@ -13,17 +13,14 @@
 // 18 / 30 MFMAs per 16-byte LDS read keep the LDS idle; the accumulators (taps x NCO x 4 registers) never leave the
 // wave.  Workgroups own a range of tiles each and write fp32 partials [chunk][tap][ci][CoP] that the shared
 // cfun_wgrad_finish reduces (deterministically) into the packed or OIDHW layout.
-#include "common.h"
+#include "b3_common.h"
 
 int cfun_wgrad_finish(const float*, CfunWgradDst, const CfunConv3dParams*, int, hipStream_t);
 int cfun_wgrad_zero(CfunWgradDst, const CfunConv3dParams*, hipStream_t);
 
 namespace {
 
-typedef float w3_f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned w3_u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned w3_u32x2 __attribute__((ext_vector_type(2)));
-struct __attribute__((packed, aligned(2))) W3Unaligned16 { w3_u32x4 v; };     // a 16-byte LDS read at 2-byte alignment
+struct __attribute__((packed, aligned(2))) W3Unaligned16 { b3_u32x4 v; };     // a 16-byte LDS read at 2-byte alignment
 
 constexpr int kTZ = 2, kTY = 4, kTX = 16, kTVox = kTZ * kTY * kTX;               // 128 output voxels per tile
 constexpr int kIZ = kTZ + 2, kIY = kTY + 2, kIX = kTX + 2, kIVox = kIZ * kIY * kIX;   // 432-voxel halo
@@ -31,50 +28,6 @@ constexpr int kCHX = 880;      // bytes per channel of the x halo (864 used; 220
 constexpr int kPX = 16 * kCHX; // one bf16 plane of the 16-channel halo
 constexpr int kCHG = 272;      // bytes per channel of the g tile (256 used; 68 dwords: conflict-free)
 constexpr int kThreads = 512, kWaves = 8, kTapsPerWave = 4;
-
-__device__ __forceinline__ unsigned w3_bits(float x) { unsigned u; memcpy(&u, &x, 4); return u; }
-__device__ __forceinline__ float w3_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
-__device__ __forceinline__ unsigned w3_bf16_rne(float x) {
-  unsigned u = w3_bits(x);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return u >> 16;
-}
-// fp32 -> (hi, mid, lo) bf16 bits; x = hi + mid + lo to 2^-27 |x| (conv3d_b3.hip has the error analysis)
-__device__ __forceinline__ void w3_split(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
-  hi = w3_bf16_rne(x);
-  const float r1 = x - w3_float(hi << 16);
-  mid = w3_bf16_rne(r1);
-  const float r2 = r1 - w3_float(mid << 16);
-  lo = w3_bf16_rne(r2);
-}
-
-#ifdef CFUN_HIP_EMULATION
-inline w3_f32x4 w3_mfma(w3_u32x4 a, w3_u32x4 b, w3_f32x4 c) { return hipemu_mfma_16x16x32_bf16(a, b, c); }
-#else
-typedef __bf16 w3_bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ w3_f32x4 w3_mfma(w3_u32x4 a, w3_u32x4 b, w3_f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(w3_bf16x8, a), __builtin_bit_cast(w3_bf16x8, b), c, 0, 0, 0);
-}
-#endif
-
-// two fp32 -> three words of packed bf16 pairs (element 0 in the low half); v_cvt_pk_bf16_f32 on the GPU
-__device__ __forceinline__ void w3_split_pair(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
-#ifdef CFUN_HIP_EMULATION
-  unsigned h0, m0, l0, h1, m1, l1;
-  w3_split(x0, h0, m0, l0);
-  w3_split(x1, h1, m1, l1);
-  hi = h0 | (h1 << 16); mid = m0 | (m1 << 16); lo = l0 | (l1 << 16);
-#else
-  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  const f32x2 v = {x0, x1};
-  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-  const f32x2 r1 = v - f32x2{w3_float(hi << 16), w3_float(hi & 0xffff0000u)};
-  mid = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
-  const f32x2 r2 = r1 - f32x2{w3_float(mid << 16), w3_float(mid & 0xffff0000u)};
-  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
-#endif
-}
 
 // Transposed staging writes whole dwords: a thread owns 2 (x halo) or 4 (g tile) CONSECUTIVE voxels of 4 channels, so
 // each (channel, plane) costs one ds_write_b32 / b64 instead of one ds_write_b16 per element (the 16-bit scatter made
@@ -85,7 +38,7 @@ __device__ __forceinline__ void w3_put_pair(unsigned char* base, int plane_bytes
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     unsigned w[3];
-    w3_split_pair(e0[j], e1[j], w[0], w[1], w[2]);
+    b3_split_pair(e0[j], e1[j], w[0], w[1], w[2]);
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<unsigned*>(base + j * ch_bytes + pl * plane_bytes) = w[pl];
   }
@@ -96,11 +49,11 @@ __device__ __forceinline__ void w3_put_quad(unsigned char* base, int plane_bytes
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     unsigned a[3], b[3];
-    w3_split_pair(e[0][j], e[1][j], a[0], a[1], a[2]);
-    w3_split_pair(e[2][j], e[3][j], b[0], b[1], b[2]);
+    b3_split_pair(e[0][j], e[1][j], a[0], a[1], a[2]);
+    b3_split_pair(e[2][j], e[3][j], b[0], b[1], b[2]);
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
-      *reinterpret_cast<w3_u32x2*>(base + j * ch_bytes + pl * plane_bytes) = w3_u32x2{a[pl], b[pl]};
+      *reinterpret_cast<b3_u32x2*>(base + j * ch_bytes + pl * plane_bytes) = b3_u32x2{a[pl], b[pl]};
   }
 }
 
@@ -135,11 +88,11 @@ k_wgrad_b3(const float* __restrict__ x, const float* __restrict__ g, float* __re
   const int a_lane = row16 * kCHX + (kr * kIX + 8 * kxh) * 2;
   const int b_lane = row16 * kCHG + (kr * kTX + 8 * kxh) * 2;
 
-  w3_f32x4 acc[kTapsPerWave][NCO];
+  b3_f32x4 acc[kTapsPerWave][NCO];
 #pragma unroll
   for (int ti = 0; ti < kTapsPerWave; ++ti)
 #pragma unroll
-    for (int nn = 0; nn < NCO; ++nn) acc[ti][nn] = w3_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nn = 0; nn < NCO; ++nn) acc[ti][nn] = b3_f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int t_begin = chunk * tiles_per_chunk;
   const int t_end = t_begin + tiles_per_chunk < ntiles ? t_begin + tiles_per_chunk : ntiles;
@@ -201,30 +154,30 @@ k_wgrad_b3(const float* __restrict__ x, const float* __restrict__ g, float* __re
     for (int ks = 0; ks < kTVox / 32; ++ks) {
       const int R = 2 * ks, rz = R / kTY, ry = R % kTY;
       const unsigned char* gp = Gl + b_lane + R * kTX * 2;
-      w3_u32x4 bq[NCO][3];
+      b3_u32x4 bq[NCO][3];
 #pragma unroll
       for (int nn = 0; nn < NCO; ++nn)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) bq[nn][pl] = *reinterpret_cast<const w3_u32x4*>(gp + pl * PG + nn * 16 * kCHG);
+        for (int pl = 0; pl < 3; ++pl) bq[nn][pl] = *reinterpret_cast<const b3_u32x4*>(gp + pl * PG + nn * 16 * kCHG);
       const unsigned char* xp = Xl + a_lane + ((rz * kIY + ry) * kIX) * 2;
 #pragma unroll
       for (int ti = 0; ti < kTapsPerWave; ++ti) {
         if (wv + kWaves * ti > 26) continue;                   // wave-uniform: waves 3..7 have three taps
-        const w3_u32x4 a0 = reinterpret_cast<const W3Unaligned16*>(xp + toff[ti])->v;
-        const w3_u32x4 a1 = reinterpret_cast<const W3Unaligned16*>(xp + toff[ti] + kPX)->v;
-        const w3_u32x4 a2 = reinterpret_cast<const W3Unaligned16*>(xp + toff[ti] + 2 * kPX)->v;
+        const b3_u32x4 a0 = reinterpret_cast<const W3Unaligned16*>(xp + toff[ti])->v;
+        const b3_u32x4 a1 = reinterpret_cast<const W3Unaligned16*>(xp + toff[ti] + kPX)->v;
+        const b3_u32x4 a2 = reinterpret_cast<const W3Unaligned16*>(xp + toff[ti] + 2 * kPX)->v;
 #pragma unroll
-        for (int nn = 0; nn < NCO; ++nn) acc[ti][nn] = w3_mfma(a2, bq[nn][0], acc[ti][nn]);
+        for (int nn = 0; nn < NCO; ++nn) acc[ti][nn] = b3_mfma(a2, bq[nn][0], acc[ti][nn]);
 #pragma unroll
-        for (int nn = 0; nn < NCO; ++nn) acc[ti][nn] = w3_mfma(a1, bq[nn][1], acc[ti][nn]);
+        for (int nn = 0; nn < NCO; ++nn) acc[ti][nn] = b3_mfma(a1, bq[nn][1], acc[ti][nn]);
 #pragma unroll
-        for (int nn = 0; nn < NCO; ++nn) acc[ti][nn] = w3_mfma(a0, bq[nn][2], acc[ti][nn]);
+        for (int nn = 0; nn < NCO; ++nn) acc[ti][nn] = b3_mfma(a0, bq[nn][2], acc[ti][nn]);
 #pragma unroll
-        for (int nn = 0; nn < NCO; ++nn) acc[ti][nn] = w3_mfma(a1, bq[nn][0], acc[ti][nn]);
+        for (int nn = 0; nn < NCO; ++nn) acc[ti][nn] = b3_mfma(a1, bq[nn][0], acc[ti][nn]);
 #pragma unroll
-        for (int nn = 0; nn < NCO; ++nn) acc[ti][nn] = w3_mfma(a0, bq[nn][1], acc[ti][nn]);
+        for (int nn = 0; nn < NCO; ++nn) acc[ti][nn] = b3_mfma(a0, bq[nn][1], acc[ti][nn]);
 #pragma unroll
-        for (int nn = 0; nn < NCO; ++nn) acc[ti][nn] = w3_mfma(a0, bq[nn][0], acc[ti][nn]);
+        for (int nn = 0; nn < NCO; ++nn) acc[ti][nn] = b3_mfma(a0, bq[nn][0], acc[ti][nn]);
       }
     }
   }
