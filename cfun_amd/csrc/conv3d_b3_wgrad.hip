@@ -4,15 +4,17 @@
 //   dW[tap][ci][co] = sum over voxels v of  x[v + tap][ci] * g[v][co]
 //
 // is a GEMM whose contraction index is the VOXEL, so both MFMA operands must hold 8 consecutive voxels of one channel
-// per lane -- the transpose of the NDHWC tensors.  A 512-thread workgroup (8 waves) stages, per 2(z) x 4(y) x 16(x)
+// per lane -- the transpose of the NDHWC tensors.  A 576-thread workgroup (9 waves) stages, per 2(z) x 4(y) x 16(x)
 // voxel tile, the halo of 16 input channels and the tile of NT = 16*NCO output-gradient channels into LDS
-// channel-major ([plane][channel][voxel], bf16, three planes each: the split happens on the way in), then every wave
-// takes 3-4 of the 27 taps: per K-step of 32 voxels (2 tile rows) it reads the NCO B operands (g, tap-invariant, reused
-// for all its taps) and per tap one A operand (x) with a single ds_read_b128 whose address carries the tap shift --
-// for dx = 1 that address is only 2-byte aligned, which gfx950's LDS serves (probed: tools/probes/lds_unaligned.hip).
-// 18 / 30 MFMAs per 16-byte LDS read keep the LDS idle; the accumulators (taps x NCO x 4 registers) never leave the
-// wave.  Workgroups own a range of tiles each and write fp32 partials [chunk][tap][ci][CoP] that the shared
-// cfun_wgrad_finish reduces (deterministically) into the packed or OIDHW layout.
+// channel-major ([plane][channel][voxel], bf16, three planes each: the split happens on the way in, whole dwords /
+// qwords per write).  Wave w owns the tap row (dz, dy) = (w / 3, w % 3): per K-step of 32 voxels (2 tile rows) it reads
+// the NCO B operands (g, tap-invariant) and ONE 16-byte-aligned x operand per plane (+ the next dword), and derives the
+// three dx taps in registers -- dx = 1 is a 16-bit funnel shift (v_alignbit), dx = 2 a dword rename.  (A ds_read_b128
+// at the tap's own, 2- or 4-byte aligned address returns the right data on gfx950 but costs 256 instead of 23 cycles --
+// tools/probes/lds_unaligned_rate.hip -- and made the first version of this kernel LDS-bound at a third of the MFMA
+// rate.)  The accumulators (3 taps x NCO x 4 registers) never leave the wave; workgroups own a range of tiles each
+// and write fp32 partials [chunk][tap][ci][CoP] that the shared cfun_wgrad_finish reduces (deterministically) into the
+// packed or OIDHW layout.
 #include "b3_common.h"
 
 int cfun_wgrad_finish(const float*, CfunWgradDst, const CfunConv3dParams*, int, hipStream_t);
@@ -20,41 +22,47 @@ int cfun_wgrad_zero(CfunWgradDst, const CfunConv3dParams*, hipStream_t);
 
 namespace {
 
-struct __attribute__((packed, aligned(2))) W3Unaligned16 { b3_u32x4 v; };     // a 16-byte LDS read at 2-byte alignment
 
 constexpr int kTZ = 2, kTY = 4, kTX = 16, kTVox = kTZ * kTY * kTX;               // 128 output voxels per tile
 constexpr int kIZ = kTZ + 2, kIY = kTY + 2, kIX = kTX + 2, kIVox = kIZ * kIY * kIX;   // 432-voxel halo
-constexpr int kCHX = 880;      // bytes per channel of the x halo (864 used; 220 dwords: conflict-free 16-lane b128 reads)
+constexpr int kXRow = 48;      // bytes per halo row in LDS: 18 voxels + padding, so that rows and x halves are 16-byte aligned
+constexpr int kCHX = 1168;     // bytes per channel of the x halo (24 rows x 48 = 1152 used; 292 dwords: conflict-free b128 reads)
 constexpr int kPX = 16 * kCHX; // one bf16 plane of the 16-channel halo
 constexpr int kCHG = 272;      // bytes per channel of the g tile (256 used; 68 dwords: conflict-free)
-constexpr int kThreads = 512, kWaves = 8, kTapsPerWave = 4;
+constexpr int kThreads = 576, kWaves = 9;      // wave w <-> tap row (dz, dy) = (w / 3, w % 3), its three dx taps
 
 // Transposed staging writes whole dwords: a thread owns 2 (x halo) or 4 (g tile) CONSECUTIVE voxels of 4 channels, so
 // each (channel, plane) costs one ds_write_b32 / b64 instead of one ds_write_b16 per element (the 16-bit scatter made
 // the LDS write port, not the MFMA, the bottleneck: 170 writes per thread and tile).
+// (component by component: local float arrays built from the float4s end up in scratch memory)
+__device__ __forceinline__ void w3_put2(unsigned char* p, int plane_bytes, float a, float b) {
+  unsigned w0, w1, w2;
+  b3_split_pair(a, b, w0, w1, w2);
+  *reinterpret_cast<unsigned*>(p) = w0;
+  *reinterpret_cast<unsigned*>(p + plane_bytes) = w1;
+  *reinterpret_cast<unsigned*>(p + 2 * plane_bytes) = w2;
+}
+__device__ __forceinline__ void w3_put4(unsigned char* p, int plane_bytes, float a, float b, float c, float d) {
+  unsigned a0, a1, a2, b0, b1, b2;
+  b3_split_pair(a, b, a0, a1, a2);
+  b3_split_pair(c, d, b0, b1, b2);
+  *reinterpret_cast<b3_u32x2*>(p) = b3_u32x2{a0, b0};
+  *reinterpret_cast<b3_u32x2*>(p + plane_bytes) = b3_u32x2{a1, b1};
+  *reinterpret_cast<b3_u32x2*>(p + 2 * plane_bytes) = b3_u32x2{a2, b2};
+}
 __device__ __forceinline__ void w3_put_pair(unsigned char* base, int plane_bytes, int ch_bytes, const float4& v0,
                                             const float4& v1) {
-  const float e0[4] = {v0.x, v0.y, v0.z, v0.w}, e1[4] = {v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    unsigned w[3];
-    b3_split_pair(e0[j], e1[j], w[0], w[1], w[2]);
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<unsigned*>(base + j * ch_bytes + pl * plane_bytes) = w[pl];
-  }
+  w3_put2(base, plane_bytes, v0.x, v1.x);
+  w3_put2(base + ch_bytes, plane_bytes, v0.y, v1.y);
+  w3_put2(base + 2 * ch_bytes, plane_bytes, v0.z, v1.z);
+  w3_put2(base + 3 * ch_bytes, plane_bytes, v0.w, v1.w);
 }
-__device__ __forceinline__ void w3_put_quad(unsigned char* base, int plane_bytes, int ch_bytes, const float4 (&v)[4]) {
-  const float e[4][4] = {{v[0].x, v[0].y, v[0].z, v[0].w}, {v[1].x, v[1].y, v[1].z, v[1].w},
-                         {v[2].x, v[2].y, v[2].z, v[2].w}, {v[3].x, v[3].y, v[3].z, v[3].w}};
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    unsigned a[3], b[3];
-    b3_split_pair(e[0][j], e[1][j], a[0], a[1], a[2]);
-    b3_split_pair(e[2][j], e[3][j], b[0], b[1], b[2]);
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-      *reinterpret_cast<b3_u32x2*>(base + j * ch_bytes + pl * plane_bytes) = b3_u32x2{a[pl], b[pl]};
-  }
+__device__ __forceinline__ void w3_put_quad(unsigned char* base, int plane_bytes, int ch_bytes, const float4& v0,
+                                            const float4& v1, const float4& v2, const float4& v3) {
+  w3_put4(base, plane_bytes, v0.x, v1.x, v2.x, v3.x);
+  w3_put4(base + ch_bytes, plane_bytes, v0.y, v1.y, v2.y, v3.y);
+  w3_put4(base + 2 * ch_bytes, plane_bytes, v0.z, v1.z, v2.z, v3.z);
+  w3_put4(base + 3 * ch_bytes, plane_bytes, v0.w, v1.w, v2.w, v3.w);
 }
 
 template <int NCO>
@@ -74,23 +82,15 @@ k_wgrad_b3(const float* __restrict__ x, const float* __restrict__ g, float* __re
   const int chunk = b / ncisub;
   const int cobase = cot * NT, cibase = cis * 16;
 
-  // the wave's taps: wv, wv + 8, wv + 16, wv + 24 (< 27)
-  int toff[kTapsPerWave];
-#pragma unroll
-  for (int ti = 0; ti < kTapsPerWave; ++ti) {
-    int t = wv + kWaves * ti;
-    t = t > 26 ? 26 : t;
-    const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
-    toff[ti] = ((dz * kIY + dy) * kIX + dx) * 2;
-  }
+  const int row_off = ((wv / 3) * kIY + (wv % 3)) * kXRow;      // the wave's (dz, dy) tap row
   // lane -> (channel row, K-block): kb = (tile row within the K-step's pair, x half)
   const int row16 = lane & 15, kb = lane >> 4, kr = kb >> 1, kxh = kb & 1;
-  const int a_lane = row16 * kCHX + (kr * kIX + 8 * kxh) * 2;
+  const int a_lane = row16 * kCHX + kr * kXRow + 16 * kxh + row_off;
   const int b_lane = row16 * kCHG + (kr * kTX + 8 * kxh) * 2;
 
-  b3_f32x4 acc[kTapsPerWave][NCO];
+  b3_f32x4 acc[3][NCO];
 #pragma unroll
-  for (int ti = 0; ti < kTapsPerWave; ++ti)
+  for (int ti = 0; ti < 3; ++ti)
 #pragma unroll
     for (int nn = 0; nn < NCO; ++nn) acc[ti][nn] = b3_f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -121,7 +121,10 @@ k_wgrad_b3(const float* __restrict__ x, const float* __restrict__ g, float* __re
     }
 #pragma unroll
     for (int i = 0; i < G_ITEMS; ++i) {
-      const int idx = tid + i * kThreads, q = idx % (NT / 4), grp = idx / (NT / 4);
+      // item -> (channel quad q, voxel quad grp): 4 quads fastest (64 contiguous bytes of one voxel in global memory),
+      // then the 32 voxel quads (consecutive qwords of a channel row in LDS), then the remaining quads -- with all
+      // NT/4 quads fastest the qword writes of a wave hit 2 bank groups 6-10 ways
+      const int idx = tid + i * kThreads, grp = (idx >> 2) % (kTVox / 4), q = (idx / kTVox) * 4 + (idx & 3);
       const int ox4 = grp % (kTX / 4), oy = (grp / (kTX / 4)) % kTY, oz = grp / ((kTX / 4) * kTY);
       const int vz = z0 + oz, vy = y0 + oy, c = cobase + 4 * q;
       const bool row_ok = idx < GQ && vz < p.Do && vy < p.Ho && c < p.Co;
@@ -140,12 +143,15 @@ k_wgrad_b3(const float* __restrict__ x, const float* __restrict__ g, float* __re
 #pragma unroll
     for (int i = 0; i < X_ITEMS; ++i) {
       const int idx = tid + i * kThreads;
-      if (idx < XQ) w3_put_pair(Xl + (idx & 3) * 4 * kCHX + (idx >> 2) * 4, kPX, kCHX, xr[i][0], xr[i][1]);
+      if (idx < XQ) w3_put_pair(Xl + (idx & 3) * 4 * kCHX + ((idx >> 2) / (kIX / 2)) * kXRow + ((idx >> 2) % (kIX / 2)) * 4, kPX, kCHX,
+                                 xr[i][0], xr[i][1]);
     }
 #pragma unroll
     for (int i = 0; i < G_ITEMS; ++i) {
       const int idx = tid + i * kThreads;
-      if (idx < GQ) w3_put_quad(Gl + (idx % (NT / 4)) * 4 * kCHG + (idx / (NT / 4)) * 8, PG, kCHG, gr[i]);
+      if (idx < GQ)
+        w3_put_quad(Gl + ((idx / kTVox) * 4 + (idx & 3)) * 4 * kCHG + ((idx >> 2) % (kTVox / 4)) * 8, PG, kCHG, gr[i][0],
+                    gr[i][1], gr[i][2], gr[i][3]);
     }
     __syncthreads();
     if (tile + 1 < t_end) load_tile(tile + 1);
@@ -159,35 +165,43 @@ k_wgrad_b3(const float* __restrict__ x, const float* __restrict__ g, float* __re
       for (int nn = 0; nn < NCO; ++nn)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) bq[nn][pl] = *reinterpret_cast<const b3_u32x4*>(gp + pl * PG + nn * 16 * kCHG);
-      const unsigned char* xp = Xl + a_lane + ((rz * kIY + ry) * kIX) * 2;
+      const unsigned char* xp = Xl + a_lane + (rz * kIY + ry) * kXRow;
+      b3_u32x4 ax0[3], ax1[3], ax2[3];                    // the dx = 0 / 1 / 2 operands, [plane]
 #pragma unroll
-      for (int ti = 0; ti < kTapsPerWave; ++ti) {
-        if (wv + kWaves * ti > 26) continue;                   // wave-uniform: waves 3..7 have three taps
-        const b3_u32x4 a0 = reinterpret_cast<const W3Unaligned16*>(xp + toff[ti])->v;
-        const b3_u32x4 a1 = reinterpret_cast<const W3Unaligned16*>(xp + toff[ti] + kPX)->v;
-        const b3_u32x4 a2 = reinterpret_cast<const W3Unaligned16*>(xp + toff[ti] + 2 * kPX)->v;
-#pragma unroll
-        for (int nn = 0; nn < NCO; ++nn) acc[ti][nn] = b3_mfma(a2, bq[nn][0], acc[ti][nn]);
-#pragma unroll
-        for (int nn = 0; nn < NCO; ++nn) acc[ti][nn] = b3_mfma(a1, bq[nn][1], acc[ti][nn]);
-#pragma unroll
-        for (int nn = 0; nn < NCO; ++nn) acc[ti][nn] = b3_mfma(a0, bq[nn][2], acc[ti][nn]);
-#pragma unroll
-        for (int nn = 0; nn < NCO; ++nn) acc[ti][nn] = b3_mfma(a1, bq[nn][0], acc[ti][nn]);
-#pragma unroll
-        for (int nn = 0; nn < NCO; ++nn) acc[ti][nn] = b3_mfma(a0, bq[nn][1], acc[ti][nn]);
-#pragma unroll
-        for (int nn = 0; nn < NCO; ++nn) acc[ti][nn] = b3_mfma(a0, bq[nn][0], acc[ti][nn]);
+      for (int pl = 0; pl < 3; ++pl) {
+        const b3_u32x4 lo = *reinterpret_cast<const b3_u32x4*>(xp + pl * kPX);        // voxels x .. x+7 (16-byte aligned)
+        const unsigned hi = *reinterpret_cast<const unsigned*>(xp + pl * kPX + 16);   // voxels x+8, x+9
+        const unsigned l0 = lo.x, l1 = lo.y, l2 = lo.z, l3 = lo.w;
+        ax0[pl] = lo;
+        ax1[pl].x = (l0 >> 16) | (l1 << 16); ax1[pl].y = (l1 >> 16) | (l2 << 16);
+        ax1[pl].z = (l2 >> 16) | (l3 << 16); ax1[pl].w = (l3 >> 16) | (hi << 16);
+        ax2[pl].x = l1; ax2[pl].y = l2; ax2[pl].z = l3; ax2[pl].w = hi;
       }
+      auto taps = [&](const b3_u32x4 (&a)[3], b3_f32x4 (&c)[NCO]) {        // six cross terms, smallest first
+#pragma unroll
+        for (int nn = 0; nn < NCO; ++nn) c[nn] = b3_mfma(a[2], bq[nn][0], c[nn]);
+#pragma unroll
+        for (int nn = 0; nn < NCO; ++nn) c[nn] = b3_mfma(a[1], bq[nn][1], c[nn]);
+#pragma unroll
+        for (int nn = 0; nn < NCO; ++nn) c[nn] = b3_mfma(a[0], bq[nn][2], c[nn]);
+#pragma unroll
+        for (int nn = 0; nn < NCO; ++nn) c[nn] = b3_mfma(a[1], bq[nn][0], c[nn]);
+#pragma unroll
+        for (int nn = 0; nn < NCO; ++nn) c[nn] = b3_mfma(a[0], bq[nn][1], c[nn]);
+#pragma unroll
+        for (int nn = 0; nn < NCO; ++nn) c[nn] = b3_mfma(a[0], bq[nn][0], c[nn]);
+      };
+      taps(ax0, acc[0]);
+      taps(ax1, acc[1]);
+      taps(ax2, acc[2]);
     }
   }
 
   // ---- partials: D row = ci (lane>>4)*4 + reg, column = co lane&15
   float* out = partial + (int64_t)chunk * 27 * p.Ci * p.CoP;
 #pragma unroll
-  for (int ti = 0; ti < kTapsPerWave; ++ti) {
-    const int t = wv + kWaves * ti;
-    if (t > 26) continue;
+  for (int ti = 0; ti < 3; ++ti) {
+    const int t = wv * 3 + ti;
 #pragma unroll
     for (int nn = 0; nn < NCO; ++nn) {
       const int co = cobase + nn * 16 + (lane & 15);
@@ -208,8 +222,10 @@ inline W3Plan w3_plan(const CfunConv3dParams& p) {
   w.ntiles = p.N * w.ntz * w.nty * w.ntx;
   w.ncisub = (p.Ci + 15) / 16;
   const int nsub = p.CoP / 16;
-  w.nco = nsub % 3 == 0 ? 3 : nsub % 5 == 0 ? 5 : nsub % 2 == 0 ? 2 : 1;
-  w.ncot = nsub / w.nco;
+  // column sub-tiles per workgroup: 3 unless that pads the columns by more than 20 % (NCO = 5 would need more than the
+  // 170 registers a 9-wave workgroup leaves each wave)
+  w.nco = nsub == 1 ? 1 : ((nsub + 2) / 3 * 3 - nsub) * 5 <= nsub ? 3 : (nsub % 2 == 0 ? 2 : 3);
+  w.ncot = (nsub + w.nco - 1) / w.nco;
   // ~3 workgroups per CU in total (one resident per CU: 81 KB of LDS), at least 4 tiles each where the volume allows
   int want = (768 + w.ncisub * w.ncot - 1) / (w.ncisub * w.ncot);
   int maxc = (w.ntiles + 3) / 4;
@@ -250,13 +266,12 @@ extern "C" {
 
 int cfun_conv3d_b3_wgrad_supported(const CfunConv3dParams* p) { return p && w3_shape_ok(p) ? 1 : 0; }
 
-// supported AND measured faster than the exact-fp32 wgrad kernels (tools/bench_b3.py): 1.2-1.3x for C_in, C_out >= 80
-// (80->80 @4x48^3 1.44 -> 1.21 ms, 160->160 @4x24^3 1.03 -> 0.79, 320->320 @4x12^3 0.55 -> 0.42), but 0.6-0.9x for the
-// 20 / 40-channel layers: a workgroup stages and computes one tile at a time (81 KB of LDS = one workgroup per CU, so
-// nothing overlaps the transposing stage-in) and the 16-row / 16-column padding costs 20-37 % there.
+// supported AND measured faster than the exact-fp32 wgrad kernels (tools/bench_b3.py): 1.2-1.6x from 16 x 40 channels
+// up (40->40 @4x96^3 3.44 -> 2.34 ms, 80->80 @4x48^3 1.46 -> 1.20, 160->160 @4x24^3 1.04 -> 0.82, 320->320 @4x12^3
+// 0.55 -> 0.39, 80->40 @4x48^3 0.87 -> 0.55); 20->20 (32 padded columns and rows for 20) stays at 0.92x.
 int cfun_conv3d_b3_wgrad_preferred(const CfunConv3dParams* p) {
   if (!p || !w3_shape_ok(p)) return 0;
-  return (p->Ci >= 64 && p->Co >= 64) ? 1 : 0;
+  return (p->Ci * p->Co >= 512) ? 1 : 0;
 }
 
 size_t cfun_conv3d_b3_wgrad_workspace_bytes(const CfunConv3dParams* p) {
@@ -278,7 +293,6 @@ int cfun_conv3d_b3_wgrad_oidhw(const float* x, const float* g, float* dw, const 
   int rc;
   switch (w.nco) {
     case 3: rc = launch_w3<3>(x, g, (float*)ws, *p, w, st); break;
-    case 5: rc = launch_w3<5>(x, g, (float*)ws, *p, w, st); break;
     case 2: rc = launch_w3<2>(x, g, (float*)ws, *p, w, st); break;
     default: rc = launch_w3<1>(x, g, (float*)ws, *p, w, st); break;
   }
