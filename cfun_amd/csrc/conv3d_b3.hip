@@ -51,8 +51,10 @@ k_pack_b3(const float* __restrict__ w, unsigned short* __restrict__ wb3, int Co,
   }
 }
 
-template <int NSUB>
-__global__ void __launch_bounds__(256)
+// GROUPED (NSUB = 5 on launches that fill the chip): two workgroups per CU = two waves per SIMD, i.e. at most 256
+// registers -- see the sub-tile groups below
+template <int NSUB, bool GROUPED>
+__global__ void __launch_bounds__(256, GROUPED ? 2 : 1)
 k_conv_b3(const float* __restrict__ x, const b3_u32x4* __restrict__ wb3, const float* __restrict__ scale,
           const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y, CfunConv3dParams p,
           int ntz, int nty, int ntx, int ncot, int nsub_total) {
@@ -118,13 +120,19 @@ k_conv_b3(const float* __restrict__ x, const b3_u32x4* __restrict__ wb3, const f
   // ---- A operand: [chunk][step][subtile][plane][lane] 16-byte entries
   const b3_u32x4* wl = wb3 + (int64_t)(cot * NSUB) * 3 * 64 + lane;
   const int64_t wstep = (int64_t)nsub_total * 3 * 64;
-  b3_u32x4 a_cur[NSUB][3], a_nxt[NSUB][3];
-  auto load_a = [&](b3_u32x4 (&a)[NSUB][3], int g) {       // g = chunk * 7 + step
-    const b3_u32x4* src = wl + (int64_t)g * wstep;
+  // GROUPED: the sub-tiles of a K-step are taken in two groups (3 + 2) that re-read the B operands from the (idle) LDS,
+  // so that only one group's weights are double-buffered in registers: 312 -> 256 registers for NSUB = 5, two waves
+  // per SIMD instead of one (80->80 @4x48^3: 0.74 -> 0.69 ms; it loses where the launch is small anyway)
+  constexpr int H = GROUPED ? 2 : 1, G0 = GROUPED ? (NSUB + 1) / 2 : NSUB;     // groups per step, size of the first
+  b3_u32x4 a_cur[G0][3], a_nxt[G0][3];
+  auto load_a = [&](b3_u32x4 (&a)[G0][3], int u) {         // u = (chunk * 7 + step) * H + group
+    const int g = u / H, h = u - g * H;
+    const b3_u32x4* src = wl + (int64_t)g * wstep + (int64_t)(h * G0) * 3 * 64;
 #pragma unroll
-    for (int nn = 0; nn < NSUB; ++nn)
+    for (int nn = 0; nn < G0; ++nn)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) a[nn][pl] = src[(nn * 3 + pl) * 64];
+      for (int pl = 0; pl < 3; ++pl)
+        if (h * G0 + nn < NSUB) a[nn][pl] = src[(nn * 3 + pl) * 64];
   };
 
   b3_f32x4 acc[4][NSUB];
@@ -146,35 +154,40 @@ k_conv_b3(const float* __restrict__ x, const b3_u32x4* __restrict__ wb3, const f
 #pragma unroll
     for (int s = 0; s < kB3Steps; ++s) {
       const int g = c * kB3Steps + s;
-      if (g + 1 < nsteps) load_a(a_nxt, g + 1);
       if (s == 3 && c + 1 < nchunks) {       // every wave left buffer (c+1)&1 at the barrier that ended chunk c-1
         commit_x((c + 1) & 1);
         if (c + 2 < nchunks) prefetch_x(c + 2);
       }
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const unsigned char* bp = xb + boff[s] + m * (kB3IX * 16);
-        const b3_u32x4 b0 = *reinterpret_cast<const b3_u32x4*>(bp);
-        const b3_u32x4 b1 = *reinterpret_cast<const b3_u32x4*>(bp + kB3Plane);
-        const b3_u32x4 b2 = *reinterpret_cast<const b3_u32x4*>(bp + 2 * kB3Plane);
-        // six cross terms, smallest first; consecutive MFMAs go to different accumulators
+      for (int h = 0; h < H; ++h) {
+        const int u = g * H + h;
+        if (u + 1 < nsteps * H) load_a(a_nxt, u + 1);
+        const int n0 = h * G0;
 #pragma unroll
-        for (int nn = 0; nn < NSUB; ++nn) acc[m][nn] = b3_mfma(a_cur[nn][2], b0, acc[m][nn]);
+        for (int m = 0; m < 4; ++m) {
+          const unsigned char* bp = xb + boff[s] + m * (kB3IX * 16);
+          const b3_u32x4 b0 = *reinterpret_cast<const b3_u32x4*>(bp);
+          const b3_u32x4 b1 = *reinterpret_cast<const b3_u32x4*>(bp + kB3Plane);
+          const b3_u32x4 b2 = *reinterpret_cast<const b3_u32x4*>(bp + 2 * kB3Plane);
+          // six cross terms, smallest first; consecutive MFMAs go to different accumulators
 #pragma unroll
-        for (int nn = 0; nn < NSUB; ++nn) acc[m][nn] = b3_mfma(a_cur[nn][1], b1, acc[m][nn]);
+          for (int nn = 0; nn < G0; ++nn) if (n0 + nn < NSUB) acc[m][n0 + nn] = b3_mfma(a_cur[nn][2], b0, acc[m][n0 + nn]);
 #pragma unroll
-        for (int nn = 0; nn < NSUB; ++nn) acc[m][nn] = b3_mfma(a_cur[nn][0], b2, acc[m][nn]);
+          for (int nn = 0; nn < G0; ++nn) if (n0 + nn < NSUB) acc[m][n0 + nn] = b3_mfma(a_cur[nn][1], b1, acc[m][n0 + nn]);
 #pragma unroll
-        for (int nn = 0; nn < NSUB; ++nn) acc[m][nn] = b3_mfma(a_cur[nn][1], b0, acc[m][nn]);
+          for (int nn = 0; nn < G0; ++nn) if (n0 + nn < NSUB) acc[m][n0 + nn] = b3_mfma(a_cur[nn][0], b2, acc[m][n0 + nn]);
 #pragma unroll
-        for (int nn = 0; nn < NSUB; ++nn) acc[m][nn] = b3_mfma(a_cur[nn][0], b1, acc[m][nn]);
+          for (int nn = 0; nn < G0; ++nn) if (n0 + nn < NSUB) acc[m][n0 + nn] = b3_mfma(a_cur[nn][1], b0, acc[m][n0 + nn]);
 #pragma unroll
-        for (int nn = 0; nn < NSUB; ++nn) acc[m][nn] = b3_mfma(a_cur[nn][0], b0, acc[m][nn]);
+          for (int nn = 0; nn < G0; ++nn) if (n0 + nn < NSUB) acc[m][n0 + nn] = b3_mfma(a_cur[nn][0], b1, acc[m][n0 + nn]);
+#pragma unroll
+          for (int nn = 0; nn < G0; ++nn) if (n0 + nn < NSUB) acc[m][n0 + nn] = b3_mfma(a_cur[nn][0], b0, acc[m][n0 + nn]);
+        }
+#pragma unroll
+        for (int nn = 0; nn < G0; ++nn)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) a_cur[nn][pl] = a_nxt[nn][pl];
       }
-#pragma unroll
-      for (int nn = 0; nn < NSUB; ++nn)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) a_cur[nn][pl] = a_nxt[nn][pl];
     }
     __syncthreads();           // chunk c+1 is complete in its buffer; chunk c's buffer is free
   }
@@ -211,14 +224,17 @@ k_conv_b3(const float* __restrict__ x, const b3_u32x4* __restrict__ wb3, const f
   }
 }
 
-template <int NSUB>
+template <int NSUB, bool GROUPED = false>
 int launch_b3(const float* x, const void* wb3, const float* scale, const float* shift, const float* res, float* y,
               const CfunConv3dParams& p, int nsub_total, hipStream_t st) {
   const int ntz = (p.Do + 3) / 4, nty = (p.Ho + 3) / 4, ntx = (p.Wo + 15) / 16, ncot = nsub_total / NSUB;
   const int64_t nblk = (int64_t)p.N * ntz * nty * ntx * ncot;
   if (nblk == 0) return CFUN_OK;
   if (nblk > 0x7fffffffLL) return CFUN_EINVAL;
-  hipLaunchKernelGGL((k_conv_b3<NSUB>), dim3((unsigned)nblk), dim3(256), (size_t)2 * 3 * kB3Plane, st, x,
+  if constexpr (NSUB == 5 && !GROUPED) {
+    if (nblk >= 256) return launch_b3<NSUB, true>(x, wb3, scale, shift, res, y, p, nsub_total, st);
+  }
+  hipLaunchKernelGGL((k_conv_b3<NSUB, GROUPED>), dim3((unsigned)nblk), dim3(256), (size_t)2 * 3 * kB3Plane, st, x,
                      (const b3_u32x4*)wb3, scale, shift, res, y, p, ntz, nty, ntx, ncot, nsub_total);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
