@@ -186,8 +186,9 @@ def main():
     ops.set_launch_timer(None)
     alt = None
     if world == 1 and not b3 and not args.no_alt and args.workload == "cfg2":
-        # NOT part of `value`: the same step with the eligible 3x3x3 convs (forward + data gradient) on the
-        # experimental 3xBF16 kernels, timed the same way, reported beside the exact-fp32 result
+        # NOT part of `value`: the same step with the eligible 3x3x3 convs on the experimental 3xBF16 kernels, timed
+        # the same way, reported beside the exact-fp32 result
+        prev_algo = os.environ.get("CFUN_CONV_ALGO")
         os.environ["CFUN_CONV_ALGO"] = "b3"
         try:
             for _ in range(2):
@@ -199,10 +200,14 @@ def main():
             fence()
             ta = time.perf_counter() - ta
         finally:
-            os.environ["CFUN_CONV_ALGO"] = "auto"
-        alt = {"what": "same step, eligible 3x3x3 convs (forward + data gradient) on the opt-in 3xBF16 kernels "
-                       "(conv3d_b3.hip: fp32 operands split into 3 bf16, 6 cross terms, fp32 accumulate; "
-                       "weight gradients stay on the exact fp32 MFMA path); not used for `value`",
+            if prev_algo is None:
+                del os.environ["CFUN_CONV_ALGO"]
+            else:
+                os.environ["CFUN_CONV_ALGO"] = prev_algo
+        alt = {"what": "same step, eligible 3x3x3 convs (forward, data and weight gradient) on the opt-in 3xBF16 kernels "
+                       "(conv3d_b3*.hip: fp32 operands split into 3 bf16, 6 cross terms, fp32 accumulate; folded "
+                       "up-convs, stride 2, 5^3 and 20-channel weight gradients stay on the exact fp32 MFMA path); "
+                       "not used for `value`",
                "value": args.steps / ta, "unit": "volumes/s", "ms_per_step": 1e3 * ta / args.steps,
                "losses": [float(l.detach()) for l in alt_losses]}
     if world > 1:
