@@ -53,11 +53,14 @@ k_pack_b3(const float* __restrict__ w, unsigned short* __restrict__ wb3, int Co,
 
 // GROUPED (NSUB = 5 on launches that fill the chip): two workgroups per CU = two waves per SIMD, i.e. at most 256
 // registers -- see the sub-tile groups below
-template <int NSUB, bool GROUPED>
+// MODE 1: depth-to-space epilogue (p.d2s: the parity-folded "nearest x2 -> 5x5x5" conv, C_out = 8 parities x cq).
+// MODE 2: the data gradient of such a conv: x is the HI-RES gradient [N,2D,2H,2W,cq]; channel chunk c of the low-res
+//         "input" is the 8-channel slice o8 of parity q = c / (cq/8), gathered while staging (cq % 8 == 0).
+template <int NSUB, bool GROUPED, int MODE>
 __global__ void __launch_bounds__(256, GROUPED ? 2 : 1)
 k_conv_b3(const float* __restrict__ x, const b3_u32x4* __restrict__ wb3, const float* __restrict__ scale,
           const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y, CfunConv3dParams p,
-          int ntz, int nty, int ntx, int ncot, int nsub_total) {
+          int ntz, int nty, int ntx, int ncot, int nsub_total, int cq) {
   constexpr int NT = 16 * NSUB;
   constexpr int ITEMS = kB3Vox * 2, IN_LOADS = (ITEMS + 255) / 256;     // float4 (4 channels) items per chunk
   CFUN_DYN_LDS(unsigned char, smem);                                     // [2 buffers][3 planes][kB3Vox][16 B]
@@ -80,16 +83,27 @@ k_conv_b3(const float* __restrict__ x, const b3_u32x4* __restrict__ wb3, const f
     if (idx < ITEMS) {
       const int ix = vox % kB3IX, iy = (vox / kB3IX) % kB3IY, iz = vox / (kB3IX * kB3IY);
       const int vz = z0 - 1 + iz, vy = y0 - 1 + iy, vx = x0 - 1 + ix;
-      if (vz >= 0 && vz < p.Di && vy >= 0 && vy < p.Hi && vx >= 0 && vx < p.Wi)
-        in_off[i] = ((((int64_t)n * p.Di + vz) * p.Hi + vy) * p.Wi + vx) * p.Ci + (idx & 1) * 4;
+      if (vz >= 0 && vz < p.Di && vy >= 0 && vy < p.Hi && vx >= 0 && vx < p.Wi) {
+        if (MODE == 2)      // parity-0 voxel of the hi-res tensor; the chunk's parity offset is added in prefetch_x()
+          in_off[i] = ((((int64_t)n * 2 * p.Di + 2 * vz) * 2 * p.Hi + 2 * vy) * 2 * p.Wi + 2 * vx) * cq + (idx & 1) * 4;
+        else
+          in_off[i] = ((((int64_t)n * p.Di + vz) * p.Hi + vy) * p.Wi + vx) * p.Ci + (idx & 1) * 4;
+      }
     }
   }
   float4 xin[IN_LOADS];
   auto prefetch_x = [&](int c) {
+    int64_t coff = (int64_t)c * 8;
+    int climit = p.Ci - c * 8;                // valid channels left in this chunk (C_in % 8 == 4: the last half is zero)
+    if (MODE == 2) {
+      const int cpq = cq >> 3, q = c / cpq, o8 = (c - q * cpq) * 8;
+      coff = ((int64_t)((q >> 2) * 2 * p.Hi + ((q >> 1) & 1)) * 2 * p.Wi + (q & 1)) * cq + o8;
+      climit = cq - o8;
+    }
 #pragma unroll
     for (int i = 0; i < IN_LOADS; ++i)
-      xin[i] = (in_off[i] >= 0 && c * 8 + ((tid + i * 256) & 1) * 4 < p.Ci)      // C_in % 8 == 4: the last half is zero
-                   ? *reinterpret_cast<const float4*>(x + in_off[i] + c * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+      xin[i] = (in_off[i] >= 0 && ((tid + i * 256) & 1) * 4 < climit)
+                   ? *reinterpret_cast<const float4*>(x + in_off[i] + coff) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
   auto commit_x = [&](int buf) {          // split the prefetched fp32 halo into its three bf16 planes of LDS buffer `buf`
 #pragma unroll
@@ -213,6 +227,20 @@ k_conv_b3(const float* __restrict__ x, const b3_u32x4* __restrict__ wb3, const f
         const float4 t = *reinterpret_cast<const float4*>(shift + co);
         r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
       }
+      if (MODE == 1) {        // depth-to-space: channel (parity q, oc) of low-res voxel v -> hi-res voxel 2v + q
+        const int CqP = p.Co >> 3, q = co / CqP, oc = co - q * CqP;
+        if (oc >= cq) continue;                                   // per-parity channel padding
+        if (p.res_mode) {                                         // the residual is low-res: nearest x2 up-sampled into y
+          const float4 t = *reinterpret_cast<const float4*>(res + v * cq + oc);
+          r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+        }
+        r.x = cfun_apply_act(r.x, p.act, p.slope); r.y = cfun_apply_act(r.y, p.act, p.slope);
+        r.z = cfun_apply_act(r.z, p.act, p.slope); r.w = cfun_apply_act(r.w, p.act, p.slope);
+        const int64_t hv = (((int64_t)n * 2 * p.Do + 2 * oz + (q >> 2)) * 2 * p.Ho + 2 * oy + ((q >> 1) & 1)) * 2 * p.Wo +
+                           2 * ox + (q & 1);
+        *reinterpret_cast<float4*>(y + hv * cq + oc) = r;
+        continue;
+      }
       if (p.res_mode) {
         const float4 t = *reinterpret_cast<const float4*>(res + v * p.Co + co);
         r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
@@ -224,26 +252,37 @@ k_conv_b3(const float* __restrict__ x, const b3_u32x4* __restrict__ wb3, const f
   }
 }
 
-template <int NSUB, bool GROUPED = false>
+template <int NSUB, bool GROUPED = false, int MODE = 0>
 int launch_b3(const float* x, const void* wb3, const float* scale, const float* shift, const float* res, float* y,
-              const CfunConv3dParams& p, int nsub_total, hipStream_t st) {
+              const CfunConv3dParams& p, int nsub_total, int cq, hipStream_t st) {
   const int ntz = (p.Do + 3) / 4, nty = (p.Ho + 3) / 4, ntx = (p.Wo + 15) / 16, ncot = nsub_total / NSUB;
   const int64_t nblk = (int64_t)p.N * ntz * nty * ntx * ncot;
   if (nblk == 0) return CFUN_OK;
   if (nblk > 0x7fffffffLL) return CFUN_EINVAL;
-  if constexpr (NSUB == 5 && !GROUPED) {
-    if (nblk >= 256) return launch_b3<NSUB, true>(x, wb3, scale, shift, res, y, p, nsub_total, st);
+  if constexpr (NSUB == 5 && !GROUPED && MODE == 0) {
+    if (nblk >= 256) return launch_b3<NSUB, true>(x, wb3, scale, shift, res, y, p, nsub_total, cq, st);
   }
-  hipLaunchKernelGGL((k_conv_b3<NSUB, GROUPED>), dim3((unsigned)nblk), dim3(256), (size_t)2 * 3 * kB3Plane, st, x,
-                     (const b3_u32x4*)wb3, scale, shift, res, y, p, ntz, nty, ntx, ncot, nsub_total);
+  hipLaunchKernelGGL((k_conv_b3<NSUB, GROUPED, MODE>), dim3((unsigned)nblk), dim3(256), (size_t)2 * 3 * kB3Plane, st, x,
+                     (const b3_u32x4*)wb3, scale, shift, res, y, p, ntz, nty, ntx, ncot, nsub_total, cq);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }
 
+inline int b3_d2s_cq(const CfunConv3dParams* p) { return p->d2s_cq > 0 ? p->d2s_cq : (p->Co >> 3); }
+
 inline bool b3_shape_ok(const CfunConv3dParams* p) {
-  return p->kd == 3 && p->kh == 3 && p->kw == 3 && p->stride == 1 && p->pd == 1 && p->ph == 1 && p->pw == 1 && !p->up2 &&
-         !p->d2s && !p->res_up2 && !p->tap_skip && (p->Ci & 3) == 0 && (p->Co & 3) == 0 && p->Ci >= 8 &&
-         p->Do == p->Di && p->Ho == p->Hi && p->Wo == p->Wi;
+  if (!(p->kd == 3 && p->kh == 3 && p->kw == 3 && p->stride == 1 && p->pd == 1 && p->ph == 1 && p->pw == 1 && !p->up2 &&
+        !p->tap_skip && (p->Ci & 3) == 0 && (p->Co & 3) == 0 && p->Ci >= 8 && p->Do == p->Di && p->Ho == p->Hi &&
+        p->Wo == p->Wi))
+    return false;
+  if (p->d2s)     // parity-folded up-conv without tap skipping (the 5x5x5 one): 8 parity groups of 4-aligned channels
+    return (p->Co & 7) == 0 && ((p->Co >> 3) & 3) == 0 && (b3_d2s_cq(p) & 3) == 0;
+  return !p->res_up2;
+}
+
+// the data gradient of a d2s conv on these kernels: chunks of 8 channels must not straddle a parity
+inline bool b3_d2s_dgrad_ok(const CfunConv3dParams* p) {
+  return b3_shape_ok(p) && p->d2s && (b3_d2s_cq(p) & 7) == 0 && p->Co == 8 * b3_d2s_cq(p);
 }
 
 inline int b3_nsub_per_block(int nsub) { return nsub % 3 == 0 ? 3 : nsub % 5 == 0 ? 5 : nsub % 4 == 0 ? 4 : nsub % 2 == 0 ? 2 : 1; }
@@ -262,6 +301,8 @@ int cfun_conv3d_b3_preferred(const CfunConv3dParams* p) {
   const int64_t nblk = (int64_t)p->N * ((p->Do + 3) / 4) * ((p->Ho + 3) / 4) * ((p->Wo + 15) / 16) * (nsub / b3_nsub_per_block(nsub));
   return nblk >= 120 ? 1 : 0;
 }
+
+int cfun_conv3d_b3_dgrad_d2s_supported(const CfunConv3dParams* p) { return p && b3_d2s_dgrad_ok(p) ? 1 : 0; }
 
 size_t cfun_weight_pack_b3_bytes(int32_t rows, int32_t kch) {
   if (rows <= 0 || kch <= 0) return 0;
@@ -287,12 +328,38 @@ int cfun_conv3d_b3_fwd(const float* x, const void* wb3, const float* scale, cons
   if (!cfun_aligned16(x) || !cfun_aligned16(wb3) || !cfun_aligned16(y)) return CFUN_EALIGN;
   const int nsub = (p->Co + 15) / 16;
   hipStream_t st = cfun_st(stream);
+  const int cq = p->d2s ? b3_d2s_cq(p) : 0;
+  if (p->d2s) {
+    switch (b3_nsub_per_block(nsub)) {
+      case 3: return launch_b3<3, false, 1>(x, wb3, scale, shift, res, y, *p, nsub, cq, st);
+      case 4: return launch_b3<4, false, 1>(x, wb3, scale, shift, res, y, *p, nsub, cq, st);
+      case 2: return launch_b3<2, false, 1>(x, wb3, scale, shift, res, y, *p, nsub, cq, st);
+      default: return launch_b3<1, false, 1>(x, wb3, scale, shift, res, y, *p, nsub, cq, st);
+    }
+  }
   switch (b3_nsub_per_block(nsub)) {
-    case 3: return launch_b3<3>(x, wb3, scale, shift, res, y, *p, nsub, st);
-    case 5: return launch_b3<5>(x, wb3, scale, shift, res, y, *p, nsub, st);
-    case 4: return launch_b3<4>(x, wb3, scale, shift, res, y, *p, nsub, st);
-    case 2: return launch_b3<2>(x, wb3, scale, shift, res, y, *p, nsub, st);
-    default: return launch_b3<1>(x, wb3, scale, shift, res, y, *p, nsub, st);
+    case 3: return launch_b3<3>(x, wb3, scale, shift, res, y, *p, nsub, cq, st);
+    case 5: return launch_b3<5>(x, wb3, scale, shift, res, y, *p, nsub, cq, st);
+    case 4: return launch_b3<4>(x, wb3, scale, shift, res, y, *p, nsub, cq, st);
+    case 2: return launch_b3<2>(x, wb3, scale, shift, res, y, *p, nsub, cq, st);
+    default: return launch_b3<1>(x, wb3, scale, shift, res, y, *p, nsub, cq, st);
+  }
+}
+
+// Data gradient of a d2s conv (p = the FORWARD conv's parameters): g = dL/dy in y's hi-res layout [N,2D,2H,2W,cq],
+// wb3t = cfun_weight_pack_b3(w, transpose_flip = 1) of the folded OIDHW weight [8*cq, Ci, 3,3,3], dx [N,D,H,W,Ci].
+int cfun_conv3d_b3_dgrad_d2s(const float* g, const void* wb3t, float* dx, const CfunConv3dParams* p, cfun_stream_t stream) {
+  if (!p || !b3_d2s_dgrad_ok(p)) return CFUN_EINVAL;
+  if (!cfun_aligned16(g) || !cfun_aligned16(wb3t) || !cfun_aligned16(dx)) return CFUN_EALIGN;
+  CfunConv3dParams q = *p;
+  q.Ci = p->Co; q.Co = p->Ci; q.CoP = (p->Ci + 15) / 16 * 16; q.CiP = p->CoP;
+  q.d2s = 0; q.d2s_cq = 0; q.res_up2 = 0; q.res_mode = 0; q.scale_mode = 0; q.has_shift = 0; q.act = CFUN_ACT_NONE;
+  const int nsub = q.CoP / 16, cq = b3_d2s_cq(p);
+  hipStream_t st = cfun_st(stream);
+  switch (b3_nsub_per_block(nsub)) {
+    case 3: return launch_b3<3, false, 2>(g, wb3t, nullptr, nullptr, nullptr, dx, q, nsub, cq, st);
+    case 2: return launch_b3<2, false, 2>(g, wb3t, nullptr, nullptr, nullptr, dx, q, nsub, cq, st);
+    default: return launch_b3<1, false, 2>(g, wb3t, nullptr, nullptr, nullptr, dx, q, nsub, cq, st);
   }
 }
 

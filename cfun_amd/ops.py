@@ -287,11 +287,19 @@ class _Conv3d(torch.autograd.Function):
             # dx of a per-sample conv goes straight into its sample of the batch's gradient (zero-copy batch split)
             dx = torch.empty_like(x) if ctx.dx_slot is None else ctx.dx_slot[0].sample(ctx.dx_slot[1], x.shape, x)
             pd = None
-            if ctx.b3:       # the data gradient is the same 3x3x3 conv on g with transposed, mirrored weights
+            if ctx.b3 and spec.d2s:          # hi-res gradient gathered by parity inside the 3xBF16 kernel
+                if lib.cfun_conv3d_b3_dgrad_d2s_supported(C.byref(p)):
+                    wb3t = pack_weight_b3(w_b3, transpose_flip=True)
+                    check(lib.cfun_conv3d_b3_dgrad_d2s(ptr(g), ptr(wb3t), ptr(dx), C.byref(p), st),
+                          "conv3d_b3_dgrad_d2s")
+                    pd = "done"
+            elif ctx.b3:     # the data gradient is the same 3x3x3 conv on g with transposed, mirrored weights
                 pd = _params(ConvSpec(k=(3, 3, 3), co=p.Ci, pad=(1, 1, 1)), g.shape, False, False, False)
                 if not _b3_wanted(lib, pd):
                     pd = None
-            if pd is not None:
+            if pd == "done":
+                pass
+            elif pd is not None:
                 wb3t = pack_weight_b3(w_b3, transpose_flip=True)     # (held until the launch is enqueued)
                 check(lib.cfun_conv3d_b3_fwd(ptr(g), ptr(wb3t), None, None, None, ptr(dx), C.byref(pd), st),
                       "conv3d_b3_fwd(dgrad)")

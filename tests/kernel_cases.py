@@ -435,3 +435,34 @@ def check_conv_b3(device, n, dhw, ci, co, seed=21, act=ACT_NONE, scale=False, sh
     e_dw = float((dw_b3.double() - dw64).abs().max()) / float(dw64.abs().max())
     assert e_dw < 3e-6, "3xBF16 weight-gradient error %.2e" % e_dw
     return e_b3, e_f32
+
+
+def check_fold5_b3(device, seed=23):
+    """The parity-folded "nearest x2 -> 5x5x5" conv (d2s epilogue + low-res residual) and its data gradient (parity gather
+    of the hi-res gradient) on the 3xBF16 kernels against the exact-fp32 MFMA path: same module-level call
+    (ops.conv3d_w on the folded weight), CFUN_CONV_ALGO=b3! vs auto."""
+    import os
+    from cfun_amd._lib import ALGO_B3
+    gen = _gen(seed)
+    x = randn(gen, 2, 6, 8, 16, 8)
+    w5 = randn(gen, 8, 8, 5, 5, 5) / float(8 * 125) ** 0.5
+    gy = randn(gen, 2, 12, 16, 32, 8)
+    outs = []
+    old = os.environ.get("CFUN_CONV_ALGO")
+    try:
+        for algo, env in ((ALGO_AUTO, "auto"), (ALGO_B3, "b3!")):
+            os.environ["CFUN_CONV_ALGO"] = env
+            xd = x.clone().to(device).requires_grad_(True)
+            wd = w5.clone().to(device).requires_grad_(True)
+            spec = ops.ConvSpec(k=(3, 3, 3), co=64, pad=(1, 1, 1), d2s=True, res_up2=True, algo=algo)
+            y = ops.conv3d_w(xd, ops.fold_up2_weight(wd), spec, res=xd)
+            y.backward(gy.to(device))
+            outs.append((y.detach().cpu(), xd.grad.cpu(), wd.grad.cpu()))
+    finally:
+        if old is None:
+            os.environ.pop("CFUN_CONV_ALGO", None)
+        else:
+            os.environ["CFUN_CONV_ALGO"] = old
+    for a, b, what in zip(outs[0], outs[1], ("y", "dx", "dw")):
+        err = float((a - b).abs().max()) / float(a.abs().max())
+        assert err < 5e-6, "fold5 on 3xBF16: %s differs from the fp32 path by %.2e" % (what, err)

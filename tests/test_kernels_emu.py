@@ -89,3 +89,7 @@ def test_conv_b3_experimental(emu):
     kc.check_conv_b3(emu, 1, (5, 6, 17), 8, 20, act=kc.ACT_LRELU, shift=True)
     kc.check_conv_b3(emu, 2, (4, 4, 16), 24, 40, scale=True, res=True)
     kc.check_conv_b3(emu, 1, (4, 5, 9), 20, 12)                        # K padded 20 -> 24, data gradient K 12 -> 16
+
+
+def test_fold5_b3_experimental(emu):
+    kc.check_fold5_b3(emu)

@@ -146,3 +146,7 @@ def test_conv_b3_experimental(gpu, n, dhw, ci, co):
     """3xBF16 conv prototype (conv3d_b3.hip): fp32-level accuracy against fp64, forward and data gradient."""
     e_b3, e_f32 = kc.check_conv_b3(gpu, n, dhw, ci, co, act=kc.ACT_LRELU, shift=True, res=True)
     print("3xBF16 max rel err %.2e, exact fp32 MFMA %.2e" % (e_b3, e_f32))
+
+
+def test_fold5_b3_experimental(gpu):
+    kc.check_fold5_b3(gpu)
