@@ -88,7 +88,8 @@ _SIGNATURES = {
     "cfun_conv3d_b3_preferred": (C.c_int, [_PP]),
     "cfun_weight_pack_b3_bytes": (_Z, [_I, _I]),
     "cfun_weight_pack_b3": (C.c_int, [_P, _P, _I, _I, _I, _P]),
-    "cfun_conv3d_b3_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _PP, _P]),
+    "cfun_conv3d_b3_fwd_workspace_bytes": (_Z, [_PP]),
+    "cfun_conv3d_b3_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _PP, _P, _Z, _P]),
     "cfun_conv3d_b3_dgrad_d2s_supported": (C.c_int, [_PP]),
     "cfun_conv3d_b3_dgrad_d2s": (C.c_int, [_P, _P, _P, _PP, _P]),
     "cfun_conv3d_b3_wgrad_supported": (C.c_int, [_PP]),

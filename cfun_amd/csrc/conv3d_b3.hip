@@ -60,7 +60,7 @@ template <int NSUB, bool GROUPED, int MODE>
 __global__ void __launch_bounds__(256, GROUPED ? 2 : 1)
 k_conv_b3(const float* __restrict__ x, const b3_u32x4* __restrict__ wb3, const float* __restrict__ scale,
           const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y, CfunConv3dParams p,
-          int ntz, int nty, int ntx, int ncot, int nsub_total, int cq) {
+          int ntz, int nty, int ntx, int ncot, int nsub_total, int cq, float* __restrict__ partial, int chunks_per_split) {
   constexpr int NT = 16 * NSUB;
   constexpr int ITEMS = kB3Vox * 2, IN_LOADS = (ITEMS + 255) / 256;     // float4 (4 channels) items per chunk
   CFUN_DYN_LDS(unsigned char, smem);                                     // [2 buffers][3 planes][kB3Vox][16 B]
@@ -157,13 +157,19 @@ k_conv_b3(const float* __restrict__ x, const b3_u32x4* __restrict__ wb3, const f
 
   // Two LDS buffers: chunk c+1 is split and written (VALU + ds_write, in the middle of chunk c's MFMA stream) while
   // chunk c is being read, so a chunk costs ONE barrier and the conversion work hides behind the matrix pipe.
-  const int nchunks = (p.Ci + 7) >> 3, nsteps = nchunks * kB3Steps;
-  prefetch_x(0);
-  load_a(a_cur, 0);
-  commit_x(0);
-  if (nchunks > 1) prefetch_x(1);
+  // split-K (small volumes: too few tiles to fill 256 CUs): blockIdx.y owns a range of channel chunks and stores raw
+  // accumulators to partial[blockIdx.y]; cfun_splitk_finish sums them in order and runs the epilogue
+  const int nchunks_all = (p.Ci + 7) >> 3;
+  const int c_first = blockIdx.y * chunks_per_split;
+  const int nchunks = (c_first + chunks_per_split < nchunks_all ? c_first + chunks_per_split : nchunks_all);
+  const int nsteps = nchunks * kB3Steps;
+  if (c_first >= nchunks) return;
+  prefetch_x(c_first);
+  load_a(a_cur, c_first * kB3Steps * H);
+  commit_x(c_first & 1);
+  if (c_first + 1 < nchunks) prefetch_x(c_first + 1);
   __syncthreads();
-  for (int c = 0; c < nchunks; ++c) {
+  for (int c = c_first; c < nchunks; ++c) {
     const unsigned char* xb = smem + (c & 1) * (3 * kB3Plane);
 #pragma unroll
     for (int s = 0; s < kB3Steps; ++s) {
@@ -219,6 +225,10 @@ k_conv_b3(const float* __restrict__ x, const b3_u32x4* __restrict__ wb3, const f
       const int co = cobase + nn * 16 + kb * 4;
       if (co >= p.Co) continue;
       float4 r = make_float4(acc[m][nn][0], acc[m][nn][1], acc[m][nn][2], acc[m][nn][3]);
+      if (gridDim.y > 1) {       // split-K partial: raw sums, plain layout
+        *reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.y * p.N * p.Do * p.Ho * p.Wo + v) * p.Co + co) = r;
+        continue;
+      }
       if (p.scale_mode) {
         const float4 s4 = *reinterpret_cast<const float4*>(scale + (p.scale_mode == 2 ? n * p.Co : 0) + co);
         r.x *= s4.x; r.y *= s4.y; r.z *= s4.z; r.w *= s4.w;
@@ -252,9 +262,20 @@ k_conv_b3(const float* __restrict__ x, const b3_u32x4* __restrict__ wb3, const f
   }
 }
 
+// split-K factor for launches of fewer than ~256 workgroups (each split keeps >= 2 chunks = 14 K-steps of work)
+inline int b3_splitk(int64_t nblk, int nchunks, const CfunConv3dParams& p, size_t ws_bytes) {
+  if (nblk >= 256 || nchunks < 4) return 1;
+  int k = (int)((512 + nblk - 1) / nblk);
+  if (k > nchunks / 2) k = nchunks / 2;
+  if (k > 16) k = 16;
+  const size_t per = (size_t)p.N * p.Do * p.Ho * p.Wo * p.Co * sizeof(float);
+  while (k > 1 && (size_t)k * per > ws_bytes) --k;
+  return k < 1 ? 1 : k;
+}
+
 template <int NSUB, bool GROUPED = false, int MODE = 0>
 int launch_b3(const float* x, const void* wb3, const float* scale, const float* shift, const float* res, float* y,
-              const CfunConv3dParams& p, int nsub_total, int cq, hipStream_t st) {
+              const CfunConv3dParams& p, int nsub_total, int cq, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0) {
   const int ntz = (p.Do + 3) / 4, nty = (p.Ho + 3) / 4, ntx = (p.Wo + 15) / 16, ncot = nsub_total / NSUB;
   const int64_t nblk = (int64_t)p.N * ntz * nty * ntx * ncot;
   if (nblk == 0) return CFUN_OK;
@@ -262,9 +283,16 @@ int launch_b3(const float* x, const void* wb3, const float* scale, const float* 
   if constexpr (NSUB == 5 && !GROUPED && MODE == 0) {
     if (nblk >= 256) return launch_b3<NSUB, true>(x, wb3, scale, shift, res, y, p, nsub_total, cq, st);
   }
-  hipLaunchKernelGGL((k_conv_b3<NSUB, GROUPED, MODE>), dim3((unsigned)nblk), dim3(256), (size_t)2 * 3 * kB3Plane, st, x,
-                     (const b3_u32x4*)wb3, scale, shift, res, y, p, ntz, nty, ntx, ncot, nsub_total, cq);
+  const int nchunks = (p.Ci + 7) >> 3;
+  int ksplit = 1;
+  if (MODE == 0) ksplit = b3_splitk(nblk, nchunks, p, ws && cfun_aligned16(ws) ? ws_bytes : 0);
+  const int cps = (nchunks + ksplit - 1) / ksplit;
+  ksplit = (nchunks + cps - 1) / cps;
+  hipLaunchKernelGGL((k_conv_b3<NSUB, GROUPED, MODE>), dim3((unsigned)nblk, (unsigned)ksplit), dim3(256),
+                     (size_t)2 * 3 * kB3Plane, st, x, (const b3_u32x4*)wb3, scale, shift, res, y, p, ntz, nty, ntx, ncot,
+                     nsub_total, cq, (float*)ws, cps);
   CFUN_LAUNCH_CHECK();
+  if (ksplit > 1) return cfun_splitk_finish((const float*)ws, ksplit, scale, shift, res, y, &p, st);
   return CFUN_OK;
 }
 
@@ -299,7 +327,18 @@ int cfun_conv3d_b3_preferred(const CfunConv3dParams* p) {
   if (!p || !b3_shape_ok(p)) return 0;
   const int nsub = (p->Co + 15) / 16;
   const int64_t nblk = (int64_t)p->N * ((p->Do + 3) / 4) * ((p->Ho + 3) / 4) * ((p->Wo + 15) / 16) * (nsub / b3_nsub_per_block(nsub));
-  return nblk >= 120 ? 1 : 0;
+  const int nchunks = (p->Ci + 7) >> 3;
+  const int k = p->d2s ? 1 : b3_splitk(nblk, nchunks, *p, (size_t)-1);      // with the workspace the caller is asked for
+  return nblk * k >= 120 ? 1 : 0;
+}
+
+// split-K partials for volumes too small to fill the chip (0: none needed); ws may be NULL -- the kernel then runs unsplit
+size_t cfun_conv3d_b3_fwd_workspace_bytes(const CfunConv3dParams* p) {
+  if (!p || !b3_shape_ok(p) || p->d2s) return 0;
+  const int nsub = (p->Co + 15) / 16;
+  const int64_t nblk = (int64_t)p->N * ((p->Do + 3) / 4) * ((p->Ho + 3) / 4) * ((p->Wo + 15) / 16) * (nsub / b3_nsub_per_block(nsub));
+  const int k = b3_splitk(nblk, (p->Ci + 7) >> 3, *p, (size_t)-1);
+  return k > 1 ? cfun_align_up((size_t)k * p->N * p->Do * p->Ho * p->Wo * p->Co * sizeof(float), 256) : 0;
 }
 
 int cfun_conv3d_b3_dgrad_d2s_supported(const CfunConv3dParams* p) { return p && b3_d2s_dgrad_ok(p) ? 1 : 0; }
@@ -323,7 +362,7 @@ int cfun_weight_pack_b3(const float* w, void* wb3, int32_t Co, int32_t Ci, int32
 }
 
 int cfun_conv3d_b3_fwd(const float* x, const void* wb3, const float* scale, const float* shift, const float* res, float* y,
-                       const CfunConv3dParams* p, cfun_stream_t stream) {
+                       const CfunConv3dParams* p, void* ws, size_t ws_bytes, cfun_stream_t stream) {
   if (!p || !b3_shape_ok(p)) return CFUN_EINVAL;
   if (!cfun_aligned16(x) || !cfun_aligned16(wb3) || !cfun_aligned16(y)) return CFUN_EALIGN;
   const int nsub = (p->Co + 15) / 16;
@@ -338,11 +377,11 @@ int cfun_conv3d_b3_fwd(const float* x, const void* wb3, const float* scale, cons
     }
   }
   switch (b3_nsub_per_block(nsub)) {
-    case 3: return launch_b3<3>(x, wb3, scale, shift, res, y, *p, nsub, cq, st);
-    case 5: return launch_b3<5>(x, wb3, scale, shift, res, y, *p, nsub, cq, st);
-    case 4: return launch_b3<4>(x, wb3, scale, shift, res, y, *p, nsub, cq, st);
-    case 2: return launch_b3<2>(x, wb3, scale, shift, res, y, *p, nsub, cq, st);
-    default: return launch_b3<1>(x, wb3, scale, shift, res, y, *p, nsub, cq, st);
+    case 3: return launch_b3<3>(x, wb3, scale, shift, res, y, *p, nsub, cq, st, ws, ws_bytes);
+    case 5: return launch_b3<5>(x, wb3, scale, shift, res, y, *p, nsub, cq, st, ws, ws_bytes);
+    case 4: return launch_b3<4>(x, wb3, scale, shift, res, y, *p, nsub, cq, st, ws, ws_bytes);
+    case 2: return launch_b3<2>(x, wb3, scale, shift, res, y, *p, nsub, cq, st, ws, ws_bytes);
+    default: return launch_b3<1>(x, wb3, scale, shift, res, y, *p, nsub, cq, st, ws, ws_bytes);
   }
 }
 

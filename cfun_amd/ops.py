@@ -238,8 +238,9 @@ class _Conv3d(torch.autograd.Function):
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         if b3:
-            check(lib.cfun_conv3d_b3_fwd(ptr(x), ptr(wb3), ptr(scale), ptr(shift), ptr(res), ptr(y), C.byref(p),
-                                         stream(x)), "conv3d_b3_fwd")
+            ws = workspace(lib.cfun_conv3d_b3_fwd_workspace_bytes(C.byref(p)), x)
+            check(lib.cfun_conv3d_b3_fwd(ptr(x), ptr(wb3), ptr(scale), ptr(shift), ptr(res), ptr(y), C.byref(p), ptr(ws),
+                                         ws.numel(), stream(x)), "conv3d_b3_fwd")
         else:
             ws = workspace(lib.cfun_conv3d_fwd_workspace_bytes(C.byref(p)), x)
             check(lib.cfun_conv3d_fwd(ptr(x), ptr(wp), ptr(scale), ptr(shift), ptr(res), ptr(y), C.byref(p), ptr(ws),
@@ -301,8 +302,9 @@ class _Conv3d(torch.autograd.Function):
                 pass
             elif pd is not None:
                 wb3t = pack_weight_b3(w_b3, transpose_flip=True)     # (held until the launch is enqueued)
-                check(lib.cfun_conv3d_b3_fwd(ptr(g), ptr(wb3t), None, None, None, ptr(dx), C.byref(pd), st),
-                      "conv3d_b3_fwd(dgrad)")
+                ws = workspace(lib.cfun_conv3d_b3_fwd_workspace_bytes(C.byref(pd)), x)
+                check(lib.cfun_conv3d_b3_fwd(ptr(g), ptr(wb3t), None, None, None, ptr(dx), C.byref(pd), ptr(ws), ws.numel(),
+                                             st), "conv3d_b3_fwd(dgrad)")
             else:
                 if wpT is None:
                     wpT = _transpose_pack(wp if wp is not None else _pack(w_b3), p.Co)
@@ -380,8 +382,9 @@ def conv3d_b3(x, wb3, co, scale=None, shift=None, res=None, act=ACT_NONE, scale_
         raise ValueError("conv3d_b3: unsupported shape (needs C_in % 4 == 0, C_in >= 8, C_out % 4 == 0)")
     y = torch.empty((p.N, p.Do, p.Ho, p.Wo, p.Co), dtype=torch.float32, device=x.device)
     scale, shift, res = [None if t is None else _c(t) for t in (scale, shift, res)]      # held across the launch
-    check(lib.cfun_conv3d_b3_fwd(ptr(x), ptr(wb3), ptr(scale), ptr(shift), ptr(res), ptr(y), C.byref(p), stream(x)),
-          "conv3d_b3_fwd")
+    ws = workspace(lib.cfun_conv3d_b3_fwd_workspace_bytes(C.byref(p)), x)
+    check(lib.cfun_conv3d_b3_fwd(ptr(x), ptr(wb3), ptr(scale), ptr(shift), ptr(res), ptr(y), C.byref(p), ptr(ws), ws.numel(),
+                                 stream(x)), "conv3d_b3_fwd")
     return y
 
 

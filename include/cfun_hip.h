@@ -263,8 +263,9 @@ int cfun_conv3d_b3_supported(const CfunConv3dParams* p);
 int cfun_conv3d_b3_preferred(const CfunConv3dParams* p);   /* supported and large enough to beat the fp32 MFMA kernel */
 size_t cfun_weight_pack_b3_bytes(int32_t rows, int32_t kch);
 int cfun_weight_pack_b3(const float* w, void* wb3, int32_t Co, int32_t Ci, int32_t transpose_flip, cfun_stream_t stream);
+size_t cfun_conv3d_b3_fwd_workspace_bytes(const CfunConv3dParams* p);   /* split-K partials of small volumes (may be 0) */
 int cfun_conv3d_b3_fwd(const float* x, const void* wb3, const float* scale, const float* shift, const float* res,
-                       float* y, const CfunConv3dParams* p, cfun_stream_t stream);
+                       float* y, const CfunConv3dParams* p, void* ws, size_t ws_bytes, cfun_stream_t stream);
 /* ... also the parity-folded "nearest x2 -> 5x5x5" conv (p->d2s = 1, no tap_skip; mask_branch.py:216-218) with its
  * depth-to-space epilogue, and that conv's data gradient: g = dL/dy in y's hi-res layout [N,2D,2H,2W,cq] is gathered
  * by parity while staging (p = the FORWARD parameters, wb3t = cfun_weight_pack_b3(folded w, transpose_flip = 1)). */
