@@ -35,6 +35,7 @@ WORKLOADS = {
     "cfg1": ("beginning", 128, 128, 64),
     "cfg0": ("beginning", 64, 64, 32),
     "cfg3": ("finetune", 512, 512, 256),   # configs[3]'s volume on however many GPUs are given (--sharded: one volume)
+    "cfg4": ("beginning", 320, 320, 256),  # the LiTS fork's shapes (P3D35, 5x7x7 stem, b = 32, 3 classes, 32x80x80 crops)
 }
 
 
@@ -139,7 +140,7 @@ def main():
 
     from cfun_amd import config, ops, step
     stage, h, w, d = WORKLOADS[args.workload]
-    cfg = config.heart_config(stage, h, w, d)
+    cfg = config.LiTSConfig(stage) if args.workload == "cfg4" else config.heart_config(stage, h, w, d)
     torch.manual_seed(0)                       # identical replicated weights on every rank
     net = step.CFUNHotPath(cfg).to(dev)
     sharded = args.sharded and world > 1
@@ -236,8 +237,10 @@ def main():
             "dtype": "f32 (conv forward/dgrad operands as 3 x bf16 on the bf16 MFMA, fp32 accumulate)" if b3 else "f32",
             "data": "synthetic",
             "config": {"workload": "%s: %dx%dx%d CT, stage '%s', 4 positive + 8 negative RoIs, U-Net b=%d, "
-                                   "96^3 -> %d^3 masks, 6 losses incl. 3-D Sobel edge loss, fwd+bwd"
-                                   % (args.workload, h, w, d, stage, b, cfg.MASK_SHAPE[0]),
+                                   "%s crops -> %s masks, 6 losses%s, fwd+bwd"
+                                   % (args.workload, h, w, d, stage, b, "x".join(map(str, side)),
+                                      "x".join(map(str, cfg.MASK_SHAPE)),
+                                      " incl. 3-D Sobel edge loss" if stage == "finetune" else ""),
                        "parallelism": ("ONE volume over %d GPUs: depth-sharded FPN/RPN with xGMI halo exchange, RPN "
                                        "all-gather, head RoIs round-robin, gradient all-reduce; losses = rank 0's shares"
                                        % world) if sharded else
@@ -249,7 +252,9 @@ def main():
                          "traffic": pmc_traffic() if args.workload == "cfg2" else None,
                          "mfma_util_pmc": pmc_mfma_util() if args.workload == "cfg2" else None,
                          "kernel": "k_conv_mfma<3,3,3,1,3> (conv_norm_lrelu_l4.0: 3x3x3 %d->%d @ %dx%d^3)"
-                                   % (2 * b, 2 * b, n_roi_launch, side[0]),
+                                   % (2 * b, 2 * b, n_roi_launch, side[0]) if len(set(side)) == 1 else
+                                   "k_conv_mfma (conv_norm_lrelu_l4.0: 3x3x3 %d->%d @ %dx%s)"
+                                   % (2 * b, 2 * b, n_roi_launch, "x".join(map(str, side))),
                          "flops_per_launch": flops, "avg_launch_ms": t_k * 1e3, "launches_timed": len(durs)},
         }
         if b3:   # algorithmic (fp32) flops against the bf16 matrix peak divided by the 6 products each one costs
