@@ -206,8 +206,7 @@ k_edge_march(const float* __restrict__ probs, const uint8_t* __restrict__ labels
         }
         if (MODE != 0) {
           const float k = gs * (pm - tm) / pm;      // 0/0 -> NaN exactly like torch's sqrt backward (App. A-13)
-          o[c * 2] = k * 2.f * p0;
-          o[c * 2 + 1] = k * p1;
+          reinterpret_cast<float2*>(o)[c] = make_float2(k * 2.f * p0, k * p1);     // (dc0, dc1) of class c+1: one 8-byte store
         }
       }
       P[0] = P[1]; P[1] = P[2]; T[0] = T[1]; T[1] = T[2];
@@ -236,10 +235,15 @@ __device__ __forceinline__ void plane_adj(const float* __restrict__ dc, int64_t 
     for (int i = 0; i < 3; ++i) {
       const int ox = x - i;
       if (ox < 0 || ox >= Wo) continue;
-      const float* d = dc + (((r * Do + zo) * Ho + oy) * Wo + ox) * (2 * (CT - 1));
+      // the voxel's 2*(CT-1) coefficients as (dc0, dc1) pairs: 8-byte loads (half the load instructions of the scalar
+      // walk; the kernel is bound by its 9 neighbour gathers per plane, not by HBM)
+      const float2* d = reinterpret_cast<const float2*>(dc + (((r * Do + zo) * Ho + oy) * Wo + ox) * (2 * (CT - 1)));
       const float wd = B[j] * A[i], ws = A[j] * A[i];
 #pragma unroll
-      for (int c = 0; c < CT - 1; ++c) { q0[c] += wd * d[c * 2]; q1[c] += ws * d[c * 2 + 1]; }
+      for (int c = 0; c < CT - 1; ++c) {
+        const float2 v = d[c];
+        q0[c] += wd * v.x; q1[c] += ws * v.y;
+      }
     }
   }
 }

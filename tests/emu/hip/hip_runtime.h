@@ -42,6 +42,10 @@ struct alignas(16) float4 {
   float x, y, z, w;
 };
 inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
+struct alignas(8) float2 {
+  float x, y;
+};
+inline float2 make_float2(float a, float b) { return float2{a, b}; }
 
 namespace hipemu {
 
