@@ -136,7 +136,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # "nccl" is RCCL on ROCm; CFUN_BENCH_BACKEND=gloo only to exercise this path on a single-GPU box
-        dist.init_process_group(os.environ.get("CFUN_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+        backend = os.environ.get("CFUN_BENCH_BACKEND", "nccl")
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     from cfun_amd import config, ops, step
     stage, h, w, d = WORKLOADS[args.workload]
@@ -170,8 +171,8 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        if world > 1:     # RCCL barriers run on a device: name this rank's (the default guess is rank % device_count)
+            dist.barrier(device_ids=[local]) if backend == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
     b3 = os.environ.get("CFUN_CONV_ALGO", "auto") == "b3"     # the whole run on the opt-in 3xBF16 kernels: labelled below
