@@ -75,6 +75,12 @@ _SIGNATURES = {
     "cfun_edge_loss_fwd_save": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "cfun_mask_losses_bwd_saved": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cfun_mask_target_labels": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "cfun_ce_weighted_workspace_bytes": (_Z, []),
+    "cfun_softmax_ce_weighted_fwd": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P, _Z, _P]),
+    "cfun_softmax_ce_weighted_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "cfun_edge_raw_dc_bytes": (_Z, [_I, _I, _I, _I, _I]),
+    "cfun_edge_raw_fwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "cfun_edge_raw_bwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cfun_unmold_argmax": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "cfun_unmold_overlap": (C.c_int, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "cfun_sumsq_partials_count": (C.c_int32, []),

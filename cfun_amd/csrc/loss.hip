@@ -299,6 +299,168 @@ k_edge_bwd_gather(const float* __restrict__ dc, float* __restrict__ dprobs, int 
   }
 }
 
+// ------------------------------------------------------------------ LiTS fork: weighted CE and raw Sobel MSE
+// nn.CrossEntropyLoss(weight = w) (LiTS_2017/model.py:926, w = [1, 1, 100]): sum_i w[y_i] * (-log p_i[y_i]) / sum_i w[y_i].
+// partial[b] = numerator, partial[kMaxBlocks + b] = denominator of block b.
+template <int CT>
+__global__ void __launch_bounds__(kBlock)
+k_ce_w_fwd(const float* __restrict__ logits, const uint8_t* __restrict__ labels, const float* __restrict__ weights,
+           double* __restrict__ partial, int64_t nvox, int Crt) {
+  const int C = CT > 0 ? CT : Crt;
+  double num = 0.0, den = 0.0;
+  for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nvox; v += (int64_t)gridDim.x * kBlock) {
+    const float* l = logits + v * C;
+    float x[CT > 0 ? CT : kMaxC];
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < (CT > 0 ? CT : kMaxC); ++c)
+      if (c < C) { x[c] = l[c]; m = fmaxf(m, x[c]); }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < (CT > 0 ? CT : kMaxC); ++c)
+      if (c < C) s += expf(x[c] - m);
+    const int lab = labels[v];
+    float xl = 0.f;
+#pragma unroll
+    for (int c = 0; c < (CT > 0 ? CT : kMaxC); ++c)
+      if (c == lab) xl = x[c];
+    const float w = weights[lab];
+    num += (double)(w * ((m + logf(s)) - xl));
+    den += (double)w;
+  }
+  const double sn = block_sum(num);
+  const double sd = block_sum(den);
+  if (threadIdx.x == 0) { partial[blockIdx.x] = sn; partial[kMaxBlocks + blockIdx.x] = sd; }
+}
+
+__global__ void k_finalize_ratio(const double* __restrict__ partial, int blocks, float* __restrict__ loss,
+                                 float* __restrict__ wsum) {
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < blocks; i += 64) { a += partial[i]; b += partial[kMaxBlocks + i]; }
+  a = cfun_wave_sum_d(a);
+  b = cfun_wave_sum_d(b);
+  if (threadIdx.x == 0) { loss[0] = (float)(a / b); wsum[0] = (float)b; }
+}
+
+// dlogits = g * w[y] / sum_w * (softmax - onehot)
+template <int CT>
+__global__ void __launch_bounds__(kBlock)
+k_ce_w_bwd(const float* __restrict__ logits, const uint8_t* __restrict__ labels, const float* __restrict__ weights,
+           const float* __restrict__ gscale, const float* __restrict__ wsum, float* __restrict__ dlogits, int64_t nvox,
+           int Crt) {
+  const int C = CT > 0 ? CT : Crt;
+  const float gs = gscale[0] / wsum[0];
+  for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nvox; v += (int64_t)gridDim.x * kBlock) {
+    const float* l = logits + v * C;
+    float x[CT > 0 ? CT : kMaxC];
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < (CT > 0 ? CT : kMaxC); ++c)
+      if (c < C) { x[c] = l[c]; m = fmaxf(m, x[c]); }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < (CT > 0 ? CT : kMaxC); ++c)
+      if (c < C) { x[c] = expf(x[c] - m); s += x[c]; }
+    const int lab = labels[v];
+    const float k = gs * weights[lab], inv = 1.f / s;
+#pragma unroll
+    for (int c = 0; c < (CT > 0 ? CT : kMaxC); ++c)
+      if (c < C) dlogits[v * C + c] = k * (x[c] * inv - (c == lab ? 1.f : 0.f));
+  }
+}
+
+// Edge loss of the fork (LiTS_2017/model.py:936-979): MSE between the RAW three Sobel responses of the predicted and
+// the target mask (no magnitude), per positive RoI and foreground class, summed and divided by the RoI count:
+//   loss = sum_{roi, class j >= 1, k < 3, o} (p_k(o) - t_k(o))^2 / (3 * Do*Ho*Wo * n)
+// kernel k = 0: derivative along y (A[dz] B[dy] A[dx]), 1: along z, 2: along x; A = (1,2,1), B = (1,0,-1); valid conv.
+// One thread per output voxel and class pair; the difference field dc[o][(j-1)*3 + k] is kept for the backward.
+template <int CT>
+__global__ void __launch_bounds__(kBlock)
+k_edge_raw_fwd(const float* __restrict__ probs, const uint8_t* __restrict__ labels, double* __restrict__ partial,
+               float* __restrict__ dc, int n, int D, int H, int W) {
+  const int Do = D - 2, Ho = H - 2, Wo = W - 2;
+  const int64_t total = (int64_t)n * Do * Ho * Wo;
+  const float A[3] = {1.f, 2.f, 1.f}, B[3] = {1.f, 0.f, -1.f};
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    int64_t t = i;
+    const int xo = (int)(t % Wo); t /= Wo;
+    const int yo = (int)(t % Ho); t /= Ho;
+    const int zo = (int)(t % Do);
+    const int64_t r = t / Do;
+    float d[CT - 1][3];
+#pragma unroll
+    for (int j = 0; j < CT - 1; ++j) d[j][0] = d[j][1] = d[j][2] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int64_t v = ((r * D + zo + a) * H + yo + b) * W + xo + c;
+          const int lab = labels[v];
+          const float k0 = A[a] * B[b] * A[c], k1 = B[a] * A[b] * A[c], k2 = A[a] * A[b] * B[c];
+#pragma unroll
+          for (int j = 0; j < CT - 1; ++j) {
+            const float f = probs[v * CT + j + 1] - (lab == j + 1 ? 1.f : 0.f);     // conv is linear: conv(p) - conv(t)
+            d[j][0] += k0 * f; d[j][1] += k1 * f; d[j][2] += k2 * f;
+          }
+        }
+#pragma unroll
+    for (int j = 0; j < CT - 1; ++j)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        acc += (double)(d[j][k] * d[j][k]);
+        if (dc) dc[i * (3 * (CT - 1)) + j * 3 + k] = d[j][k];
+      }
+  }
+  const double s = block_sum(acc);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// dprobs[v][j] = g * 2 / (3*Do*Ho*Wo*n) * sum_{a,b,c, k} K_k[a][b][c] * dc[v - (a,b,c)][(j-1)*3 + k];  dprobs[v][0] = 0
+template <int CT>
+__global__ void __launch_bounds__(kBlock)
+k_edge_raw_bwd(const float* __restrict__ dc, const float* __restrict__ gscale, float* __restrict__ dprobs, int n, int D,
+               int H, int W) {
+  const int Do = D - 2, Ho = H - 2, Wo = W - 2;
+  const int64_t total = (int64_t)n * D * H * W;
+  const float A[3] = {1.f, 2.f, 1.f}, B[3] = {1.f, 0.f, -1.f};
+  const float gs = gscale[0] * 2.f / (3.f * (float)Do * (float)Ho * (float)Wo * (float)n);
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    int64_t t = i;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H); t /= H;
+    const int z = (int)(t % D);
+    const int64_t r = t / D;
+    float g[CT - 1];
+#pragma unroll
+    for (int j = 0; j < CT - 1; ++j) g[j] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int zo = z - a;
+      if (zo < 0 || zo >= Do) continue;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const int yo = y - b;
+        if (yo < 0 || yo >= Ho) continue;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int xo = x - c;
+          if (xo < 0 || xo >= Wo) continue;
+          const float* d = dc + ((((r * Do + zo) * Ho + yo) * Wo + xo)) * (3 * (CT - 1));
+          const float k0 = A[a] * B[b] * A[c], k1 = B[a] * A[b] * A[c], k2 = A[a] * A[b] * B[c];
+#pragma unroll
+          for (int j = 0; j < CT - 1; ++j) g[j] += k0 * d[j * 3] + k1 * d[j * 3 + 1] + k2 * d[j * 3 + 2];
+        }
+      }
+    }
+    dprobs[i * CT] = 0.f;
+#pragma unroll
+    for (int j = 0; j < CT - 1; ++j) dprobs[i * CT + j + 1] = gs * g[j];
+  }
+}
+
 #define DISPATCH_C(C, CALL)            \
   if ((C) == 8) { CALL(8) }            \
   else if ((C) == 3) { CALL(3) }       \
@@ -450,5 +612,67 @@ int cfun_mask_losses_bwd(const float* probs, const uint8_t* labels, const float*
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }
+
+// ---- LiTS fork losses (LiTS_2017/model.py:907-979)
+size_t cfun_ce_weighted_workspace_bytes(void) { return 2 * kMaxBlocks * sizeof(double); }
+
+int cfun_softmax_ce_weighted_fwd(const float* logits, const uint8_t* labels, const float* weights, float* loss,
+                                 float* wsum, int64_t nvox, int32_t C, void* ws, size_t ws_bytes, cfun_stream_t stream) {
+  if (C <= 0 || C > kMaxC || !weights || !wsum) return CFUN_EINVAL;
+  if (nvox <= 0) return CFUN_EINVAL;                    // 0 / 0: the reference returns a constant 0 before getting here
+  if (ws_bytes < cfun_ce_weighted_workspace_bytes()) return CFUN_EWORKSPACE;
+  const unsigned blocks = vox_grid(nvox);
+#define CALL(CT) hipLaunchKernelGGL(k_ce_w_fwd<CT>, dim3(blocks), dim3(kBlock), 0, cfun_st(stream), logits, labels, weights, (double*)ws, nvox, C);
+  DISPATCH_C(C, CALL)
+#undef CALL
+  hipLaunchKernelGGL(k_finalize_ratio, dim3(1), dim3(64), 0, cfun_st(stream), (const double*)ws, (int)blocks, loss, wsum);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+int cfun_softmax_ce_weighted_bwd(const float* logits, const uint8_t* labels, const float* weights, const float* gscale,
+                                 const float* wsum, float* dlogits, int64_t nvox, int32_t C, cfun_stream_t stream) {
+  if (nvox <= 0) return CFUN_OK;
+  if (C <= 0 || C > kMaxC || !weights || !wsum) return CFUN_EINVAL;
+#define CALL(CT) hipLaunchKernelGGL(k_ce_w_bwd<CT>, dim3(vox_grid(nvox)), dim3(kBlock), 0, cfun_st(stream), logits, labels, weights, gscale, wsum, dlogits, nvox, C);
+  DISPATCH_C(C, CALL)
+#undef CALL
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+size_t cfun_edge_raw_dc_bytes(int32_t n, int32_t D, int32_t H, int32_t W, int32_t C) {
+  if (n <= 0 || D < 3 || H < 3 || W < 3 || C < 2) return 256;
+  return cfun_align_up((size_t)n * (D - 2) * (H - 2) * (W - 2) * 3 * (C - 1) * sizeof(float), 256);
+}
+
+// dc (cfun_edge_raw_dc_bytes; may be NULL for a forward-only call); ws: cfun_loss_workspace_bytes
+int cfun_edge_raw_fwd(const float* probs, const uint8_t* labels, float* loss, float* dc, int32_t n, int32_t D, int32_t H,
+                      int32_t W, int32_t C, void* ws, size_t ws_bytes, cfun_stream_t stream) {
+  if (C != 3 && C != 2) return CFUN_EINVAL;
+  if (n <= 0 || D < 3 || H < 3 || W < 3) return (int)hipMemsetAsync(loss, 0, sizeof(float), cfun_st(stream));
+  if (ws_bytes < kMaxBlocks * sizeof(double)) return CFUN_EWORKSPACE;
+  const int64_t per = (int64_t)(D - 2) * (H - 2) * (W - 2);
+  const unsigned blocks = vox_grid((int64_t)n * per);
+  if (C == 3) hipLaunchKernelGGL(k_edge_raw_fwd<3>, dim3(blocks), dim3(kBlock), 0, cfun_st(stream), probs, labels, (double*)ws, dc, n, D, H, W);
+  else hipLaunchKernelGGL(k_edge_raw_fwd<2>, dim3(blocks), dim3(kBlock), 0, cfun_st(stream), probs, labels, (double*)ws, dc, n, D, H, W);
+  hipLaunchKernelGGL(k_finalize_sum, dim3(1), dim3(64), 0, cfun_st(stream), (const double*)ws, (int)blocks,
+                     1.0 / (3.0 * (double)per * (double)n), loss);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+int cfun_edge_raw_bwd(const float* dc, const float* gscale, float* dprobs, int32_t n, int32_t D, int32_t H, int32_t W,
+                      int32_t C, cfun_stream_t stream) {
+  if (C != 3 && C != 2) return CFUN_EINVAL;
+  const int64_t total = (int64_t)n * D * H * W;
+  if (total <= 0) return CFUN_OK;
+  if (D < 3 || H < 3 || W < 3) return (int)hipMemsetAsync(dprobs, 0, total * C * sizeof(float), cfun_st(stream));
+  if (C == 3) hipLaunchKernelGGL(k_edge_raw_bwd<3>, dim3(vox_grid(total)), dim3(kBlock), 0, cfun_st(stream), dc, gscale, dprobs, n, D, H, W);
+  else hipLaunchKernelGGL(k_edge_raw_bwd<2>, dim3(vox_grid(total)), dim3(kBlock), 0, cfun_st(stream), dc, gscale, dprobs, n, D, H, W);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
 
 }  // extern "C"

@@ -845,9 +845,76 @@ class _MaskCE(torch.autograd.Function):
         return dl, None
 
 
-def mask_cross_entropy(logits, labels):
-    """CrossEntropyLoss(logits [n,D,H,W,C], labels uint8 [n,D,H,W]) -- model.py:909-935."""
-    return _MaskCE.apply(logits, labels)
+class _MaskCEWeighted(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, weight):
+        lib = _lib.load()
+        logits, labels = _c(logits), _c(labels)
+        weight = _c(weight.detach().to(device=logits.device, dtype=torch.float32))
+        c = logits.shape[-1]
+        nvox = logits.numel() // c
+        if labels.dtype != torch.uint8 or labels.numel() != nvox or weight.numel() != c:
+            raise RuntimeError("mask_cross_entropy: labels must be uint8 [n,D,H,W], weight [C]")
+        loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
+        wsum = torch.empty((1,), dtype=torch.float32, device=logits.device)
+        ws = workspace(lib.cfun_ce_weighted_workspace_bytes(), logits)
+        check(lib.cfun_softmax_ce_weighted_fwd(ptr(logits), ptr(labels), ptr(weight), ptr(loss), ptr(wsum), nvox, c, ptr(ws),
+                                               ws.numel(), stream(logits)), "softmax_ce_weighted_fwd")
+        ctx.save_for_backward(logits, labels, weight, wsum)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        logits, labels, weight, wsum = ctx.saved_tensors
+        c = logits.shape[-1]
+        gs = _c(g.reshape(1).float())
+        dl = torch.empty_like(logits)
+        check(lib.cfun_softmax_ce_weighted_bwd(ptr(logits), ptr(labels), ptr(weight), ptr(gs), ptr(wsum), ptr(dl),
+                                               logits.numel() // c, c, stream(logits)), "softmax_ce_weighted_bwd")
+        return dl, None, None
+
+
+def mask_cross_entropy(logits, labels, weight=None):
+    """CrossEntropyLoss(logits [n,D,H,W,C], labels uint8 [n,D,H,W]) -- model.py:909-935; ``weight`` [C]: the LiTS
+    fork's class weights (LiTS_2017/model.py:926)."""
+    if weight is None:
+        return _MaskCE.apply(logits, labels)
+    return _MaskCEWeighted.apply(logits, labels, torch.as_tensor(weight, dtype=torch.float32))
+
+
+class _EdgeRaw(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, probs, labels):
+        lib = _lib.load()
+        probs, labels = _c(probs), _c(labels)
+        n, d, h, w, c = probs.shape
+        loss = torch.empty((1,), dtype=torch.float32, device=probs.device)
+        keep = ctx.needs_input_grad[0]
+        dc = torch.empty(lib.cfun_edge_raw_dc_bytes(n, d, h, w, c) // 4, dtype=torch.float32, device=probs.device) \
+            if keep else None
+        ws = workspace(lib.cfun_loss_workspace_bytes(n * d * h * w), probs)
+        check(lib.cfun_edge_raw_fwd(ptr(probs), ptr(labels), ptr(loss), ptr(dc), n, d, h, w, c, ptr(ws), ws.numel(),
+                                    stream(probs)), "edge_raw_fwd")
+        ctx.shape = tuple(probs.shape)
+        ctx.save_for_backward(dc)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (dc,) = ctx.saved_tensors
+        n, d, h, w, c = ctx.shape
+        gs = _c(g.reshape(1).float())
+        dp = torch.empty(ctx.shape, dtype=torch.float32, device=dc.device)
+        check(lib.cfun_edge_raw_bwd(ptr(dc), ptr(gs), ptr(dp), n, d, h, w, c, stream(dc)), "edge_raw_bwd")
+        return dp, None
+
+
+def edge_loss_raw(probs, labels):
+    """The LiTS fork's edge loss (LiTS_2017/model.py:936-979): MSE on the raw three Sobel responses of NDHWC probabilities
+    vs uint8 labels, foreground classes only; differentiable w.r.t. ``probs``."""
+    return _EdgeRaw.apply(probs, labels)
 
 
 class _EdgeLoss(torch.autograd.Function):

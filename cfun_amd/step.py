@@ -190,7 +190,17 @@ class CFUNHotPath(nn.Module):
                   model.compute_rpn_bbox_loss(rpn_bbox_t, rpn_match, out["rpn_bbox"]),
                   model.compute_mrcnn_class_loss(target_class_ids, out["mrcnn_class_logits"]),
                   model.compute_mrcnn_bbox_loss(target_deltas, target_class_ids, out["mrcnn_bbox"])]
-        if self.config.STAGE == "finetune":   # CE + Sobel edge loss share one fused backward pass
+        cw = getattr(self.config, "MASK_CE_CLASS_WEIGHTS", None)
+        raw = getattr(self.config, "EDGE_LOSS_RAW_SOBEL", False)
+        if cw is not None or raw:             # LiTS fork: class-weighted CE, edge loss on the raw Sobel responses
+            ce = ops.mask_cross_entropy(out["mrcnn_mask_logits"], mask_labels, weight=cw)
+            if self.config.STAGE == "finetune":
+                edge = ops.edge_loss_raw(out["mrcnn_mask"], mask_labels) if raw else \
+                    ops.edge_loss(out["mrcnn_mask"], mask_labels)
+            else:
+                edge = torch.zeros((), device=mask_labels.device)
+            losses += [ce, edge]
+        elif self.config.STAGE == "finetune":   # CE + Sobel edge loss share one fused backward pass
             losses += list(ops.mask_losses(out["mrcnn_mask_logits"], out["mrcnn_mask"], mask_labels))
         else:
             losses += [ops.mask_cross_entropy(out["mrcnn_mask_logits"], mask_labels),

@@ -175,6 +175,24 @@ int cfun_unmold_argmax(const float* probs, uint8_t* out, int32_t D, int32_t H, i
 int cfun_unmold_overlap(const float* probs, const int32_t* boxes, int32_t n, uint8_t* labels, float* full, int32_t D,
                         int32_t H, int32_t W, int32_t md, int32_t mh, int32_t mw, int32_t C, cfun_stream_t stream);
 
+/* LiTS fork mask losses (LiTS_2017/model.py:907-979).
+ * Weighted cross entropy: nn.CrossEntropyLoss(weight = w) (model.py:926, w = [1, 1, 100]) on logits [nvox, C] and uint8
+ * labels: loss = sum w[y] * (-log softmax[y]) / sum w[y]; wsum receives sum w[y] (device float, needed by the backward).
+ * weights: device float[C].  ws: cfun_ce_weighted_workspace_bytes(). */
+size_t cfun_ce_weighted_workspace_bytes(void);
+int cfun_softmax_ce_weighted_fwd(const float* logits, const uint8_t* labels, const float* weights, float* loss,
+                                 float* wsum, int64_t nvox, int32_t C, void* ws, size_t ws_bytes, cfun_stream_t stream);
+int cfun_softmax_ce_weighted_bwd(const float* logits, const uint8_t* labels, const float* weights, const float* gscale,
+                                 const float* wsum, float* dlogits, int64_t nvox, int32_t C, cfun_stream_t stream);
+/* Edge loss of the fork (model.py:936-979): MSE between the RAW three Sobel responses of predicted probabilities
+ * [n,D,H,W,C] and target labels, classes 1..C-1, summed over RoIs and classes, / n.  dc (cfun_edge_raw_dc_bytes, may be
+ * NULL when no backward follows) keeps the response differences; cfun_edge_raw_bwd turns them into dL/dprobs. */
+size_t cfun_edge_raw_dc_bytes(int32_t n, int32_t D, int32_t H, int32_t W, int32_t C);
+int cfun_edge_raw_fwd(const float* probs, const uint8_t* labels, float* loss, float* dc, int32_t n, int32_t D, int32_t H,
+                      int32_t W, int32_t C, void* ws, size_t ws_bytes, cfun_stream_t stream);
+int cfun_edge_raw_bwd(const float* dc, const float* gscale, float* dprobs, int32_t n, int32_t D, int32_t H, int32_t W,
+                      int32_t C, cfun_stream_t stream);
+
 /* GT mask targets of detection_target_layer (model.py:481-493, utils.py:318-339) as uint8 class labels:
  * labels [D,H,W] (class id per voxel = argmax of the one-hot GT), bounds [R,6] int32 voxel crop
  * (z1,y1,x1,z2,y2,x2) = int(shape * normalised coordinate), out [R,md,mh,mw] = nearest-resized crop. */

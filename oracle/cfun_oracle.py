@@ -478,6 +478,26 @@ def mask_ce_loss(target_onehot, logits):
     return F.cross_entropy(logits, y)
 
 
+def mask_ce_loss_weighted(target_onehot, logits, weight):
+    """LiTS_2017/model.py:907-933: as mask_ce_loss with nn.CrossEntropyLoss(weight=[1, 1, 100])."""
+    y = torch.argmax(target_onehot.long(), dim=1)
+    return F.cross_entropy(logits, y, weight=torch.as_tensor(weight, dtype=torch.float32))
+
+
+def edge_loss_raw(target_onehot, probs):
+    """LiTS_2017/model.py:936-979: per (roi, class 1..C-1) valid Sobel conv of target and prediction, MSE over the raw
+    [1,3,D-2,H-2,W-2] responses (the magnitude is commented out in the fork), summed, / n_pos."""
+    k = sobel_stack()
+    n, c = probs.shape[:2]
+    loss = torch.zeros(1, dtype=torch.float32)
+    for i in range(n):
+        for j in range(1, c):
+            t = F.conv3d(target_onehot[i, j][None, None].float(), k)
+            p = F.conv3d(probs[i, j][None, None], k)
+            loss = loss + F.mse_loss(p, t)
+    return loss / n
+
+
 def sobel_stack():
     """model.py:947-952."""
     kx = np.array([[[1, 2, 1], [0, 0, 0], [-1, -2, -1]],
@@ -617,9 +637,11 @@ LOSS_WEIGHTS = (100.0, 50.0, 1.0, 20.0, 1.0, 1.0)  # heart_main.py:161-168
 
 def training_step(sd, image, anchors, rpn_match, rpn_bbox_t, p_rois, n_rois, target_class_ids,
                   target_deltas, target_mask, stage, pool_size, mask_pool_size, dropout_masks=None,
-                  proposal_count=500, nms_threshold=0.7, pre_nms_limit=1000, layers=(2, 3), stem_pad=(1, 3, 3)):
+                  proposal_count=500, nms_threshold=0.7, pre_nms_limit=1000, layers=(2, 3), stem_pad=(1, 3, 3),
+                  ce_class_weights=None, edge_raw=False):
     """predict('training') dataflow (model.py:1391-1514) + compute_losses (984-1000) with the
     head RoIs injected (p_rois positives first, then n_rois).  image [1,1,D,H,W].
+    ce_class_weights / edge_raw: the LiTS fork's mask losses (LiTS_2017/model.py:926, 959-972).
     Returns dict of outputs and the 6 losses."""
     p2, p3 = fpn(image, sd, layers=layers, stem_pad=stem_pad)
     l2, pr2, b2 = rpn(p2, sd)
@@ -637,8 +659,10 @@ def training_step(sd, image, anchors, rpn_match, rpn_bbox_t, p_rois, n_rois, tar
               rpn_bbox_loss(rpn_bbox_t, rpn_match, rpn_box),
               mrcnn_class_loss(target_class_ids, cls_logits),
               mrcnn_bbox_loss(target_deltas, target_class_ids, cls_bbox),
-              mask_ce_loss(target_mask, m_logits),
-              edge_loss(target_mask, m_probs)[0] if stage == "finetune" else torch.zeros(())]
+              mask_ce_loss(target_mask, m_logits) if ce_class_weights is None
+              else mask_ce_loss_weighted(target_mask, m_logits, ce_class_weights),
+              ((edge_loss_raw if edge_raw else edge_loss)(target_mask, m_probs)[0]) if stage == "finetune"
+              else torch.zeros(())]
     total = sum(wt * l for wt, l in zip(LOSS_WEIGHTS, losses))
     return dict(p2=p2, p3=p3, rpn_logits=rpn_logits, rpn_probs=rpn_probs, rpn_bbox=rpn_box, rpn_rois=rpn_rois,
                 nms_keep=keep, cls_logits=cls_logits, cls_bbox=cls_bbox, mask_logits=m_logits, mask_probs=m_probs,

@@ -303,6 +303,30 @@ def case_losses():
          edge_grad_probs=probs_leaf.grad.numpy())
 
 
+def case_losses_lits():
+    """LiTS fork: compute_mrcnn_mask_loss (class weights [1, 1, 100]) and compute_mrcnn_mask_edge_loss (MSE on the raw
+    three Sobel responses) of LiTS_2017/model.py:907-979 on 2 RoIs x 3 classes x 10x12x14 voxels."""
+    lits_model, _ = import_lits()
+    n, c, dhw = 2, 3, (10, 12, 14)
+    logits = torch.from_numpy(formula.uniform("lossl.logits", (n, c) + dhw, -3, 3)).requires_grad_(True)
+    lab = (formula.uniform("lossl.lab", (n,) + dhw, 0, 1) * c).astype(np.int64).clip(0, c - 1)
+    lab = np.repeat(np.repeat(np.repeat(lab[:, ::2, ::3, ::2], 2, 1), 3, 2), 2, 3)[:, :dhw[0], :dhw[1], :dhw[2]]
+    onehot = np.zeros((n, c) + dhw, np.float64)
+    for k in range(c):
+        onehot[:, k] = (lab == k)
+    target = torch.from_numpy(onehot)
+    ids = torch.tensor([1, 2])
+    ce = lits_model.compute_mrcnn_mask_loss(target, ids, logits)
+    ce.backward()
+    g_ce = logits.grad.clone(); logits.grad = None
+    probs = torch.softmax(logits, dim=1)
+    el = lits_model.compute_mrcnn_mask_edge_loss(target, ids, probs)
+    el.backward()
+    save("losses_lits", logits=logits.detach().numpy(), labels=lab.astype(np.uint8), ce=ce.detach().numpy(),
+         ce_grad=g_ce.numpy(), edge=el.detach().numpy(), edge_grad_logits=logits.grad.numpy(),
+         class_weights=np.array([1.0, 1.0, 100.0], np.float32))
+
+
 def case_proposal():
     cfg = make_cfg("beginning", 64, 32)
     shapes = ref_model.compute_backbone_shapes(cfg, cfg.IMAGE_SHAPE)
@@ -511,7 +535,7 @@ def case_unmold_lits():
          boxes=boxes, class_ids=ids, scores=scores, class_map=cmap.astype(np.uint8))
 
 
-CASES = dict(unmold_lits=case_unmold_lits, unmold=case_unmold, refine=case_refine, nms=case_nms, anchors=case_anchors, roi_align=case_roi_align, fpn_rpn=case_fpn_rpn, unet=case_unet,
+CASES = dict(losses_lits=case_losses_lits, unmold_lits=case_unmold_lits, unmold=case_unmold, refine=case_refine, nms=case_nms, anchors=case_anchors, roi_align=case_roi_align, fpn_rpn=case_fpn_rpn, unet=case_unet,
              losses=case_losses, proposal=case_proposal, classifier=case_classifier, predict=case_predict)
 
 if __name__ == "__main__":

@@ -466,3 +466,24 @@ def check_fold5_b3(device, seed=23):
     for a, b, what in zip(outs[0], outs[1], ("y", "dx", "dw")):
         err = float((a - b).abs().max()) / float(a.abs().max())
         assert err < 5e-6, "fold5 on 3xBF16: %s differs from the fp32 path by %.2e" % (what, err)
+
+
+def check_mask_losses_lits(device, g):
+    """LiTS fork mask losses on the device (ops.mask_cross_entropy(weight=...), ops.edge_loss_raw through the
+    differentiable softmax) vs the fork's own values and gradients (golden ``g`` = losses_lits.npz)."""
+    lg = torch.from_numpy(g["logits"])
+    ld = lg.permute(0, 2, 3, 4, 1).contiguous().to(device).requires_grad_(True)
+    labd = torch.from_numpy(g["labels"]).to(device)
+    ce = ops.mask_cross_entropy(ld, labd, weight=g["class_weights"])
+    ce.backward()
+    assert abs(float(ce) - float(g["ce"])) < 1e-5 * abs(float(g["ce"]))
+    assert_close(ld.grad.permute(0, 4, 1, 2, 3), torch.from_numpy(g["ce_grad"]), "golden weighted dCE", 1e-4)
+    ld.grad = None
+    el = ops.edge_loss_raw(ops.softmax_channels(ld), labd)
+    el.backward()
+    assert abs(float(el) - float(g["edge"].reshape(-1)[0])) < 1e-4 * abs(float(g["edge"].reshape(-1)[0]))
+    assert_close(ld.grad.permute(0, 4, 1, 2, 3), torch.from_numpy(g["edge_grad_logits"]), "golden raw-Sobel dEdge", 1e-3)
+    # forward-only call keeps no difference field
+    with torch.no_grad():
+        el2 = ops.edge_loss_raw(ops.softmax_channels(ld.detach()), labd)
+    assert float(el2) == float(el)

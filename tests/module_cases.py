@@ -201,7 +201,7 @@ def tiny_lits_config(stage="beginning", max_dim=32, min_dim=16):
         UNET_MASK_BRANCH_CHANNEL=4, TOP_DOWN_PYRAMID_SIZE=20, RPN_CONV_CHANNELS=40, FPN_CLASSIFY_FC_LAYERS_SIZE=16,
         RPN_ANCHOR_SCALES=(16, 32), PRE_NMS_LIMIT=64, POST_NMS_ROIS_TRAINING=16))
     cfg = cls(stage)
-    cfg.MASK_SHAPE = cfg.MINI_MASK_SHAPE = (32, 48, 32)
+    cfg.MASK_SHAPE = cfg.MINI_MASK_SHAPE = (64, 96, 64) if stage == "finetune" else (32, 48, 32)
     return cfg
 
 
@@ -236,7 +236,9 @@ def check_training_step_vs_oracle(device, cfg, seed=0, n_pos=None):
                             cfg.POOL_SIZE, cfg.MASK_POOL_SIZE, dropout_masks=masks,
                             proposal_count=cfg.POST_NMS_ROIS_TRAINING, nms_threshold=cfg.RPN_NMS_THRESHOLD,
                             pre_nms_limit=cfg.PRE_NMS_LIMIT, layers=tuple(getattr(cfg, "BACKBONE_LAYERS", (2, 3))),
-                            stem_pad=(getattr(cfg, "BACKBONE_STEM_KD", 3) // 2, 3, 3))
+                            stem_pad=(getattr(cfg, "BACKBONE_STEM_KD", 3) // 2, 3, 3),
+                            ce_class_weights=getattr(cfg, "MASK_CE_CLASS_WEIGHTS", None),
+                            edge_raw=getattr(cfg, "EDGE_LOSS_RAW_SOBEL", False))
     ref["total"].backward()
     # forward parity
     np.testing.assert_allclose(out["rpn_class_logits"].detach().cpu().numpy(), ref["rpn_logits"].detach().numpy(),

@@ -94,3 +94,7 @@ def test_conv_b3_experimental(emu):
 
 def test_fold5_b3_experimental(emu):
     kc.check_fold5_b3(emu)
+
+
+def test_mask_losses_lits_golden(emu):
+    kc.check_mask_losses_lits(emu, load_golden("losses_lits"))

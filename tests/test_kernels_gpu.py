@@ -150,3 +150,7 @@ def test_conv_b3_experimental(gpu, n, dhw, ci, co):
 
 def test_fold5_b3_experimental(gpu):
     kc.check_fold5_b3(gpu)
+
+
+def test_mask_losses_lits_golden(gpu):
+    kc.check_mask_losses_lits(gpu, load_golden("losses_lits"))

@@ -101,3 +101,8 @@ def test_b3_training_step_vs_oracle(emu, monkeypatch):
     """Opt-in 3xBF16 conv kernels through the module path (CFUN_CONV_ALGO=b3) on the emulator."""
     monkeypatch.setenv("CFUN_CONV_ALGO", "b3!")
     mc.check_training_step_vs_oracle(emu, mc.tiny_config("beginning"), n_pos=1)
+
+
+def test_training_step_lits_finetune(emu_direct):
+    """LiTS fork 'finetune': class-weighted mask CE + raw-Sobel edge loss through the whole step vs the oracle."""
+    mc.check_training_step_vs_oracle(emu_direct, mc.tiny_lits_config("finetune"), n_pos=1)

@@ -321,3 +321,8 @@ def test_b3_training_step_cfg0_vs_oracle(gpu, monkeypatch):
 def test_b3_predict_cfg0_reference_golden(gpu, monkeypatch):
     monkeypatch.setenv("CFUN_CONV_ALGO", "b3!")
     mc.check_predict_cfg0_golden(gpu)
+
+
+def test_training_step_lits_finetune(gpu):
+    """LiTS fork 'finetune': class-weighted mask CE + raw-Sobel edge loss through the whole step vs the oracle."""
+    mc.check_training_step_vs_oracle(gpu, mc.tiny_lits_config("finetune"))

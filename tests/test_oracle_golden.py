@@ -258,3 +258,22 @@ def test_unmold_lits_golden():
     np.testing.assert_array_equal(scores, g["scores"])
     np.testing.assert_array_equal(cmap.astype(np.uint8), g["class_map"])
     assert boxes.shape[0] == 4                      # the zero-volume detection was dropped
+
+
+def test_mask_losses_lits():
+    """LiTS fork: weighted CE ([1, 1, 100]) and the raw-Sobel edge MSE (LiTS_2017/model.py:907-979) vs the fork's own
+    outputs and gradients."""
+    g = load_golden("losses_lits")
+    lab = g["labels"].astype(np.int64)
+    c = g["logits"].shape[1]
+    onehot = torch.stack([t(lab == k) for k in range(c)], dim=1).double()
+    logits = t(g["logits"]).requires_grad_(True)
+    ce = orc.mask_ce_loss_weighted(onehot, logits, g["class_weights"])
+    np.testing.assert_allclose(ce.item(), g["ce"], rtol=1e-6)
+    ce.backward()
+    np.testing.assert_allclose(logits.grad.numpy(), g["ce_grad"], rtol=1e-5, atol=1e-10)
+    logits.grad = None
+    el = orc.edge_loss_raw(onehot, torch.softmax(logits, dim=1))
+    np.testing.assert_allclose(el.item(), g["edge"].item(), rtol=1e-6)
+    el.backward()
+    np.testing.assert_allclose(logits.grad.numpy(), g["edge_grad_logits"], rtol=1e-4, atol=1e-8)
