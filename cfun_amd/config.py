@@ -102,6 +102,9 @@ class LiTSConfig(Config):
     MASK_POOL_SIZE = [32, 80, 80]
     UNET_DROPOUT = 0.0
     UNMOLD_OVERLAP_TILE = True          # utils.unmold_mask averages ALL detections (LiTS_2017/utils.py:383-408)
+    TRAIN_ROIS_PER_IMAGE = 4            # LiTS_2017/config.py:222-226 ('beginning' / 'finetune'): positives only
+    ROI_POSITIVE_RATIO = 1.0
+    ROI_COUNT_ROUND = True              # RoI counts by int(round()) (LiTS_2017/model.py:448, 496; heart truncates)
     MASK_CE_CLASS_WEIGHTS = (1.0, 1.0, 100.0)   # nn.CrossEntropyLoss(weight=...) of the mask loss (LiTS_2017/model.py:926)
     EDGE_LOSS_RAW_SOBEL = True          # edge loss = MSE on the raw 3 Sobel responses, no magnitude (LiTS_2017/model.py:959-972)
 

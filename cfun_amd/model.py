@@ -136,7 +136,9 @@ def detection_target_layer(proposals, gt_class_ids, gt_boxes, gt_labels, config,
         e = torch.zeros((0, 6), device=dev)
         return e, e, torch.zeros((0,), dtype=torch.long, device=dev), e, torch.zeros(
             (0,) + tuple(config.MASK_SHAPE), dtype=torch.uint8, device=dev)
-    want = int(config.TRAIN_ROIS_PER_IMAGE * config.ROI_POSITIVE_RATIO)
+    # heart: int() truncation (model.py:457, 504); LiTS fork: int(round()) (LiTS_2017/model.py:448, 496)
+    count = (lambda v: int(round(v))) if getattr(config, "ROI_COUNT_ROUND", False) else int
+    want = count(config.TRAIN_ROIS_PER_IMAGE * config.ROI_POSITIVE_RATIO)
     perm = torch.randperm(pos_idx.numel()) if perms is None else perms[0]
     pos_idx = pos_idx[perm[:want].to(dev)]
     n_pos = pos_idx.numel()
@@ -149,7 +151,7 @@ def detection_target_layer(proposals, gt_class_ids, gt_boxes, gt_labels, config,
     neg_idx = torch.nonzero(iou_max < config.DETECTION_TARGET_IOU_THRESHOLD)[:, 0]
     rois = p_rois
     if neg_idx.numel() != 0:
-        n_neg = int((1.0 / config.ROI_POSITIVE_RATIO) * n_pos - n_pos)
+        n_neg = count((1.0 / config.ROI_POSITIVE_RATIO) * n_pos - n_pos)
         perm = torch.randperm(neg_idx.numel()) if perms is None else perms[1]
         neg_idx = neg_idx[perm[:n_neg].to(dev)]
         rois = torch.cat([p_rois, proposals[neg_idx]], dim=0)

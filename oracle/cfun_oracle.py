@@ -600,7 +600,7 @@ def bbox_overlaps(boxes1, boxes2):
 
 def detection_target_layer(proposals, gt_class_ids, gt_boxes, gt_masks, mask_shape, perm_pos, perm_neg,
                            train_rois=15, positive_ratio=0.33, iou_threshold=0.5,
-                           std_dev=(0.1, 0.1, 0.1, 0.2, 0.2, 0.2)):
+                           std_dev=(0.1, 0.1, 0.1, 0.2, 0.2, 0.2), count_round=False):
     """model.py:414-563 with the two torch.randperm draws (459, 505) injected: proposals [N,6] and gt_boxes [G,6]
     normalised, gt_class_ids [G], gt_masks one-hot [C,D,H,W].  Returns (positive_rois, rois, class_ids, deltas,
     masks [n_pos,C,*mask_shape]) -- positives first.  Only the 'positives and negatives' / 'positives only' branches
@@ -610,7 +610,8 @@ def detection_target_layer(proposals, gt_class_ids, gt_boxes, gt_masks, mask_sha
     pos_idx = torch.nonzero(iou_max >= iou_threshold)[:, 0]
     if pos_idx.numel() == 0:
         raise ValueError("no positive RoI: the reference skips the heads for this sample")
-    pos_idx = pos_idx[perm_pos[:int(train_rois * positive_ratio)]]
+    count = (lambda v: int(round(v))) if count_round else int     # LiTS_2017/model.py:448, 496 round; heart truncates
+    pos_idx = pos_idx[perm_pos[:count(train_rois * positive_ratio)]]
     n_pos = pos_idx.numel()
     p_rois = proposals[pos_idx]
     assign = overlaps[pos_idx].max(dim=1)[1]
@@ -620,7 +621,7 @@ def detection_target_layer(proposals, gt_class_ids, gt_boxes, gt_masks, mask_sha
     neg_idx = torch.nonzero(iou_max < iou_threshold)[:, 0]
     rois = p_rois
     if neg_idx.numel() != 0:
-        n_neg = int((1.0 / positive_ratio) * n_pos - n_pos)
+        n_neg = count((1.0 / positive_ratio) * n_pos - n_pos)
         neg_idx = neg_idx[perm_neg[:n_neg]]
         rois = torch.cat([p_rois, proposals[neg_idx]], dim=0)
         class_ids = torch.cat([class_ids, torch.zeros(neg_idx.numel(), dtype=torch.long)])

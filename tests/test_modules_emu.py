@@ -83,6 +83,7 @@ def test_inference_vs_oracle(emu_direct):
 
 def test_detection_target_layer(emu):
     mc.check_detection_target_layer(emu)
+    mc.check_detection_target_layer(emu, lits=True)
 
 
 def test_flat_sgd_vs_torch(emu):

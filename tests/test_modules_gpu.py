@@ -148,6 +148,7 @@ def test_predict_cfg0_reference_golden(gpu):
 
 def test_detection_target_layer(gpu):
     mc.check_detection_target_layer(gpu)
+    mc.check_detection_target_layer(gpu, lits=True)
 
 
 def test_gradient_reducer_streams(gpu):
