@@ -142,6 +142,8 @@ def main():
     from cfun_amd import config, ops, step
     stage, h, w, d = WORKLOADS[args.workload]
     cfg = config.LiTSConfig(stage) if args.workload == "cfg4" else config.heart_config(stage, h, w, d)
+    if args.workload == "cfg4":       # BASELINE configs[4]: "LiTS_2017 config, same pipeline" -- all heads and losses in
+        cfg.STAGE_SPLIT = False       # one step (the fork itself trains detector and mask branch in separate phases)
     torch.manual_seed(0)                       # identical replicated weights on every rank
     net = step.CFUNHotPath(cfg).to(dev)
     sharded = args.sharded and world > 1

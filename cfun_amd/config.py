@@ -102,8 +102,10 @@ class LiTSConfig(Config):
     MASK_POOL_SIZE = [32, 80, 80]
     UNET_DROPOUT = 0.0
     UNMOLD_OVERLAP_TILE = True          # utils.unmold_mask averages ALL detections (LiTS_2017/utils.py:383-408)
-    TRAIN_ROIS_PER_IMAGE = 4            # LiTS_2017/config.py:222-226 ('beginning' / 'finetune'): positives only
-    ROI_POSITIVE_RATIO = 1.0
+    # the fork trains in two phases (LiTS_2017/model.py:985-1001, 1518-1545, 1282-1296): 'beginning' = detector only
+    # (FPN, RPN, classifier; no mask head, mask losses 0), any other stage = mask branch only (everything else frozen,
+    # classifier not run, detection losses 0).  False: the heart pipeline (all heads, all six losses) at LiTS shapes.
+    STAGE_SPLIT = True
     ROI_COUNT_ROUND = True              # RoI counts by int(round()) (LiTS_2017/model.py:448, 496; heart truncates)
     MASK_CE_CLASS_WEIGHTS = (1.0, 1.0, 100.0)   # nn.CrossEntropyLoss(weight=...) of the mask loss (LiTS_2017/model.py:926)
     EDGE_LOSS_RAW_SOBEL = True          # edge loss = MSE on the raw 3 Sobel responses, no magnitude (LiTS_2017/model.py:959-972)
@@ -111,3 +113,5 @@ class LiTSConfig(Config):
     def __init__(self, stage="beginning"):
         super().__init__(stage)
         self.MASK_SHAPE = self.MINI_MASK_SHAPE = (64, 160, 160) if stage == "finetune" else (32, 80, 80)
+        # LiTS_2017/config.py:216-226: 50 RoIs at 33 % positives for the detector phase, 4 positives for the mask phase
+        self.TRAIN_ROIS_PER_IMAGE, self.ROI_POSITIVE_RATIO = (50, 0.33) if stage == "beginning" else (4, 1.0)

@@ -40,6 +40,9 @@ class CFUNHotPath(nn.Module):
                              config.RPN_CONV_CHANNELS)
         self.classifier = model.Classifier(config.TOP_DOWN_PYRAMID_SIZE, config.POOL_SIZE, config.IMAGE_SHAPE, 2,
                                            config.FPN_CLASSIFY_FC_LAYERS_SIZE, test_flag)
+        if self.mask_phase_only:      # LiTS fork, stage != 'beginning': everything built so far is frozen
+            for p in self.parameters():                                   # (LiTS_2017/model.py:1282-1284)
+                p.requires_grad = False
         self.mask = model.Mask(1, config.MASK_POOL_SIZE, config.NUM_CLASSES, config.UNET_MASK_BRANCH_CHANNEL,
                                config.STAGE, test_flag, dropout_p=getattr(config, "UNET_DROPOUT", 0.6))
         if not config.TRAIN_BN:                           # model.py:1297-1304
@@ -48,6 +51,16 @@ class CFUNHotPath(nn.Module):
                     for p in m.parameters():
                         p.requires_grad = False
         self.initialize_weights()
+
+    @property
+    def detector_phase_only(self):
+        """LiTS fork 'beginning': no mask head, mask losses 0 (LiTS_2017/model.py:985-994, 1528-1535)."""
+        return bool(getattr(self.config, "STAGE_SPLIT", False)) and self.config.STAGE == "beginning"
+
+    @property
+    def mask_phase_only(self):
+        """LiTS fork, any other stage: no classifier head, detection losses 0 (LiTS_2017/model.py:995-1001, 1536-1548)."""
+        return bool(getattr(self.config, "STAGE_SPLIT", False)) and self.config.STAGE != "beginning"
 
     def initialize_weights(self):
         """model.py:1306-1319: xavier-uniform convs, zero biases, BN 1/0, Linear N(0, 0.01)."""
@@ -109,11 +122,15 @@ class CFUNHotPath(nn.Module):
         """BatchNorm stays in eval mode while the rest trains (model.py:1397-1406): folded BN needs no switch.
         p_rois [n_pos,6] / n_rois [n_neg,6] normalised.  Returns a dict of the path's outputs."""
         self.train()
-        mask_logits, mask_probs, join = self._mask_head(image, p_rois)      # enqueued first, on its own stream
+        mask_logits = mask_probs = cls_logits = cls_probs = cls_bbox = None
+        join = lambda: None
+        if not self.detector_phase_only:
+            mask_logits, mask_probs, join = self._mask_head(image, p_rois)  # enqueued first, on its own stream
         p2, p3, rpn_logits, rpn_probs, rpn_bbox = self.backbone_rpn(image)
         rpn_rois = self.proposals(rpn_probs, rpn_bbox, "training")
-        rois = torch.cat([p_rois, n_rois], dim=0)
-        cls_logits, cls_probs, cls_bbox = self.classifier.forward_ndhwc([p2[0], p3[0]], rois)
+        if not self.mask_phase_only:
+            rois = torch.cat([p_rois, n_rois], dim=0)
+            cls_logits, cls_probs, cls_bbox = self.classifier.forward_ndhwc([p2[0], p3[0]], rois)
         join()
         return dict(rpn_class_logits=rpn_logits, rpn_probs=rpn_probs, rpn_bbox=rpn_bbox, rpn_rois=rpn_rois,
                     mrcnn_class_logits=cls_logits, mrcnn_class=cls_probs, mrcnn_bbox=cls_bbox,
@@ -139,9 +156,12 @@ class CFUNHotPath(nn.Module):
         if rois.shape[0]:
             # the mask head waits for this step's targets, then runs beside the classifier head; in backward it
             # overlaps the FPN / RPN gradients (see _mask_head)
-            out["mrcnn_mask_logits"], out["mrcnn_mask"], join = self._mask_head(image, p_rois)
-            out["mrcnn_class_logits"], out["mrcnn_class"], out["mrcnn_bbox"] = self.classifier.forward_ndhwc(
-                [p2[0], p3[0]], rois)
+            join = lambda: None
+            if not self.detector_phase_only and p_rois.shape[0]:
+                out["mrcnn_mask_logits"], out["mrcnn_mask"], join = self._mask_head(image, p_rois)
+            if not self.mask_phase_only:
+                out["mrcnn_class_logits"], out["mrcnn_class"], out["mrcnn_bbox"] = self.classifier.forward_ndhwc(
+                    [p2[0], p3[0]], rois)
             join()
         return out
 
@@ -164,6 +184,9 @@ class CFUNHotPath(nn.Module):
         if det.shape[0] == 0:
             ms = tuple(int(v) for v in cfg.MASK_SHAPE)
             return [det.unsqueeze(0), torch.zeros((1, 0, n_cls) + ms, device=det.device)]
+        if self.detector_phase_only:      # LiTS fork 'beginning': no mask branch yet, zeros (LiTS_2017/model.py:1485-1489)
+            ms = tuple(int(v) for v in cfg.MINI_MASK_SHAPE)
+            return [det.unsqueeze(0), torch.zeros((1, det.shape[0], n_cls) + ms, device=det.device)]
         scale = torch.tensor([depth, height, width, depth, height, width], dtype=torch.float32, device=det.device)
         _, mask_probs = self.mask.forward_ndhwc(ops.to_ndhwc(image)[0], det[:, :6] / scale)
         return [det.unsqueeze(0), ops.to_ncdhw(mask_probs).unsqueeze(0)]
@@ -186,10 +209,16 @@ class CFUNHotPath(nn.Module):
 
     def compute_losses(self, out, rpn_match, rpn_bbox_t, target_class_ids, target_deltas, mask_labels):
         """The 6 losses of model.py:984-1000 (mask labels: uint8 [n_pos,d,h,w])."""
-        losses = [model.compute_rpn_class_loss(rpn_match, out["rpn_class_logits"]),
-                  model.compute_rpn_bbox_loss(rpn_bbox_t, rpn_match, out["rpn_bbox"]),
-                  model.compute_mrcnn_class_loss(target_class_ids, out["mrcnn_class_logits"]),
-                  model.compute_mrcnn_bbox_loss(target_deltas, target_class_ids, out["mrcnn_bbox"])]
+        zero = torch.zeros((), device=mask_labels.device)
+        if self.mask_phase_only:      # LiTS_2017/model.py:995-999
+            losses = [zero, zero, zero, zero]
+        else:
+            losses = [model.compute_rpn_class_loss(rpn_match, out["rpn_class_logits"]),
+                      model.compute_rpn_bbox_loss(rpn_bbox_t, rpn_match, out["rpn_bbox"]),
+                      model.compute_mrcnn_class_loss(target_class_ids, out["mrcnn_class_logits"]),
+                      model.compute_mrcnn_bbox_loss(target_deltas, target_class_ids, out["mrcnn_bbox"])]
+        if self.detector_phase_only:  # LiTS_2017/model.py:993-994
+            return losses + [zero, zero]
         cw = getattr(self.config, "MASK_CE_CLASS_WEIGHTS", None)
         raw = getattr(self.config, "EDGE_LOSS_RAW_SOBEL", False)
         if cw is not None or raw:             # LiTS fork: class-weighted CE, edge loss on the raw Sobel responses

@@ -639,10 +639,12 @@ LOSS_WEIGHTS = (100.0, 50.0, 1.0, 20.0, 1.0, 1.0)  # heart_main.py:161-168
 def training_step(sd, image, anchors, rpn_match, rpn_bbox_t, p_rois, n_rois, target_class_ids,
                   target_deltas, target_mask, stage, pool_size, mask_pool_size, dropout_masks=None,
                   proposal_count=500, nms_threshold=0.7, pre_nms_limit=1000, layers=(2, 3), stem_pad=(1, 3, 3),
-                  ce_class_weights=None, edge_raw=False):
+                  ce_class_weights=None, edge_raw=False, stage_split=False):
     """predict('training') dataflow (model.py:1391-1514) + compute_losses (984-1000) with the
     head RoIs injected (p_rois positives first, then n_rois).  image [1,1,D,H,W].
-    ce_class_weights / edge_raw: the LiTS fork's mask losses (LiTS_2017/model.py:926, 959-972).
+    ce_class_weights / edge_raw: the LiTS fork's mask losses (LiTS_2017/model.py:926, 959-972); stage_split: its two
+    training phases ('beginning': no mask head, mask losses 0; otherwise: no classifier head, detection losses 0;
+    LiTS_2017/model.py:985-1001, 1528-1548).
     Returns dict of outputs and the 6 losses."""
     p2, p3 = fpn(image, sd, layers=layers, stem_pad=stem_pad)
     l2, pr2, b2 = rpn(p2, sd)
@@ -654,16 +656,25 @@ def training_step(sd, image, anchors, rpn_match, rpn_bbox_t, p_rois, n_rois, tar
     rpn_rois, keep, order = proposal_layer(rpn_probs[0], rpn_box[0], anchors, proposal_count, nms_threshold,
                                            (D, H, W), pre_nms_limit)
     rois = torch.cat([p_rois, n_rois], dim=0)
-    cls_logits, cls_probs, cls_bbox = classifier([p2[0], p3[0]], rois, sd, pool_size)
-    m_logits, m_probs = mask_head(image[0], p_rois, sd, mask_pool_size, stage, dropout_masks=dropout_masks)
-    losses = [rpn_class_loss(rpn_match, rpn_logits),
-              rpn_bbox_loss(rpn_bbox_t, rpn_match, rpn_box),
-              mrcnn_class_loss(target_class_ids, cls_logits),
-              mrcnn_bbox_loss(target_deltas, target_class_ids, cls_bbox),
-              mask_ce_loss(target_mask, m_logits) if ce_class_weights is None
-              else mask_ce_loss_weighted(target_mask, m_logits, ce_class_weights),
-              ((edge_loss_raw if edge_raw else edge_loss)(target_mask, m_probs)[0]) if stage == "finetune"
-              else torch.zeros(())]
+    det_only, mask_only = stage_split and stage == "beginning", stage_split and stage != "beginning"
+    cls_logits = cls_probs = cls_bbox = m_logits = m_probs = None
+    zero = torch.zeros(())
+    if not mask_only:
+        cls_logits, cls_probs, cls_bbox = classifier([p2[0], p3[0]], rois, sd, pool_size)
+        losses = [rpn_class_loss(rpn_match, rpn_logits),
+                  rpn_bbox_loss(rpn_bbox_t, rpn_match, rpn_box),
+                  mrcnn_class_loss(target_class_ids, cls_logits),
+                  mrcnn_bbox_loss(target_deltas, target_class_ids, cls_bbox)]
+    else:
+        losses = [zero, zero, zero, zero]
+    if not det_only:
+        m_logits, m_probs = mask_head(image[0], p_rois, sd, mask_pool_size, stage, dropout_masks=dropout_masks)
+        losses += [mask_ce_loss(target_mask, m_logits) if ce_class_weights is None
+                   else mask_ce_loss_weighted(target_mask, m_logits, ce_class_weights),
+                   ((edge_loss_raw if edge_raw else edge_loss)(target_mask, m_probs)[0]) if stage == "finetune"
+                   else zero]
+    else:
+        losses += [zero, zero]
     total = sum(wt * l for wt, l in zip(LOSS_WEIGHTS, losses))
     return dict(p2=p2, p3=p3, rpn_logits=rpn_logits, rpn_probs=rpn_probs, rpn_bbox=rpn_box, rpn_rois=rpn_rois,
                 nms_keep=keep, cls_logits=cls_logits, cls_bbox=cls_bbox, mask_logits=m_logits, mask_probs=m_probs,

@@ -71,7 +71,7 @@ def test_refine_detections_golden(emu):
 def test_inference_lits_overlap_tile(emu_direct):
     """LiTS fork inference: P3D35 + 3-class heads, two overlapping detections un-molded with the overlap-tile average
     (64x64x32: on the 32x32x16 volume the clipped proposals coincide and their class scores tie exactly)."""
-    r = mc.check_inference_vs_oracle(emu_direct, mc.tiny_lits_config(max_dim=64, min_dim=32), max_instances=2)
+    r = mc.check_inference_vs_oracle(emu_direct, mc.tiny_lits_config("together", max_dim=64, min_dim=32), max_instances=2)
     assert r["n_det"] == 2
 
 
@@ -107,3 +107,19 @@ def test_b3_training_step_vs_oracle(emu, monkeypatch):
 def test_training_step_lits_finetune(emu_direct):
     """LiTS fork 'finetune': class-weighted mask CE + raw-Sobel edge loss through the whole step vs the oracle."""
     mc.check_training_step_vs_oracle(emu_direct, mc.tiny_lits_config("finetune"), n_pos=1)
+
+
+def test_lits_detector_phase_inference_masks_are_zero(emu_direct):
+    """LiTS fork, stage 'beginning': predict('inference') has no mask branch yet and returns zero masks
+    (LiTS_2017/model.py:1485-1489)."""
+    import torch
+    from cfun_amd import step
+    cfg = mc.tiny_lits_config("beginning", max_dim=64, min_dim=32)
+    cfg.DETECTION_MIN_CONFIDENCE, cfg.DETECTION_MAX_INSTANCES = 0.0, 2
+    torch.manual_seed(0)
+    net = step.CFUNHotPath(cfg).to(emu_direct)
+    assert net.detector_phase_only and not net.mask_phase_only
+    s = step.synthetic_inputs(cfg, emu_direct, 0)
+    det, masks = net.predict_inference(s["image"])
+    assert det.shape[1] >= 1 and tuple(masks.shape) == (1, det.shape[1], 3) + tuple(cfg.MINI_MASK_SHAPE)
+    assert float(masks.abs().max()) == 0.0

@@ -130,7 +130,7 @@ def test_inference_vs_oracle(gpu, stage):
 def test_inference_lits_overlap_tile(gpu):
     """LiTS fork inference: P3D35 + 3-class heads, several detections un-molded with the overlap-tile average."""
     # 64x64x32: on the 32x32x16 volume the clipped proposals coincide and their class scores tie exactly
-    r = mc.check_inference_vs_oracle(gpu, mc.tiny_lits_config(max_dim=64, min_dim=32), max_instances=3)
+    r = mc.check_inference_vs_oracle(gpu, mc.tiny_lits_config("together", max_dim=64, min_dim=32), max_instances=3)
     assert r["n_det"] >= 2
 
 
@@ -241,23 +241,38 @@ def test_cfg3_volume_forward_properties(gpu):
 
 def test_lits_full_size_step_properties(gpu):
     """BASELINE.json configs[4] at the fork's real sizes (320x320x256 volume, P3D35, (5,7,7) stem, b = 32, 3 classes,
-    32x80x80 crops): one training step runs, the 6 losses are finite, every trainable tensor receives a finite
-    gradient.  (Value parity for these shapes: test_training_step_lits_shapes and the unet_lits_eval golden.)"""
+    32x80x80 crops), both training phases of the fork: 'beginning' trains the detector only (no mask head), 'together'
+    the mask branch only (everything else frozen, no classifier head).  The step runs, the losses are finite, exactly
+    the phase's trainable tensors receive finite gradients.  (Value parity for these shapes:
+    test_training_step_lits_shapes / _finetune and the unet_lits_eval golden.)"""
     from cfun_amd import config, step
-    cfg = config.LiTSConfig("beginning")
-    torch.manual_seed(0)
-    net = step.CFUNHotPath(cfg).to(gpu)
-    s = step.synthetic_inputs(cfg, gpu, 0)
-    assert tuple(s["image"].shape) == (1, 1, 256, 320, 320)
-    net.zero_grad(set_to_none=True)
-    out, losses, total = step.training_step(net, s)
-    assert tuple(out["mrcnn_mask_logits"].shape) == (4, 32, 80, 80, 3)
-    assert all(bool(torch.isfinite(l)) for l in losses)
-    for k, p in net.named_parameters():
-        if p.requires_grad and "bn" not in k and "downsample.1" not in k and "C1.1" not in k \
-                and "out_upscale_conv" not in k:        # ('finetune'-only conv, mask_branch.py:118-122)
-            assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
-
+    for stage in ("beginning", "together"):
+        cfg = config.LiTSConfig(stage)
+        torch.manual_seed(0)
+        net = step.CFUNHotPath(cfg).to(gpu)
+        s = step.synthetic_inputs(cfg, gpu, 0)
+        assert tuple(s["image"].shape) == (1, 1, 256, 320, 320)
+        net.zero_grad(set_to_none=True)
+        out, losses, total = step.training_step(net, s)
+        assert all(bool(torch.isfinite(l)) for l in losses)
+        if stage == "beginning":
+            assert out["mrcnn_mask_logits"] is None and tuple(out["mrcnn_class_logits"].shape) == (12, 2)
+            assert float(losses[4]) == 0.0 and float(losses[5]) == 0.0 and float(losses[0]) > 0.0
+        else:
+            assert out["mrcnn_class_logits"] is None and tuple(out["mrcnn_mask_logits"].shape) == (4, 32, 80, 80, 3)
+            assert float(losses[0]) == 0.0 and float(losses[2]) == 0.0 and float(losses[4]) > 0.0
+        for k, p in net.named_parameters():
+            in_mask = k.startswith("mask.")
+            if stage == "beginning":
+                assert (p.grad is None) == (in_mask or not p.requires_grad), k
+            else:
+                assert p.requires_grad == in_mask, k
+                if in_mask and "out_upscale_conv" not in k:     # ('finetune'-only conv, mask_branch.py:118-122)
+                    assert p.grad is not None, k
+            if p.grad is not None:
+                assert bool(torch.isfinite(p.grad).all()), k
+        del net, out, losses, total
+        torch.cuda.empty_cache()
 
 def test_unmold_golden(gpu):
     mc.check_unmold_golden(gpu)
