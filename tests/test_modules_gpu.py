@@ -342,3 +342,7 @@ def test_b3_predict_cfg0_reference_golden(gpu, monkeypatch):
 def test_training_step_lits_finetune(gpu):
     """LiTS fork 'finetune': class-weighted mask CE + raw-Sobel edge loss through the whole step vs the oracle."""
     mc.check_training_step_vs_oracle(gpu, mc.tiny_lits_config("finetune"))
+
+
+def test_b3_module_path(gpu):
+    mc.check_b3_module_path(gpu)
