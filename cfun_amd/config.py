@@ -109,6 +109,10 @@ class LiTSConfig(Config):
     ROI_COUNT_ROUND = True              # RoI counts by int(round()) (LiTS_2017/model.py:448, 496; heart truncates)
     MASK_CE_CLASS_WEIGHTS = (1.0, 1.0, 100.0)   # nn.CrossEntropyLoss(weight=...) of the mask loss (LiTS_2017/model.py:926)
     EDGE_LOSS_RAW_SOBEL = True          # edge loss = MSE on the raw 3 Sobel responses, no magnitude (LiTS_2017/model.py:959-972)
+    LOSS_WEIGHTS = {"rpn_class_loss": 50., "rpn_bbox_loss": 5., "mrcnn_class_loss": 50., "mrcnn_bbox_loss": 5.,
+                    "mrcnn_mask_loss": 2., "mrcnn_mask_edge_loss": 0.25}     # LiTS_2017/LiTS_main.py:162-169
+    POST_NMS_ROIS_INFERENCE = 50        # LiTS_2017/LiTS_main.py:107
+    DETECTION_NMS_THRESHOLD = 0.7       # LiTS_2017/LiTS_main.py:147
 
     def __init__(self, stage="beginning"):
         super().__init__(stage)

@@ -24,6 +24,7 @@ __device__ __forceinline__ double block_sum(double v) {
   double s = 0.0;
   if (threadIdx.x == 0)
     for (int w = 0; w < kBlock / 64; ++w) s += red[w];
+  __syncthreads();   // red[] is reused by a back-to-back call (k_ce_w_fwd sums numerator and denominator)
   return s;  // valid in thread 0
 }
 

@@ -278,7 +278,10 @@ def sharded_training_step(net, s, shard=None):
     rois = torch.cat([s["p_rois"], s["n_rois"]], dim=0)
     n_all, n_pos = rois.shape[0], s["p_rois"].shape[0]
     mine = torch.arange(r, n_all, R, device=rois.device)
-    zero = p2.sum() * 0.0
+    # Every rank must run BOTH gathered maps' backward (an all-reduce each, _AllGatherDepth.backward): a rank whose
+    # RoIs all sit on one pyramid level -- or that holds no RoI at all when R > number of RoIs -- would otherwise skip
+    # a collective its peers issue.  `zero` touches p2 and p3 and is added to the total unconditionally.
+    zero = (p2.sum() + p3.sum()) * 0.0
     l_cls = l_box = zero
     if mine.numel():
         cls_logits, _, cls_bbox = net.classifier.forward_ndhwc([p2[0], p3[0]], rois[mine])
@@ -301,7 +304,7 @@ def sharded_training_step(net, s, shard=None):
         else:
             l_mask = ops.mask_cross_entropy(mlog, labels) * share
     losses = [l_rpn_cls, l_rpn_box, l_cls, l_box, l_mask, l_edge]
-    total = net.total_loss(losses)
+    total = net.total_loss(losses) + zero
     total.backward()
     return losses, total, rpn_rois
 
@@ -327,11 +330,20 @@ class GradientReducer:
     launches whatever bucket did not complete through the hooks.  With world size 1 it is a no-op container
     (``always_reduce`` keeps the collectives for single-rank tests of the stream logic)."""
 
-    def __init__(self, params, bucket_bytes=64 << 20, group=None, always_reduce=False, average=True):
-        self.group = group
+    def __init__(self, params, bucket_bytes=64 << 20, group=None, always_reduce=False, average=True, own_group=True):
         self.average = average      # False: plain sum (the ranks hold additive shares of ONE sample's gradient)
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.active = self.world > 1 or (always_reduce and dist.is_available() and dist.is_initialized())
+        # The bucket all-reduces are launched from autograd hooks, i.e. interleaved with whatever collectives the
+        # backward pass itself issues (sharded_training_step: halo send/recv, the p2/p3 all-reduces).  Ranks whose
+        # graphs differ (no positive RoI on one rank) reach the hooks at different points of that sequence, and
+        # collectives of ONE communicator must be issued in the same order everywhere -- so the reducer gets a
+        # communicator of its own (same ranks), on which only its own, index-ordered launches run.
+        if self.active and own_group and self.world > 1:
+            ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
+            group = dist.new_group(ranks=ranks)       # collective: every rank of `group` constructs the reducer
+        self.group = group
+        self._next = 0              # buckets are launched strictly in index order (see _on_grad)
         self.params = [p for p in params if p.requires_grad]
         self.buckets = []       # dicts: flat, params, pending, ready, work
         order = list(reversed(self.params))
@@ -380,6 +392,7 @@ class GradientReducer:
 
     def zero_grad(self):
         """Zero the buckets and (re)attach ``p.grad`` to its bucket view; call instead of ``net.zero_grad()``."""
+        self._next = 0
         for bucket in self.buckets:
             bucket["flat"].zero_()
             bucket["pending"], bucket["work"], bucket["launched"] = len(bucket["params"]), None, False
@@ -406,16 +419,21 @@ class GradientReducer:
         if p.grad is None or p.grad.data_ptr() != bucket["views"][slot].data_ptr():
             raise RuntimeError("GradientReducer: call zero_grad() of the reducer before backward()")
         bucket["pending"] -= 1
-        if bucket["pending"] == 0 and not bucket["launched"]:
-            self._launch(bucket)
+        # Fixed launch order, as DDP does: bucket i goes out only once buckets 0..i-1 have.  A rank on which some
+        # bucket never completes through the hooks (its heads were skipped: no positive proposal / no mask RoI on
+        # this rank) defers that bucket and all later ones to finish(); the sequence of collectives is the same on
+        # every rank either way, only the overlap with backward is lost behind the gap.
+        while self._next < len(self.buckets) and self.buckets[self._next]["pending"] == 0:
+            self._launch(self.buckets[self._next])
+            self._next += 1
 
     def finish(self):
         """Complete every bucket's reduction and scale to the mean; the compute stream waits for the comm stream."""
         if not self.active:
             return
-        for bucket in self.buckets:
-            if not bucket["launched"]:
-                self._launch(bucket)
+        for bucket in self.buckets[self._next:]:          # the rest, still in index order
+            self._launch(bucket)
+        self._next = len(self.buckets)
         for bucket in self.buckets:
             bucket["work"].wait()
         if self.comm_stream is not None:

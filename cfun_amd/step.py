@@ -38,11 +38,12 @@ class CFUNHotPath(nn.Module):
         self.anchors = torch.from_numpy(anchors).float()   # plain attribute, not in the state dict (model.py:1276)
         self.rpn = model.RPN(len(config.RPN_ANCHOR_RATIOS), config.RPN_ANCHOR_STRIDE, config.TOP_DOWN_PYRAMID_SIZE,
                              config.RPN_CONV_CHANNELS)
+        if self.mask_phase_only:      # LiTS fork, stage != 'beginning': everything built SO FAR -- FPN and RPN -- is
+            for p in self.parameters():   # frozen (LiTS_2017/model.py:1309-1311).  The classifier is built after this
+                p.requires_grad = False   # point and keeps requires_grad (it just never runs in this phase, so it
+                                          # receives no gradient); pinned by tests/golden/predict_lits_together.npz
         self.classifier = model.Classifier(config.TOP_DOWN_PYRAMID_SIZE, config.POOL_SIZE, config.IMAGE_SHAPE, 2,
                                            config.FPN_CLASSIFY_FC_LAYERS_SIZE, test_flag)
-        if self.mask_phase_only:      # LiTS fork, stage != 'beginning': everything built so far is frozen
-            for p in self.parameters():                                   # (LiTS_2017/model.py:1282-1284)
-                p.requires_grad = False
         self.mask = model.Mask(1, config.MASK_POOL_SIZE, config.NUM_CLASSES, config.UNET_MASK_BRANCH_CHANNEL,
                                config.STAGE, test_flag, dropout_p=getattr(config, "UNET_DROPOUT", 0.6))
         if not config.TRAIN_BN:                           # model.py:1297-1304
@@ -223,7 +224,11 @@ class CFUNHotPath(nn.Module):
         raw = getattr(self.config, "EDGE_LOSS_RAW_SOBEL", False)
         if cw is not None or raw:             # LiTS fork: class-weighted CE, edge loss on the raw Sobel responses
             ce = ops.mask_cross_entropy(out["mrcnn_mask_logits"], mask_labels, weight=cw)
-            if self.config.STAGE == "finetune":
+            # the fork computes its edge loss in EVERY non-'beginning' stage ('finetune' and 'together',
+            # LiTS_2017/model.py:995-1001); the heart code only in 'finetune' (model.py:995-996)
+            edge_on = self.config.STAGE != "beginning" if (getattr(self.config, "STAGE_SPLIT", False) or raw) \
+                else self.config.STAGE == "finetune"
+            if edge_on:
                 edge = ops.edge_loss_raw(out["mrcnn_mask"], mask_labels) if raw else \
                     ops.edge_loss(out["mrcnn_mask"], mask_labels)
             else:
@@ -303,7 +308,10 @@ def synthetic_inputs(config, device, seed=0):
 def training_step_full(net, image, gt_class_ids, gt_boxes, gt_labels, rpn_match, rpn_bbox_t, perms=None):
     """Forward + 6 losses + backward of the un-injected dataflow (targets sampled on device from the proposals)."""
     out = net.predict_training_full(image, gt_class_ids, gt_boxes, gt_labels, perms)
-    if out["mrcnn_mask_logits"] is None:
+    # "no RoIs" = detection_target_layer found no positive proposal and both heads were skipped (model.py:1481-1491).
+    # NOT `mrcnn_mask_logits is None`: in the LiTS fork's detector phase the mask head never runs, yet the
+    # classifier's two losses are computed (LiTS_2017/model.py:985-994).
+    if out["rois"].shape[0] == 0:
         z = torch.zeros((), device=image.device)
         losses = [model.compute_rpn_class_loss(rpn_match, out["rpn_class_logits"]),
                   model.compute_rpn_bbox_loss(rpn_bbox_t, rpn_match, out["rpn_bbox"]), z, z, z, z]

@@ -639,7 +639,7 @@ LOSS_WEIGHTS = (100.0, 50.0, 1.0, 20.0, 1.0, 1.0)  # heart_main.py:161-168
 def training_step(sd, image, anchors, rpn_match, rpn_bbox_t, p_rois, n_rois, target_class_ids,
                   target_deltas, target_mask, stage, pool_size, mask_pool_size, dropout_masks=None,
                   proposal_count=500, nms_threshold=0.7, pre_nms_limit=1000, layers=(2, 3), stem_pad=(1, 3, 3),
-                  ce_class_weights=None, edge_raw=False, stage_split=False):
+                  ce_class_weights=None, edge_raw=False, stage_split=False, loss_weights=None):
     """predict('training') dataflow (model.py:1391-1514) + compute_losses (984-1000) with the
     head RoIs injected (p_rois positives first, then n_rois).  image [1,1,D,H,W].
     ce_class_weights / edge_raw: the LiTS fork's mask losses (LiTS_2017/model.py:926, 959-972); stage_split: its two
@@ -671,11 +671,13 @@ def training_step(sd, image, anchors, rpn_match, rpn_bbox_t, p_rois, n_rois, tar
         m_logits, m_probs = mask_head(image[0], p_rois, sd, mask_pool_size, stage, dropout_masks=dropout_masks)
         losses += [mask_ce_loss(target_mask, m_logits) if ce_class_weights is None
                    else mask_ce_loss_weighted(target_mask, m_logits, ce_class_weights),
-                   ((edge_loss_raw if edge_raw else edge_loss)(target_mask, m_probs)[0]) if stage == "finetune"
-                   else zero]
+                   ((edge_loss_raw if edge_raw else edge_loss)(target_mask, m_probs)[0])
+                   # heart: 'finetune' only (model.py:995-996); the fork: every non-'beginning' stage, incl. 'together'
+                   # (LiTS_2017/model.py:995-1001)
+                   if (stage != "beginning" if (stage_split or edge_raw) else stage == "finetune") else zero]
     else:
         losses += [zero, zero]
-    total = sum(wt * l for wt, l in zip(LOSS_WEIGHTS, losses))
+    total = sum(wt * l for wt, l in zip(LOSS_WEIGHTS if loss_weights is None else loss_weights, losses))
     return dict(p2=p2, p3=p3, rpn_logits=rpn_logits, rpn_probs=rpn_probs, rpn_bbox=rpn_box, rpn_rois=rpn_rois,
                 nms_keep=keep, cls_logits=cls_logits, cls_bbox=cls_bbox, mask_logits=m_logits, mask_probs=m_probs,
                 losses=losses, total=total)

@@ -135,6 +135,34 @@ def main():
         sizes = [int(p.numel()) for k, p in net5.named_parameters() if p.requires_grad]
         res["grad_sizes"] = np.array(sizes)
         res["grad_names"] = np.array(names5)
+    # 6) more ranks than RoIs of a kind, through the GradientReducer: 1 positive + 1 negative RoI on 2 ranks -> rank 1
+    #    holds no mask RoI (its U-Net parameters get no gradient: that bucket never completes through the hooks) and
+    #    each rank's single classifier RoI sits on ONE pyramid level (the other gathered map is reached only through
+    #    the unconditional anchor term).  Must neither hang nor mis-pair collectives; summed gradients = single process.
+    s6 = dict(s5)
+    s6["p_rois"], s6["mask_labels"], s6["n_rois"] = s5["p_rois"][:1], s5["mask_labels"][:1], s5["n_rois"][:1]
+    s6["target_class_ids"], s6["target_deltas"] = s5["target_class_ids"][[0, 2]], s5["target_deltas"][[0, 2]]
+    net5.mask.modified_u_net.dropout_masks = [mk[:1] for mk in masks5]
+    for p in net5.parameters():
+        p.grad = None
+    red6 = cdist.GradientReducer(net5.parameters(), bucket_bytes=4096, average=False)
+    assert len(red6.buckets) > 4
+    red6.zero_grad()
+    with cdist.depth_sharded():
+        losses6, _, _ = cdist.sharded_training_step(net5, s6)
+    red6.finish()
+    red6.remove()
+    lv6 = torch.stack([l.detach().float() for l in losses6])
+    dist.all_reduce(lv6)
+    res["sh6_losses"] = lv6.numpy()
+    res["sh6_grads"] = torch.cat([p.grad.reshape(-1) for k, p in net5.named_parameters() if p.requires_grad]).numpy()
+    if rank == 0:
+        for p in net5.parameters():
+            p.grad = None
+        _, losses_r6, _ = step.training_step(net5, s6)
+        res["ref6_losses"] = np.array([float(l.detach()) for l in losses_r6], np.float32)
+        res["ref6_grads"] = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                                       for k, p in net5.named_parameters() if p.requires_grad]).numpy()
     np.savez(out % rank, **res)
     dist.barrier()
     dist.destroy_process_group()

@@ -500,19 +500,249 @@ def case_unmold():
          boxes=boxes, class_ids=ids, scores=scores, class_map=cmap.astype(np.uint8))
 
 
-def import_lits():
-    """The LiTS fork's model/utils under their own names (its files shadow the heart modules' names)."""
-    saved = {k: sys.modules.pop(k) for k in ("utils", "model", "backbone", "mask_branch", "config") if k in sys.modules}
-    sys.path.insert(0, os.path.join(REF, "LiTS_2017"))
-    try:
-        import model as lits_model
-        import utils as lits_utils
-    finally:
-        sys.path.pop(0)
-        for k in ("utils", "model", "backbone", "mask_branch", "config"):
-            sys.modules.pop(k, None)
-        sys.modules.update(saved)
-    return lits_model, lits_utils
+_LITS = {}
+
+
+def import_lits(full=False):
+    """The LiTS fork's model/utils under their own names (its files shadow the heart modules' names).  ``full``: also
+    its backbone, mask_branch and LiTS_main (the LiTSConfig) modules."""
+    if not _LITS:
+        saved = {k: sys.modules.pop(k) for k in ("utils", "model", "backbone", "mask_branch", "config") if k in sys.modules}
+        sys.path.insert(0, os.path.join(REF, "LiTS_2017"))
+        try:
+            import model as lits_model
+            import utils as lits_utils
+            import backbone as lits_backbone
+            import mask_branch as lits_mask_branch
+            import LiTS_main as lits_main
+        finally:
+            sys.path.pop(0)
+            for k in ("utils", "model", "backbone", "mask_branch", "config", "LiTS_main"):
+                sys.modules.pop(k, None)
+            sys.modules.update(saved)
+        _LITS.update(model=lits_model, utils=lits_utils, backbone=lits_backbone, mask_branch=lits_mask_branch,
+                     main=lits_main)
+    if full:
+        return _LITS
+    return _LITS["model"], _LITS["utils"]
+
+
+def make_lits_cfg(stage, max_dim=32, min_dim=16, **over):
+    """The fork's own LiTSConfig (LiTS_2017/LiTS_main.py:28-175, config.py:196-226) shrunk to fixture size: channel
+    counts in the fork's 24:48:160:320 ratios, P3D35, mask crops in a non-cubic ratio."""
+    lits = import_lits(full=True)
+    ns = dict(GPU_COUNT=0, IMAGE_MAX_DIM=max_dim, IMAGE_MIN_DIM=min_dim, BACKBONE_CHANNELS=[12, 24],
+              TOP_DOWN_PYRAMID_SIZE=20, RPN_CONV_CHANNELS=40, FPN_CLASSIFY_FC_LAYERS_SIZE=16, UNET_MASK_BRANCH_CHANNEL=4,
+              RPN_ANCHOR_SCALES=(16, 32), PRE_NMS_LIMIT=64, POST_NMS_ROIS_TRAINING=16, POOL_SIZE=[4, 4, 4],
+              MASK_POOL_SIZE=[32, 48, 32])
+    ns.update(over)
+    cfg = type("Cfg", (lits["main"].LiTSConfig,), ns)(stage)
+    cfg.MASK_SHAPE = cfg.MINI_MASK_SHAPE = (64, 96, 64) if stage == "finetune" else (32, 48, 32)
+    return cfg
+
+
+def case_fpn_rpn_lits():
+    """The fork's detector trunk: P3D35 ([4,5] bottlenecks -> ST pattern A,B,C,A / A,B,C,A,B) with the (5,7,7) stem
+    (LiTS_2017/backbone.py:124,172-176) + its FPN and RPN (LiTS_2017/model.py), values and parameter gradients."""
+    lits = import_lits(full=True)
+    cfg = make_lits_cfg("beginning")
+    p3d = lits["backbone"].P3D35(config=cfg)
+    c1, c2, c3 = p3d.stages()
+    holder = nn.Module()
+    holder.fpn = lits["model"].FPN(c1, c2, c3, out_channels=cfg.TOP_DOWN_PYRAMID_SIZE, config=cfg)
+    holder.rpn = lits["model"].RPN(len(cfg.RPN_ANCHOR_RATIOS), cfg.RPN_ANCHOR_STRIDE, cfg.TOP_DOWN_PYRAMID_SIZE,
+                                   cfg.RPN_CONV_CHANNELS)
+    shapes = load_formula(holder)
+    holder.eval()
+    x = torch.from_numpy(formula.uniform("fpnl.x", (1, 1, 16, 32, 32), -2, 2)).requires_grad_(True)
+    feats = {}
+    h = holder.fpn.C1(x); feats["c1"] = h
+    h = holder.fpn.C2(h); feats["c2"] = h
+    h = holder.fpn.C3(h); feats["c3"] = h
+    p2, p3 = holder.fpn(x)
+    outs = dict(p2=p2, p3=p3)
+    for tag, p in (("l2", p2), ("l3", p3)):
+        lg, pr, bb = holder.rpn(p)
+        outs["rpn_logits_" + tag], outs["rpn_probs_" + tag], outs["rpn_bbox_" + tag] = lg, pr, bb
+    loss = 0
+    for k in ("p2", "p3", "rpn_logits_l2", "rpn_bbox_l2", "rpn_logits_l3", "rpn_bbox_l3"):
+        g = torch.from_numpy(formula.uniform("fpnl.g." + k, tuple(outs[k].shape), -1, 1))
+        loss = loss + (outs[k] * g).sum()
+    loss.backward()
+    grads = {}
+    params = dict(holder.named_parameters())
+    for k in ("fpn.C1.0.weight", "fpn.C1.0.bias", "fpn.C2.0.conv1.weight", "fpn.C2.3.conv2.weight",
+              "fpn.C2.2.conv3.weight", "fpn.C2.0.downsample.0.weight", "fpn.C3.4.conv3.weight", "fpn.C3.3.conv2.weight",
+              "fpn.C3.1.conv4.bias", "fpn.P2_conv2.weight", "fpn.P3_conv1.weight", "rpn.conv_shared.weight",
+              "rpn.conv_bbox.bias"):
+        grads["grad:" + k] = params[k].grad.numpy()
+    arrs = dict(x=x.detach().numpy(), x_grad=x.grad.numpy(), **shapes_to_npz(shapes))
+    arrs.update({k: v.detach().numpy() for k, v in feats.items()})
+    arrs.update({k: v.detach().numpy() for k, v in outs.items()})
+    arrs.update(grads)
+    save("fpn_rpn_lits", **arrs)
+
+
+def case_unet_lits():
+    """The fork's OWN Modified3DUNet (LiTS_2017/mask_branch.py: no dropout) in train mode on a NON-cubic crop in the
+    32x80x80 family (32x48x48), 3 classes, b = 4: logits and gradients."""
+    lits = import_lits(full=True)
+    tag, stage, b, ncls = "unet_lits_noncubic", "beginning", 4, 3
+    net = lits["mask_branch"].Modified3DUNet(1, ncls, stage, b)
+    shapes = load_formula(net, gain=1.0)
+    net.train(True)
+    x = torch.from_numpy(formula.uniform(tag + ".x", (1, 1, 32, 48, 48), -2, 2)).requires_grad_(True)
+    y = net(x)
+    gy = torch.from_numpy(formula.uniform(tag + ".gy", tuple(y.shape), -1, 1))
+    (y * gy).sum().backward()
+    params = dict(net.named_parameters())
+    arrs = dict(x=x.detach().numpy(), stage=np.array(stage), b=np.array(b), ncls=np.array(ncls), y=y.detach().numpy(),
+                x_grad=x.grad.numpy(), no_dropout=np.array(True), **shapes_to_npz(shapes))
+    for k in ("conv3d_c1_1.weight", "conv3d_c1_2.weight", "lrelu_conv_c1.1.weight", "conv3d_c2.weight",
+              "norm_lrelu_conv_c3.2.weight", "norm_lrelu_conv_c5.2.weight",
+              "norm_lrelu_upscale_conv_norm_lrelu_l0.3.weight", "conv_norm_lrelu_l2.0.weight", "conv3d_l3.weight",
+              "conv_norm_lrelu_l4.0.weight", "conv3d_l4.weight", "ds2_1x1_conv3d.weight", "ds3_1x1_conv3d.weight"):
+        arrs["grad:" + k] = params[k].grad.numpy()
+    save(tag, **arrs)
+
+
+class PermRecorder:
+    """Seeded, recorded stand-in for the torch.randperm draws of detection_target_layer."""
+
+    def __init__(self):
+        self.perms = []
+        self._orig = torch.randperm
+
+    def __enter__(self):
+        rec = self
+
+        def rp(n, *a, **k):
+            g = torch.Generator().manual_seed(100 + len(rec.perms))
+            p = rec._orig(n, generator=g)
+            rec.perms.append(p.numpy())
+            return p
+        torch.randperm = rp
+        return self
+
+    def __exit__(self, *a):
+        torch.randperm = self._orig
+
+
+def case_dtl_lits():
+    """The fork's detection_target_layer (LiTS_2017/model.py:405-557): RoI counts by int(round()) at a ratio where
+    rounding and truncation differ (15 * 0.37 = 5.55 -> 6; heart: 5), 3-class GT masks, recorded permutations."""
+    lits_model, _ = import_lits()
+    cfg = make_lits_cfg("beginning")
+    cfg.TRAIN_ROIS_PER_IMAGE, cfg.ROI_POSITIVE_RATIO = 15, 0.37
+    cfg.MASK_SHAPE = (8, 12, 8)
+    D, H, W = 16, 32, 32
+    gt = torch.tensor([[0.05, 0.1, 0.1, 0.6, 0.55, 0.5], [0.4, 0.5, 0.45, 0.95, 0.95, 0.9]])
+    gt_ids = torch.tensor([1, 2])
+    jit = torch.from_numpy(formula.uniform("dtl.jit", (20, 6), -0.1, 0.1))
+    props = torch.cat([(gt[i % 2] + jit[i]).clamp(0, 1)[None] for i in range(20)] +
+                      [torch.tensor([[0.0, 0.0, 0.6, 0.2, 0.2, 0.9]]), torch.tensor([[0.7, 0.0, 0.0, 1.0, 0.3, 0.3]])] * 6)
+    props[:, 3:] = torch.max(props[:, 3:], props[:, :3] + 0.05)
+    lab = (formula.uniform("dtl.lab", (D, H, W), 0, 1) * 3).astype(np.int64).clip(0, 2)
+    onehot = np.stack([(lab == k) for k in range(3)], axis=0).astype(np.float32)
+    with PermRecorder() as rec:
+        p_rois, rois, ids, deltas, masks = lits_model.detection_target_layer(
+            props[None].clone(), gt_ids[None], gt[None].clone(), torch.from_numpy(onehot)[None], cfg)
+    assert p_rois.shape[0] == 6, p_rois.shape
+    save("dtl_lits", proposals=props.numpy(), gt_boxes=gt.numpy(), gt_class_ids=gt_ids.numpy(),
+         gt_labels=lab.astype(np.uint8), mask_shape=np.array(cfg.MASK_SHAPE), train_rois=np.array(15),
+         positive_ratio=np.array(0.37), randperm0=rec.perms[0], randperm1=rec.perms[1], p_rois=p_rois.numpy(),
+         rois=rois.numpy(), class_ids=ids.numpy(), deltas=deltas.numpy(),
+         mask_labels=masks.numpy().argmax(1).astype(np.uint8),
+         masks_onehot=np.array(bool(np.all(masks.numpy().sum(1) == 1))))
+
+
+def case_predict_lits():
+    """The fork's OWN two training phases end to end (LiTS_2017/model.py:1282-1296 build, 1441-1560 predict,
+    985-1001 compute_losses) at fixture size: stage 'beginning' = detector only (classifier on 50 RoIs at 33 %, no
+    mask head, mask losses 0) and stage 'together' = mask branch only (everything else frozen, 4 positive RoIs, no
+    classifier, detection losses 0, class-weighted CE + raw-Sobel edge MSE)."""
+    lits_model, lits_utils = import_lits()
+    for stage in ("beginning", "together"):
+        cfg = make_lits_cfg(stage, POST_NMS_ROIS_TRAINING=64)       # every NMS survivor of the 36 anchors is a proposal
+        net = lits_model.MaskRCNN(cfg, "/tmp/cfun_logs", test_flag=False)
+        shapes = load_formula(net)
+        # closed-form weights give box deltas that throw every proposal off the GT box; damp the RPN's box head so
+        # that positives exist and the heads run (the factor is part of the fixture: the test applies it too)
+        net.eval()
+        with torch.no_grad():
+            probe = torch.from_numpy(formula.uniform("predl.noise", (1, 1, 16, 32, 32), -1, 1))
+            amax = max(float(net.rpn(p)[2].abs().max()) for p in net.fpn(probe))
+        bbox_gain = float("%.0e" % (0.2 / amax))            # one significant digit: deltas of ~0.2 * std_dev
+        print("rpn bbox absmax", amax, "-> gain", bbox_gain)
+        with torch.no_grad():
+            net.rpn.conv_bbox.weight.mul_(bbox_gain)
+            net.rpn.conv_bbox.bias.mul_(bbox_gain)
+        H, W, D = [int(v) for v in cfg.IMAGE_SHAPE[:3]]
+        lab = np.zeros((D, H, W), np.int64)
+        lab[2:, :, :W // 2] = 1
+        lab[2:, :, W // 2:] = 2
+        hu = np.where(lab == 0, -1000.0, (lab - 1) * 100.0) + formula.uniform("predl.noise", (D, H, W), -50, 50)
+        img = ((hu - hu.mean()) / hu.std()).astype(np.float32)
+        image = torch.from_numpy(img)[None, None]
+        gt_masks = np.stack([(lab == k) for k in range(3)], axis=0).astype(np.float32)[None]
+        # two GT boxes that clipped anchors reproduce: the whole volume (class 1) and its x < W/2 half (class 2)
+        gt_boxes = np.array([[0, 0, 0, D, H, W], [0, 0, 0, D, H, W // 2]], np.float32)[None]
+        gt_class_ids = np.arange(1, 3, dtype=np.int32)[None]
+        anchors = net.anchors.numpy()
+        ov = lits_utils.compute_overlaps(anchors.astype(np.float64), gt_boxes[0, :1].astype(np.float64))[:, 0]
+        rpn_match = np.zeros((1, anchors.shape[0], 1), np.int32)
+        rpn_match[0, ov < 0.1, 0] = -1
+        pos = np.argsort(-ov)[:6]
+        rpn_match[0, pos, 0] = 1
+        rpn_bbox_t = np.zeros((1, cfg.RPN_TRAIN_ANCHORS_PER_IMAGE, 6), np.float32)
+        rb = lits_utils.box_refinement(torch.from_numpy(anchors[np.sort(pos)]).float(),
+                                       torch.from_numpy(np.tile(gt_boxes[0, :1], (6, 1))).float()).numpy()
+        rpn_bbox_t[0, :6] = rb / cfg.RPN_BBOX_STD_DEV
+        with PermRecorder() as rec:
+            outs = net.predict([image, None, torch.from_numpy(gt_class_ids), torch.from_numpy(gt_boxes),
+                                torch.from_numpy(gt_masks)], "training")
+        (rpn_class_logits, rpn_pred_bbox, target_class_ids, mrcnn_class_logits, target_deltas, mrcnn_bbox,
+         target_mask, mrcnn_mask, mrcnn_mask_logits) = outs
+        losses = lits_model.compute_losses(torch.from_numpy(rpn_match), torch.from_numpy(rpn_bbox_t), rpn_class_logits,
+                                           rpn_pred_bbox, target_class_ids, mrcnn_class_logits, target_deltas,
+                                           mrcnn_bbox, target_mask, mrcnn_mask, mrcnn_mask_logits, stage)
+        w = cfg.LOSS_WEIGHTS
+        keys = ("rpn_class_loss", "rpn_bbox_loss", "mrcnn_class_loss", "mrcnn_bbox_loss", "mrcnn_mask_loss",
+                "mrcnn_mask_edge_loss")
+        total = sum(w[k] * l for k, l in zip(keys, losses))
+        total.backward()
+        params = dict(net.named_parameters())
+        n_pos, n_all = int((target_class_ids > 0).sum()), int(target_class_ids.shape[0])
+        print("predict_lits", stage, "n_pos", n_pos, "n_rois", n_all, "losses", [float(l) for l in losses])
+        assert n_pos > 0, "heads were skipped -- golden would be void"
+        arrs = dict(image=img, gt_labels=lab.astype(np.uint8), gt_boxes=gt_boxes, gt_class_ids=gt_class_ids,
+                    rpn_match=rpn_match, rpn_bbox_t=rpn_bbox_t, randperm0=rec.perms[0],
+                    randperm1=rec.perms[1] if len(rec.perms) > 1 else np.zeros((0,), np.int64),
+                    rpn_class_logits=rpn_class_logits.detach().numpy(), rpn_pred_bbox=rpn_pred_bbox.detach().numpy(),
+                    target_class_ids=target_class_ids.numpy(), target_deltas=target_deltas.numpy(),
+                    target_mask_labels=target_mask.numpy().argmax(1).astype(np.uint8),
+                    losses=np.array([float(l) for l in losses]), total=np.array(float(total)),
+                    loss_weights=np.array([w[k] for k in keys]), n_pos=np.array(n_pos), n_rois=np.array(n_all),
+                    stage=np.array(stage), rpn_bbox_gain=np.array(bbox_gain), trainable=np.array(sorted(k for k, p in params.items() if p.requires_grad)),
+                    with_grad=np.array(sorted(k for k, p in params.items() if p.grad is not None)),
+                    **shapes_to_npz(shapes))
+        if stage == "beginning":
+            assert mrcnn_mask_logits.numel() == 0 and mrcnn_class_logits.numel() > 0
+            arrs.update(mrcnn_class_logits=mrcnn_class_logits.detach().numpy(), mrcnn_bbox=mrcnn_bbox.detach().numpy())
+            gk = ("fpn.C1.0.weight", "fpn.C3.4.conv3.weight", "fpn.P2_conv2.bias", "rpn.conv_class.weight",
+                  "classifier.linear_class.weight", "classifier.conv2.weight", "classifier.conv1.weight")
+        else:
+            assert mrcnn_class_logits.numel() == 0 and mrcnn_mask_logits.numel() > 0
+            ml = mrcnn_mask_logits.detach().numpy()
+            arrs.update(mask_logits_sub=ml[:, :, ::2, ::2, ::2].copy(),
+                        mask_logits_sum=np.array([ml.astype(np.float64).sum(), np.abs(ml).astype(np.float64).sum()]))
+            gk = ("mask.modified_u_net.conv3d_c1_1.weight", "mask.modified_u_net.norm_lrelu_conv_c3.2.weight",
+                  "mask.modified_u_net.conv_norm_lrelu_l4.0.weight", "mask.modified_u_net.conv3d_l4.weight",
+                  "mask.modified_u_net.ds2_1x1_conv3d.weight")
+        for k in gk:
+            arrs["grad:" + k] = params[k].grad.numpy()
+        save("predict_lits_" + stage, **arrs)
+
 
 
 def case_unmold_lits():
@@ -535,12 +765,13 @@ def case_unmold_lits():
          boxes=boxes, class_ids=ids, scores=scores, class_map=cmap.astype(np.uint8))
 
 
-CASES = dict(losses_lits=case_losses_lits, unmold_lits=case_unmold_lits, unmold=case_unmold, refine=case_refine, nms=case_nms, anchors=case_anchors, roi_align=case_roi_align, fpn_rpn=case_fpn_rpn, unet=case_unet,
+CASES = dict(fpn_rpn_lits=case_fpn_rpn_lits, unet_lits=case_unet_lits, dtl_lits=case_dtl_lits, predict_lits=case_predict_lits,
+             losses_lits=case_losses_lits, unmold_lits=case_unmold_lits, unmold=case_unmold, refine=case_refine, nms=case_nms, anchors=case_anchors, roi_align=case_roi_align, fpn_rpn=case_fpn_rpn, unet=case_unet,
              losses=case_losses, proposal=case_proposal, classifier=case_classifier, predict=case_predict)
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or [k for k in CASES if k != "predict"]
+    which = sys.argv[1:] or [k for k in CASES if k not in ("predict", "predict_lits")]
     for k in which:
         print("== case", k)
         CASES[k]()

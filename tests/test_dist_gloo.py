@@ -76,3 +76,13 @@ def test_depth_sharding_world2(emu_lib, tmp_path):
         off += n
         den = max(np.linalg.norm(b), 1e-12)
         assert np.linalg.norm(a - b) / den < 2e-3 or np.abs(a - b).max() < 1e-6, (str(name), np.linalg.norm(a - b) / den)
+
+    # R > RoIs of a kind + differing autograd graphs per rank, through the ordered GradientReducer (sum)
+    np.testing.assert_allclose(r[0]["sh6_losses"], ref["ref6_losses"], rtol=2e-4, atol=1e-6)
+    np.testing.assert_array_equal(r[0]["sh6_grads"], r[1]["sh6_grads"])      # both ranks hold the same reduced sums
+    off = 0
+    for name, n in zip(ref["grad_names"], ref["grad_sizes"]):
+        a, b = r[0]["sh6_grads"][off:off + n], ref["ref6_grads"][off:off + n]
+        off += n
+        den = max(np.linalg.norm(b), 1e-12)
+        assert np.linalg.norm(a - b) / den < 2e-3 or np.abs(a - b).max() < 1e-6, (str(name), np.linalg.norm(a - b) / den)

@@ -123,3 +123,20 @@ def test_lits_detector_phase_inference_masks_are_zero(emu_direct):
     det, masks = net.predict_inference(s["image"])
     assert det.shape[1] >= 1 and tuple(masks.shape) == (1, det.shape[1], 3) + tuple(cfg.MINI_MASK_SHAPE)
     assert float(masks.abs().max()) == 0.0
+
+
+def test_fpn_rpn_lits_golden(emu_direct):
+    mc.check_fpn_rpn_lits_golden(emu_direct)
+
+
+def test_unet_lits_noncubic_golden(emu_direct):
+    mc.check_unet_golden(emu_direct, "unet_lits_noncubic")
+
+
+def test_detection_target_layer_lits_golden(emu):
+    mc.check_detection_target_layer_lits_golden(emu)
+
+
+@pytest.mark.parametrize("stage", ["beginning", "together"])
+def test_predict_lits_golden(emu_direct, stage):
+    mc.check_predict_lits_golden(emu_direct, stage)

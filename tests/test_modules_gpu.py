@@ -266,7 +266,7 @@ def test_lits_full_size_step_properties(gpu):
             if stage == "beginning":
                 assert (p.grad is None) == (in_mask or not p.requires_grad), k
             else:
-                assert p.requires_grad == in_mask, k
+                assert p.requires_grad == (in_mask or (k.startswith("classifier.") and ".bn" not in k)), k
                 if in_mask and "out_upscale_conv" not in k:     # ('finetune'-only conv, mask_branch.py:118-122)
                     assert p.grad is not None, k
             if p.grad is not None:
@@ -346,3 +346,20 @@ def test_training_step_lits_finetune(gpu):
 
 def test_b3_module_path(gpu):
     mc.check_b3_module_path(gpu)
+
+
+def test_fpn_rpn_lits_golden(gpu):
+    mc.check_fpn_rpn_lits_golden(gpu)
+
+
+def test_unet_lits_noncubic_golden(gpu):
+    mc.check_unet_golden(gpu, "unet_lits_noncubic")
+
+
+def test_detection_target_layer_lits_golden(gpu):
+    mc.check_detection_target_layer_lits_golden(gpu)
+
+
+@pytest.mark.parametrize("stage", ["beginning", "together"])
+def test_predict_lits_golden(gpu, stage):
+    mc.check_predict_lits_golden(gpu, stage)

@@ -277,3 +277,156 @@ def test_mask_losses_lits():
     np.testing.assert_allclose(el.item(), g["edge"].item(), rtol=1e-6)
     el.backward()
     np.testing.assert_allclose(logits.grad.numpy(), g["edge_grad_logits"], rtol=1e-4, atol=1e-8)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# LiTS fork detector side + two-phase control flow, pinned by goldens from the fork's OWN modules
+# (gen_golden.case_fpn_rpn_lits / case_unet_lits / case_dtl_lits / case_predict_lits)
+# ---------------------------------------------------------------------------------------------------------------
+LITS_LAYERS, LITS_STEM_PAD = (4, 5), (2, 3, 3)     # P3D35, stem k(5,7,7) p(2,3,3): LiTS_2017/backbone.py:124,172-176
+
+
+def test_fpn_rpn_lits_forward_and_grads():
+    g = load_golden("fpn_rpn_lits")
+    sd = golden_state_dict(g)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype == torch.float32}
+    sd_live = dict(sd)
+    sd_live.update(params)
+    x = t(g["x"]).requires_grad_(True)
+    c1, c2, c3 = orc.p3d_stages(x, sd_live, "fpn.", layers=LITS_LAYERS, stem_pad=LITS_STEM_PAD)
+    for k, v in (("c1", c1), ("c2", c2), ("c3", c3)):
+        np.testing.assert_allclose(v.detach().numpy(), g[k], rtol=1e-5, atol=2e-6)
+    p2, p3 = orc.fpn(x, sd_live, layers=LITS_LAYERS, stem_pad=LITS_STEM_PAD)
+    outs = dict(p2=p2, p3=p3)
+    for tag, p in (("l2", p2), ("l3", p3)):
+        lg, pr, bb = orc.rpn(p, sd_live)
+        outs["rpn_logits_" + tag], outs["rpn_probs_" + tag], outs["rpn_bbox_" + tag] = lg, pr, bb
+    for k, v in outs.items():
+        np.testing.assert_allclose(v.detach().numpy(), g[k], rtol=1e-5, atol=5e-6, err_msg=k)
+    from oracle import formula
+    loss = 0
+    for k in ("p2", "p3", "rpn_logits_l2", "rpn_bbox_l2", "rpn_logits_l3", "rpn_bbox_l3"):
+        loss = loss + (outs[k] * t(formula.uniform("fpnl.g." + k, tuple(outs[k].shape), -1, 1))).sum()
+    loss.backward()
+    np.testing.assert_allclose(x.grad.numpy(), g["x_grad"], rtol=1e-4, atol=1e-5 * np.abs(g["x_grad"]).max())
+    n = 0
+    for k in [k for k in g if k.startswith("grad:")]:
+        n += 1
+        np.testing.assert_allclose(params[k[5:]].grad.numpy(), g[k], rtol=1e-4,
+                                   atol=1e-5 * max(np.abs(g[k]).max(), 1.0), err_msg=k)
+    assert n >= 10
+
+
+def test_unet_lits_noncubic():
+    """The fork's own mask_branch.py (no Dropout3d) on a 32x48x48 crop: logits and gradients."""
+    g = load_golden("unet_lits_noncubic")
+    sd = golden_state_dict(g)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    x = t(g["x"]).requires_grad_(True)
+    y = orc.unet(x, params, "", str(g["stage"]), None)
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], rtol=1e-4, atol=1e-4)
+    from oracle import formula
+    (y * t(formula.uniform("unet_lits_noncubic.gy", tuple(y.shape), -1, 1))).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g["x_grad"], rtol=1e-3, atol=1e-3 * np.abs(g["x_grad"]).max())
+    for k in [k for k in g if k.startswith("grad:")]:
+        np.testing.assert_allclose(params[k[5:]].grad.numpy(), g[k], rtol=1e-3, atol=1e-3 * np.abs(g[k]).max(), err_msg=k)
+
+
+def test_detection_target_layer_lits_round():
+    """int(round()) RoI counts of the fork (LiTS_2017/model.py:448, 496) vs its own detection_target_layer."""
+    g = load_golden("dtl_lits")
+    lab = torch.from_numpy(g["gt_labels"].astype(np.int64))
+    onehot = torch.stack([(lab == k) for k in range(3)], dim=0).float()
+    r = orc.detection_target_layer(t(g["proposals"]), torch.from_numpy(g["gt_class_ids"]), t(g["gt_boxes"]), onehot,
+                                   tuple(int(v) for v in g["mask_shape"]), torch.from_numpy(g["randperm0"]),
+                                   torch.from_numpy(g["randperm1"]), int(g["train_rois"]), float(g["positive_ratio"]),
+                                   count_round=True)
+    assert r[0].shape[0] == 6                          # truncation would give 5
+    np.testing.assert_array_equal(r[0].numpy(), g["p_rois"])
+    np.testing.assert_array_equal(r[1].numpy(), g["rois"])
+    np.testing.assert_array_equal(r[2].numpy(), g["class_ids"])
+    np.testing.assert_allclose(r[3].numpy(), g["deltas"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(r[4].argmax(1).numpy().astype(np.uint8), g["mask_labels"])
+
+
+def lits_predict_oracle(g):
+    """The fork's predict('training') + compute_losses dataflow restated with the oracle's functions, for one of the
+    two predict_lits_* goldens.  Returns (params, outputs dict, losses, total)."""
+    stage = str(g["stage"])
+    sd = golden_state_dict(g)
+    params = {k: v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v
+              for k, v in sd.items()}
+    with torch.no_grad():
+        for k in ("rpn.conv_bbox.weight", "rpn.conv_bbox.bias"):
+            params[k].mul_(float(g["rpn_bbox_gain"]))
+    image = t(g["image"])[None, None]
+    D, H, W = [int(v) for v in image.shape[2:]]
+    p2, p3 = orc.fpn(image, params, layers=LITS_LAYERS, stem_pad=LITS_STEM_PAD)
+    l2, pr2, b2 = orc.rpn(p2, params)
+    l3, pr3, b3 = orc.rpn(p3, params)
+    rpn_logits, rpn_probs, rpn_box = [torch.cat(v, dim=1) for v in ((l2, l3), (pr2, pr3), (b2, b3))]
+    anchors = torch.from_numpy(orc.generate_pyramid_anchors((16, 32), np.array([[D // 8, H // 8, W // 8],
+                                                                               [D // 16, H // 16, W // 16]]),
+                                                           (8, 16), 1)).float()
+    rois_all, _, _ = orc.proposal_layer(rpn_probs[0].detach(), rpn_box[0].detach(), anchors, 64, 0.7, (D, H, W), 64)
+    gt_boxes = t(g["gt_boxes"][0]) / torch.tensor([D, H, W, D, H, W], dtype=torch.float32)
+    lab = torch.from_numpy(g["gt_labels"].astype(np.int64))
+    onehot = torch.stack([(lab == k) for k in range(3)], dim=0).float()
+    train_rois, ratio = (50, 0.33) if stage == "beginning" else (4, 1.0)        # LiTS_2017/config.py:216-226
+    p_rois, rois, cls_ids, deltas, masks = orc.detection_target_layer(
+        rois_all, torch.from_numpy(g["gt_class_ids"][0].astype(np.int64)), gt_boxes, onehot, (32, 48, 32),
+        torch.from_numpy(g["randperm0"]), torch.from_numpy(g["randperm1"]), train_rois, ratio, count_round=True)
+    out = dict(rpn_logits=rpn_logits, rpn_box=rpn_box, p_rois=p_rois, rois=rois, cls_ids=cls_ids, deltas=deltas,
+               masks=masks)
+    zero = torch.zeros(())
+    if stage == "beginning":        # detector phase: classifier on all sampled RoIs, no mask head
+        cls_logits, _, cls_bbox = orc.classifier([p2[0], p3[0]], rois, params, [4, 4, 4])
+        out.update(cls_logits=cls_logits, cls_bbox=cls_bbox)
+        losses = [orc.rpn_class_loss(torch.from_numpy(g["rpn_match"]), rpn_logits),
+                  orc.rpn_bbox_loss(t(g["rpn_bbox_t"]), torch.from_numpy(g["rpn_match"]), rpn_box),
+                  orc.mrcnn_class_loss(cls_ids, cls_logits), orc.mrcnn_bbox_loss(deltas, cls_ids, cls_bbox), zero, zero]
+    else:                           # mask phase: U-Net on the positives, weighted CE + raw-Sobel edge MSE
+        m_logits, m_probs = orc.mask_head(image[0], p_rois, params, [32, 48, 32], stage, dropout_masks=None)
+        out.update(m_logits=m_logits)
+        losses = [zero, zero, zero, zero, orc.mask_ce_loss_weighted(masks.double(), m_logits, [1.0, 1.0, 100.0]),
+                  orc.edge_loss_raw(masks.double(), m_probs)]
+    total = sum(float(w) * l for w, l in zip(g["loss_weights"], losses))
+    return params, out, losses, total
+
+
+@pytest.mark.parametrize("stage", ["beginning", "together"])
+def test_predict_lits_two_phase(stage):
+    """The fork's own predict('training') + compute_losses + backward in both of its training phases
+    (gen_golden.case_predict_lits) against the oracle chain -- pins the P3D35 detector, the int(round()) sampler, the
+    phase control flow (which head runs, which losses are zero, which parameters are frozen) and the fork's losses."""
+    g = load_golden("predict_lits_" + stage)
+    params, out, losses, total = lits_predict_oracle(g)
+    np.testing.assert_allclose(out["rpn_logits"].detach().numpy(), g["rpn_class_logits"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out["rpn_box"].detach().numpy(), g["rpn_pred_bbox"], rtol=1e-4, atol=1e-5)
+    assert out["p_rois"].shape[0] == int(g["n_pos"]) and out["rois"].shape[0] == int(g["n_rois"])
+    np.testing.assert_array_equal(out["cls_ids"].numpy(), g["target_class_ids"])
+    np.testing.assert_allclose(out["deltas"].numpy(), g["target_deltas"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_array_equal(out["masks"].argmax(1).numpy().astype(np.uint8), g["target_mask_labels"])
+    if stage == "beginning":
+        np.testing.assert_allclose(out["cls_logits"].detach().numpy(), g["mrcnn_class_logits"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(out["cls_bbox"].detach().numpy(), g["mrcnn_bbox"], rtol=1e-4, atol=1e-5)
+    else:
+        ml = out["m_logits"].detach().numpy()
+        assert np.abs(ml[:, :, ::2, ::2, ::2] - g["mask_logits_sub"]).max() < 1e-3
+    for i, (a, r) in enumerate(zip(losses, g["losses"])):
+        assert abs(float(a.detach()) - float(r)) <= 1e-4 * max(abs(float(r)), 1e-3), "loss %d: %g vs %g" % (i, float(a), r)
+    assert abs(float(total) - float(g["total"])) <= 1e-4 * abs(float(g["total"]))
+    total.backward()
+    # which tensors the phase trains (LiTS_2017/model.py:1282-1296): 'together' freezes everything but the mask branch
+    trainable = set(str(k) for k in g["trainable"])
+    with_grad = set(str(k) for k in g["with_grad"])
+    if stage == "together":      # FPN + RPN frozen; the classifier (built after the freeze) keeps requires_grad but gets no gradient
+        assert all(k.startswith(("mask.", "classifier.")) for k in trainable)
+        assert all(k.startswith("mask.") for k in with_grad)
+    got = set(k for k, v in params.items() if torch.is_tensor(v) and v.requires_grad and v.grad is not None
+              and float(v.grad.abs().max()) > 0)
+    assert got & trainable == with_grad & got, sorted((got & trainable) ^ (with_grad & got))[:5]
+    for k in [k[5:] for k in g if k.startswith("grad:")]:
+        a, r = params[k].grad.numpy(), g["grad:" + k]
+        e = np.linalg.norm((a - r).ravel()) / max(np.linalg.norm(r.ravel()), 1e-30)
+        assert e < 2e-2, "%s: rel L2 %.3e" % (k, e)

@@ -15,7 +15,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cfun_amd import _lib  # noqa: E402
 
-lib = _lib.load()
+lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes", "bin", "libcfun_probe.so"))   # make -C tools/probes
 lib.cfun_debug_dispatch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
 nblocks = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 lds = int(sys.argv[2]) if len(sys.argv) > 2 else 52 * 1024

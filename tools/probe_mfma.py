@@ -4,7 +4,7 @@ import ctypes, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cfun_amd import _lib
-lib = ctypes.CDLL(_lib.DEFAULT_LIB)
+lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes", "bin", "libcfun_probe.so"))   # make -C tools/probes
 lib.cfun_debug_mfma_4x4x1.argtypes = [ctypes.c_void_p] * 4
 a = torch.arange(1, 65, dtype=torch.float32, device="cuda")            # a[l] = l + 1
 b = torch.arange(0, 64, dtype=torch.float32, device="cuda") + 1000.0   # b[l] = 1000 + l
