@@ -369,8 +369,18 @@ def _inorm(x):
     return F.instance_norm(x, eps=1e-5)
 
 
+# Test instrumentation (tests/module_cases.flip_fit): when a list, every LeakyReLU site appends (pre-activation, output)
+# -- both still attached to the autograd graph, the output with retain_grad() -- so that a test can ask "which voxels
+# sit within rounding of the kink at 0, and how would the gradient change if their slope flipped".
+KINK_TAPS = None
+
+
 def _lrelu(x):
-    return F.leaky_relu(x, 0.01)
+    y = F.leaky_relu(x, 0.01)
+    if KINK_TAPS is not None and y.requires_grad:
+        y.retain_grad()
+        KINK_TAPS.append((x, y))
+    return y
 
 
 def unet(x, sd, prefix="", stage="beginning", dropout_masks=None):
@@ -481,18 +491,18 @@ def mask_ce_loss(target_onehot, logits):
 def mask_ce_loss_weighted(target_onehot, logits, weight):
     """LiTS_2017/model.py:907-933: as mask_ce_loss with nn.CrossEntropyLoss(weight=[1, 1, 100])."""
     y = torch.argmax(target_onehot.long(), dim=1)
-    return F.cross_entropy(logits, y, weight=torch.as_tensor(weight, dtype=torch.float32))
+    return F.cross_entropy(logits, y, weight=torch.as_tensor(weight, dtype=logits.dtype))
 
 
 def edge_loss_raw(target_onehot, probs):
     """LiTS_2017/model.py:936-979: per (roi, class 1..C-1) valid Sobel conv of target and prediction, MSE over the raw
     [1,3,D-2,H-2,W-2] responses (the magnitude is commented out in the fork), summed, / n_pos."""
-    k = sobel_stack()
+    k = sobel_stack().to(probs.dtype)      # (fp32 as the reference; fp64 when the caller runs the whole oracle in fp64)
     n, c = probs.shape[:2]
-    loss = torch.zeros(1, dtype=torch.float32)
+    loss = torch.zeros(1, dtype=probs.dtype)
     for i in range(n):
         for j in range(1, c):
-            t = F.conv3d(target_onehot[i, j][None, None].float(), k)
+            t = F.conv3d(target_onehot[i, j][None, None].to(probs.dtype), k)
             p = F.conv3d(probs[i, j][None, None], k)
             loss = loss + F.mse_loss(p, t)
     return loss / n
@@ -511,12 +521,12 @@ def sobel_stack():
 def edge_loss(target_onehot, probs):
     """model.py:938-981: per (roi, class 1..C-1) valid Sobel conv, magnitude sqrt(c0^2+c1^2+c0^2)
     (channel 0 twice, channel 2 unused -- reproduced as is), MSE mean; sum / n_pos."""
-    k = sobel_stack()
+    k = sobel_stack().to(probs.dtype)
     n, c = probs.shape[:2]
-    loss = torch.zeros(1, dtype=torch.float32)
+    loss = torch.zeros(1, dtype=probs.dtype)
     for i in range(n):
         for j in range(1, c):
-            t = F.conv3d(target_onehot[i, j][None, None].float(), k)
+            t = F.conv3d(target_onehot[i, j][None, None].to(probs.dtype), k)
             p = F.conv3d(probs[i, j][None, None], k)
             tm = torch.sqrt(t[:, 0] ** 2 + t[:, 1] ** 2 + t[:, 0] ** 2)
             pm = torch.sqrt(p[:, 0] ** 2 + p[:, 1] ** 2 + p[:, 0] ** 2)

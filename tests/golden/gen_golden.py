@@ -237,6 +237,26 @@ class DropRecorder:
         nn.Dropout3d.forward = self._orig
 
 
+def unet_grads_fp64(net, x, masks, gy, keys):
+    """Gradients of sum(net(x) * gy) with the reference module converted to fp64; Dropout3d replays ``masks``."""
+    import copy
+    net64 = copy.deepcopy(net).double()
+    for p in net64.parameters():
+        p.grad = None
+    it = iter(masks)
+    orig = nn.Dropout3d.forward
+    nn.Dropout3d.forward = lambda mod, inp: inp * next(it).to(inp.dtype)[:, :, None, None, None] if mod.training else inp
+    try:
+        x64 = x.double().requires_grad_(True)
+        (net64(x64) * gy.double()).sum().backward()
+    finally:
+        nn.Dropout3d.forward = orig
+    params = dict(net64.named_parameters())
+    out = {k: params[k].grad.numpy() for k in keys if params[k].grad is not None}
+    out["x"] = x64.grad.numpy()
+    return out
+
+
 def case_unet():
     for tag, stage, b, n, size, ncls, train in (("unet_beginning_eval", "beginning", 4, 2, 32, 8, False),
                                                 ("unet_beginning_train", "beginning", 4, 2, 32, 8, True),
@@ -259,15 +279,22 @@ def case_unet():
             (y * gy).sum().backward()
             arrs["x_grad"] = x.grad.numpy()
             params = dict(net.named_parameters())
-            for k in ("conv3d_c1_1.weight", "conv3d_c1_2.weight", "lrelu_conv_c1.1.weight", "conv3d_c2.weight",
-                      "norm_lrelu_conv_c3.2.weight", "norm_lrelu_conv_c5.2.weight",
-                      "norm_lrelu_upscale_conv_norm_lrelu_l0.3.weight", "conv3d_l0.weight",
-                      "conv_norm_lrelu_l2.0.weight", "conv3d_l3.weight",
-                      "norm_lrelu_upscale_conv_norm_lrelu_l3.3.weight", "conv_norm_lrelu_l4.0.weight",
-                      "conv3d_l4.weight", "ds2_1x1_conv3d.weight", "ds3_1x1_conv3d.weight",
-                      "out_upscale_conv.1.weight"):
+            gkeys = ("conv3d_c1_1.weight", "conv3d_c1_2.weight", "lrelu_conv_c1.1.weight", "conv3d_c2.weight",
+                     "norm_lrelu_conv_c3.2.weight", "norm_lrelu_conv_c5.2.weight",
+                     "norm_lrelu_upscale_conv_norm_lrelu_l0.3.weight", "conv3d_l0.weight",
+                     "conv_norm_lrelu_l2.0.weight", "conv3d_l3.weight",
+                     "norm_lrelu_upscale_conv_norm_lrelu_l3.3.weight", "conv_norm_lrelu_l4.0.weight",
+                     "conv3d_l4.weight", "ds2_1x1_conv3d.weight", "ds3_1x1_conv3d.weight",
+                     "out_upscale_conv.1.weight")
+            for k in gkeys:
                 if params[k].grad is not None:
                     arrs["grad:" + k] = params[k].grad.numpy()
+            # the SAME reference module in fp64 (same weights, input, recorded dropout masks): the yardstick that
+            # says how far the reference's own fp32 gradients are from exact -- tests hold the HIP path to that bound
+            g64 = unet_grads_fp64(net, x.detach(), rec.masks, gy, gkeys)
+            arrs["x_grad64"] = g64.pop("x").astype(np.float32)
+            for k, v in g64.items():
+                arrs["grad64:" + k] = v.astype(np.float32)
         yn = y.detach().numpy()
         if yn.size > 600000:  # 'finetune' 8x64^3: keep a strided subsample + fp64 checksums
             arrs["y_sub"] = yn[:, :, ::2, ::2, ::2].copy()
@@ -598,11 +625,16 @@ def case_unet_lits():
     params = dict(net.named_parameters())
     arrs = dict(x=x.detach().numpy(), stage=np.array(stage), b=np.array(b), ncls=np.array(ncls), y=y.detach().numpy(),
                 x_grad=x.grad.numpy(), no_dropout=np.array(True), **shapes_to_npz(shapes))
-    for k in ("conv3d_c1_1.weight", "conv3d_c1_2.weight", "lrelu_conv_c1.1.weight", "conv3d_c2.weight",
-              "norm_lrelu_conv_c3.2.weight", "norm_lrelu_conv_c5.2.weight",
-              "norm_lrelu_upscale_conv_norm_lrelu_l0.3.weight", "conv_norm_lrelu_l2.0.weight", "conv3d_l3.weight",
-              "conv_norm_lrelu_l4.0.weight", "conv3d_l4.weight", "ds2_1x1_conv3d.weight", "ds3_1x1_conv3d.weight"):
+    gkeys = ("conv3d_c1_1.weight", "conv3d_c1_2.weight", "lrelu_conv_c1.1.weight", "conv3d_c2.weight",
+             "norm_lrelu_conv_c3.2.weight", "norm_lrelu_conv_c5.2.weight",
+             "norm_lrelu_upscale_conv_norm_lrelu_l0.3.weight", "conv_norm_lrelu_l2.0.weight", "conv3d_l3.weight",
+             "conv_norm_lrelu_l4.0.weight", "conv3d_l4.weight", "ds2_1x1_conv3d.weight", "ds3_1x1_conv3d.weight")
+    for k in gkeys:
         arrs["grad:" + k] = params[k].grad.numpy()
+    g64 = unet_grads_fp64(net, x.detach(), [], gy, gkeys)
+    arrs["x_grad64"] = g64.pop("x").astype(np.float32)
+    for k, v in g64.items():
+        arrs["grad64:" + k] = v.astype(np.float32)
     save(tag, **arrs)
 
 

@@ -50,15 +50,50 @@ def check_unet_golden(device, name, check_grads=True, logits_atol=1e-3):
     if train and check_grads:
         gy = torch.from_numpy(formula.uniform(name + ".gy", tuple(y.shape), -1, 1)).to(device)
         (y * gy).sum().backward()
-        assert rel_l2(x.grad.cpu().numpy(), g["x_grad"]) < UNET_GRAD_L2_TOL
         params = dict(net.named_parameters())
-        n = 0
-        for k in g:
-            if k.startswith("grad:"):
-                n += 1
-                e = rel_l2(params[k[5:]].grad.cpu().numpy(), g[k])
-                assert e < UNET_GRAD_L2_TOL, "%s: rel L2 %.3e" % (k, e)
-        assert n >= 10
+
+        def grad_ok(what, got, ref32, ref64):
+            """Measured bound (GRAD_FP64_FACTOR): as close to the REFERENCE module's fp64 gradient as the reference's own
+            fp32 gradient is, x3 (+ floor); goldens without the fp64 leg keep the blanket tolerance."""
+            if ref64 is None:
+                e = rel_l2(got, ref32)
+                assert e < UNET_GRAD_L2_TOL, "%s: rel L2 %.3e" % (what, e)
+                return
+            e_hip, e_ref = rel_l2(got, ref64), rel_l2(ref32, ref64)
+            assert e_hip <= GRAD_FP64_FACTOR * e_ref + GRAD_FP64_FLOOR, \
+                "%s: relL2(HIP,fp64) %.3e vs relL2(reference fp32,fp64) %.3e" % (what, e_hip, e_ref)
+
+        keys = [k[5:] for k in g if k.startswith("grad:")]
+        assert len(keys) >= 10
+        try:
+            grad_ok("x", x.grad.cpu().numpy(), g["x_grad"], g.get("x_grad64"))
+            for k in keys:
+                grad_ok(k, params[k].grad.cpu().numpy(), g["grad:" + k], g.get("grad64:" + k))
+        except AssertionError as first:
+            if "x_grad64" not in g:
+                raise
+            # kink flips?  Basis from OUR oracle's fp64 graph (pinned to the reference by test_oracle_golden.py); what the
+            # flips do not explain must meet the bound (see flip_fit)
+            taps = []
+            p64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+            x64 = torch.from_numpy(g["x"]).double()
+            orc.KINK_TAPS = taps
+            try:
+                y64 = orc.unet(x64, p64, "", str(g["stage"]), None if nodrop else [m.double() for m in net.dropout_masks])
+            finally:
+                orc.KINK_TAPS = None
+            (y64 * gy.cpu().double()).sum().backward(retain_graph=True)
+            sub = {k: p64[k] for k in keys}
+            fit = flip_fit(taps, None, sub, {k: params[k].grad.cpu().numpy() for k in keys},
+                           {k: g["grad:" + k] for k in keys})
+            assert fit is not None, first
+            res_hip, res_ref, nk = fit
+            for k in keys:
+                den = np.linalg.norm(sub[k].grad.numpy()) + 1e-30
+                e_hip, e_ref = np.linalg.norm(res_hip[k]) / den, np.linalg.norm(res_ref[k]) / den
+                assert e_hip <= GRAD_FP64_FACTOR * e_ref + GRAD_FP64_FLOOR, \
+                    "%s: after removing %d kink flips relL2(HIP,fp64) %.3e vs reference fp32 %.3e (first failure: %s)" \
+                    % (k, nk, e_hip, e_ref, first)
         # downstream of the last norm nothing is discontinuous: tight
         for k in ("conv3d_l4.weight", "ds2_1x1_conv3d.weight", "ds3_1x1_conv3d.weight"):
             if "grad:" + k in g:
@@ -317,9 +352,109 @@ def tiny_lits_config(stage="beginning", max_dim=32, min_dim=16):
     return cfg
 
 
-def check_training_step_vs_oracle(device, cfg, seed=0, n_pos=None):
+# Gradient tolerance, measured instead of blanket: the oracle is run in fp64 as well as in fp32 and every parameter
+# gradient of the HIP path has to be as close to the fp64 result as the reference's own fp32 arithmetic is, up to a
+# factor: relL2(HIP, fp64) <= GRAD_FP64_FACTOR * relL2(oracle-fp32, fp64) + GRAD_FP64_FLOOR.  The right-hand side is
+# the reference's own noise floor for THAT tensor in THAT configuration (InstanceNorm over the 2^3..6^3 voxels of the
+# deep levels amplifies fp32 rounding, and LeakyReLU mask flips move single entries): 1e-2 for the deep U-Net tensors
+# of the 32^3 toy configuration, 1e-5..1e-4 for the full-size layers -- where a 3 % error in one layer's weight gradient
+# now fails.
+GRAD_FP64_FACTOR = 3.0
+GRAD_FP64_FLOOR = 2e-5
+
+
+def flip_fit(taps64, taps32, params64, got, ref32, max_basis=96, max_params=3_000_000):
+    """LeakyReLU is not differentiable at 0: a pre-activation that sits within fp32 rounding of 0 can land on either
+    side in two correct fp32 evaluations (torch's, ours) and in fp64, and the one voxel's slope (1 vs 0.01) moves every
+    gradient upstream of it by up to ~1e-2 in the small test configurations.  This separates that effect from real
+    errors: the fp64 oracle graph (``taps64`` = oracle.KINK_TAPS of the fp64 run, graph retained) names the voxels
+    whose pre-activation is within 8x the observed fp32-vs-fp64 deviation of their site (1e-6 of the site's largest value without an fp32 run) (``taps32``) of the kink; for
+    each such voxel v the change of ALL parameter gradients under a slope flip is  c * dL/dy_v * grad_theta(a_v)  (one
+    partial backward each).  ``got`` - fp64 and ``ref32`` - fp64 (dicts name -> array over ``params64``'s keys) are
+    least-squares fitted on that basis; returned are the residual dicts (what no combination of kink flips explains)
+    and the number of basis voxels.  None when the configuration is too large for the dense fit."""
+    names = list(params64)
+    plist = [params64[k] for k in names]
+    if sum(p.numel() for p in plist) > max_params:
+        return None
+    cand = []
+    for s, (a, y) in enumerate(taps64):
+        if y.grad is None:
+            continue
+        a64 = a.detach()
+        noise = float((taps32[s][0].detach().double() - a64).abs().max()) if taps32 is not None else 1e-6 * float(a64.abs().max())
+        idx = torch.nonzero((a64.abs().flatten() < 8.0 * max(noise, 1e-12)) & (a64.flatten() != 0))[:, 0]
+        gs = y.grad.flatten()[idx].abs()
+        cand += [(float(g), s, int(i)) for g, i in zip(gs, idx)]
+    cand = sorted(cand, reverse=True)[:max_basis]
+    if not cand:
+        return ({k: got[k] - params64[k].grad.numpy() for k in names},
+                {k: ref32[k] - params64[k].grad.numpy() for k in names}, 0)
+    cols = []
+    for _, s, i in cand:
+        a, y = taps64[s]
+        gr = torch.autograd.grad(a.flatten()[i], plist, retain_graph=True, allow_unused=True)
+        gi = float(y.grad.flatten()[i])
+        cols.append(np.concatenate([(np.zeros(p.numel()) if g is None else (gi * g).reshape(-1).numpy())
+                                    for g, p in zip(gr, plist)]))
+    A = np.stack(cols, axis=1)
+    g64 = np.concatenate([params64[k].grad.reshape(-1).numpy() for k in names])
+    out = []
+    for vec in (got, ref32):
+        d = np.concatenate([np.asarray(vec[k], np.float64).reshape(-1) for k in names]) - g64
+        coef = np.linalg.lstsq(A, d, rcond=None)[0]
+        r = d - A @ coef
+        res, off = {}, 0
+        for k, p in zip(names, plist):
+            res[k] = r[off:off + p.numel()]
+            off += p.numel()
+        out.append(res)
+    return out[0], out[1], len(cand)
+
+
+def _oracle_step(cfg, net, cpu, masks, dtype, taps=None):
+    """orc.training_step on the product's weights / sample in ``dtype`` (fp32: the reference's arithmetic; fp64: the
+    yardstick).  Returns (state dict with .grad populated, result dict)."""
+    def cast(v):
+        return v.to(dtype) if torch.is_tensor(v) and v.dtype == torch.float32 else v
+    sd = {k: cast(v.detach().cpu().clone()) for k, v in net.state_dict().items()}
+    for k, v in sd.items():
+        if v.dtype == dtype and "running" not in k:
+            v.requires_grad_(True)
+    ncls = cfg.NUM_CLASSES
+    onehot = torch.stack([(cpu["mask_labels"] == k) for k in range(ncls)], dim=1).double()
+    orc.KINK_TAPS = taps
+    try:
+        ref = _oracle_forward(cfg, net, cpu, masks, sd, cast, onehot)
+    finally:
+        orc.KINK_TAPS = None
+    if ref["total"].requires_grad:
+        ref["total"].backward(retain_graph=taps is not None)
+    return sd, ref
+
+
+def _oracle_forward(cfg, net, cpu, masks, sd, cast, onehot):
+    ref = orc.training_step(sd, cast(cpu["image"]), cast(net.anchors.cpu()), cpu["rpn_match"], cast(cpu["rpn_bbox_t"]),
+                            cast(cpu["p_rois"]), cast(cpu["n_rois"]), cpu["target_class_ids"], cast(cpu["target_deltas"]),
+                            onehot, cfg.STAGE, cfg.POOL_SIZE, cfg.MASK_POOL_SIZE,
+                            dropout_masks=None if masks is None else [cast(m) for m in masks],
+                            proposal_count=cfg.POST_NMS_ROIS_TRAINING, nms_threshold=cfg.RPN_NMS_THRESHOLD,
+                            pre_nms_limit=cfg.PRE_NMS_LIMIT, layers=tuple(getattr(cfg, "BACKBONE_LAYERS", (2, 3))),
+                            stem_pad=(getattr(cfg, "BACKBONE_STEM_KD", 3) // 2, 3, 3),
+                            ce_class_weights=getattr(cfg, "MASK_CE_CLASS_WEIGHTS", None),
+                            edge_raw=getattr(cfg, "EDGE_LOSS_RAW_SOBEL", False),
+                            stage_split=getattr(cfg, "STAGE_SPLIT", False),
+                            loss_weights=[float(cfg.LOSS_WEIGHTS[k]) for k in (
+                                "rpn_class_loss", "rpn_bbox_loss", "mrcnn_class_loss", "mrcnn_bbox_loss",
+                                "mrcnn_mask_loss", "mrcnn_mask_edge_loss")])
+    return ref
+
+
+def check_training_step_vs_oracle(device, cfg, seed=0, n_pos=None, fp64_bound=True, report=None):
     """One training step of cfun_amd.step (forward, 6 losses, backward) against oracle.training_step on the
-    same weights, inputs and dropout masks."""
+    same weights, inputs and dropout masks.  ``fp64_bound``: gradients are held to the measured per-tensor bound (see
+    GRAD_FP64_FACTOR); False (the emulator tier's budget): the blanket UNET_GRAD_L2_TOL.  ``report``: a list that
+    receives (name, err HIP-vs-fp64, err fp32-vs-fp64) per tensor."""
     from cfun_amd import step
     torch.manual_seed(seed)
     net = step.CFUNHotPath(cfg).to(device)
@@ -338,25 +473,10 @@ def check_training_step_vs_oracle(device, cfg, seed=0, n_pos=None):
     net.mask.modified_u_net.dropout_masks = masks
     out, losses, total = step.training_step(net, s)
 
-    sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype == torch.float32 and "running" not in k)
-          for k, v in net.state_dict().items()}
     cpu = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in s.items()}
-    ncls = cfg.NUM_CLASSES
-    onehot = torch.stack([(cpu["mask_labels"] == k) for k in range(ncls)], dim=1).double()
-    ref = orc.training_step(sd, cpu["image"], net.anchors.cpu(), cpu["rpn_match"], cpu["rpn_bbox_t"], cpu["p_rois"],
-                            cpu["n_rois"], cpu["target_class_ids"], cpu["target_deltas"], onehot, cfg.STAGE,
-                            cfg.POOL_SIZE, cfg.MASK_POOL_SIZE, dropout_masks=masks,
-                            proposal_count=cfg.POST_NMS_ROIS_TRAINING, nms_threshold=cfg.RPN_NMS_THRESHOLD,
-                            pre_nms_limit=cfg.PRE_NMS_LIMIT, layers=tuple(getattr(cfg, "BACKBONE_LAYERS", (2, 3))),
-                            stem_pad=(getattr(cfg, "BACKBONE_STEM_KD", 3) // 2, 3, 3),
-                            ce_class_weights=getattr(cfg, "MASK_CE_CLASS_WEIGHTS", None),
-                            edge_raw=getattr(cfg, "EDGE_LOSS_RAW_SOBEL", False),
-                            stage_split=getattr(cfg, "STAGE_SPLIT", False),
-                            loss_weights=[float(cfg.LOSS_WEIGHTS[k]) for k in (
-                                "rpn_class_loss", "rpn_bbox_loss", "mrcnn_class_loss", "mrcnn_bbox_loss",
-                                "mrcnn_mask_loss", "mrcnn_mask_edge_loss")])
-    if ref["total"].requires_grad:
-        ref["total"].backward()
+    taps32, taps64 = ([], []) if fp64_bound else (None, None)
+    sd, ref = _oracle_step(cfg, net, cpu, masks, torch.float32, taps32)
+    sd64 = _oracle_step(cfg, net, cpu, masks, torch.float64, taps64)[0] if fp64_bound else None
     # forward parity
     np.testing.assert_allclose(out["rpn_class_logits"].detach().cpu().numpy(), ref["rpn_logits"].detach().numpy(),
                                rtol=1e-4, atol=2e-5)
@@ -379,18 +499,50 @@ def check_training_step_vs_oracle(device, cfg, seed=0, n_pos=None):
         assert float((mp.argmax(1) != ref["mask_probs"].detach().numpy().argmax(1)).mean()) <= 1e-4
     for i, (a, r) in enumerate(zip(losses, ref["losses"])):
         assert abs(float(a) - float(r)) <= 1e-4 * max(abs(float(r)), 1e-3), "loss %d: %g vs %g" % (i, float(a), float(r))
-    # gradient parity (relative L2 over each tensor; see UNET_GRAD_L2_TOL)
-    worst = 0.0
+    # gradient parity (relative L2 over each tensor): measured bound against the fp64 oracle, see GRAD_FP64_FACTOR
+    worst, worst_ratio, bad = 0.0, 0.0, {}
     for k, p in net.named_parameters():
         if not p.requires_grad:
             continue
         if p.grad is None:
             assert sd[k].grad is None or float(sd[k].grad.abs().max()) == 0.0, k
             continue
-        e = rel_l2(p.grad.cpu().numpy(), sd[k].grad.numpy())
+        got = p.grad.cpu().numpy()
+        e = rel_l2(got, sd[k].grad.numpy())
         worst = max(worst, e)
-        assert e < UNET_GRAD_L2_TOL, "%s: rel L2 %.3e" % (k, e)
-    return dict(losses=[float(l) for l in losses], worst_grad_l2=worst)
+        if sd64 is None:
+            assert e < UNET_GRAD_L2_TOL, "%s: rel L2 %.3e" % (k, e)
+            continue
+        g64 = sd64[k].grad.numpy()
+        e_hip, e_ref = rel_l2(got, g64), rel_l2(sd[k].grad.numpy(), g64)
+        bound = GRAD_FP64_FACTOR * e_ref + GRAD_FP64_FLOOR
+        worst_ratio = max(worst_ratio, e_hip / bound)
+        if report is not None:
+            report.append((k, e_hip, e_ref))
+        if e_hip > bound:
+            bad[k] = "%s: relL2(HIP,fp64) %.3e > %.1f * relL2(fp32,fp64) %.3e + %.0e" % (k, e_hip, GRAD_FP64_FACTOR, e_ref,
+                                                                                        GRAD_FP64_FLOOR)
+    n_kink = None
+    if bad:
+        # Are the excesses LeakyReLU kink flips (a pre-activation within rounding of 0 landing on the other side)?  Fit
+        # HIP - fp64 and oracle-fp32 - fp64 on the kink-flip basis of the fp64 graph; what the fit does not explain has
+        # to meet the same bound, now with both sides flip-free.
+        unet = {k: v for k, v in sd64.items() if k.startswith("mask.") and v.grad is not None}
+        got = {k: dict(net.named_parameters())[k].grad.cpu().numpy() for k in unet}
+        fit = flip_fit(taps64, taps32, unet, got, {k: sd[k].grad.numpy() for k in unet})
+        if fit is not None:
+            res_hip, res_ref, n_kink = fit
+            for k in unet:
+                bad.pop(k, None)
+                den = np.linalg.norm(unet[k].grad.numpy()) + 1e-30
+                e_hip, e_ref = np.linalg.norm(res_hip[k]) / den, np.linalg.norm(res_ref[k]) / den
+                if e_hip > GRAD_FP64_FACTOR * e_ref + GRAD_FP64_FLOOR:
+                    bad[k] = ("%s: after removing %d kink flips relL2(HIP,fp64) %.3e > %.1f * %.3e + %.0e"
+                              % (k, n_kink, e_hip, GRAD_FP64_FACTOR, e_ref, GRAD_FP64_FLOOR))
+    bad = list(bad.values())
+    assert not bad or report is not None, "\n".join(bad)
+    return dict(losses=[float(l) for l in losses], worst_grad_l2=worst, worst_bound_ratio=worst_ratio, bad=bad,
+                kink_basis=n_kink)
 
 
 def check_inference_vs_oracle(device, cfg, seed=0, max_instances=2):
@@ -594,6 +746,21 @@ def check_unmold_golden(device):
     assert np.all(cmap[~inside] == 0)
     assert (cmap != g["class_map"]).sum() <= 1e-3 * inside.sum()
     assert (cmap != 0).any()
+    # probability level (as for the LiTS variant): the resized probabilities of detection 0 to 2e-6 -- cfun_unmold_overlap
+    # with ONE detection is the same trilinear resize without the arg-max (sum / (1 + 1e-6) undone here) -- and the class
+    # map exact wherever the top two classes are not tied to that precision
+    from cfun_amd import ops
+    box = g["detections"][0, :6].astype(np.int32)
+    _, full = ops.unmold_overlap(probs[:1].to(device), box[None], shape[1:], want_full=True)
+    full = full.cpu().numpy().astype(np.float64) * (1.0 + 1e-6)
+    ref_full = orc.unmold_mask(g["probs"][0], box, shape)
+    np.testing.assert_array_equal(ref_full[::3, ::3, ::3], g["full_mask_sub"])          # the oracle is the reference's function
+    np.testing.assert_allclose(full, ref_full, rtol=0, atol=2e-6)
+    top2 = np.sort(ref_full, axis=3)[..., -2:]
+    tie = (top2[..., 1] - top2[..., 0]) < 1e-5
+    got = cmap.transpose(2, 0, 1)
+    want = g["class_map"].transpose(2, 0, 1).astype(np.int64)
+    assert np.array_equal(got[~tie], want[~tie])
 
 
 def check_unmold_lits_golden(device):

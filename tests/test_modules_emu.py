@@ -55,13 +55,15 @@ def test_nms_dropin(emu):
 
 @pytest.mark.parametrize("stage", ["beginning", "finetune"])
 def test_training_step_vs_oracle(emu_direct, stage):
-    r = mc.check_training_step_vs_oracle(emu_direct, mc.tiny_config(stage), n_pos=1)
+    # (the fp64-bounded gradient check on one stage only: the emulator tier has a wall-clock budget; the GPU tier
+    # applies it to every step test)
+    r = mc.check_training_step_vs_oracle(emu_direct, mc.tiny_config(stage), n_pos=1, fp64_bound=(stage == "finetune"))
     assert all(l == l for l in r["losses"])   # finite
 
 
 def test_training_step_lits_shapes(emu_direct):
     """LiTS fork shapes: P3D35, (5,7,7) stem, 3 classes (C % 4 != 0 heads on the direct kernels), no dropout."""
-    mc.check_training_step_vs_oracle(emu_direct, mc.tiny_lits_config(), n_pos=1)
+    mc.check_training_step_vs_oracle(emu_direct, mc.tiny_lits_config(), n_pos=1, fp64_bound=False)
 
 
 def test_refine_detections_golden(emu):
@@ -106,7 +108,7 @@ def test_b3_module_path(emu):
 
 def test_training_step_lits_finetune(emu_direct):
     """LiTS fork 'finetune': class-weighted mask CE + raw-Sobel edge loss through the whole step vs the oracle."""
-    mc.check_training_step_vs_oracle(emu_direct, mc.tiny_lits_config("finetune"), n_pos=1)
+    mc.check_training_step_vs_oracle(emu_direct, mc.tiny_lits_config("finetune"), n_pos=1, fp64_bound=False)
 
 
 def test_lits_detector_phase_inference_masks_are_zero(emu_direct):
