@@ -56,57 +56,93 @@ def dominant_kernel_match(cfg):
     return match
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
-    (FETCH_SIZE / WRITE_SIZE collected in their own runs and corrected as MI355X_MICROARCH.md prescribes)."""
-    path = os.path.join(ROOT, "profiles", "round1_pmc_conv_l4_0.json")
+PMC_TRAFFIC_JSON = "profiles/round2_pmc_conv_l4_0.json"
+PMC_MFMA_JSON = "profiles/round2_pmc_mfma_conv_l4_0.json"
+
+
+def git_blob_sha1(path):
+    """= `git hash-object path` (works without a .git directory, as on the GPU box)."""
+    import hashlib
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def pmc_record(rel_path, field):
+    """A counter figure of the dominant kernel from a rocprofv3 --pmc pass committed under profiles/ (tools/pmc_*.sh;
+    FETCH_SIZE / WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes).  It is NOT measured by this
+    run, so it is reported with its source, and only while the kernel source it was collected on (git blob of
+    conv3d_mfma.h, recorded in the JSON) is still the one in the tree -- otherwise null."""
+    src = {"file": rel_path, "collected_by": "rocprofv3 --pmc, separate run (tools/pmc_traffic.sh / tools/pmc_mfma.sh)"}
     try:
-        with open(path) as f:
-            return float(json.load(f)["traffic_bytes_per_launch"])
-    except Exception:
-        return None
+        with open(os.path.join(ROOT, rel_path)) as f:
+            rec = json.load(f)
+        src["kernel_src_blob"] = rec.get("kernel_src_blob")
+        cur = git_blob_sha1(os.path.join(ROOT, rec.get("kernel_src", "cfun_amd/csrc/conv3d_mfma.h")))
+        src["current"] = bool(rec.get("kernel_src_blob") == cur)
+        return (float(rec[field]) if src["current"] else None), src
+    except Exception as e:       # no counter pass for this tree
+        src["current"] = False
+        src["error"] = str(e)[:80]
+        return None, src
 
 
-def pmc_mfma_util():
-    """MFMA-pipe busy fraction of the dominant kernel from the committed counter pass (tools/pmc_mfma.sh)."""
-    path = os.path.join(ROOT, "profiles", "round1_pmc_mfma_conv_l4_0.json")
-    try:
-        with open(path) as f:
-            return float(json.load(f)["mfma_util"])
-    except Exception:
-        return None
-
-
-def cpu_baseline(cfg, threads):
-    """The oracle (plain fp32 torch-CPU restatement of the reference path) on the host cores: bounded sample =
-    FPN+RPN forward+backward on the full volume + U-Net mask head forward+backward on ONE 96^3 RoI;
-    a step is estimated as fpn_rpn + n_pos * unet (>= 96 % of the step's FLOPs)."""
+def cpu_baseline(cfg, net, sample, threads, iters=1):
+    """The reference's CPU path timed beside the GPU run: the oracle (oracle/cfun_oracle.py -- the plain fp32 torch-CPU
+    restatement of the reference, pinned to it by tests/golden) runs THE SAME training step -- this run's weights, image,
+    4 + 8 injected RoIs, targets, all six losses incl. the 3-D Sobel edge loss, forward + backward -- on the host cores.
+    Nothing is extrapolated: `value` = 1 / (median wall time of `iters` full iterations).  One untimed warm-up iteration
+    of the same step at 64x64x32 / 1 RoI primes the thread pool and oneDNN's primitive caches; the default is ONE timed
+    iteration (the step takes the better part of a minute on CPU), --cpu-baseline-iters 3 gives the median of three."""
     from oracle import cfun_oracle as orc
-    from cfun_amd import step
+    from cfun_amd import config as ccfg, step
     torch.set_num_threads(threads)
-    net = step.CFUNHotPath(cfg)
-    sd = {k: v.detach().clone().requires_grad_(v.dtype == torch.float32 and "running" not in k)
-          for k, v in net.state_dict().items()}
+    keys = ("rpn_class_loss", "rpn_bbox_loss", "mrcnn_class_loss", "mrcnn_bbox_loss", "mrcnn_mask_loss",
+            "mrcnn_mask_edge_loss")
+
+    def one(cfg_i, net_i, s, n_pos):
+        sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype == torch.float32 and "running" not in k)
+              for k, v in net_i.state_dict().items()}
+        c = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in s.items()}
+        b = cfg_i.UNET_MASK_BRANCH_CHANNEL
+        gen = torch.Generator().manual_seed(1)
+        masks = [torch.empty(n_pos, ch).bernoulli_(0.4, generator=gen) / 0.4 for ch in (b, 2 * b, 4 * b, 8 * b, 16 * b)]
+        if getattr(cfg_i, "UNET_DROPOUT", 0.6) <= 0:
+            masks = None
+        keep = list(range(n_pos)) + list(range(4, 4 + 2 * n_pos))
+        onehot = torch.stack([(c["mask_labels"][:n_pos] == k) for k in range(cfg_i.NUM_CLASSES)], dim=1).double()
+        t0 = time.perf_counter()
+        ref = orc.training_step(sd, c["image"], net_i.anchors.cpu(), c["rpn_match"], c["rpn_bbox_t"], c["p_rois"][:n_pos],
+                                c["n_rois"][:2 * n_pos], c["target_class_ids"][keep], c["target_deltas"][keep], onehot,
+                                cfg_i.STAGE, cfg_i.POOL_SIZE, cfg_i.MASK_POOL_SIZE, dropout_masks=masks,
+                                proposal_count=cfg_i.POST_NMS_ROIS_TRAINING, nms_threshold=cfg_i.RPN_NMS_THRESHOLD,
+                                pre_nms_limit=cfg_i.PRE_NMS_LIMIT,
+                                layers=tuple(getattr(cfg_i, "BACKBONE_LAYERS", (2, 3))),
+                                stem_pad=(getattr(cfg_i, "BACKBONE_STEM_KD", 3) // 2, 3, 3),
+                                ce_class_weights=getattr(cfg_i, "MASK_CE_CLASS_WEIGHTS", None),
+                                edge_raw=getattr(cfg_i, "EDGE_LOSS_RAW_SOBEL", False),
+                                stage_split=getattr(cfg_i, "STAGE_SPLIT", False),
+                                loss_weights=[float(cfg_i.LOSS_WEIGHTS[k]) for k in keys])
+        ref["total"].backward()
+        return time.perf_counter() - t0, [float(l) for l in ref["losses"]]
+
+    # warm-up: the same code path at the smallest configuration
+    wcfg = ccfg.heart_config(cfg.STAGE, 64, 64, 32) if not hasattr(cfg, "BACKBONE_LAYERS") else None
+    if wcfg is not None:
+        wnet = step.CFUNHotPath(wcfg)
+        one(wcfg, wnet, step.synthetic_inputs(wcfg, torch.device("cpu"), 0), 1)
+    times, losses = [], None
+    for _ in range(max(1, iters)):
+        t, losses = one(cfg, net, sample, 4)
+        times.append(t)
+    med = sorted(times)[len(times) // 2]
     d, h, w = cfg.image_dhw
-    g = torch.Generator().manual_seed(0)
-    image = torch.randn(1, 1, d, h, w, generator=g)
-    t0 = time.time()
-    p2, p3 = orc.fpn(image, sd)
-    outs = [orc.rpn(p, sd) for p in (p2, p3)]
-    sum(o[0].sum() + o[2].sum() for o in outs).backward()
-    t_fpn = time.time() - t0
-    x = torch.randn(1, 1, *cfg.MASK_POOL_SIZE, generator=g)
-    b = cfg.UNET_MASK_BRANCH_CHANNEL
-    masks = [torch.ones(1, c) for c in (b, 2 * b, 4 * b, 8 * b, 16 * b)]
-    t0 = time.time()
-    y = orc.unet(x, sd, "mask.modified_u_net.", cfg.STAGE, masks)
-    torch.softmax(y, dim=1).sum().backward()
-    t_unet = time.time() - t0
-    est = t_fpn + 4 * t_unet
-    return dict(value=1.0 / est, unit="volumes/s", cores=threads, kind="port",
-                sample="oracle (torch-CPU fp32): FPN+RPN fwd+bwd on the %dx%dx%d volume (%.2fs) + U-Net '%s' fwd+bwd on "
-                       "1 of 4 RoIs at 96^3 (%.2fs); step estimated as fpn_rpn + 4*unet, losses/classifier excluded"
-                       % (h, w, d, t_fpn, cfg.STAGE, t_unet))
+    return dict(value=1.0 / med, unit="volumes/s", cores=threads, kind="port",
+                sample="oracle (torch %s CPU fp32, torch.get_num_threads() = %d of os.cpu_count() = %d): the identical "
+                       "%dx%dx%d '%s' training step -- same weights, image, 4 + 8 RoIs, targets, six losses, forward + "
+                       "backward; %d timed full iteration(s) after one warm-up at 64x64x32: %s s (median %.1f s); "
+                       "nothing extrapolated" % (torch.__version__, torch.get_num_threads(), os.cpu_count() or 0, h, w, d,
+                                                 cfg.STAGE, len(times), ", ".join("%.1f" % t for t in times), med),
+                losses=losses)
 
 
 def main():
@@ -116,6 +152,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-iters", type=int, default=1,
+                    help="timed full iterations of the oracle's CPU step (median reported); each takes ~1 min at cfg2")
     ap.add_argument("--no-alt", action="store_true",
                     help="skip the extra, separately reported leg on the opt-in 3xBF16 conv kernels (CFUN_CONV_ALGO=b3)")
     ap.add_argument("--sharded", action="store_true",
@@ -252,14 +290,17 @@ def main():
             "losses": lv,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                         "traffic": pmc_traffic() if args.workload == "cfg2" else None,
-                         "mfma_util_pmc": pmc_mfma_util() if args.workload == "cfg2" else None,
+                         "traffic": None, "mfma_util_pmc": None,
                          "kernel": "k_conv_mfma<3,3,3,1,3> (conv_norm_lrelu_l4.0: 3x3x3 %d->%d @ %dx%d^3)"
                                    % (2 * b, 2 * b, n_roi_launch, side[0]) if len(set(side)) == 1 else
                                    "k_conv_mfma (conv_norm_lrelu_l4.0: 3x3x3 %d->%d @ %dx%s)"
                                    % (2 * b, 2 * b, n_roi_launch, "x".join(map(str, side))),
                          "flops_per_launch": flops, "avg_launch_ms": t_k * 1e3, "launches_timed": len(durs)},
         }
+        if args.workload == "cfg2" and not b3:
+            r = result["roofline"]
+            r["traffic"], r["traffic_source"] = pmc_record(PMC_TRAFFIC_JSON, "traffic_bytes_per_launch")
+            r["mfma_util_pmc"], r["mfma_util_pmc_source"] = pmc_record(PMC_MFMA_JSON, "mfma_util")
         if b3:   # algorithmic (fp32) flops against the bf16 matrix peak divided by the 6 products each one costs
             peak = PEAK_BF16_MFMA_TFLOPS / B3_PRODUCTS
             result["roofline"].update(peak=peak, frac=achieved / peak, traffic=None, mfma_util_pmc=None,
@@ -278,7 +319,9 @@ def main():
                 "kernel": "k_conv_stem<3,3,3,1,%d> (conv3d_c1_1: 3x3x3 1->%d @ %dx%d^3)" % (b, b, n_roi_launch, side[0]),
                 "bytes_per_launch": nbytes, "avg_launch_ms": t_h * 1e3, "launches_timed": len(durs_h)}
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(cfg, threads=min(os.cpu_count() or 1, 32))
+            torch.cuda.empty_cache()
+            result["cpu_baseline"] = cpu_baseline(cfg, net, sample, threads=min(os.cpu_count() or 1, 64),
+                                                  iters=args.cpu_baseline_iters)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()

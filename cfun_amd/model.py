@@ -304,9 +304,10 @@ def pyramid_roi_align(inputs, pool_size, test_flag=False):
 
 # ------------------------------------------------------------------------------------------ heads
 class Classifier(nn.Module):
-    """model.py:750-784.  RoIAlign runs on the HIP kernel; conv1 (kernel == pool size) is a plain
-    [R x C*pd*ph*pw] x [.. x fc] GEMM that streams a 113 MB weight once (HBM-bound), so it and the two tiny
-    linear layers go to the library GEMM (rocBLAS via torch) -- SURVEY.md section 8(a) row A15 "adjacent"."""
+    """model.py:750-784 on HIP kernels end to end: RoIAlign (cfun_roi_align3d), then conv1 -- whose kernel equals the
+    pool size, i.e. a [R x C*pd*ph*pw] . [.. x fc] GEMM that streams the model's largest tensor (113 MB) once --
+    with bias + folded BN + ReLU in its epilogue, the 1x1x1 conv2 + BN + ReLU and the two linear heads, all on the
+    weight-streaming GEMM kernels of csrc/fc.hip (``ops.fc``); only the 2-way softmax of R <= 64 rows is torch."""
 
     def __init__(self, channel, pool_size, image_shape, num_classes, fc_size, test_flag=False):
         super().__init__()
@@ -319,17 +320,22 @@ class Classifier(nn.Module):
         self.linear_bbox = nn.Linear(fc_size, num_classes * 6)
 
     @staticmethod
-    def _bn(x, bn):
+    def _conv_bn_relu(x, conv, bn):
+        """relu(bn(conv(x))) for a conv that reduces its whole input: one GEMM, bias and the frozen BN in the epilogue."""
         s, t = folded_bn(bn, bn.eps)
-        return F.relu(torch.addcmul(t, x, s))
+        return ops.fc(x, conv.weight.reshape(conv.out_channels, -1), s, torch.addcmul(t, conv.bias, s), ACT_RELU)
 
     def forward_ndhwc(self, feature_maps, rois):
         x = pyramid_roi_align_ndhwc(rois, feature_maps, self.pool_size)            # [R,pd,ph,pw,C]
         x = x.permute(0, 4, 1, 2, 3).reshape(x.shape[0], -1)                        # OIDHW flatten order
-        x = self._bn(F.linear(x, self.conv1.weight.reshape(self.fc_size, -1), self.conv1.bias), self.bn1)
-        x = self._bn(F.linear(x, self.conv2.weight.reshape(self.fc_size, -1), self.conv2.bias), self.bn2)
-        logits = self.linear_class(x)
-        bbox = self.linear_bbox(x)
+        outs = []
+        for i in range(0, max(x.shape[0], 1), 64):                                   # (64 RoIs per launch)
+            h = self._conv_bn_relu(x[i:i + 64], self.conv1, self.bn1)
+            h = self._conv_bn_relu(h, self.conv2, self.bn2)
+            outs.append((ops.fc(h, self.linear_class.weight, None, self.linear_class.bias),
+                         ops.fc(h, self.linear_bbox.weight, None, self.linear_bbox.bias)))
+        logits = torch.cat([o[0] for o in outs], dim=0) if len(outs) > 1 else outs[0][0]
+        bbox = torch.cat([o[1] for o in outs], dim=0) if len(outs) > 1 else outs[0][1]
         return [logits, F.softmax(logits, dim=1), bbox.view(bbox.shape[0], -1, 6)]
 
     def forward(self, x, rois):

@@ -484,6 +484,70 @@ def channel_sum(g2d):
     return out
 
 
+# ---- classifier head GEMMs (fc.hip) --------------------------------------------------------------------------------
+class _FC(torch.autograd.Function):
+    """y = act(scale * (x . w^T) + shift): x [R,K], w [O,K] (a Conv3d weight whose kernel covers its whole input, a
+    1x1x1 conv or an nn.Linear weight, viewed 2-D), scale / shift [O] or None.  The weight streams through
+    cfun_fc_fwd / cfun_fc_bwd_* in its own layout; gradients for x, w and shift (scale is a frozen-BN fold)."""
+
+    @staticmethod
+    def forward(ctx, x, w, scale, shift, act):
+        lib = _lib.load()
+        x, w = _c(x), _c(w)
+        scale = None if scale is None else _c(scale)
+        shift = None if shift is None else _c(shift)
+        r, k = x.shape
+        o = w.shape[0]
+        if w.shape[1] != k:
+            raise RuntimeError("fc: x %s does not match w %s" % (tuple(x.shape), tuple(w.shape)))
+        if r > 64:
+            raise RuntimeError("fc: at most 64 rows per call (got %d)" % r)
+        y = torch.empty((r, o), dtype=torch.float32, device=x.device)
+        ws = workspace(lib.cfun_fc_workspace_bytes(r, k, o), x)
+        check(lib.cfun_fc_fwd(ptr(x), ptr(w), ptr(scale), ptr(shift), ptr(y), r, k, o, act, ptr(ws), ws.numel(), stream(x)),
+              "fc_fwd")
+        ctx.act = act
+        ctx.save_for_backward(x, w, scale, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w, scale, y = ctx.saved_tensors
+        need_x, need_w, need_scale, need_shift = ctx.needs_input_grad[:4]
+        if need_scale:
+            raise RuntimeError("cfun_amd fc: gradient w.r.t. the epilogue scale is not implemented (frozen BatchNorm)")
+        r, k = x.shape
+        o = w.shape[0]
+        dy = _c(dy)
+        st = stream(dy)
+        gp = dy
+        if ctx.act != ACT_NONE:
+            gp = torch.empty_like(dy)
+            check(lib.cfun_act_bwd(ptr(y), ptr(dy), None, ptr(gp), r, o, 1, ctx.act, LRELU_SLOPE, 0, st), "act_bwd")
+        g = gp
+        if scale is not None:
+            g = torch.empty_like(dy)
+            check(lib.cfun_act_bwd(None, ptr(gp), ptr(scale), ptr(g), r, o, 1, ACT_NONE, LRELU_SLOPE, 1, st), "act_bwd(scale)")
+        dx = dw = dshift = None
+        if need_x:
+            dx = torch.empty_like(x)
+            check(lib.cfun_fc_bwd_data(ptr(g), ptr(w), ptr(dx), r, k, o, st), "fc_bwd_data")
+        if need_w:
+            dw = torch.empty_like(w)
+            check(lib.cfun_fc_bwd_weight(ptr(x), ptr(g), ptr(dw), r, k, o, st), "fc_bwd_weight")
+        if need_shift:
+            dshift = channel_sum(gp) if r else torch.zeros((o,), dtype=torch.float32, device=dy.device)
+        return dx, dw, None, dshift, None
+
+
+def fc(x, w, scale=None, shift=None, act=ACT_NONE):
+    """act(scale * (x [R,K] . w [O,K]^T) + shift) on the weight-streaming GEMM kernels (classifier head, model.py:750-784)."""
+    if x.shape[0] == 0:
+        return x.new_zeros((0, w.shape[0])) + 0.0 * w.sum()
+    return _FC.apply(x, w, scale, shift, act)
+
+
 # ---- zero-copy channel concatenation ------------------------------------------------------------------------------
 class ConcatBuffer:
     """A [N,D,H,W,C_total] NDHWC buffer whose channel ranges are filled IN PLACE by the ops that produce the operands

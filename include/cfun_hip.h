@@ -122,6 +122,22 @@ int cfun_channel_sum(const float* g, float* out, int64_t nvox, int32_t C, void* 
                      cfun_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Classifier head GEMMs (model.py:750-784): Conv3d(C -> fc, kernel = pool size) on a pool-sized input, the 1x1x1 conv
+ * and the two nn.Linear layers are all  y[R][O] = act(scale[o] * (x[R][K] . w[O][K]^T) + shift[o])  with few rows
+ * (R <= 64 RoIs) and, for conv1, a weight that dominates the model (K = C*pd*ph*pw = 221 184, 113 MB): it is streamed
+ * once, in the checkpoint's OIDHW layout (w = conv1.weight viewed [O][K], x = the RoI-aligned features [R][C][pd][ph][pw]
+ * viewed [R][K]).  K % 4 == 0; x, w, dw, dx 16-byte aligned; scale / shift [O] or NULL; act NONE or RELU.
+ * Replaces F.conv3d / F.linear + batch_norm + relu of model.py:767-779.  Deterministic (fixed summation order).
+ * ---------------------------------------------------------------------------------------------- */
+size_t cfun_fc_workspace_bytes(int32_t R, int32_t K, int32_t O);
+int cfun_fc_fwd(const float* x, const float* w, const float* scale, const float* shift, float* y, int32_t R, int32_t K,
+                int32_t O, int32_t act, void* ws, size_t ws_bytes, cfun_stream_t stream);
+/* dw[O][K] = g[R][O]^T . x[R][K]   (g = dL/d(x.w^T), i.e. already multiplied by act' and scale: cfun_act_bwd) */
+int cfun_fc_bwd_weight(const float* x, const float* g, float* dw, int32_t R, int32_t K, int32_t O, cfun_stream_t stream);
+/* dx[R][K] = g[R][O] . w[O][K] */
+int cfun_fc_bwd_data(const float* g, const float* w, float* dx, int32_t R, int32_t K, int32_t O, cfun_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Elementwise / normalisation (mask_branch.py:18,28,34,40,46,57,94,99,110,115; backbone.py:56,78,89).
  * ---------------------------------------------------------------------------------------------- */
 int cfun_lrelu_fwd(const float* x, float* y, int64_t n, float slope, cfun_stream_t stream);

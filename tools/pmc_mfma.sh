@@ -13,9 +13,11 @@ rm -rf /tmp/pmc_mfma
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d /tmp/pmc_mfma -o p -- \
     python "$REPO/tools/bench_layers.py" --filter l4.0 --iters 1 > "$REPO/gpurun_out/pmc_mfma.log" 2>&1
 cp "$(find /tmp/pmc_mfma -name '*counter_collection.csv' | head -1)" "$REPO/gpurun_out/pmc_mfma.csv"
-python - "$REPO/gpurun_out/pmc_mfma.csv" <<'PY'
-import csv, json, sys
-K = "k_conv_mfma<3, 3, 3, 1, 3, false, 0>"
+REPO="$REPO" python - "$REPO/gpurun_out/pmc_mfma.csv" <<'PY'
+import csv, json, os, sys
+sys.path.insert(0, os.path.join(os.environ["REPO"], "tools"))
+from pmc_traffic import git_blob_sha1, SRC
+K = os.environ.get("CFUN_PMC_KERNEL", "k_conv_mfma<3, 3, 3, 1, 3, false, 0>")
 acc = {}
 for row in csv.DictReader(open(sys.argv[1])):
     if K in row["Kernel_Name"]:
@@ -24,14 +26,13 @@ avg = {k: sum(v) / len(v) for k, v in acc.items()}
 cus = 256
 rec = {"what": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES (one pass, --kernel-trace only) "
                "around tools/bench_layers.py --filter l4.0 --iters 1 on MI355X (tools/pmc_mfma.sh)",
-       "kernel": "cfun_mfma::k_conv_mfma<3,3,3,1,3,false,0> (3x3x3 40->40 @ 4x96^3, forward / data gradient)",
+       "kernel": "cfun_mfma::%s (3x3x3 40->40 @ 4x96^3, forward / data gradient)" % K,
+       "kernel_src": "cfun_amd/csrc/conv3d_mfma.h", "kernel_src_blob": git_blob_sha1(SRC),
        "dispatches": len(next(iter(acc.values()))) if acc else 0, "counters_avg": avg}
 if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and "GRBM_GUI_ACTIVE" in avg and avg["GRBM_GUI_ACTIVE"] > 0:
     busy = avg["GRBM_GUI_ACTIVE"] / 8.0            # the counter is reported summed over the 8 XCDs
     rec["busy_cycles_per_xcd"] = busy
     rec["mfma_util"] = avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (busy * cus * 4)
     rec["formula"] = "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 256 CUs * 4 SIMDs)"
-    rec["check"] = ("SQ_VALU_MFMA_BUSY_CYCLES = 32 cycles x 179.2 M v_mfma_f32_16x16x4_f32 issued (13 824 tiles x 4 waves x "
-                    "3 240); busy cycles / 2.4 GHz = the kernel's 2.68 ms")
 print(json.dumps(rec, indent=2))
 PY
