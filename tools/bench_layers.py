@@ -119,7 +119,11 @@ def main():
         t_w = timeit(lambda: check(lib.cfun_conv3d_bwd_weight(ptr(x), ptr(g), ptr(dwp), C.byref(p), ptr(ws_w), ws_w.numel(), st), "w"), args.iters)
         for i, t in enumerate((t_f, t_d, t_w)):
             tot[i] += t
-        print("%-44s %9.3f %9.3f %9.3f   %6.1f %6.1f %6.1f" % (L[0], t_f, t_d, t_w, flops / t_f / 1e9, flops / t_d / 1e9, flops / t_w / 1e9))
+        extra = ""
+        if L[3] == 1:      # C_in = 1 stem: HBM-bound, algorithmic bytes = input + output + weights
+            nbytes = 4.0 * (x.numel() + y.numel() + wp.numel())
+            extra = "   fwd %.0f GB/s" % (nbytes / t_f / 1e6)
+        print("%-44s %9.3f %9.3f %9.3f   %6.1f %6.1f %6.1f%s" % (L[0], t_f, t_d, t_w, flops / t_f / 1e9, flops / t_d / 1e9, flops / t_w / 1e9, extra))
     print("%-44s %9.3f %9.3f %9.3f" % ("sum", *tot))
 
 
