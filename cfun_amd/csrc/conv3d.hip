@@ -273,12 +273,6 @@ static int pick_tile(const Shape* s, int co, bool per_parity) {
   // measured (tools/bench_layers.py): v_mfma_f32_4x4x1_16b issues at half the 16x16x4 MAC rate, so a remainder quad
   // pays off for 20 = 16 + 4 (1.2x) and for the 8-channel 3x3x3 data gradient (1.3x), not for 40 = 32 + 8
   if (rem_ok && s->max_nsub > 1) {
-    // CFUN_REM_VALU (tuning knob, bit 0: Co = 40, bit 1: Co = 20): the remainder channels on the vector ALU in the
-    // shadow of the MFMAs (k_conv_mfma<..., RV = true>) instead of padded MFMA columns / 4x4x1 MFMAs
-    static int rv = -1;
-    if (rv < 0) { const char* e = getenv("CFUN_REM_VALU"); rv = e ? atoi(e) : 0; }
-    if (co == 40 && s->kd == 3 && (rv & 1)) return 2 + 8 * 2 + 64;
-    if (co == 20 && s->kd == 3 && (rv & 2)) return 1 + 8 * 1 + 64;
     if (co == 20) return 1 + 8 * 1;
     if (co == 8 && s->kd == 3) return 0 + 8 * 2;
   }

@@ -106,12 +106,8 @@ struct FwdTile {
 // v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 outer products: lane 4b+j supplies voxel j of block b, lane 4b+i the
 // weight of channel i; result lane = voxel, 4 registers = 4 channels -- measured with tools/probe_mfma.py), so
 // Co = 20 / 40 / 8 tiles carry no channel padding (a 16-wide MFMA subtile would be 75 % / 50 % / 50 % idle).
-// RV = true: the REM trailing 4-channel groups run on the VECTOR ALU instead (v_pk_fma_f32, lane = voxel, the
-// wave-uniform weights read from the LDS chunk as broadcast 16-byte reads), in the shadow of the 16-wide MFMAs of the
-// same wave: the matrix pipe then only carries full 16-column tiles (Co = 40 -> 32 on MFMA + 8 on VALU instead of 48
-// MFMA columns, 17 % of them padding).
-template <int KD, int KH, int KW, int S, int NSUB, bool SPECIAL, int REM, bool RV = false>
-__global__ void __launch_bounds__(256, RV ? 2 : 1)      // RV: keep two waves per SIMD (<= 256 registers)
+template <int KD, int KH, int KW, int S, int NSUB, bool SPECIAL, int REM>
+__global__ void __launch_bounds__(256)
 k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale,
             const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
             CfunConv3dParams p, ConvMode md, int ntz, int nty, int ntx, int ncot, float* __restrict__ partial,
@@ -263,14 +259,8 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
 #pragma unroll
             for (int q = 0; q < REM; ++q)
 #pragma unroll
-              for (int cc = 0; cc < 4; ++cc) {
-                if constexpr (RV) {
-                  const f32x4 w4 = *reinterpret_cast<const f32x4*>(Wl + (tap * 4 + cc) * NTP + 16 * NSUB + 4 * q);
-                  accr[q] += w4 * xb[cc];
-                } else {
-                  accr[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(Wr[(tap * 4 + cc) * NTP + 4 * q], xb[cc], accr[q], 0, 0, 0);
-                }
-              }
+              for (int cc = 0; cc < 4; ++cc)
+                accr[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(Wr[(tap * 4 + cc) * NTP + 4 * q], xb[cc], accr[q], 0, 0, 0);
           }
         }
   }
@@ -343,7 +333,7 @@ inline size_t splitk_workspace(int64_t nblk, int nchunks, const CfunConv3dParams
   return k > 1 ? (size_t)k * p.N * p.Do * p.Ho * p.Wo * p.Co * sizeof(float) : 0;
 }
 
-template <int KD, int KH, int KW, int S, int NSUB, int REM = 0, bool RV = false>
+template <int KD, int KH, int KW, int S, int NSUB, int REM = 0>
 int launch_conv_mfma(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
                      float* y, const CfunConv3dParams& p, const ConvMode& md, void* ws, size_t ws_bytes, hipStream_t st) {
   using T = FwdTile<KD, KH, KW, S>;
@@ -357,9 +347,9 @@ int launch_conv_mfma(const float* x, const float* wp, const float* scale, const 
   constexpr bool kHasSpecial = (KD == 3 && KH == 3 && KW == 3 && S == 1);
   const bool special = md.in_s2d || md.tap_skip;
   if (special && !kHasSpecial) return CFUN_EINVAL;
-  auto kern = k_conv_mfma<KD, KH, KW, S, NSUB, false, REM, RV>;
+  auto kern = k_conv_mfma<KD, KH, KW, S, NSUB, false, REM>;
   if constexpr (kHasSpecial) {
-    if (special) kern = k_conv_mfma<KD, KH, KW, S, NSUB, true, REM, RV>;
+    if (special) kern = k_conv_mfma<KD, KH, KW, S, NSUB, true, REM>;
   }
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -378,7 +368,7 @@ int launch_conv_mfma(const float* x, const float* wp, const float* scale, const 
 template <int KD, int KH, int KW, int S>
 size_t fwd_workspace(int nsub, const CfunConv3dParams& p, const ConvMode& md) {
   using T = FwdTile<KD, KH, KW, S>;
-  const int nt = 16 * (nsub & 7) + 4 * ((nsub >> 3) & 7);
+  const int nt = 16 * (nsub & 7) + 4 * (nsub >> 3);
   const int64_t nblk = (int64_t)p.N * cdiv(p.Do, T::TD) * cdiv(p.Ho, T::TH) * cdiv(p.Wo, T::TW) * cdiv(p.Co, nt);
   const int nchunks = md.in_s2d ? 8 * (md.in_cq >> 2) : (p.Ci >> 2);
   return splitk_workspace(nblk, nchunks, p);
@@ -401,10 +391,6 @@ int dispatch_nsub(int nsub, const float* x, const float* wp, const float* scale,
     if (nsub == 1 + 8 * 1) return launch_conv_mfma<KD, KH, KW, S, 1, 1>(x, wp, scale, shift, res, y, p, flip, ws, wsb, st);
     if (nsub == 2 + 8 * 2) return launch_conv_mfma<KD, KH, KW, S, 2, 2>(x, wp, scale, shift, res, y, p, flip, ws, wsb, st);
     if (nsub == 0 + 8 * 2) return launch_conv_mfma<KD, KH, KW, S, 0, 2>(x, wp, scale, shift, res, y, p, flip, ws, wsb, st);
-    if constexpr (KD == 3) {   // + 64: remainder quads on the vector ALU (3x3x3 shapes)
-      if (nsub == 2 + 8 * 2 + 64) return launch_conv_mfma<KD, KH, KW, S, 2, 2, true>(x, wp, scale, shift, res, y, p, flip, ws, wsb, st);
-      if (nsub == 1 + 8 * 1 + 64) return launch_conv_mfma<KD, KH, KW, S, 1, 1, true>(x, wp, scale, shift, res, y, p, flip, ws, wsb, st);
-    }
   }
   if (nsub >= 8 || nsub < 1) return CFUN_EINVAL;
   if constexpr (max_nsub<KD, KH, KW, S>() == 1) {
@@ -663,13 +649,6 @@ k_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ g, float* __
 template <int KD, int KH, int KW, int S>
 constexpr bool wgrad_fused_shape() { return KD * KH * KW == 27; }
 
-// tuning knob (tools/bench_layers.py A/B): CFUN_WGRAD_SPLIT=0 keeps the single-workgroup form of the C_in = 40 kernel
-inline bool wgrad_split_enabled() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("CFUN_WGRAD_SPLIT"); v = e ? atoi(e) : 0; }
-  return v != 0;
-}
-
 // 0: not applicable; else NPL | PACK << 4
 inline int wgrad_fused_mode(const CfunConv3dParams& p, int nsub) {
   if (p.kd * p.kh * p.kw != 27 || (p.d2s && p.tap_skip) || nsub > 3) return 0;
@@ -678,47 +657,36 @@ inline int wgrad_fused_mode(const CfunConv3dParams& p, int nsub) {
   return 0;
 }
 
-// SPLIT = 2 (C_in = 40): the tile's work is dealt to TWO workgroups -- each takes one of the two plain 16-channel
-// subtiles plus half of the packed remainder rows (27 + 7 = 34 MFMA rows each, balanced) and stages only the 24
-// channels it reads.  Half the accumulators and a smaller staging set: <= 256 registers, two waves per SIMD, so one
-// workgroup's MFMAs cover the other's stage-in (the single-workgroup form needs 489 registers: one wave per SIMD and
-// nothing to hide a barrier behind).
-template <int KD, int KH, int KW, int S, int NSUB, int NPL, int PACK, int SPLIT = 1>
-__global__ void __launch_bounds__(256, SPLIT)
+template <int KD, int KH, int KW, int S, int NSUB, int NPL, int PACK>
+__global__ void __launch_bounds__(256)
 k_wgrad_fused(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ partial, CfunConv3dParams p,
               int ntz, int nty, int ntx, int ncot, int tiles_per_chunk, int ntiles) {
   using T = WgTile<KD, KH, KW, S>;
   constexpr int TAPS = T::TAPS, NT = 16 * NSUB, GS = pad_row16(NT);
-  constexpr int NPLW = NPL / SPLIT;             // plain subtiles of this workgroup
-  constexpr int R = 16 / PACK, CH = 16 * NPLW + R, C4 = CH / 4;
-  constexpr int XS = (CH == 20 || CH == 24) ? 24 : CH;   // floats per staged voxel; fragment reads at most 2-way conflicted
+  constexpr int R = 16 / PACK, CH = 16 * NPL + R, C4 = CH / 4;
+  constexpr int XS = CH == 20 ? 24 : CH;        // floats per staged voxel; fragment reads at most 2-way conflicted
   constexpr int TPW = cdiv(TAPS, 4);            // 7 plain tap rows per wave and subtile
   constexpr int NQ = cdiv(TAPS, PACK);          // packed rows
-  constexpr int NQH = cdiv(NQ, SPLIT);          // ... of this workgroup
-  constexpr int TPP = cdiv(NQH, 4);             // per wave
+  constexpr int TPP = cdiv(NQ, 4);              // per wave
   constexpr int X_ITEMS = T::IVOX * C4, X_LOADS = cdiv(X_ITEMS, 256);
   constexpr int G_ITEMS = T::TVOX * (NT / 4), G_LOADS = cdiv(G_ITEMS, 256);
-  static_assert(NPL % SPLIT == 0, "plain subtiles must divide over the split");
   CFUN_DYN_LDS(float, smem);
   float* Xl = smem;                      // [IVOX][XS]
   float* Gl = smem + T::IVOX * XS;       // [TVOX][GS]
 
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int half = SPLIT > 1 ? (int)(lid % SPLIT) : 0;
-  if (SPLIT > 1) lid /= SPLIT;
   const int cot = lid % ncot;
   const int chunk = lid / ncot;
   const int cobase = cot * NT;
   const int sh = p.up2 ? 1 : 0;
   const int Dv = p.Di << sh, Hv = p.Hi << sh, Wv = p.Wi << sh;
-  const int cplain = 16 * NPLW * half;   // first plain channel of this workgroup
 
-  f32x4 acc[NPLW][TPW][NSUB], accp[TPP][NSUB];
+  f32x4 acc[NPL][TPW][NSUB], accp[TPP][NSUB];
 #pragma unroll
   for (int nn = 0; nn < NSUB; ++nn) {
 #pragma unroll
-    for (int s = 0; s < NPLW; ++s)
+    for (int s = 0; s < NPL; ++s)
 #pragma unroll
       for (int t = 0; t < TPW; ++t) acc[s][t][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -738,9 +706,7 @@ k_wgrad_fused(const float* __restrict__ x, const float* __restrict__ g, float* _
 #pragma unroll
     for (int i = 0; i < X_LOADS; ++i) {
       const int it = tid + i * 256;
-      const int idx = it / C4, j = it - idx * C4;
-      // staged channel group j -> channel: the workgroup's plain subtile(s), then the remainder channels
-      const int c = j < 4 * NPLW ? cplain + 4 * j : 16 * NPL + 4 * (j - 4 * NPLW);
+      const int idx = it / C4, c = (it - idx * C4) * 4;
       const int ix = idx % T::IX, iy = (idx / T::IX) % T::IY, iz = idx / (T::IX * T::IY);
       const int vz = z0 * S - p.pd + iz, vy = y0 * S - p.ph + iy, vx = x0 * S - p.pw + ix;
       const bool ok = (it < X_ITEMS) & (c < p.Ci) & (vz >= 0) & (vz < Dv) & (vy >= 0) & (vy < Hv) & (vx >= 0) & (vx < Wv);
@@ -798,7 +764,6 @@ k_wgrad_fused(const float* __restrict__ x, const float* __restrict__ g, float* _
     const int dz = tap / (KH * KW), dy = (tap / KW) % KH, dx = tap % KW;
     return ((dz * T::IY + dy) * T::IX + dx) * XS;
   };
-  const int qlo = half * NQH, qhi = (qlo + NQH < NQ) ? qlo + NQH : NQ;   // this workgroup's packed rows
   int toff[TPW], toffp[TPP];
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {       // plain rows: tap t*4 + wave, channel lane&15 (surplus slots recompute tap 26)
@@ -806,11 +771,9 @@ k_wgrad_fused(const float* __restrict__ x, const float* __restrict__ g, float* _
     toff[t] = tap_off(tap < TAPS ? tap : TAPS - 1) + (lane & 15);
   }
 #pragma unroll
-  for (int u = 0; u < TPP; ++u) {       // packed rows: q = qlo + u*4 + wave; row i -> tap PACK*q + i/R, channel 16*NPL + i%R
-    int q = qlo + u * 4 + wv;
-    if (q >= qhi) q = qhi - 1;
-    const int tap = q * PACK + (lane & 15) / R;
-    toffp[u] = tap_off(tap < TAPS ? tap : TAPS - 1) + 16 * NPLW + (lane & 15) % R;
+  for (int u = 0; u < TPP; ++u) {       // packed rows: q = u*4 + wave; row i -> tap PACK*q + i/R, channel 16*NPL + i%R
+    const int tap = (u * 4 + wv) * PACK + (lane & 15) / R;
+    toffp[u] = tap_off(tap < TAPS ? tap : TAPS - 1) + 16 * NPL + (lane & 15) % R;
   }
 
   if (t_begin < t_end) prefetch(t_begin);
@@ -819,22 +782,21 @@ k_wgrad_fused(const float* __restrict__ x, const float* __restrict__ g, float* _
     commit();
     __syncthreads();
     if (tile + 1 < t_end) prefetch(tile + 1);
-    constexpr int kUnroll = SPLIT > 1 ? 1 : 2;   // (two waves per SIMD cover each other; the register budget is 256)
-#pragma unroll kUnroll
+#pragma unroll 2
     for (int grp = 0; grp < T::TVOX / 4; ++grp) {
       const int xq = grp & 3, ly = (grp >> 2) & 3, lz = grp >> 4;
-      float b[NSUB], a[NPLW][TPW], ap[TPP];
+      float b[NSUB], a[NPL][TPW], ap[TPP];
 #pragma unroll
       for (int nn = 0; nn < NSUB; ++nn) b[nn] = Gw[(grp * 4) * GS + nn * 16];
       const float* Xg = Xv + ((lz * T::RS * T::IY + ly * T::RS) * T::IX + xq * 4 * T::RS) * XS;
 #pragma unroll
-      for (int s = 0; s < NPLW; ++s)
+      for (int s = 0; s < NPL; ++s)
 #pragma unroll
         for (int t = 0; t < TPW; ++t) a[s][t] = Xg[toff[t] + 16 * s];
 #pragma unroll
       for (int u = 0; u < TPP; ++u) ap[u] = Xg[toffp[u]];
 #pragma unroll
-      for (int s = 0; s < NPLW; ++s)
+      for (int s = 0; s < NPL; ++s)
 #pragma unroll
         for (int t = 0; t < TPW; ++t)
 #pragma unroll
@@ -862,14 +824,13 @@ k_wgrad_fused(const float* __restrict__ x, const float* __restrict__ g, float* _
         const int tap = t * 4 + wv;
         if (tap < TAPS) {
 #pragma unroll
-          for (int s = 0; s < NPLW; ++s) out[((int64_t)tap * p.Ci + cplain + 16 * s + i) * p.CoP + co] = acc[s][t][nn][r];
+          for (int s = 0; s < NPL; ++s) out[((int64_t)tap * p.Ci + 16 * s + i) * p.CoP + co] = acc[s][t][nn][r];
         }
       }
 #pragma unroll
       for (int u = 0; u < TPP; ++u) {
-        const int q = qlo + u * 4 + wv;
-        const int tap = q * PACK + i / R, ci = 16 * NPL + i % R;
-        if (q < qhi && tap < TAPS && ci < p.Ci) out[((int64_t)tap * p.Ci + ci) * p.CoP + co] = accp[u][nn][r];
+        const int tap = (u * 4 + wv) * PACK + i / R, ci = 16 * NPL + i % R;
+        if (tap < TAPS && ci < p.Ci) out[((int64_t)tap * p.Ci + ci) * p.CoP + co] = accp[u][nn][r];
       }
     }
   }
@@ -916,23 +877,14 @@ int launch_wgrad_mfma(const float* x, const float* g, float* partial, const Cfun
       const size_t ldsf = (size_t)(T::IVOX * xs + T::TVOX * GS) * sizeof(float);
       void (*kf)(const float*, const float*, float*, CfunConv3dParams, int, int, int, int, int, int) =
           k_wgrad_fused<KD, KH, KW, S, NSUB, 1, 4>;
-      int split = 1;
-      size_t ldsf2 = ldsf;
       if constexpr (S == 1) {
-        if ((mode & 15) == 2) {
-          kf = k_wgrad_fused<KD, KH, KW, S, NSUB, 2, 2>;
-          if (wgrad_split_enabled()) {     // two workgroups per tile, two waves per SIMD
-            kf = k_wgrad_fused<KD, KH, KW, S, NSUB, 2, 2, 2>;
-            split = 2;
-            ldsf2 = (size_t)(T::IVOX * 24 + T::TVOX * GS) * sizeof(float);
-          }
-        }
+        if ((mode & 15) == 2) kf = k_wgrad_fused<KD, KH, KW, S, NSUB, 2, 2>;
       }
-      if (ldsf2 > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf2);
+      if (ldsf > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
         if (e != hipSuccess) return (int)e;
       }
-      hipLaunchKernelGGL(kf, dim3((unsigned)(w.nchunks * w.ncot * split)), dim3(256), ldsf2, st, x, g, partial, p, w.ntz, w.nty,
+      hipLaunchKernelGGL(kf, dim3((unsigned)(w.nchunks * w.ncot)), dim3(256), ldsf, st, x, g, partial, p, w.ntz, w.nty,
                          w.ntx, w.ncot, w.tiles_per_chunk, w.ntiles);
       CFUN_LAUNCH_CHECK();
       return CFUN_OK;

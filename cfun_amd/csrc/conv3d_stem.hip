@@ -214,9 +214,11 @@ k_conv_stem333z(const float* __restrict__ x, const float* __restrict__ wp, const
   }
 }
 
-inline int stem_zpt() {      // tuning knob: CFUN_STEM_ZPT = 1 (one voxel per thread) | 2 | 4
+// measured on MI355X, conv3d_c1_1 at 4 x 96^3 (tools/bench_layers.py, profiles/round2_ab_layers.log): one voxel per
+// thread 0.093 ms = 3.2 TB/s, ZPT = 2 0.081 ms = 3.7 TB/s, ZPT = 4 0.085 ms (3 456 workgroups: the tail shows)
+inline int stem_zpt() {      // tuning knob: CFUN_STEM_ZPT = 1 (one voxel per thread) | 2 (default) | 4
   static int v = -1;
-  if (v < 0) { const char* e = getenv("CFUN_STEM_ZPT"); v = e ? atoi(e) : 1; if (v != 2 && v != 4) v = 1; }
+  if (v < 0) { const char* e = getenv("CFUN_STEM_ZPT"); v = e ? atoi(e) : 2; if (v != 1 && v != 4) v = 2; }
   return v;
 }
 

@@ -89,25 +89,28 @@ k_fc_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __rest
   }
 }
 
-// y[r][o] = act(scale[o] * sum_chunk partial[chunk][r][o] + shift[o]); block = (r, 64 channels) x 4 chunk groups
-__global__ void __launch_bounds__(256)
+// y[r][o] = act(scale[o] * sum_chunk partial[chunk][r][o] + shift[o]).  The partials are a [nchunks x R*O] matrix summed
+// along its rows: a block of 1024 threads owns 16 consecutive columns, thread (g, c) adds rows g, g + 64, ... (64-byte
+// coalesced segments, ~14 independent loads per thread at the heart shapes), then the 64 row-group sums of a column are
+// added in a fixed order -- deterministic, and short enough (a few microseconds) not to matter beside the weight stream.
+__global__ void __launch_bounds__(1024)
 k_fc_finish(const float* __restrict__ partial, int nchunks, const float* __restrict__ scale,
             const float* __restrict__ shift, float* __restrict__ y, int R, int O, int act) {
-  __shared__ float red[4][64];
-  const int r = blockIdx.x, o = blockIdx.y * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+  __shared__ float red[64][17];
+  const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int64_t ncol = (int64_t)R * O, col = (int64_t)blockIdx.x * 16 + c;
   float s = 0.f;
-  if (o < O) {
-    const int per = (nchunks + 3) / 4;
-    const int c0 = grp * per, c1 = c0 + per < nchunks ? c0 + per : nchunks;
-    for (int c = c0; c < c1; ++c) s += partial[((int64_t)c * R + r) * O + o];
-  }
-  red[grp][threadIdx.x & 63] = s;
+  if (col < ncol)
+    for (int row = g; row < nchunks; row += 64) s += partial[(int64_t)row * ncol + col];
+  red[g][c] = s;
   __syncthreads();
-  if (grp == 0 && o < O) {
-    float v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+  if (g == 0 && col < ncol) {
+    float v = 0.f;
+    for (int i = 0; i < 64; ++i) v += red[i][c];
+    const int o = (int)(col % O);
     if (scale) v *= scale[o];
     if (shift) v += shift[o];
-    y[(int64_t)r * O + o] = cfun_apply_act(v, act, 0.f);
+    y[col] = cfun_apply_act(v, act, 0.f);
   }
 }
 
@@ -156,24 +159,25 @@ k_fc_bwd_weight(const float* __restrict__ x, const float* __restrict__ g, float*
 }
 
 // ------------------------------------------------------------------------------------------------ data gradient
-// grid = (K / 1024, r-tiles of 16); lane owns 4 consecutive k; g tile [16][O] in LDS, read wave-uniformly
-__global__ void __launch_bounds__(256)
+// grid = (K / 512, r-tiles of 16); lane owns 4 consecutive k; g tile [16][O] in LDS, read wave-uniformly.  128-thread
+// blocks (432 of them at the heart shapes: every CU has work) with 16 weight rows in flight per lane
+__global__ void __launch_bounds__(128)
 k_fc_bwd_data(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ dx, int R, int K, int O) {
   CFUN_DYN_LDS(float, Gl);   // [O][kRT]: g transposed so that one o's 16 RoIs are 4 float4
   const int tid = threadIdx.x;
   const int r0 = blockIdx.y * kRT;
-  for (int it = tid; it < O * kRT; it += 256) {
+  for (int it = tid; it < O * kRT; it += 128) {
     const int o = it / kRT, rr = it % kRT;
     Gl[it] = (r0 + rr < R) ? g[(int64_t)(r0 + rr) * O + o] : 0.f;
   }
   __syncthreads();
-  const int64_t k = ((int64_t)blockIdx.x * 256 + tid) * 4;
+  const int64_t k = ((int64_t)blockIdx.x * 128 + tid) * 4;
   if (k >= K) return;
   float4 acc[kRT];
 #pragma unroll
   for (int r = 0; r < kRT; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
   const float* wp = w + k;
-  constexpr int U = 8;   // weight rows in flight per lane
+  constexpr int U = 16;   // weight rows in flight per lane
   int o = 0;
   for (; o + U <= O; o += U) {
     float4 wv[U];
@@ -232,7 +236,8 @@ extern "C" int cfun_fc_fwd(const float* x, const float* w, const float* scale, c
   }
   hipLaunchKernelGGL(kern, dim3(nch), dim3(256), lds, st, x, w, (float*)ws, R, K, O);
   CFUN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_fc_finish, dim3(R, (O + 63) / 64), dim3(256), 0, st, (const float*)ws, nch, scale, shift, y, R, O, act);
+  hipLaunchKernelGGL(k_fc_finish, dim3((unsigned)(((int64_t)R * O + 15) / 16)), dim3(1024), 0, st, (const float*)ws, nch, scale,
+                     shift, y, R, O, act);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }
@@ -266,7 +271,7 @@ extern "C" int cfun_fc_bwd_data(const float* g, const float* w, float* dx, int32
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(k_fc_bwd_data, dim3((K / 4 + 255) / 256, (R + kRT - 1) / kRT), dim3(256), lds, cfun_st(stream), g, w,
+  hipLaunchKernelGGL(k_fc_bwd_data, dim3((K / 4 + 127) / 128, (R + kRT - 1) / kRT), dim3(128), lds, cfun_st(stream), g, w,
                      dx, R, K, O);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
