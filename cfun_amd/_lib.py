@@ -109,6 +109,7 @@ _SIGNATURES = {
     "cfun_weight_unpack": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "cfun_halo_pack": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "cfun_halo_unpack": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "cfun_resize3d": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

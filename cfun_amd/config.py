@@ -111,6 +111,7 @@ class LiTSConfig(Config):
     EDGE_LOSS_RAW_SOBEL = True          # edge loss = MSE on the raw 3 Sobel responses, no magnitude (LiTS_2017/model.py:959-972)
     LOSS_WEIGHTS = {"rpn_class_loss": 50., "rpn_bbox_loss": 5., "mrcnn_class_loss": 50., "mrcnn_bbox_loss": 5.,
                     "mrcnn_mask_loss": 2., "mrcnn_mask_edge_loss": 0.25}     # LiTS_2017/LiTS_main.py:162-169
+    PAD_IMAGE_SHAPE = [646, 646, 536]   # LiTS_2017/LiTS_main.py:121: every volume is centred in this zero frame, then resized
     POST_NMS_ROIS_INFERENCE = 50        # LiTS_2017/LiTS_main.py:107
     DETECTION_NMS_THRESHOLD = 0.7       # LiTS_2017/LiTS_main.py:147
 

@@ -1066,6 +1066,28 @@ def mask_losses(logits, probs, labels):
     return _MaskLosses.apply(logits, probs.detach(), labels)
 
 
+def resize3d(vol, out_dims, order=1, frame=None, offset=None, clip=False):
+    """Resize a 3-D float volume (any strides: a permuted view of the loader's [H,W,D] array is read in place) to the
+    dense ``out_dims`` with cfun_resize3d: order 1 = skimage.transform.resize(order=1, mode='constant') as evaluated
+    for 3-D inputs (scipy zoom, grid-constant, grid_mode), order 0 = nearest; ``frame`` / ``offset``: the volume sits
+    at ``offset`` inside a virtual zero frame of extent ``frame`` and that frame is what gets resized (LiTS
+    pad-and-resize); ``clip``: skimage's clip=True (to the source's range)."""
+    lib = _lib.load()
+    if vol.dim() != 3 or vol.dtype != torch.float32:
+        raise RuntimeError("resize3d: float32 [a,b,c] volume expected, got %s %s" % (vol.dtype, tuple(vol.shape)))
+    out = torch.empty(tuple(int(v) for v in out_dims), dtype=torch.float32, device=vol.device)
+    i64, i32 = C.c_int64 * 3, C.c_int32 * 3
+    mm = None
+    if clip:
+        lo, hi = torch.aminmax(vol)
+        mm = torch.stack([lo, hi]).contiguous()
+    check(lib.cfun_resize3d(ptr_raw(vol), i64(*vol.stride()), i32(*vol.shape),
+                            i32(*[int(v) for v in frame]) if frame is not None else None,
+                            i32(*[int(v) for v in offset]) if offset is not None else None,
+                            ptr(out), i32(*out.shape), int(order), ptr(mm), stream(vol)), "resize3d")
+    return out
+
+
 def halo_pack(x, z0, planes):
     lib = _lib.load()
     x = _c(x)

@@ -208,6 +208,20 @@ class CFUNHotPath(nn.Module):
         rois, class_ids, scores, mask = unmold(det[0], probs, [1, depth, height, width], win)
         return dict(rois=rois, class_ids=class_ids, scores=scores, mask=mask)
 
+    def mold_inputs(self, images):
+        """``MaskRCNN.mold_inputs`` (model.py:1774-1810; LiTS_2017/model.py:1730-1775 for the fork's configs) on the
+        device: raw volumes [H,W,D,1] (heart) / [H,W,D] (LiTS) -> (molded [N,1,D,H,W], image_metas, windows)."""
+        dev = next(self.parameters()).device
+        if hasattr(self.config, "PAD_IMAGE_SHAPE"):
+            return utils.mold_inputs_lits(self.config, images, device=dev)
+        return utils.mold_inputs(self.config, images, device=dev)
+
+    def detect_images(self, images):
+        """``MaskRCNN.detect`` (model.py:1341-1389) from raw volumes: mold (resize + normalise, on the device), run the
+        inference dataflow, un-mold.  One result dict per image, as the reference returns."""
+        molded, _, windows = self.mold_inputs(images)
+        return [self.detect(molded[i:i + 1], window=tuple(float(v) for v in windows[i])) for i in range(molded.shape[0])]
+
     def compute_losses(self, out, rpn_match, rpn_bbox_t, target_class_ids, target_deltas, mask_labels):
         """The 6 losses of model.py:984-1000 (mask labels: uint8 [n_pos,d,h,w])."""
         zero = torch.zeros((), device=mask_labels.device)

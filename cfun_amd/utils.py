@@ -100,3 +100,91 @@ def compose_image_meta(image_id, image_shape, window, active_class_ids):
 def parse_image_meta(meta):
     """model.py:1890-1899."""
     return meta[:, 0], meta[:, 1:5], meta[:, 5:11], meta[:, 11:]
+
+
+# ---- input pipeline (SURVEY.md section 8(f) row 4) ---------------------------------------------------------------------
+def resize_image(image, min_dim=None, max_dim=None, min_scale=None, mode="square", device=None):
+    """utils.py:342-393 drop-in: image [H,W,D,C=1] (numpy or tensor).  The reference implements two modes: 'none' and
+    'self' -- resize to [max_dim, max_dim, min_dim, 1] with skimage.transform.resize(order=1, mode='constant',
+    preserve_range=True) -- and falls off the end (returns None) for the documented 'square' / 'pad64' / 'crop'; those
+    raise here.  Returns the reference's tuple (image [H',W',D',1] in the input's dtype, window (z1,y1,x1,z2,y2,x2),
+    scale, padding, crop); the resize runs on the device (cfun_resize3d), numpy in -> numpy out."""
+    h, w, d = image.shape[:3]
+    if mode == "none":
+        return image, (0, 0, 0, d, h, w), 1, [(0, 0), (0, 0), (0, 0), (0, 0)], None
+    if mode != "self":
+        raise NotImplementedError("resize_image: mode %r is not implemented by the reference either (utils.py:380-393)" % (mode,))
+    was_numpy = not torch.is_tensor(image)
+    t = torch.as_tensor(np.ascontiguousarray(image) if was_numpy else image)
+    dtype = t.dtype
+    if t.dim() != 4 or t.shape[3] != 1:
+        raise ValueError("resize_image: [H,W,D,1] volume expected, got %s" % (tuple(t.shape),))
+    dev = torch.device(device) if device is not None else (t.device if t.is_cuda else _device())
+    vol = t[..., 0].to(device=dev, dtype=torch.float32)
+    out = ops.resize3d(vol, (max_dim, max_dim, min_dim), order=1, clip=True)[..., None].to(dtype)
+    out = out.cpu().numpy() if was_numpy else out
+    return out, (0, 0, 0, min_dim, max_dim, max_dim), -1, [(0, 0), (0, 0), (0, 0), (0, 0)], None
+
+
+def resize_mask(mask, scale, padding, max_dim=0, min_dim=0, crop=None, mode="square", device=None):
+    """utils.py:396-408 drop-in, mode 'self': nearest resize of a [H,W,D] label volume to [max_dim, max_dim, min_dim],
+    rounded to int32."""
+    if mode != "self":
+        raise NotImplementedError("resize_mask: only mode 'self' exists in the reference (utils.py:404-408)")
+    was_numpy = not torch.is_tensor(mask)
+    t = torch.as_tensor(np.ascontiguousarray(mask) if was_numpy else mask)
+    dev = torch.device(device) if device is not None else (t.device if t.is_cuda else _device())
+    out = torch.round(ops.resize3d(t.to(device=dev, dtype=torch.float32), (max_dim, max_dim, min_dim), order=0)).to(torch.int32)
+    return out.cpu().numpy() if was_numpy else out
+
+
+def mold_inputs(config, images, device=None):
+    """MaskRCNN.mold_inputs (model.py:1774-1810): every image [H,W,D,1] is resized to the network size (mode 'self'),
+    z-scored (mold_image) and laid out [1,D,H,W]; resize, statistics and normalisation run on the device and the source
+    array is read in place through its strides (no host transpose).  Returns (molded_images float32 tensor [N,1,D,H,W]
+    on the device, image_metas numpy [N, 1+4+6+NUM_CLASSES], windows numpy [N,6])."""
+    dev = torch.device(device) if device is not None else _device()
+    molded, metas, windows = [], [], []
+    mx, mn = int(config.IMAGE_MAX_DIM), int(config.IMAGE_MIN_DIM)
+    for image in images:
+        if config.IMAGE_RESIZE_MODE != "self":
+            raise NotImplementedError("mold_inputs: IMAGE_RESIZE_MODE %r" % (config.IMAGE_RESIZE_MODE,))
+        t = torch.as_tensor(np.ascontiguousarray(image) if not torch.is_tensor(image) else image)
+        dtype = t.dtype
+        vol = t[..., 0].to(device=dev, dtype=torch.float32).permute(2, 0, 1)        # [D,H,W] view of the [H,W,D] array
+        out = ops.resize3d(vol, (mn, mx, mx), order=1, clip=True)
+        if not dtype.is_floating_point:       # the reference casts the resized image back to the loader's dtype
+            out = out.to(dtype).to(torch.float32)
+        molded.append(mold_image(out)[None])
+        window = (0, 0, 0, mn, mx, mx)
+        metas.append(compose_image_meta(0, tuple(image.shape), window, np.zeros([config.NUM_CLASSES], dtype=np.int32)))
+        windows.append(window)
+    return torch.stack(molded), np.stack(metas), np.stack(windows)
+
+
+def preprocess_image_lits(image):
+    """LiTS_2017/model.py:1875-1883 (sic: MIN_BOUND = 300, MAX_BOUND = -300): (x - 300) / (-600), clamped to [0, 1]."""
+    return ((image - 300.0) / (-600.0)).clamp(0.0, 1.0)
+
+
+def mold_inputs_lits(config, images, device=None):
+    """The LiTS fork's MaskRCNN.mold_inputs (LiTS_2017/model.py:1730-1775): clamp-normalise, centre in a zero
+    PAD_IMAGE_SHAPE frame, nearest-resize the frame to IMAGE_SHAPE, fractional window.  The frame is virtual
+    (cfun_resize3d's ``frame`` / ``offset``): the 646x646x536 host array of the reference is never built.  Returns
+    (molded [N,1,D,H,W] device tensor, image_metas, windows) with the fork's 3-entry image shape in the meta."""
+    dev = torch.device(device) if device is not None else _device()
+    ph, pw, pd = [int(v) for v in config.PAD_IMAGE_SHAPE]
+    h, w, d = [int(v) for v in config.IMAGE_SHAPE[:3]]
+    molded, metas, windows = [], [], []
+    for image in images:
+        t = torch.as_tensor(np.ascontiguousarray(image) if not torch.is_tensor(image) else image)
+        vol = preprocess_image_lits(t.to(device=dev, dtype=torch.float32))          # [H,W,D]
+        ih, iw, idp = [int(v) for v in vol.shape]
+        sx, sy, sz = int((ph - ih) / 2.0), int((pw - iw) / 2.0), int((pd - idp) / 2.0)
+        out = ops.resize3d(vol.permute(2, 0, 1), (d, h, w), order=0, frame=(pd, ph, pw), offset=(sz, sx, sy))
+        window = (sz * d / pd, sx * h / ph, sy * w / pw, config.IMAGE_MIN_DIM - sz * d / pd,
+                  config.IMAGE_MAX_DIM - sx * h / ph, config.IMAGE_MAX_DIM - sy * w / pw)
+        molded.append(out[None])
+        metas.append(compose_image_meta(0, (h, w, d), window, np.zeros([config.NUM_CLASSES], dtype=np.int32)))
+        windows.append(window)
+    return torch.stack(molded), np.stack(metas), np.stack(windows)

@@ -343,6 +343,20 @@ int cfun_halo_pack(const float* x, float* buf, int32_t N, int32_t D, int32_t H, 
 int cfun_halo_unpack(const float* buf, float* x, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C, int32_t z0,
                      int32_t planes, cfun_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Input pipeline: the volume resize in front of the network (utils.resize_image mode 'self', utils.py:389-393 ->
+ * skimage.transform.resize order 1, 'constant'; LiTS_2017/model.py:1741-1761: zero-pad to PAD_IMAGE_SHAPE, then order 0).
+ * in: the source volume addressed by element `strides[3]` over `dims[3]` (both in OUTPUT axis order, so a [H,W,D] array
+ * is resized into [D,H,W] without a transpose); `frame[3]` / `offset[3]` (NULL: none) place it inside a virtual zero
+ * frame that is resized instead; out: dense [out_dims[0], out_dims[1], out_dims[2]].  order 0: nearest
+ * (floor((o + 0.5) * n / m)); order 1: linear, samples outside are 0 ('grid-constant'), c = (o + 0.5) * n / m - 0.5;
+ * clip_minmax: device pointer to {min, max} of the source for skimage's clip = True, or NULL.  All array arguments
+ * except in / out / clip_minmax are HOST pointers, read before the call returns.
+ * ---------------------------------------------------------------------------------------------- */
+int cfun_resize3d(const float* in, const int64_t* strides, const int32_t* dims, const int32_t* frame,
+                  const int32_t* offset, float* out, const int32_t* out_dims, int32_t order, const float* clip_minmax,
+                  cfun_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -718,3 +718,59 @@ def inference_step(sd, image, anchors, stage, pool_size, mask_pool_size, window=
         boxes = det[:, :6] / torch.tensor([D, H, W, D, H, W], dtype=torch.float32)
         _, m_probs = mask_head(image[0], boxes, sd, mask_pool_size, stage, dropout_masks=None)
     return dict(rpn_rois=rpn_rois, cls_probs=cls_probs, detections=det, mask_probs=m_probs)
+
+
+# --------------------------------------------------------------------------------------
+# input pipeline.  PARITY UNPINNED by the reference: scikit-image is not in this image, so
+# no golden can be produced from utils.resize_image itself.  skimage.transform.resize (>= 0.19, _warps.py) evaluates an
+# n-D (n > 2) resize without anti-aliasing as scipy.ndimage.zoom(image, out/in, order, mode = 'grid-constant' for
+# mode = 'constant', cval, grid_mode = True) followed by a clip to the input's range; scipy 1.15.3 IS here and is what
+# this restatement calls.
+# --------------------------------------------------------------------------------------
+def skimage_resize(image, output_shape, order):
+    import scipy.ndimage as ndi
+    image = np.asarray(image)
+    zoom = [o / float(i) for o, i in zip(output_shape, image.shape)]
+    out = ndi.zoom(image.astype(np.float64) if order else image, zoom, order=order, mode="grid-constant", cval=0.0, grid_mode=True)
+    if order:
+        out = np.clip(out, image.min(), image.max())
+    return out
+
+
+def resize_image_self(image, min_dim, max_dim):
+    """utils.resize_image(mode='self') (utils.py:389-393): [H,W,D,1] -> [max,max,min,1], cast back to the input dtype."""
+    out = skimage_resize(image, (max_dim, max_dim, min_dim, 1), 1)
+    return out.astype(image.dtype), (0, 0, 0, min_dim, max_dim, max_dim), -1, [(0, 0)] * 4, None
+
+
+def mold_inputs(images, min_dim, max_dim, num_classes):
+    """MaskRCNN.mold_inputs (model.py:1774-1810): resize 'self', mold_image (z-score, population std), [C,D,H,W]."""
+    molded, metas, windows = [], [], []
+    for image in images:
+        m, window, _, _, _ = resize_image_self(image, min_dim, max_dim)
+        m = (m - m.mean()) / m.std()
+        molded.append(m.transpose((3, 2, 0, 1)))
+        metas.append(np.array([0] + list(image.shape) + list(window) + [0] * num_classes))
+        windows.append(window)
+    return np.stack(molded), np.stack(metas), np.stack(windows)
+
+
+def mold_inputs_lits(images, pad_shape, image_shape, min_dim, max_dim, num_classes):
+    """LiTS_2017/model.py:1730-1775: preprocess_image ((x - 300) / -600 clamped to [0,1], :1875-1883), centre in a zero
+    PAD_IMAGE_SHAPE frame, resize(order = 0) to IMAGE_SHAPE, [1,D,H,W], fractional window."""
+    molded, metas, windows = [], [], []
+    for image in images:
+        img = (np.asarray(image, dtype=np.float64) - 300.0) / (-600.0)
+        img[img > 1.0] = 1.0
+        img[img < 0.0] = 0.0
+        whole = np.zeros(pad_shape)
+        sx, sy, sz = [int((p - i) / 2.0) for p, i in zip(pad_shape, img.shape)]
+        whole[sx:sx + img.shape[0], sy:sy + img.shape[1], sz:sz + img.shape[2]] = img
+        out = skimage_resize(whole, tuple(image_shape[:3]), 0)
+        window = (sz * image_shape[2] / pad_shape[2], sx * image_shape[0] / pad_shape[0], sy * image_shape[1] / pad_shape[1],
+                  min_dim - sz * image_shape[2] / pad_shape[2], max_dim - sx * image_shape[0] / pad_shape[0],
+                  max_dim - sy * image_shape[1] / pad_shape[1])
+        molded.append(np.expand_dims(out.transpose((2, 0, 1)), axis=0))
+        metas.append(np.array([0] + list(out.shape) + list(window) + [0] * num_classes))
+        windows.append(window)
+    return np.stack(molded), np.stack(metas), np.stack(windows)

@@ -833,3 +833,49 @@ def check_b3_module_path(device, seed=31):
     for a, b, what in zip(res[0], res[1], ("y", "dx", "dw1", "db1", "dw2")):
         err = float((a - b).abs().max()) / max(float(a.abs().max()), 1e-12)
         assert err < 2e-5, "3xBF16 module path: %s differs from the fp32 path by %.2e" % (what, err)
+
+
+def check_input_pipeline(device, seed=11):
+    """f-4: utils.resize_image / resize_mask / mold_inputs (heart) and the LiTS pad-and-resize mold_inputs on the device
+    (cfun_resize3d) against the oracle's scipy.ndimage.zoom restatement of skimage.transform.resize (the code path
+    skimage takes for 3-D volumes; skimage itself is not in the image -- see the oracle's note).  float32 and int16
+    loaders, up- and down-sizing, non-cubic."""
+    from cfun_amd import config, utils
+    rng = np.random.default_rng(seed)
+    cfg = config.heart_config("beginning", 48, 48, 32)
+    img = (rng.normal(0, 300, (37, 29, 23, 1)) + 100).astype(np.float32)
+    out, window, scale, padding, crop = utils.resize_image(img, min_dim=32, max_dim=48, mode="self", device=device)
+    ref = orc.resize_image_self(img, 32, 48)
+    assert out.shape == (48, 48, 32, 1) and out.dtype == np.float32 and window == ref[1] and scale == -1 and crop is None
+    np.testing.assert_allclose(out, ref[0], rtol=0, atol=2e-4 * 1.0)          # values ~1e3: 2e-7 relative
+    for images in ([img], [(rng.normal(0, 300, (40, 52, 20, 1))).astype(np.int16), img]):
+        molded, metas, windows = utils.mold_inputs(cfg, images, device=device)
+        rm, rmeta, rwin = orc.mold_inputs(images, 32, 48, cfg.NUM_CLASSES)
+        assert tuple(molded.shape) == rm.shape == (len(images), 1, 32, 48, 48)
+        # an int16 loader: the resized volume is truncated back to integers before the z-score (utils.py:391).  Integer
+        # inputs with weights like 1/2 and 1/4 make many interpolated values EXACT integers, which fp64 roundoff puts at
+        # 348.9999999999998 (-> 348) and fp32 at 349.0 (-> 349): one grey level on <= 1e-3 of the voxels is the
+        # reference's own rounding ambiguity, everything else agrees to 2e-5
+        d = np.abs(molded.cpu().numpy() - rm)
+        if images[0].dtype == np.int16:
+            level = 1.0 / float(orc.resize_image_self(images[0], 32, 48)[0].astype(np.float64).std())
+            assert float((d[0] > 2e-5).mean()) <= 1e-3 and float(d[0].max()) <= 1.01 * level + 2e-5
+            assert float(d[1:].max()) < 2e-5
+        else:
+            assert float(d.max()) < 2e-5
+        np.testing.assert_array_equal(metas, rmeta)
+        np.testing.assert_array_equal(windows, rwin)
+    lab = rng.integers(0, 8, (37, 29, 23)).astype(np.int32)
+    np.testing.assert_array_equal(utils.resize_mask(lab, -1, None, max_dim=48, min_dim=32, mode="self", device=device),
+                                  np.round(orc.skimage_resize(lab, (48, 48, 32), 0)).astype(np.int32))
+    # LiTS: pad-and-resize with a virtual frame
+    lcfg = tiny_lits_config("beginning", max_dim=48, min_dim=32)
+    lcfg.PAD_IMAGE_SHAPE = [70, 66, 50]
+    ct = rng.normal(0, 400, (51, 40, 33)).astype(np.float32)
+    molded, metas, windows = utils.mold_inputs_lits(lcfg, [ct], device=device)
+    rm, rmeta, rwin = orc.mold_inputs_lits([ct], lcfg.PAD_IMAGE_SHAPE, [48, 48, 32], 32, 48, lcfg.NUM_CLASSES)
+    assert tuple(molded.shape) == rm.shape == (1, 1, 32, 48, 48)
+    np.testing.assert_allclose(molded.cpu().numpy(), rm, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(metas, rmeta, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(windows, rwin, rtol=0, atol=1e-12)
+    assert float(molded.max()) <= 1.0 and float(molded.min()) >= 0.0 and float(molded.std()) > 0.05

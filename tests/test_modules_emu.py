@@ -142,3 +142,7 @@ def test_detection_target_layer_lits_golden(emu):
 @pytest.mark.parametrize("stage", ["beginning", "together"])
 def test_predict_lits_golden(emu_direct, stage):
     mc.check_predict_lits_golden(emu_direct, stage)
+
+
+def test_input_pipeline(emu):
+    mc.check_input_pipeline(emu)

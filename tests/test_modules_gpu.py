@@ -436,3 +436,7 @@ def test_detection_target_layer_lits_golden(gpu):
 @pytest.mark.parametrize("stage", ["beginning", "together"])
 def test_predict_lits_golden(gpu, stage):
     mc.check_predict_lits_golden(gpu, stage)
+
+
+def test_input_pipeline(gpu):
+    mc.check_input_pipeline(gpu)
