@@ -59,6 +59,8 @@ _SIGNATURES = {
     "cfun_instnorm_lrelu_bwd": (C.c_int, [_P, _P, _P, _P, _I, _L, _I, _F, _P, _Z, _P]),
     "cfun_instnorm_lrelu_fwd_strided": (C.c_int, [_P, _P, _P, _I, _L, _I, _L, _F, _P]),
     "cfun_instnorm_lrelu_bwd_strided": (C.c_int, [_P, _P, _P, _P, _I, _L, _I, _L, _F, _P, _Z, _P]),
+    "cfun_instnorm_bwd_means": (C.c_int, [_P, _P, _P, _P, _I, _L, _I, _L, _F, _P, _Z, _P]),
+    "cfun_instnorm_lrelu_bwd_apply": (C.c_int, [_P, _P, _P, _P, _P, _I, _L, _I, _L, _F, _P]),
     "cfun_lrelu_fwd_strided": (C.c_int, [_P, _P, _L, _I, _L, _L, _F, _P]),
     "cfun_lrelu_bwd_strided": (C.c_int, [_P, _P, _P, _L, _I, _L, _F, _P]),
     "cfun_maxpool2_fwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -701,6 +701,49 @@ int cfun_instnorm_lrelu_bwd_strided(const float* x, const float* stats, const fl
   return CFUN_OK;
 }
 
+// The two halves of cfun_instnorm_lrelu_bwd, for a volume that is depth-sharded over several GPUs (cfun_amd.dist): the
+// per-(n,c) means of gn and gn*xhat over the LOCAL voxels are written to `means` [N,C,2]; the caller combines them across
+// ranks (weighted by the local voxel counts, one small all-reduce) and passes the global means to the apply half.
+int cfun_instnorm_bwd_means(const float* x, const float* stats, const float* dy, float* means, int32_t N, int64_t V,
+                            int32_t C, int64_t dy_stride, float slope, void* ws, size_t ws_bytes, cfun_stream_t stream) {
+  if (N <= 0 || V <= 0) return CFUN_OK;
+  if (C <= 0 || C / vec_of(C) > kBlock || dy_stride < C) return CFUN_EINVAL;
+  const int vec = vec_of(C);
+  if (dy_stride != C && (vec != 4 || (dy_stride & 3))) return CFUN_EINVAL;
+  const int64_t dyg = dy_stride / vec;
+  if (vec == 4 && (!cfun_aligned16(x) || !cfun_aligned16(dy))) return CFUN_EALIGN;
+  if (ws_bytes < reduce_ws(N, V, C, 2)) return CFUN_EWORKSPACE;
+  const ReducePlan r = reduce_plan(N, V, C);
+  double* partial = (double*)ws;
+  if (vec == 4) {
+    auto kern = k_channel_reduce<StatNormBwd<4>, 4>;
+    hipLaunchKernelGGL(kern, dim3(r.blocks, N), dim3(kBlock), 0, cfun_st(stream), StatNormBwd<4>{x, dy, stats, C, slope, dyg}, partial, V, C, r.lanes);
+  } else {
+    auto kern = k_channel_reduce<StatNormBwd<1>, 1>;
+    hipLaunchKernelGGL(kern, dim3(r.blocks, N), dim3(kBlock), 0, cfun_st(stream), StatNormBwd<1>{x, dy, stats, C, slope, dyg}, partial, V, C, r.lanes);
+  }
+  hipLaunchKernelGGL(k_channel_finalize, dim3((N * C * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, cfun_st(stream),
+                     (const double*)partial, means, N * C, C, r.blocks, 2, V, 0.f, 2);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+int cfun_instnorm_lrelu_bwd_apply(const float* x, const float* stats, const float* means, const float* dy, float* dx,
+                                  int32_t N, int64_t V, int32_t C, int64_t dy_stride, float slope, cfun_stream_t stream) {
+  if (N <= 0 || V <= 0) return CFUN_OK;
+  if (C <= 0 || C / vec_of(C) > kBlock || dy_stride < C) return CFUN_EINVAL;
+  const int vec = vec_of(C);
+  if (dy_stride != C && (vec != 4 || (dy_stride & 3))) return CFUN_EINVAL;
+  const int64_t dyg = dy_stride / vec;
+  if (vec == 4 && (!cfun_aligned16(x) || !cfun_aligned16(dy) || !cfun_aligned16(dx))) return CFUN_EALIGN;
+  const ReducePlan r = reduce_plan(N, V, C);
+  const dim3 grid(apply_blocks(V, r.lanes), (unsigned)N);
+  if (vec == 4) hipLaunchKernelGGL(k_instnorm_lrelu_bwd<4>, grid, dim3(kBlock), 0, cfun_st(stream), x, stats, means, dy, dx, V, C, slope, dyg, r.lanes);
+  else hipLaunchKernelGGL(k_instnorm_lrelu_bwd<1>, grid, dim3(kBlock), 0, cfun_st(stream), x, stats, means, dy, dx, V, C, slope, dyg, r.lanes);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
 int cfun_upsample2_bwd(const float* hi, float* lo, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C,
                        cfun_stream_t stream) {
   if (C <= 0) return CFUN_EINVAL;

@@ -132,6 +132,105 @@ class _HaloExchange(torch.autograd.Function):
         return gx, None, None, None
 
 
+class _HaloEdges(torch.autograd.Function):
+    """The two EDGE inputs of a depth-coupled conv on a slab: (lo halo planes from the previous rank ++ the slab's first
+    ``n_lo`` planes, the slab's last ``n_hi`` planes ++ hi halo planes from the next rank); zeros stand in for a
+    neighbour at the volume boundary (= the conv's zero padding).  The transfers run on a side HIP stream: the caller
+    launches the interior conv -- which needs no halo -- before it touches these outputs (``wait`` makes the current
+    stream wait for the transfer).  Backward: the halo planes' gradients travel back to the ranks that own the planes."""
+
+    @staticmethod
+    def forward(ctx, x, lo, hi, n_lo, n_hi, shard):
+        n, d, h, w, c = x.shape
+        send_next = ops.halo_pack(x, d - lo, lo) if lo > 0 else None      # my top planes are next's low halo
+        send_prev = ops.halo_pack(x, 0, hi) if hi > 0 else None           # my bottom planes are prev's high halo
+        from_prev, from_next, wait = _exchange_async(shard, send_prev, send_next, (n, lo, h, w, c) if lo > 0 else None,
+                                                     (n, hi, h, w, c) if hi > 0 else None, x)
+        ctx.shard, ctx.dims, ctx.xshape = shard, (lo, hi, n_lo, n_hi), tuple(x.shape)
+        head, tail = x[:, :n_lo], x[:, d - n_hi:]
+        wait()
+        zl = from_prev if from_prev is not None else x.new_zeros((n, lo, h, w, c))
+        zh = from_next if from_next is not None else x.new_zeros((n, hi, h, w, c))
+        return torch.cat([zl, head], dim=1), torch.cat([tail, zh], dim=1)
+
+    @staticmethod
+    def backward(ctx, g_lo, g_hi):
+        lo, hi, n_lo, n_hi = ctx.dims
+        shard = ctx.shard
+        n, d, h, w, c = ctx.xshape
+        g_lo, g_hi = g_lo.contiguous(), g_hi.contiguous()
+        send_prev = g_lo[:, :lo].contiguous() if lo > 0 else None         # gradient of prev's top planes
+        send_next = g_hi[:, n_hi:].contiguous() if hi > 0 else None       # gradient of next's bottom planes
+        from_prev, from_next, wait = _exchange_async(shard, send_prev, send_next, (n, hi, h, w, c) if hi > 0 else None,
+                                                     (n, lo, h, w, c) if lo > 0 else None, g_lo)
+        gx = g_lo.new_zeros(ctx.xshape)
+        gx[:, :n_lo] += g_lo[:, lo:]
+        gx[:, d - n_hi:] += g_hi[:, :n_hi]
+        wait()
+        if from_prev is not None:      # prev used my bottom `hi` planes as its high halo
+            gx[:, :hi] += from_prev
+        if from_next is not None:      # next used my top `lo` planes as its low halo
+            gx[:, d - lo:] += from_next
+        return gx, None, None, None, None, None
+
+
+def _exchange_async(ctx, send_prev, send_next, recv_prev_shape, recv_next_shape, like):
+    """``_exchange`` issued on a side HIP stream (GPU tensors): returns (from_prev, from_next, wait) immediately; ``wait()``
+    makes the CURRENT stream wait for the transfers.  Everything enqueued on the current stream between the call and
+    ``wait()`` overlaps the xGMI transfer.  CPU tensors (gloo tier): plain blocking exchange."""
+    if not like.is_cuda:
+        fp, fn = _exchange(ctx, send_prev, send_next, recv_prev_shape, recv_next_shape, like)
+        return fp, fn, (lambda: None)
+    main = torch.cuda.current_stream(like.device)
+    side = ops.side_stream(like.device, "halo")
+    side.wait_stream(main)                       # the packed planes are complete
+    with torch.cuda.stream(side):
+        fp, fn = _exchange(ctx, send_prev, send_next, recv_prev_shape, recv_next_shape, like)
+    for t in (send_prev, send_next, fp, fn):     # allocated on `main`, used on `side` (and back)
+        if t is not None:
+            t.record_stream(side)
+
+    def wait():
+        main.wait_stream(side)
+    return fp, fn, wait
+
+
+def halo_conv(x, run, kd, stride, pd, out_tail, shard=None):
+    """A depth-coupled conv on this rank's slab x [1,d,H,W,C] WITHOUT building a padded copy of the slab: the outputs
+    whose receptive field is local are computed straight from x while the halo planes are in flight on a side stream;
+    the few boundary output planes are then computed from two small edge tensors (halo ++ the slab's first / last
+    planes).  ``run(inp, out, z0, z1)`` runs the conv depth-VALID on ``inp``, writing output planes [z0, z1) into
+    ``out`` (that dense depth range of the result buffer [1, d/stride, *out_tail]) and returns the tensor; the three
+    results are joined without a copy.  Output plane j reads input planes [j*stride - pd, j*stride - pd + kd).
+    Returns None when the split does not apply (N > 1, odd slab) -- the caller then uses the padded-slab path."""
+    shard = shard or _CTX
+    lo, hi = conv_depth_halo(kd, stride, pd)
+    n, d = x.shape[0], x.shape[1]
+    if shard is None or shard.world == 1 or n != 1 or d % stride or (lo == 0 and hi == 0):
+        return None
+    do = d // stride
+    j_lo = -(-pd // stride)                                           # first output plane that is fully local
+    j_hi = (d - kd + pd) // stride                                    # last one
+    if j_hi < j_lo:                                                   # slab thinner than the kernel: edges only
+        return None
+    n_head = (j_lo - 1) * stride - pd + kd if j_lo > 0 else 0         # local planes the low edge reads
+    first_hi = (j_hi + 1) * stride - pd                               # first local plane the high edge reads
+    n_tail = d - first_hi if j_hi + 1 < do else 0
+    if n_head > d or n_tail > d or first_hi < 0:
+        return None
+    edge_lo, edge_hi = _HaloEdges.apply(x, lo, hi, max(n_head, 0), max(n_tail, 0), shard)
+    buf = x.new_empty((1, do) + tuple(out_tail))
+    parts = []
+    # interior first: it needs no halo, so it is enqueued while the transfer is in flight
+    mid = run(x[:, j_lo * stride - pd:j_hi * stride - pd + kd], buf[:, j_lo:j_hi + 1], j_lo, j_hi + 1)
+    if j_lo > 0:
+        parts.append(run(edge_lo, buf[:, 0:j_lo], 0, j_lo))
+    parts.append(mid)
+    if j_hi + 1 < do:
+        parts.append(run(edge_hi, buf[:, j_hi + 1:do], j_hi + 1, do))
+    return ops.join_depth(buf, parts)
+
+
 def halo_exchange(x, lo, hi, shard=None):
     shard = shard or _CTX
     if shard is None or shard.world == 1 or (lo == 0 and hi == 0):

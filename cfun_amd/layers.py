@@ -51,24 +51,55 @@ class Conv3dParams(nn.Module):
         shift = self.bias
         per_n = False
         pad = None
-        shard = dist.current()
-        if shard is not None and shard.world > 1 and self.kernel_size[0] > 1:
-            # depth-sharded volume: fetch the depth halo from the ring neighbours, then convolve depth-VALID
-            if up2:
-                raise NotImplementedError("depth sharding of up-sampling convs (U-Net) is not part of the path")
-            lo, hi = dist.conv_depth_halo(self.kernel_size[0], self.stride, self.padding[0])
-            x = dist.halo_exchange(x, lo, hi, shard)
-            pad = (0, self.padding[1], self.padding[2])
         if bn is not None:
             scale, t = folded_bn(bn, bn.eps if bn_eps is None else bn_eps)
             shift = t if self.bias is None else torch.addcmul(t, self.bias, scale)   # (b - mean) * s + beta
         elif scale is not None:
             per_n = True
+        shard = dist.current()
+        if shard is not None and shard.world > 1 and self.kernel_size[0] > 1:
+            # depth-sharded volume: the conv runs depth-VALID with the halo planes of the ring neighbours
+            if up2:
+                raise NotImplementedError("depth sharding of unfolded up-sampling convs: use mask_branch._up_conv")
+            return sharded_conv(x, self.weight, self.spec(act, False, res_up2, per_n, (0, self.padding[1], self.padding[2])),
+                                self.kernel_size[0], self.stride, self.padding[0], scale, shift, res, shard)
         return ops.conv3d_w(x, self.weight, self.spec(act, up2, res_up2, per_n, pad), scale=scale, shift=shift, res=res)
 
     def extra_repr(self):
         return "%d, %d, kernel_size=%s, stride=%d, padding=%s, bias=%s" % (
             self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding, self.bias is not None)
+
+
+def sharded_conv(x, w, spec, kd, stride, pd, scale, shift, res, shard):
+    """conv3d_w on this rank's depth slab of a z-sharded tensor (``spec`` already has depth padding 0; kd / stride / pd
+    are the conv's depth geometry): interior output planes straight from the slab while the halo transfer is in flight,
+    boundary planes from the edge tensors (``dist.halo_conv``); thin slabs fall back to the padded-slab exchange.  A
+    residual ``res`` (same resolution, or low resolution with res_up2 / a depth-to-space conv's parity layout) is sliced
+    to each region's output planes."""
+    co = spec.d2s_cq or (spec.co // 8) if spec.d2s else spec.co
+    sc = 2 if spec.d2s else 1                              # output planes per conv output plane (depth-to-space)
+    ho = (x.shape[2] + 2 * spec.pad[1] - spec.k[1]) // spec.stride + 1
+    wo = (x.shape[3] + 2 * spec.pad[2] - spec.k[2]) // spec.stride + 1
+
+    def res_rows(z0, z1):
+        if res is None:
+            return None
+        if spec.d2s:                                       # residual at the conv's (low) resolution, d2s epilogue
+            return res[:, z0:z1]
+        if spec.res_up2:                                   # residual at half the output resolution
+            return res[:, z0 // 2:(z1 + 1) // 2]
+        return res[:, z0:z1]
+
+    def run(inp, out, z0, z1):
+        return ops.conv3d_w(inp, w, spec, scale=scale, shift=shift, res=res_rows(z0, z1),
+                            out=None if out is None else out)
+
+    if not spec.d2s and not (spec.res_up2 and res is not None):
+        y = dist.halo_conv(x, run, kd, stride, pd, (ho, wo, co), shard)
+        if y is not None:
+            return y
+    lo, hi = dist.conv_depth_halo(kd, stride, pd)
+    return ops.conv3d_w(dist.halo_exchange(x, lo, hi, shard), w, spec, scale=scale, shift=shift, res=res)
 
 
 def folded_bn(bn, eps):

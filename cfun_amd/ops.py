@@ -229,6 +229,11 @@ class _Conv3d(torch.autograd.Function):
         if spec.d2s:
             cq = spec.d2s_cq or p.Co // 8
             y = torch.empty((p.N, 2 * p.Do, 2 * p.Ho, 2 * p.Wo, cq), dtype=torch.float32, device=x.device)
+        elif torch.is_tensor(out):   # write into a caller-provided dense region (a depth range of a larger buffer)
+            y = out.view(out.shape)
+            if tuple(y.shape) != (p.N, p.Do, p.Ho, p.Wo, p.Co) or not y.is_contiguous():
+                raise RuntimeError("conv3d: out %s / contiguous=%s does not fit the result %s"
+                                   % (tuple(y.shape), y.is_contiguous(), (p.N, p.Do, p.Ho, p.Wo, p.Co)))
         elif out is not None:        # write into sample `i` of a BatchBuffer (zero-copy batch join)
             y = out[0].sample(out[1], (p.N, p.Do, p.Ho, p.Wo, p.Co), x)
         else:
@@ -473,6 +478,31 @@ def join_batch(buf, parts):
     return _JoinBatch.apply(buf, *parts)
 
 
+class _JoinDepth(torch.autograd.Function):
+    """Results that convs wrote into consecutive depth ranges of ``buf`` [1,D,...] (``conv3d(out=buf[:, a:b])``) as one
+    tensor, without a copy; the backward hands each producer its depth range of the gradient (dense views: N == 1)."""
+
+    @staticmethod
+    def forward(ctx, buf, *parts):
+        ctx.sizes = [p.shape[1] for p in parts]
+        if buf.shape[0] != 1 or sum(ctx.sizes) != buf.shape[1]:
+            raise RuntimeError("join_depth: the parts do not tile the buffer")
+        return buf.view(buf.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        outs, z = [], 0
+        for n in ctx.sizes:
+            outs.append(g[:, z:z + n])
+            z += n
+        return (None,) + tuple(outs)
+
+
+def join_depth(buf, parts):
+    return _JoinDepth.apply(buf, *parts)
+
+
 def channel_sum(g2d):
     """[V, C] -> [C] sum over rows (bias gradients)."""
     lib = _lib.load()
@@ -616,20 +646,38 @@ class _JoinChannels(torch.autograd.Function):
         return (None,) + tuple(outs)
 
 
+def _combine_stats_over_ranks(stats, eps, shard):
+    """(mean, rstd) of every rank's depth slab [n,c,2] -> the statistics of the whole volume, identical on every rank of
+    ``shard`` (equal slabs): E[x] and E[x^2] are averaged with ONE all-reduce of 2*C values per sample (SURVEY.md section
+    8(e): "all_reduce of 2*C floats per InstanceNorm"); fp64 on these few values keeps the variance cancellation exact."""
+    import torch.distributed as dist
+    m = stats[..., 0].double()
+    ex2 = (1.0 / stats[..., 1].double() ** 2 - eps).clamp_(min=0.0) + m * m
+    both = torch.stack([m, ex2], dim=-1)
+    dist.all_reduce(both, group=shard.group)
+    both /= shard.world
+    mean = both[..., 0]
+    var = (both[..., 1] - mean * mean).clamp_(min=0.0)
+    return torch.stack([mean, torch.rsqrt(var + eps)], dim=-1).float().contiguous()
+
+
 class _InstNormLReLU(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, eps, out=None):
+    def forward(ctx, x, eps, out=None, shard=None):
         lib = _lib.load()
         x = _c(x)
         n, c = x.shape[0], x.shape[-1]
         v = x.numel() // (n * c)
-        if v <= 1:
+        zs = shard is not None and shard.world > 1       # x is this rank's depth slab of a z-sharded volume
+        if v * (shard.world if zs else 1) <= 1:
             raise ValueError("Expected more than 1 spatial element when training, got input size %s"
                              % (tuple(x.shape),))  # InstanceNorm3d behaviour, SURVEY.md App. A-3
         stats = torch.empty((n, c, 2), dtype=torch.float32, device=x.device)
         ws = workspace(lib.cfun_instnorm_workspace_bytes(n, v, c), x)
         st = stream(x)
         check(lib.cfun_instnorm_stats(ptr(x), ptr(stats), n, v, c, eps, ptr(ws), ws.numel(), st), "instnorm_stats")
+        if zs:
+            stats = _combine_stats_over_ranks(stats, eps, shard)
         if out is None:
             y = torch.empty_like(x)
             check(lib.cfun_instnorm_lrelu_fwd(ptr(x), ptr(stats), ptr(y), n, v, c, LRELU_SLOPE, st), "instnorm_lrelu_fwd")
@@ -639,6 +687,7 @@ class _InstNormLReLU(torch.autograd.Function):
                 raise RuntimeError("instnorm_lrelu: out slot %s does not match %s" % (tuple(y.shape), tuple(x.shape)))
             check(lib.cfun_instnorm_lrelu_fwd_strided(ptr(x), ptr(stats), ptr_raw(y), n, v, c, out[0].c_total,
                                                       LRELU_SLOPE, st), "instnorm_lrelu_fwd_strided")
+        ctx.shard = shard if zs else None
         ctx.save_for_backward(x, stats)
         return y
 
@@ -653,15 +702,27 @@ class _InstNormLReLU(torch.autograd.Function):
             dy, rs = dy.contiguous(), c
         dx = torch.empty_like(x)
         ws = workspace(lib.cfun_instnorm_workspace_bytes(n, v, c), x)
-        check(lib.cfun_instnorm_lrelu_bwd_strided(ptr(x), ptr(stats), ptr_raw(dy), ptr(dx), n, v, c, rs, LRELU_SLOPE,
-                                                  ptr(ws), ws.numel(), stream(x)), "instnorm_lrelu_bwd")
-        return dx, None, None
+        if ctx.shard is None:
+            check(lib.cfun_instnorm_lrelu_bwd_strided(ptr(x), ptr(stats), ptr_raw(dy), ptr(dx), n, v, c, rs, LRELU_SLOPE,
+                                                      ptr(ws), ws.numel(), stream(x)), "instnorm_lrelu_bwd")
+        else:       # z-sharded volume: the two means are over ALL slabs -- one all-reduce between the two kernel halves
+            import torch.distributed as dist
+            means = torch.empty((n, c, 2), dtype=torch.float32, device=x.device)
+            check(lib.cfun_instnorm_bwd_means(ptr(x), ptr(stats), ptr_raw(dy), ptr(means), n, v, c, rs, LRELU_SLOPE, ptr(ws),
+                                              ws.numel(), stream(x)), "instnorm_bwd_means")
+            dist.all_reduce(means, group=ctx.shard.group)
+            means /= ctx.shard.world
+            check(lib.cfun_instnorm_lrelu_bwd_apply(ptr(x), ptr(stats), ptr(means), ptr_raw(dy), ptr(dx), n, v, c, rs,
+                                                    LRELU_SLOPE, stream(x)), "instnorm_lrelu_bwd_apply")
+        return dx, None, None, None
 
 
-def instnorm_lrelu(x, eps=1e-5, out=None):
+def instnorm_lrelu(x, eps=1e-5, out=None, shard=None):
     """LeakyReLU(InstanceNorm3d(x)) (affine=False, biased variance), mask_branch.py:28-116.  ``out``: a
-    ``ConcatBuffer.slot`` to write the result into (zero-copy concat)."""
-    return _InstNormLReLU.apply(x, eps, out)
+    ``ConcatBuffer.slot`` to write the result into (zero-copy concat).  ``shard``: x is this rank's equal depth slab of
+    a volume z-sharded over ``shard``'s ranks -- the statistics (forward) and the two gradient means (backward) are
+    combined with one small all-reduce each."""
+    return _InstNormLReLU.apply(x, eps, out, shard)
 
 
 class _LReLU(torch.autograd.Function):

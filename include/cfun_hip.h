@@ -168,6 +168,14 @@ int cfun_instnorm_lrelu_fwd_strided(const float* x, const float* stats, float* y
 int cfun_instnorm_lrelu_bwd_strided(const float* x, const float* stats, const float* dy, float* dx, int32_t N, int64_t V,
                                     int32_t C, int64_t dy_stride, float slope, void* ws, size_t ws_bytes,
                                     cfun_stream_t stream);
+/* cfun_instnorm_lrelu_bwd in two halves, for a volume depth-sharded over several GPUs: the
+ * means of gn = dy * lrelu'(xhat) and gn * xhat over the LOCAL voxels -> means [N,C,2]; the caller combines them across
+ * the ranks (local voxel count weights, one all-reduce of 2*C floats per sample) and applies
+ * dx = rstd * (gn - means[0] - xhat * means[1]).  `stats` must already be the GLOBAL (mean, rstd). */
+int cfun_instnorm_bwd_means(const float* x, const float* stats, const float* dy, float* means, int32_t N, int64_t V,
+                            int32_t C, int64_t dy_stride, float slope, void* ws, size_t ws_bytes, cfun_stream_t stream);
+int cfun_instnorm_lrelu_bwd_apply(const float* x, const float* stats, const float* means, const float* dy, float* dx,
+                                  int32_t N, int64_t V, int32_t C, int64_t dy_stride, float slope, cfun_stream_t stream);
 
 /* MaxPool3d(kernel 2, stride 2) (backbone.py:127).  idx[v,c] = argmax child 0..7 (uint8). */
 int cfun_maxpool2_fwd(const float* x, float* y, uint8_t* idx, int32_t N, int32_t Do, int32_t Ho, int32_t Wo,
