@@ -195,14 +195,17 @@ def main():
         from cfun_amd import dist as cdist
         reducer = cdist.GradientReducer(net.parameters(), average=not (args.sharded))   # sharded: additive shares -> sum
 
+    step_no = [0]
+
     def one_step():
+        step_no[0] += 1
         if reducer is None:
             net.zero_grad(set_to_none=True)
         else:
             reducer.zero_grad()
         if sharded:     # the ranks' loss shares / gradients add up to the single-GPU step (the reducer sums)
             with cdist.depth_sharded():
-                losses, total, _ = cdist.sharded_training_step(net, sample)
+                losses, total, _ = cdist.sharded_training_step(net, sample, dropout_seed=step_no[0])
         else:
             out, losses, total = step.training_step(net, sample)
         if reducer is not None:
@@ -282,9 +285,10 @@ def main():
                                    % (args.workload, h, w, d, stage, b, "x".join(map(str, side)),
                                       "x".join(map(str, cfg.MASK_SHAPE)),
                                       " incl. 3-D Sobel edge loss" if stage == "finetune" else ""),
-                       "parallelism": ("ONE volume over %d GPUs: depth-sharded FPN/RPN with xGMI halo exchange, RPN "
-                                       "all-gather, head RoIs round-robin, gradient all-reduce; losses = rank 0's shares"
-                                       % world) if sharded else
+                       "parallelism": ("ONE volume over %d GPUs: depth-sharded FPN/RPN with xGMI halo exchange overlapped "
+                                       "with the interior planes, RPN all-gather, classifier RoIs round-robin, every "
+                                       "positive RoI's U-Net z-sharded over world/4 ranks when world > 4 (else one RoI per "
+                                       "rank), gradient all-reduce; losses = rank 0's shares" % world) if sharded else
                                       ("1 volume per GPU x %d, bucketed gradient all-reduce (RCCL) overlapped with backward"
                                        % world) if world > 1 else "single GPU"},
             "losses": lv,

@@ -54,6 +54,20 @@ def depth_sharded(group=None):
 
 
 @contextlib.contextmanager
+def depth_sharded_as(ctx):
+    """``depth_sharded`` with an existing ShardContext (e.g. a RoI's sub-group)."""
+    global _CTX
+    old, _CTX = _CTX, ctx
+    try:
+        yield ctx
+    finally:
+        _CTX = old
+
+
+nullcontext = contextlib.nullcontext
+
+
+@contextlib.contextmanager
 def slab_local():
     """Suspend depth sharding inside a ``depth_sharded`` block: the convolutions executed here work on whole,
     rank-private tensors (the per-RoI heads: a RoI crop is not a slab of anything)."""
@@ -318,6 +332,71 @@ def gather_depth(x, shard=None):
     return _AllGatherDepth.apply(x, shard)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# z-sharded per-RoI U-Net: with 4 positive RoIs only 4 ranks would run a mask head.  A
+# RoI's U-Net is therefore split along depth over a SUB-GROUP of ranks at its two high-resolution levels (96^3 and
+# 48^3: 84 % of its FLOPs) -- 1-plane halos per 3x3x3 conv, one all-reduce of 2*C floats per InstanceNorm -- while the
+# levels at 24^3 and below, where a slab would be thinner than a conv's halo, are "folded": the 24^3 tensor is
+# all-gathered once and those levels are computed redundantly on every rank of the sub-group (no communication).
+#
+#   sharded (slabs)  --GatherReplicated-->  replicated (whole tensor on every rank)  --EnterSlab-->  sharded
+#
+# Gradient bookkeeping (every rank finally SUMS its parameter gradients with the other ranks'): the replicated section
+# is evaluated R times with identical values, so its gradient is scaled by 1/R where it enters (EnterSlab.backward:
+# all-reduce of the slabs' contributions, divided by R) and scaled back by R where it leaves towards the sharded
+# encoder (GatherReplicated.backward: own depth range times R).  Sum over ranks = the single-GPU gradient.
+# ---------------------------------------------------------------------------------------------------------------
+class _GatherReplicated(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, shard):
+        ctx.shard = shard
+        x = x.contiguous()
+        parts = [torch.empty_like(x) for _ in range(shard.world)]
+        dist.all_gather(parts, x, group=shard.group)
+        return torch.cat(parts, dim=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        shard = ctx.shard
+        d = g.shape[1] // shard.world
+        return g.narrow(1, shard.rank * d, d) * float(shard.world), None
+
+
+def gather_replicated(x, shard):
+    """Depth slabs [N,d,H,W,C] -> the whole tensor on every rank of ``shard``, entering a replicated section."""
+    return _GatherReplicated.apply(x, shard)
+
+
+class _EnterSlab(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, full, lo, hi, shard):
+        d = full.shape[1] // shard.world
+        z0 = shard.rank * d
+        ctx.shard, ctx.geom, ctx.shape = shard, (z0, d, lo, hi), tuple(full.shape)
+        a, b = max(z0 - lo, 0), min(z0 + d + hi, full.shape[1])
+        out = full[:, a:b]
+        pad_lo, pad_hi = a - (z0 - lo), (z0 + d + hi) - b
+        if pad_lo or pad_hi:                                   # volume boundary: the conv's zero padding
+            out = torch.nn.functional.pad(out, (0, 0, 0, 0, 0, 0, pad_lo, pad_hi))
+        return out.contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        shard = ctx.shard
+        z0, d, lo, hi = ctx.geom
+        full = g.new_zeros(ctx.shape)
+        a, b = max(z0 - lo, 0), min(z0 + d + hi, ctx.shape[1])
+        full[:, a:b] = g[:, a - (z0 - lo):a - (z0 - lo) + (b - a)]
+        dist.all_reduce(full, group=shard.group)
+        return full / float(shard.world), None, None, None
+
+
+def enter_slab(full, shard, lo=0, hi=0):
+    """Replicated tensor [N,D,H,W,C] -> this rank's depth slab plus ``lo`` / ``hi`` halo planes (zeros beyond the
+    volume), leaving a replicated section for a sharded one; no communication in forward (every rank holds the planes)."""
+    return _EnterSlab.apply(full, lo, hi, shard)
+
+
 def local_anchor_index(level_counts, shard=None):
     """Global flat indices of the anchors this rank's slabs produce, in local order (its level-2 block, then its
     level-3 block): level l's A_l anchors are flattened (z, y, x) (model.py:727-729), so a depth slab owns the
@@ -331,13 +410,34 @@ def local_anchor_index(level_counts, shard=None):
     return torch.cat(idx)
 
 
-def sharded_training_step(net, s, shard=None):
+_ZPLANS = {}
+
+
+def zshard_plan(shard, n_pos):
+    """Sub-groups for z-sharded mask heads: with more ranks than positive RoIs (8 GPUs, 4 RoIs) every RoI's U-Net is
+    split over world / n_pos consecutive ranks.  Returns (ranks per RoI, [process group per RoI]) or None when the ranks
+    do not divide evenly (then RoIs are dealt round-robin, one whole U-Net per rank).  ``dist.new_group`` is collective:
+    every rank of ``shard`` must call this with the same arguments; the groups are cached."""
+    if n_pos <= 0 or shard.world <= n_pos or shard.world % n_pos:
+        return None
+    key = (id(shard.group), shard.world, n_pos)
+    if key not in _ZPLANS:
+        rs = shard.world // n_pos
+        base = dist.get_process_group_ranks(shard.group) if shard.group is not None else list(range(shard.world))
+        _ZPLANS[key] = (rs, [dist.new_group(ranks=base[i * rs:(i + 1) * rs]) for i in range(n_pos)])
+    return _ZPLANS[key]
+
+
+def sharded_training_step(net, s, shard=None, zshard_unet=True, dropout_seed=0):
     """ONE volume on R ranks: forward + the 6 losses + backward of ``cfun_amd.step.training_step`` with
 
     * FPN / RPN depth-sharded (halo exchange inside the depth-coupled convs), proposals from one all-gather;
     * RPN losses on the rank's own anchors with the global normalisation (so local gradients are exact);
     * head RoIs dealt round-robin: rank r classifies rois[r::R] (on the all-gathered p2 / p3) and runs the mask
       U-Net on p_rois[r::R] (crops of the raw image, which every rank holds);
+    * with more ranks than positive RoIs (``zshard_unet``; 8 GPUs, 4 RoIs): every RoI's U-Net z-sharded over
+      world / n_pos ranks (``zshard_plan``, ``Modified3DUNet.forward_ndhwc(zshard=...)``), its logits all-gathered inside
+      the sub-group and the mask losses evaluated redundantly there (each rank reports 1 / sub-group size of them);
     * every loss returned as THIS rank's additive share: sum over ranks = the single-GPU loss, and the sum over
       ranks of the parameter gradients = the single-GPU gradient (all-reduce them with op=SUM).
 
@@ -392,7 +492,36 @@ def sharded_training_step(net, s, shard=None):
             l_box = F.smooth_l1_loss(cls_bbox[pos, 1, :], s["target_deltas"][mine][pos], reduction="sum") / (npos_all * 6)
     pmine = torch.arange(r, n_pos, R, device=rois.device)
     l_mask = l_edge = zero
-    if pmine.numel():
+    plan = zshard_plan(shard, n_pos) if (zshard_unet and not net.detector_phase_only) else None
+    unet = net.mask.modified_u_net
+    if plan is not None:        # this rank is one of `rs` ranks that share RoI `roi`
+        rs, groups = plan
+        roi = r // rs
+        zs = ShardContext(groups[roi])
+        preset = unet.dropout_masks
+        if unet.training and unet.dropout_p > 0 and preset is None:
+            # Dropout3d masks must agree inside the sub-group: drawn for ALL RoIs from a generator every rank seeds alike
+            b, keep = unet.base_n_filter, 1.0 - unet.dropout_p
+            gen = torch.Generator().manual_seed(int(dropout_seed))
+            unet.dropout_masks = [torch.empty((n_pos, c)).bernoulli_(keep, generator=gen).div_(keep)[roi:roi + 1]
+                                  for c in (b, 2 * b, 4 * b, 8 * b, 16 * b)]
+        try:
+            crop = ops.roi_align(ops.to_ndhwc(image)[0], s["p_rois"][roi:roi + 1].detach(), net.mask.pool_size)[0]
+            with slab_local():
+                mslab = unet.forward_ndhwc(slab(crop, dim=1, shard=zs).contiguous(), zshard=zs)
+        finally:
+            unet.dropout_masks = preset
+        mlog = gather_replicated(mslab, zs)
+        mprob = ops.softmax_channels(mlog)
+        pmine = torch.tensor([roi], device=rois.device)
+        labels = s["mask_labels"][pmine].contiguous()
+        share = 1.0 / float(n_pos * rs)
+        if cfg.STAGE == "finetune":
+            ce, edge = ops.mask_losses(mlog, mprob, labels)
+            l_mask, l_edge = ce * share, edge * share
+        else:
+            l_mask = ops.mask_cross_entropy(mlog, labels) * share
+    elif pmine.numel():
         with slab_local():      # the U-Net's 3x3x3 convs see whole RoI crops, not depth slabs
             mlog, mprob = net.mask.forward_ndhwc(ops.to_ndhwc(image)[0], s["p_rois"][pmine])
         labels = s["mask_labels"][pmine].contiguous()

@@ -12,8 +12,8 @@ mask_branch.py:11-220, but runs as NDHWC HIP kernels:
 import torch
 import torch.nn as nn
 
-from . import ops
-from .layers import Conv3dParams, default_algo
+from . import dist, ops
+from .layers import Conv3dParams, default_algo, sharded_conv
 
 
 def _holder(index, length, conv):
@@ -141,80 +141,127 @@ class Modified3DUNet(nn.Module):
         ybuf, gbuf = ops.BatchBuffer(n), ops.BatchBuffer(n)     # outputs / conv1 input gradients, written in place
         outs = []
         w1s, w2s = ops.gather_slices(conv1.weight, 0, idxs), ops.gather_slices(conv2.weight, 1, idxs)
+        zs = dist.current()
+        zs = zs if zs is not None and zs.world > 1 else None      # z-sharded RoI: slabs, halos inside the convs
         for i in range(n):
             a, res = a_parts[i], res_parts[i]
             idx = idxs[i]
             w1 = w1s[i]
+            sc1 = drop[i:i + 1].index_select(1, idx).contiguous()
+            if zs is not None:
+                p1, p2 = (0,) + tuple(conv1.padding[1:]), (0,) + tuple(conv2.padding[1:])
+                spec1 = ops.ConvSpec(k=conv1.kernel_size, co=idx.numel(), pad=p1, scale_per_n=True, algo=algo)
+                t = sharded_conv(a, w1, spec1, conv1.kernel_size[0], 1, conv1.padding[0], sc1, None, None, zs)
+                spec2 = ops.ConvSpec(k=conv2.kernel_size, co=conv2.out_channels, pad=p2, algo=algo)
+                outs.append(sharded_conv(pre2(t), w2s[i], spec2, conv2.kernel_size[0], 1, conv2.padding[0], None, None, res, zs))
+                continue
             spec1 = ops.ConvSpec(k=conv1.kernel_size, co=idx.numel(), pad=conv1.padding, scale_per_n=True, algo=algo)
-            t = ops.conv3d_w(a, w1, spec1, scale=drop[i:i + 1].index_select(1, idx).contiguous(),
-                           dx_slot=(gbuf, i))
+            t = ops.conv3d_w(a, w1, spec1, scale=sc1, dx_slot=(gbuf, i))
             w2 = w2s[i]
             spec2 = ops.ConvSpec(k=conv2.kernel_size, co=conv2.out_channels, pad=conv2.padding, algo=algo)
             outs.append(ops.conv3d_w(pre2(t), w2, spec2, res=res, out=(ybuf, i)))
+        if zs is not None:
+            return outs[0] if n == 1 else torch.cat(outs, dim=0)
         return ops.join_batch(ybuf, outs)
 
     @staticmethod
-    def _up_conv(h, conv):
+    def _up_conv(h, conv, depth_padded=False):
         """conv3x3x3(nearest_up2(h)).  On the up-sampled grid each output parity only sees 2x2x2 distinct
         low-resolution voxels, so the weights are folded per parity (ops.fold_up2_weight, differentiable) and the
         conv runs on the LOW-resolution tensor with a depth-to-space epilogue, skipping the 19 folded-zero taps:
         8/27 of the FLOPs of the straightforward "read (z>>1,y>>1,x>>1)" form, for forward, dgrad and wgrad."""
         ci, co = conv.in_channels, conv.out_channels
         if ci % 4 or co % 4:
+            if depth_padded:
+                raise NotImplementedError("z-sharded up-conv needs C % 4 == 0 (the folded form)")
             return conv(h, up2=True)
         cqp = (co + 15) // 16 * 16
-        spec = ops.ConvSpec(k=(3, 3, 3), co=8 * cqp, pad=(1, 1, 1), d2s=True, d2s_cq=co, tap_skip=True,
-                            algo=default_algo())
+        # depth_padded: h already carries one low-resolution halo plane on each side (z-sharded RoI) -> depth-VALID
+        spec = ops.ConvSpec(k=(3, 3, 3), co=8 * cqp, pad=(0 if depth_padded else 1, 1, 1), d2s=True, d2s_cq=co,
+                            tap_skip=True, algo=default_algo())
         return ops.conv3d_w(h, ops.fold_up2_weight(conv.weight, cqp), spec)
 
-    def forward_ndhwc(self, x):
-        nl = ops.instnorm_lrelu
+    def forward_ndhwc(self, x, zshard=None):
+        """x [N,D,H,W,in]: the RoI crops.  ``zshard`` (a ``dist.ShardContext`` over the RoI's sub-group of ranks, N == 1):
+        x is this rank's depth slab of ONE crop and the result is its slab of the logits -- the two high-resolution levels
+        run on slabs (halo planes inside the 3x3x3 convs, InstanceNorm statistics all-reduced), the levels at 1/4
+        resolution and below are folded onto every rank (``dist.gather_replicated`` / ``dist.enter_slab``)."""
+        zs = zshard if zshard is not None and zshard.world > 1 else None
+        if zs is not None and x.shape[0] != 1:
+            raise ValueError("a z-sharded U-Net handles one RoI per sub-group")
+        sharded = (lambda: dist.depth_sharded_as(zs)) if zs is not None else dist.nullcontext
+        folded = dist.slab_local if zs is not None else dist.nullcontext
+
+        def nl(t, out=None, rep=False):      # rep: t is a replicated (folded) tensor -> plain local statistics
+            return ops.instnorm_lrelu(t, out=out, shard=None if rep else zs)
+
         drop = self._upload_dropout(self._drop_masks(x.shape[0], x.device), x.device)
 
-        def nluc(h, holder, out=None):   # norm -> lrelu -> nearest x2 -> 3x3x3 conv -> norm -> lrelu  (mask_branch.py:108-116)
-            return nl(self._up_conv(nl(h), holder[3]), out=out)
+        def nluc(h, holder, out=None, src="same"):
+            """norm -> lrelu -> nearest x2 -> 3x3x3 conv -> norm -> lrelu (mask_branch.py:108-116).  src: where h lives --
+            'same' (no sharding, or sharded in and out), 'rep' (replicated in and out) or 'enter' (replicated in, sharded out)."""
+            a = nl(h, rep=src != "same")
+            if zs is None or src == "rep":
+                return nl(self._up_conv(a, holder[3]), out=out, rep=src == "rep")
+            a = dist.enter_slab(a, zs, 1, 1) if src == "enter" else dist.halo_exchange(a, 1, 1, zs)
+            return nl(self._up_conv(a, holder[3], depth_padded=True), out=out)
 
-        # level 1: residual is the pre-activation stem output, context_1 is taken before the norm
-        def head1(xp):
-            res = self.conv3d_c1_1(xp)
-            return ops.lrelu(res), res
-        out = self._dropout_pair(x, head1, self.conv3d_c1_2, self.lrelu_conv_c1[1], drop[0], ops.lrelu)
-        # context_1 is only ever read by the level-1 concat (mask_branch.py:203): it is written straight into the second
-        # half of that concat's buffer, the decoder later writes the first half -- no torch.cat, no gradient slices copied
-        b1 = self.base_n_filter
-        cat1 = ops.ConcatBuffer(out, 2 * b1) if b1 % 4 == 0 else None
-        ctx = [ops.lrelu(out, out=None if cat1 is None else cat1.slot(b1, 2 * b1))]
-        h = nl(out)
+        with sharded():
+            # level 1: residual is the pre-activation stem output, context_1 is taken before the norm
+            def head1(xp):
+                res = self.conv3d_c1_1(xp)
+                return ops.lrelu(res), res
+            out = self._dropout_pair(x, head1, self.conv3d_c1_2, self.lrelu_conv_c1[1], drop[0], ops.lrelu)
+            # context_1 is only ever read by the level-1 concat (mask_branch.py:203): it is written straight into the
+            # second half of that concat's buffer, the decoder later writes the first half -- no torch.cat, no copies
+            b1 = self.base_n_filter
+            cat1 = ops.ConcatBuffer(out, 2 * b1) if b1 % 4 == 0 else None
+            ctx = [ops.lrelu(out, out=None if cat1 is None else cat1.slot(b1, 2 * b1))]
+            h = nl(out)
         # levels 2..5: stride-2 conv, then the SAME norm_lrelu_conv weights twice around the dropout
         for lvl in (2, 3, 4, 5):
             down = getattr(self, "conv3d_c%d" % lvl)
+            rep = zs is not None and lvl >= 3          # folded levels
 
-            def head(hp, down=down):
-                res = down(hp)
-                return nl(res), res
+            def head(hp, down=down, lvl=lvl, rep=rep):
+                if zs is not None and lvl == 3:        # the fold: slabs of the 1/4-resolution tensor -> every rank
+                    with dist.depth_sharded_as(zs):
+                        res = down(hp)
+                    res = dist.gather_replicated(res, zs)
+                else:
+                    res = down(hp)
+                return nl(res, rep=rep), res
             head.stride = 2
             conv = getattr(self, "norm_lrelu_conv_c%d" % lvl)[2]
-            out = self._dropout_pair(h, head, conv, conv, drop[lvl - 1], nl)
-            if lvl < 5:
-                h = nl(out)
-                ctx.append(h)
-        h = nluc(out, self.norm_lrelu_upscale_conv_norm_lrelu_l0)
-        h = nl(self.conv3d_l0(h))
-        h = nl(self.conv_norm_lrelu_l1[0](torch.cat([h, ctx[3]], dim=-1)))
-        h = nluc(self.conv3d_l1(h), self.norm_lrelu_upscale_conv_norm_lrelu_l1)
-        ds2 = nl(self.conv_norm_lrelu_l2[0](torch.cat([h, ctx[2]], dim=-1)))
-        h = nluc(self.conv3d_l2(ds2), self.norm_lrelu_upscale_conv_norm_lrelu_l2)
-        ds3 = nl(self.conv_norm_lrelu_l3[0](torch.cat([h, ctx[1]], dim=-1)))
-        if cat1 is None:
-            h = nluc(self.conv3d_l3(ds3), self.norm_lrelu_upscale_conv_norm_lrelu_l3)
-            joined = torch.cat([h, ctx[0]], dim=-1)
-        else:
-            h = nluc(self.conv3d_l3(ds3), self.norm_lrelu_upscale_conv_norm_lrelu_l3, out=cat1.slot(0, b1))
-            joined = cat1.join(h, ctx[0])
-        h = nl(self.conv_norm_lrelu_l4[0](joined))
-        # deep supervision: up(up(ds2_1x1) + ds3_1x1) + out_pred, each add is a conv epilogue
-        s = self.ds3_1x1_conv3d(ds3, res=self.ds2_1x1_conv3d(ds2), res_up2=True)
-        out = self.conv3d_l4(h, res=s, res_up2=True)
+            with (folded() if rep else sharded()):
+                out = self._dropout_pair(h, head, conv, conv, drop[lvl - 1], lambda t, rep=rep: nl(t, rep=rep))
+                if lvl < 5:
+                    h = nl(out, rep=rep)
+                    ctx.append(h)
+        R = zs is not None       # decoder: replicated up to 1/4 resolution, sharded from 1/2
+        with folded():
+            h = nluc(out, self.norm_lrelu_upscale_conv_norm_lrelu_l0, src="rep" if R else "same")
+            h = nl(self.conv3d_l0(h), rep=R)
+            h = nl(self.conv_norm_lrelu_l1[0](torch.cat([h, ctx[3]], dim=-1)), rep=R)
+            h = nluc(self.conv3d_l1(h), self.norm_lrelu_upscale_conv_norm_lrelu_l1, src="rep" if R else "same")
+            ds2 = nl(self.conv_norm_lrelu_l2[0](torch.cat([h, ctx[2]], dim=-1)), rep=R)
+            h_l2 = self.conv3d_l2(ds2)
+            ds2_out = self.ds2_1x1_conv3d(ds2)
+        h = nluc(h_l2, self.norm_lrelu_upscale_conv_norm_lrelu_l2, src="enter" if R else "same")
+        if R:
+            ds2_out = dist.enter_slab(ds2_out, zs)
+        with sharded():
+            ds3 = nl(self.conv_norm_lrelu_l3[0](torch.cat([h, ctx[1]], dim=-1)))
+            if cat1 is None:
+                h = nluc(self.conv3d_l3(ds3), self.norm_lrelu_upscale_conv_norm_lrelu_l3)
+                joined = torch.cat([h, ctx[0]], dim=-1)
+            else:
+                h = nluc(self.conv3d_l3(ds3), self.norm_lrelu_upscale_conv_norm_lrelu_l3, out=cat1.slot(0, b1))
+                joined = cat1.join(h, ctx[0])
+            h = nl(self.conv_norm_lrelu_l4[0](joined))
+            # deep supervision: up(up(ds2_1x1) + ds3_1x1) + out_pred, each add is a conv epilogue
+            s = self.ds3_1x1_conv3d(ds3, res=ds2_out, res_up2=True)
+            out = self.conv3d_l4(h, res=s, res_up2=True)
         if self.stage == "finetune":   # up(out) + conv5(up(out)), mask_branch.py:216-218
             # The 5x5x5 conv reads a nearest-x2 up-sampled tensor, so its 125 taps collapse onto 27 low-resolution
             # taps per output parity: run it as ONE 3x3x3 conv (n_classes -> 8 parities x n_classes channels) on
@@ -222,9 +269,9 @@ class Modified3DUNet(nn.Module):
             # to the fp32 pre-summation of the folded weights.  The up(out) skip is the epilogue residual.
             conv = self.out_upscale_conv[1]
             wf = ops.fold_up2_weight(conv.weight)
-            spec = ops.ConvSpec(k=(3, 3, 3), co=8 * self.n_classes, pad=(1, 1, 1), d2s=True, res_up2=True,
+            spec = ops.ConvSpec(k=(3, 3, 3), co=8 * self.n_classes, pad=(0 if R else 1, 1, 1), d2s=True, res_up2=True,
                                 algo=default_algo())
-            out = ops.conv3d_w(out, wf, spec, res=out)
+            out = ops.conv3d_w(dist.halo_exchange(out, 1, 1, zs) if R else out, wf, spec, res=out)
         return out
 
     def forward(self, x):

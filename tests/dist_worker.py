@@ -149,7 +149,7 @@ def main():
     assert len(red6.buckets) > 4
     red6.zero_grad()
     with cdist.depth_sharded():
-        losses6, _, _ = cdist.sharded_training_step(net5, s6)
+        losses6, _, _ = cdist.sharded_training_step(net5, s6, zshard_unet=False)
     red6.finish()
     red6.remove()
     lv6 = torch.stack([l.detach().float() for l in losses6])
@@ -163,6 +163,50 @@ def main():
         res["ref6_losses"] = np.array([float(l.detach()) for l in losses_r6], np.float32)
         res["ref6_grads"] = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
                                        for k, p in net5.named_parameters() if p.requires_grad]).numpy()
+    # 6b) the same 1 + 1 RoI step with the positive RoI's U-Net z-sharded over BOTH ranks (more ranks than positive RoIs):
+    #     loss shares and summed gradients again equal the single-process step
+    for p in net5.parameters():
+        p.grad = None
+    with cdist.depth_sharded():
+        losses6b, _, _ = cdist.sharded_training_step(net5, s6, zshard_unet=True)
+    lv6b = torch.stack([l.detach().float() for l in losses6b])
+    dist.all_reduce(lv6b)
+    flat6b = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                        for k, p in net5.named_parameters() if p.requires_grad])
+    dist.all_reduce(flat6b)
+    res["sh6b_losses"], res["sh6b_grads"] = lv6b.numpy(), flat6b.numpy()
+
+    # 7) ONE RoI's U-Net z-sharded over the 2 ranks (levels at full and half resolution on depth slabs with halos and
+    #    all-reduced InstanceNorm statistics, the lower levels folded onto both ranks): logits slabs and the summed
+    #    parameter gradients equal the single-process U-Net, in both stages, with Dropout3d active
+    from cfun_amd.mask_branch import Modified3DUNet
+    for stage7 in ("beginning", "finetune"):
+        torch.manual_seed(7)
+        unet = Modified3DUNet(1, 8, stage7, 4)
+        unet.train()
+        g7 = torch.Generator().manual_seed(17)
+        unet.dropout_masks = [torch.empty(1, c).bernoulli_(0.4, generator=g7) / 0.4 for c in (4, 8, 16, 32, 64)]
+        x7 = torch.randn(1, 32, 32, 32, 1, generator=g7)
+        side = 64 if stage7 == "finetune" else 32
+        gy7 = torch.randn(1, side, side, side, 8, generator=g7)
+        zs = cdist.ShardContext()
+        for p_ in unet.parameters():
+            p_.grad = None
+        y7 = unet.forward_ndhwc(cdist.slab(x7, dim=1, shard=zs).contiguous(), zshard=zs)
+        (y7 * cdist.slab(gy7, dim=1, shard=zs)).sum().backward()
+        flat7 = torch.cat([(p_.grad if p_.grad is not None else torch.zeros_like(p_)).reshape(-1) for p_ in unet.parameters()])
+        dist.all_reduce(flat7)
+        res["zu_y_" + stage7], res["zu_g_" + stage7] = y7.detach().numpy(), flat7.numpy()
+        if rank == 0:
+            for p_ in unet.parameters():
+                p_.grad = None
+            yr7 = unet.forward_ndhwc(x7)
+            (yr7 * gy7).sum().backward()
+            res["zu_ref_y_" + stage7] = yr7.detach().numpy()
+            res["zu_ref_g_" + stage7] = torch.cat([(p_.grad if p_.grad is not None else torch.zeros_like(p_)).reshape(-1)
+                                                   for p_ in unet.parameters()]).numpy()
+            res["zu_sizes"] = np.array([int(p_.numel()) for p_ in unet.parameters()])
+            res["zu_names"] = np.array([k for k, _ in unet.named_parameters()])
     np.savez(out % rank, **res)
     dist.barrier()
     dist.destroy_process_group()

@@ -86,3 +86,29 @@ def test_depth_sharding_world2(emu_lib, tmp_path):
         off += n
         den = max(np.linalg.norm(b), 1e-12)
         assert np.linalg.norm(a - b) / den < 2e-3 or np.abs(a - b).max() < 1e-6, (str(name), np.linalg.norm(a - b) / den)
+
+    # z-sharded per-RoI U-Net: slabs of the logits and summed gradients equal the single-process U-Net
+    for stage in ("beginning", "finetune"):
+        y = np.concatenate([r[0]["zu_y_" + stage], r[1]["zu_y_" + stage]], axis=1)
+        assert y.shape == ref["zu_ref_y_" + stage].shape
+        assert np.abs(y - ref["zu_ref_y_" + stage]).max() < 1e-4 * max(1.0, np.abs(ref["zu_ref_y_" + stage]).max())
+        np.testing.assert_array_equal(r[0]["zu_g_" + stage], r[1]["zu_g_" + stage])
+        off = 0
+        for name, n in zip(ref["zu_names"], ref["zu_sizes"]):
+            a, b = r[0]["zu_g_" + stage][off:off + n], ref["zu_ref_g_" + stage][off:off + n]
+            off += n
+            den = max(np.linalg.norm(b), 1e-12)
+            assert np.linalg.norm(a - b) / den < 2e-3 or np.abs(a - b).max() < 1e-6, (stage, str(name), np.linalg.norm(a - b) / den)
+
+    # the whole sharded step with the positive RoI's U-Net z-sharded over both ranks
+    np.testing.assert_allclose(r[0]["sh6b_losses"], ref["ref6_losses"], rtol=2e-4, atol=1e-6)
+    off = 0
+    for name, n in zip(ref["grad_names"], ref["grad_sizes"]):
+        a, b = r[0]["sh6b_grads"][off:off + n], ref["ref6_grads"][off:off + n]
+        off += n
+        den = max(np.linalg.norm(b), 1e-12)
+        # U-Net tensors of this 32^3 toy configuration carry a 1e-2 fp32 noise floor of their own (InstanceNorm over
+        # 2^3..4^3 voxels; measured against fp64 by check_training_step_vs_oracle): a different summation order of the
+        # statistics (slab sums combined across ranks) moves them by a few 1e-3; everything else is held to 2e-3
+        tol = 2e-2 if str(name).startswith("mask.") else 2e-3
+        assert np.linalg.norm(a - b) / den < tol or np.abs(a - b).max() < 1e-6, (str(name), np.linalg.norm(a - b) / den)
