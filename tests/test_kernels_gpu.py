@@ -101,6 +101,15 @@ def test_mask_losses_multi_segment(gpu):
     kc.check_mask_losses(gpu, logits, labels)
 
 
+def test_mask_losses_multi_tile(gpu):
+    """Volumes wider than one 8 x 32 (y, x) LDS tile and deeper than one 32-plane segment of the tiled edge kernels, with
+    ragged tiles on every axis; 2 samples."""
+    rng = np.random.default_rng(6)
+    logits = rng.normal(size=(2, 8, 37, 13, 39)).astype(np.float32)
+    labels = np.repeat(rng.integers(0, 8, size=(2, 37, 13, 13)), 3, axis=3).astype(np.uint8)
+    kc.check_mask_losses(gpu, logits, labels)
+
+
 def test_mask_losses_3class(gpu):
     rng = np.random.default_rng(0)
     logits = rng.normal(size=(1, 3, 6, 7, 8)).astype(np.float32)
