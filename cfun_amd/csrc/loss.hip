@@ -462,257 +462,6 @@ k_edge_raw_bwd(const float* __restrict__ dc, const float* __restrict__ gscale, f
   }
 }
 
-// ------------------------------------------------------------------ Sobel edge loss, LDS-tiled
-// The marching kernels above read every probability voxel through L1 nine times (once per thread of its 3x3 (y,x)
-// neighbourhood; lanes 32 bytes apart, so every load instruction touches 16 cache lines): measured 2.5 TB/s = 0.32 of
-// the HBM peak, bound by the texture path.  Here a 256-thread workgroup owns an 8 (y) x 32 (x) column tile and marches
-// along z; each input plane's (8+2) x (32+2) halo tile is staged ONCE, coalesced, in LDS (double-buffered: the next
-// plane's global loads are in flight while the current plane is reduced, one barrier per plane) and the nine
-// neighbour reads hit LDS.  Same arithmetic, same order as plane_sums / plane_adj.
-constexpr int kTY = 8, kTX = 32, kTV = (kTY + 2) * (kTX + 2);   // tile and halo-tile voxels (340)
-constexpr int kZSegT = 32;                                       // output planes per work item
-
-template <int CT>
-struct EdgeTileSmem {
-  float v[2][kTV * CT];
-  uint8_t lab[2][kTV + 4];
-};
-
-template <int CT, int MODE>
-__global__ void __launch_bounds__(kBlock)
-k_edge_march_t(const float* __restrict__ probs, const uint8_t* __restrict__ labels, const float* __restrict__ gscale,
-               double* __restrict__ partial, float* __restrict__ dc, int n, int D, int H, int W) {
-  __shared__ EdgeTileSmem<CT> sm;
-  const int Do = D - 2, Ho = H - 2, Wo = W - 2;
-  const int ntx = (Wo + kTX - 1) / kTX, nty = (Ho + kTY - 1) / kTY, nseg = (Do + kZSegT - 1) / kZSegT;
-  const int64_t items = (int64_t)n * nseg * nty * ntx;
-  const float gs = MODE == 0 ? 0.f : (MODE == 1 ? gscale[0] : 1.f) * 2.f / ((float)Do * (float)Ho * (float)Wo * (float)n);
-  const int tid = threadIdx.x, lx = tid % kTX, ly = tid / kTX;
-  constexpr int NF = kTV * CT / 4;                       // float4s per plane tile (CT % 4 == 0) ...
-  constexpr int NLD = (CT % 4 == 0) ? (NF + kBlock - 1) / kBlock : (kTV * CT + kBlock - 1) / kBlock;
-  const float A[3] = {1.f, 2.f, 1.f}, B[3] = {1.f, 0.f, -1.f};
-  double acc = 0.0;
-  for (int64_t it = blockIdx.x; it < items; it += gridDim.x) {
-    int64_t t = it;
-    const int tx = (int)(t % ntx); t /= ntx;
-    const int ty = (int)(t % nty); t /= nty;
-    const int seg = (int)(t % nseg);
-    const int64_t r = t / nseg;
-    const int x0 = tx * kTX, y0 = ty * kTY, z0 = seg * kZSegT;
-    const int z1 = z0 + kZSegT < Do ? z0 + kZSegT : Do;
-    const int64_t nbase = r * D * H * W;
-    // ---- staging: this thread's share of a plane tile in registers, then to LDS buffer `b`
-    float4 rv[NLD];
-    float rs[(CT % 4 == 0) ? 1 : NLD];
-    uint8_t rl[2];
-    auto load_plane = [&](int z) {
-#pragma unroll
-      for (int k = 0; k < NLD; ++k) {
-        const int e = tid + k * kBlock;                 // float4 (or float) index inside the tile
-        const int vox = (CT % 4 == 0) ? e / (CT / 4) : e / CT, sub = (CT % 4 == 0) ? e % (CT / 4) : e % CT;
-        const int j = vox / (kTX + 2), i = vox % (kTX + 2);
-        const bool ok = vox < kTV && y0 + j < H && x0 + i < W;
-        const int64_t vi = nbase + ((int64_t)z * H + (y0 + j)) * W + (x0 + i);
-        if (CT % 4 == 0) rv[k] = ok ? *reinterpret_cast<const float4*>(probs + vi * CT + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        else rs[k] = ok ? probs[vi * CT + sub] : 0.f;
-      }
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int vox = tid + k * kBlock;
-        const int j = vox / (kTX + 2), i = vox % (kTX + 2);
-        const bool ok = vox < kTV && y0 + j < H && x0 + i < W;
-        rl[k] = ok ? labels[nbase + ((int64_t)z * H + (y0 + j)) * W + (x0 + i)] : (uint8_t)0;
-      }
-    };
-    auto store_plane = [&](int b) {
-#pragma unroll
-      for (int k = 0; k < NLD; ++k) {
-        const int e = tid + k * kBlock;
-        if (CT % 4 == 0) { if (e < NF) *reinterpret_cast<float4*>(&sm.v[b][e * 4]) = rv[k]; }
-        else if (e < kTV * CT) sm.v[b][e] = rs[k];
-      }
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int vox = tid + k * kBlock;
-        if (vox < kTV) sm.lab[b][vox] = rl[k];
-      }
-    };
-    auto sums = [&](int b, PlaneSums<CT>& P, PlaneSums<CT>& T) {
-#pragma unroll
-      for (int c = 0; c < CT - 1; ++c) { P.dy[c] = 0.f; P.sm[c] = 0.f; T.dy[c] = 0.f; T.sm[c] = 0.f; }
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          const int vox = (ly + j) * (kTX + 2) + lx + i;
-          const float wd = B[j] * A[i], ws = A[j] * A[i];
-          const float* pp = &sm.v[b][vox * CT];
-          const int lab = sm.lab[b][vox];
-#pragma unroll
-          for (int c = 1; c < CT; ++c) {
-            const float pv = pp[c];
-            P.dy[c - 1] += wd * pv;
-            P.sm[c - 1] += ws * pv;
-            if (c == lab) { T.dy[c - 1] += wd; T.sm[c - 1] += ws; }
-          }
-        }
-    };
-    const bool live = y0 + ly < Ho && x0 + lx < Wo;
-    PlaneSums<CT> P[3], T[3];
-    __syncthreads();                                     // the previous item's last reads of the buffers are done
-    load_plane(z0);
-    store_plane(0);
-    __syncthreads();
-    for (int p = z0; p < z1 + 2; ++p) {                  // input planes z0 .. z1+1
-      const int b = (p - z0) & 1;
-      if (p + 1 < z1 + 2) load_plane(p + 1);             // in flight while this plane is reduced
-      sums(b, P[2], T[2]);
-      if (p - z0 >= 2 && live) {
-        const int zo = p - 2;
-        float* o = MODE != 0 ? dc + ((((r * Do + zo) * Ho + (y0 + ly)) * Wo + (x0 + lx))) * (2 * (CT - 1)) : nullptr;
-#pragma unroll
-        for (int c = 0; c < CT - 1; ++c) {
-          const float p0 = P[0].dy[c] + 2.f * P[1].dy[c] + P[2].dy[c], p1 = P[0].sm[c] - P[2].sm[c];
-          const float t0 = T[0].dy[c] + 2.f * T[1].dy[c] + T[2].dy[c], t1 = T[0].sm[c] - T[2].sm[c];
-          const float pm = sqrtf(p0 * p0 + p1 * p1 + p0 * p0);   // channel 0 twice (model.py:969-972)
-          const float tm = sqrtf(t0 * t0 + t1 * t1 + t0 * t0);
-          if (MODE != 1) {
-            const float d = pm - tm;
-            acc += (double)(d * d);
-          }
-          if (MODE != 0) {
-            const float k = gs * (pm - tm) / pm;      // 0/0 -> NaN exactly like torch's sqrt backward (App. A-13)
-            reinterpret_cast<float2*>(o)[c] = make_float2(k * 2.f * p0, k * p1);
-          }
-        }
-      }
-      P[0] = P[1]; P[1] = P[2]; T[0] = T[1]; T[1] = T[2];
-      if (p + 1 < z1 + 2) store_plane(b ^ 1);
-      __syncthreads();
-    }
-  }
-  if (MODE != 1) {
-    const double s = block_sum(acc);
-    if (threadIdx.x == 0) partial[blockIdx.x] = s;
-  }
-}
-
-// backward gather, LDS-tiled: input tile (y0.., x0..) of 8 x 32 voxels needs the coefficient plane at (y-2..y, x-2..x)
-template <int CT>
-struct EdgeDcSmem {
-  float v[2][kTV * 2 * (CT - 1)];
-};
-
-template <int CT, bool FUSE>
-__global__ void __launch_bounds__(kBlock)
-k_edge_bwd_gather_t(const float* __restrict__ dc, float* __restrict__ dprobs, int n, int D, int H, int W,
-                    const float* __restrict__ probs, const uint8_t* __restrict__ labels, const float* __restrict__ gce,
-                    const float* __restrict__ gedge) {
-  __shared__ EdgeDcSmem<CT> sm;
-  constexpr int DV = 2 * (CT - 1);                       // floats per coefficient voxel
-  constexpr int ROW2 = (kTX + 2) * DV / 2;               // float2s per tile row (contiguous in memory)
-  constexpr int N2 = (kTY + 2) * ROW2;                   // float2s per plane tile
-  constexpr int NLD = (N2 + kBlock - 1) / kBlock;
-  const int Do = D - 2, Ho = H - 2, Wo = W - 2;
-  const int ntx = (W + kTX - 1) / kTX, nty = (H + kTY - 1) / kTY, nseg = (D + kZSegT - 1) / kZSegT;
-  const int64_t items = (int64_t)n * nseg * nty * ntx;
-  const int tid = threadIdx.x, lx = tid % kTX, ly = tid / kTX;
-  const float A[3] = {1.f, 2.f, 1.f}, B[3] = {1.f, 0.f, -1.f};
-  for (int64_t it = blockIdx.x; it < items; it += gridDim.x) {
-    int64_t t = it;
-    const int tx = (int)(t % ntx); t /= ntx;
-    const int ty = (int)(t % nty); t /= nty;
-    const int seg = (int)(t % nseg);
-    const int64_t r = t / nseg;
-    const int x0 = tx * kTX, y0 = ty * kTY, z0 = seg * kZSegT;
-    const int z1 = z0 + kZSegT < D ? z0 + kZSegT : D;
-    float2 rv[NLD];
-    auto load_plane = [&](int zo) {                      // coefficient plane zo, tile origin (y0 - 2, x0 - 2)
-#pragma unroll
-      for (int k = 0; k < NLD; ++k) {
-        const int e = tid + k * kBlock;
-        const int j = e / ROW2, q = e % ROW2;            // tile row, float2 inside the row
-        const int i = (q * 2) / DV;                      // tile column of this float2
-        const int oy = y0 - 2 + j, ox = x0 - 2 + i;
-        const bool ok = e < N2 && zo >= 0 && zo < Do && oy >= 0 && oy < Ho && ox >= 0 && ox < Wo;
-        rv[k] = ok ? *reinterpret_cast<const float2*>(dc + (((r * Do + zo) * Ho + oy) * (int64_t)Wo + (x0 - 2)) * DV + q * 2)
-                   : make_float2(0.f, 0.f);
-      }
-    };
-    auto store_plane = [&](int b) {
-#pragma unroll
-      for (int k = 0; k < NLD; ++k) {
-        const int e = tid + k * kBlock;
-        if (e < N2) *reinterpret_cast<float2*>(&sm.v[b][e * 2]) = rv[k];
-      }
-    };
-    auto adj = [&](int b, float (&q0)[CT - 1], float (&q1)[CT - 1]) {
-#pragma unroll
-      for (int c = 0; c < CT - 1; ++c) { q0[c] = 0.f; q1[c] = 0.f; }
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {                    // neighbour (y - j, x - i) = tile (ly + 2 - j, lx + 2 - i); zeros where invalid
-          const float2* d = reinterpret_cast<const float2*>(&sm.v[b][((ly + 2 - j) * (kTX + 2) + lx + 2 - i) * DV]);
-          const float wd = B[j] * A[i], ws = A[j] * A[i];
-#pragma unroll
-          for (int c = 0; c < CT - 1; ++c) {
-            const float2 v = d[c];
-            q0[c] += wd * v.x; q1[c] += ws * v.y;
-          }
-        }
-    };
-    const bool live = y0 + ly < H && x0 + lx < W;
-    float q0[3][CT - 1], q1[3][CT - 1];                  // ring: [0] = zo = z-2, [1] = z-1, [2] = z
-    __syncthreads();
-    // prologue: planes z0-2, z0-1 (through buffer 0 / 1), then the march with plane z in buffer (z - z0) & 1
-    load_plane(z0 - 2); store_plane(0); __syncthreads(); adj(0, q0[0], q1[0]); __syncthreads();
-    load_plane(z0 - 1); store_plane(0); __syncthreads(); adj(0, q0[1], q1[1]); __syncthreads();
-    load_plane(z0); store_plane(0); __syncthreads();
-    for (int z = z0; z < z1; ++z) {
-      const int b = (z - z0) & 1;
-      if (z + 1 < z1) load_plane(z + 1);
-      adj(b, q0[2], q1[2]);
-      if (live) {
-        const int64_t vox = ((r * D + z) * H + (y0 + ly)) * W + (x0 + lx);
-        float* o = dprobs + vox * CT;
-        float g[CT];
-        g[0] = 0.f;
-        const float ge = gedge ? gedge[0] : 1.f;
-#pragma unroll
-        for (int c = 0; c < CT - 1; ++c)
-          g[c + 1] = ge * ((q0[2][c] + 2.f * q0[1][c] + q0[0][c]) + (q1[2][c] - q1[0][c]));
-        if (FUSE) {
-          const float gs = gce[0] / (float)((int64_t)n * D * H * W);
-          const int lab = labels[vox];
-          float pr[CT], dot = 0.f;
-#pragma unroll
-          for (int c = 0; c < CT; ++c) { pr[c] = probs[vox * CT + c]; dot += pr[c] * g[c]; }
-#pragma unroll
-          for (int c = 0; c < CT; ++c) o[c] = pr[c] * (g[c] - dot) + gs * (pr[c] - (c == lab ? 1.f : 0.f));
-        } else {
-#pragma unroll
-          for (int c = 0; c < CT; ++c) o[c] = g[c];
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < CT - 1; ++c) { q0[0][c] = q0[1][c]; q0[1][c] = q0[2][c]; q1[0][c] = q1[1][c]; q1[1][c] = q1[2][c]; }
-      if (z + 1 < z1) store_plane(b ^ 1);
-      __syncthreads();
-    }
-  }
-}
-
-inline unsigned tile_grid(int64_t items) {
-  int64_t b = items;
-  if (b > kMaxBlocks) b = kMaxBlocks;
-  if (b < 1) b = 1;
-  return (unsigned)b;
-}
-inline int64_t march_items(int n, int Dz, int Hy, int Wx) {   // work items of the tiled kernels over a [Dz,Hy,Wx] index space
-  return (int64_t)n * ((Dz + kZSegT - 1) / kZSegT) * ((Hy + kTY - 1) / kTY) * ((Wx + kTX - 1) / kTX);
-}
-
 #define DISPATCH_C(C, CALL)            \
   if ((C) == 8) { CALL(8) }            \
   else if ((C) == 3) { CALL(3) }       \
@@ -777,9 +526,10 @@ int cfun_edge_loss_fwd(const float* probs, const uint8_t* labels, float* loss, i
   if (n <= 0 || D < 3 || H < 3 || W < 3) return (int)hipMemsetAsync(loss, 0, sizeof(float), cfun_st(stream));
   if (ws_bytes < kMaxBlocks * sizeof(double)) return CFUN_EWORKSPACE;
   const int64_t per = (int64_t)(D - 2) * (H - 2) * (W - 2);
-  const unsigned blocks = tile_grid(march_items(n, D - 2, H - 2, W - 2));
-  if (C == 8) hipLaunchKernelGGL((k_edge_march_t<8, 0>), dim3(blocks), dim3(kBlock), 0, cfun_st(stream), probs, labels, (const float*)nullptr, (double*)ws, (float*)nullptr, n, D, H, W);
-  else hipLaunchKernelGGL((k_edge_march_t<3, 0>), dim3(blocks), dim3(kBlock), 0, cfun_st(stream), probs, labels, (const float*)nullptr, (double*)ws, (float*)nullptr, n, D, H, W);
+  const int64_t cols = (int64_t)n * ((D - 2 + kZSeg - 1) / kZSeg) * (H - 2) * (W - 2);
+  const unsigned blocks = vox_grid(cols);
+  if (C == 8) hipLaunchKernelGGL((k_edge_march<8, 0>), dim3(blocks), dim3(kBlock), 0, cfun_st(stream), probs, labels, (const float*)nullptr, (double*)ws, (float*)nullptr, n, D, H, W);
+  else hipLaunchKernelGGL((k_edge_march<3, 0>), dim3(blocks), dim3(kBlock), 0, cfun_st(stream), probs, labels, (const float*)nullptr, (double*)ws, (float*)nullptr, n, D, H, W);
   hipLaunchKernelGGL(k_finalize_sum, dim3(1), dim3(64), 0, cfun_st(stream), (const double*)ws, (int)blocks,
                      1.0 / ((double)per * (double)n), loss);
   CFUN_LAUNCH_CHECK();
@@ -798,13 +548,14 @@ int cfun_edge_loss_bwd(const float* probs, const uint8_t* labels, const float* g
   if (total <= 0) return CFUN_OK;
   if (D < 3 || H < 3 || W < 3) return (int)hipMemsetAsync(dprobs, 0, total * C * sizeof(float), cfun_st(stream));
   if (ws_bytes < cfun_edge_loss_bwd_workspace_bytes(n, D, H, W, C)) return CFUN_EWORKSPACE;
-  const unsigned go = tile_grid(march_items(n, D - 2, H - 2, W - 2)), gi = tile_grid(march_items(n, D, H, W));
+  const int64_t cols_o = (int64_t)n * ((D - 2 + kZSeg - 1) / kZSeg) * (H - 2) * (W - 2);
+  const int64_t cols_i = (int64_t)n * ((D + kZSeg - 1) / kZSeg) * H * W;
   if (C == 8) {
-    hipLaunchKernelGGL((k_edge_march_t<8, 1>), dim3(go), dim3(kBlock), 0, cfun_st(stream), probs, labels, gscale, (double*)nullptr, (float*)ws, n, D, H, W);
-    hipLaunchKernelGGL((k_edge_bwd_gather_t<8, false>), dim3(gi), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dprobs, n, D, H, W, (const float*)nullptr, (const uint8_t*)nullptr, (const float*)nullptr, (const float*)nullptr);
+    hipLaunchKernelGGL((k_edge_march<8, 1>), dim3(vox_grid(cols_o)), dim3(kBlock), 0, cfun_st(stream), probs, labels, gscale, (double*)nullptr, (float*)ws, n, D, H, W);
+    hipLaunchKernelGGL((k_edge_bwd_gather<8, false>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dprobs, n, D, H, W, (const float*)nullptr, (const uint8_t*)nullptr, (const float*)nullptr, (const float*)nullptr);
   } else {
-    hipLaunchKernelGGL((k_edge_march_t<3, 1>), dim3(go), dim3(kBlock), 0, cfun_st(stream), probs, labels, gscale, (double*)nullptr, (float*)ws, n, D, H, W);
-    hipLaunchKernelGGL((k_edge_bwd_gather_t<3, false>), dim3(gi), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dprobs, n, D, H, W, (const float*)nullptr, (const uint8_t*)nullptr, (const float*)nullptr, (const float*)nullptr);
+    hipLaunchKernelGGL((k_edge_march<3, 1>), dim3(vox_grid(cols_o)), dim3(kBlock), 0, cfun_st(stream), probs, labels, gscale, (double*)nullptr, (float*)ws, n, D, H, W);
+    hipLaunchKernelGGL((k_edge_bwd_gather<3, false>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dprobs, n, D, H, W, (const float*)nullptr, (const uint8_t*)nullptr, (const float*)nullptr, (const float*)nullptr);
   }
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
@@ -817,9 +568,10 @@ int cfun_edge_loss_fwd_save(const float* probs, const uint8_t* labels, float* lo
   if (n <= 0 || D < 3 || H < 3 || W < 3) return CFUN_EINVAL;
   if (ws_bytes < kMaxBlocks * sizeof(double)) return CFUN_EWORKSPACE;
   const int64_t per = (int64_t)(D - 2) * (H - 2) * (W - 2);
-  const unsigned blocks = tile_grid(march_items(n, D - 2, H - 2, W - 2));
-  if (C == 8) hipLaunchKernelGGL((k_edge_march_t<8, 2>), dim3(blocks), dim3(kBlock), 0, cfun_st(stream), probs, labels, (const float*)nullptr, (double*)ws, dc, n, D, H, W);
-  else hipLaunchKernelGGL((k_edge_march_t<3, 2>), dim3(blocks), dim3(kBlock), 0, cfun_st(stream), probs, labels, (const float*)nullptr, (double*)ws, dc, n, D, H, W);
+  const int64_t cols = (int64_t)n * ((D - 2 + kZSeg - 1) / kZSeg) * (H - 2) * (W - 2);
+  const unsigned blocks = vox_grid(cols);
+  if (C == 8) hipLaunchKernelGGL((k_edge_march<8, 2>), dim3(blocks), dim3(kBlock), 0, cfun_st(stream), probs, labels, (const float*)nullptr, (double*)ws, dc, n, D, H, W);
+  else hipLaunchKernelGGL((k_edge_march<3, 2>), dim3(blocks), dim3(kBlock), 0, cfun_st(stream), probs, labels, (const float*)nullptr, (double*)ws, dc, n, D, H, W);
   hipLaunchKernelGGL(k_finalize_sum, dim3(1), dim3(64), 0, cfun_st(stream), (const double*)ws, (int)blocks,
                      1.0 / ((double)per * (double)n), loss);
   CFUN_LAUNCH_CHECK();
@@ -834,9 +586,9 @@ int cfun_mask_losses_bwd_saved(const float* probs, const uint8_t* labels, const 
   const int64_t total = (int64_t)n * D * H * W;
   if (total <= 0) return CFUN_OK;
   if (D < 3 || H < 3 || W < 3 || !dc || !g_edge) return CFUN_EINVAL;
-  const unsigned gi = tile_grid(march_items(n, D, H, W));
-  if (C == 8) hipLaunchKernelGGL((k_edge_bwd_gather_t<8, true>), dim3(gi), dim3(kBlock), 0, cfun_st(stream), dc, dlogits, n, D, H, W, probs, labels, g_ce, g_edge);
-  else hipLaunchKernelGGL((k_edge_bwd_gather_t<3, true>), dim3(gi), dim3(kBlock), 0, cfun_st(stream), dc, dlogits, n, D, H, W, probs, labels, g_ce, g_edge);
+  const int64_t cols_i = (int64_t)n * ((D + kZSeg - 1) / kZSeg) * H * W;
+  if (C == 8) hipLaunchKernelGGL((k_edge_bwd_gather<8, true>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), dc, dlogits, n, D, H, W, probs, labels, g_ce, g_edge);
+  else hipLaunchKernelGGL((k_edge_bwd_gather<3, true>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), dc, dlogits, n, D, H, W, probs, labels, g_ce, g_edge);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }
@@ -849,13 +601,14 @@ int cfun_mask_losses_bwd(const float* probs, const uint8_t* labels, const float*
   if (total <= 0) return CFUN_OK;
   if (D < 3 || H < 3 || W < 3) return CFUN_EINVAL;   // no edge term: use cfun_softmax_ce_bwd
   if (ws_bytes < cfun_edge_loss_bwd_workspace_bytes(n, D, H, W, C)) return CFUN_EWORKSPACE;
-  const unsigned go = tile_grid(march_items(n, D - 2, H - 2, W - 2)), gi = tile_grid(march_items(n, D, H, W));
+  const int64_t cols_o = (int64_t)n * ((D - 2 + kZSeg - 1) / kZSeg) * (H - 2) * (W - 2);
+  const int64_t cols_i = (int64_t)n * ((D + kZSeg - 1) / kZSeg) * H * W;
   if (C == 8) {
-    hipLaunchKernelGGL((k_edge_march_t<8, 1>), dim3(go), dim3(kBlock), 0, cfun_st(stream), probs, labels, g_edge, (double*)nullptr, (float*)ws, n, D, H, W);
-    hipLaunchKernelGGL((k_edge_bwd_gather_t<8, true>), dim3(gi), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dlogits, n, D, H, W, probs, labels, g_ce, (const float*)nullptr);
+    hipLaunchKernelGGL((k_edge_march<8, 1>), dim3(vox_grid(cols_o)), dim3(kBlock), 0, cfun_st(stream), probs, labels, g_edge, (double*)nullptr, (float*)ws, n, D, H, W);
+    hipLaunchKernelGGL((k_edge_bwd_gather<8, true>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dlogits, n, D, H, W, probs, labels, g_ce, (const float*)nullptr);
   } else {
-    hipLaunchKernelGGL((k_edge_march_t<3, 1>), dim3(go), dim3(kBlock), 0, cfun_st(stream), probs, labels, g_edge, (double*)nullptr, (float*)ws, n, D, H, W);
-    hipLaunchKernelGGL((k_edge_bwd_gather_t<3, true>), dim3(gi), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dlogits, n, D, H, W, probs, labels, g_ce, (const float*)nullptr);
+    hipLaunchKernelGGL((k_edge_march<3, 1>), dim3(vox_grid(cols_o)), dim3(kBlock), 0, cfun_st(stream), probs, labels, g_edge, (double*)nullptr, (float*)ws, n, D, H, W);
+    hipLaunchKernelGGL((k_edge_bwd_gather<3, true>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dlogits, n, D, H, W, probs, labels, g_ce, (const float*)nullptr);
   }
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;

@@ -70,8 +70,8 @@ def test_mask_losses_multi_segment(emu):
 
 
 def test_mask_losses_multi_tile(emu):
-    """Volumes wider than one 8 x 32 (y, x) LDS tile and deeper than one 32-plane segment of the tiled edge kernels, with
-    ragged tiles on every axis; 2 samples."""
+    """Two samples, three z-segments of the marching edge kernels (one ragged), non-cubic (y, x) extent, labels in blocks
+    of three along x (flat target regions: the sqrt at 0 of App. A-13 is exercised on the target side)."""
     rng = np.random.default_rng(6)
     logits = rng.normal(size=(2, 8, 37, 13, 39)).astype(np.float32)
     labels = np.repeat(rng.integers(0, 8, size=(2, 37, 13, 13)), 3, axis=3).astype(np.uint8)
