@@ -43,3 +43,21 @@ def test_bench_line_contract():
     alt = d.get("alt_3xbf16")        # the opt-in path is reported beside, never as, `value`
     if alt is not None:
         assert alt["unit"] == d["unit"] and alt["value"] > 0 and "not used for `value`" in alt["what"]
+
+
+def test_pmc_records_match_the_kernel_source():
+    """`roofline.traffic` / `mfma_util_pmc` come from committed rocprofv3 --pmc passes, not from the bench run itself; the
+    JSONs record the git blob of the kernel source they were collected on, and bench.py reports them only while that is
+    still the tree's conv3d_mfma.h -- so a kernel change without a new counter pass fails HERE instead of going stale."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    for rel, field in ((bench.PMC_TRAFFIC_JSON, "traffic_bytes_per_launch"), (bench.PMC_MFMA_JSON, "mfma_util")):
+        value, src = bench.pmc_record(rel, field)
+        assert src["current"] is True and value is not None and value > 0, src
+        assert src["file"] == rel and len(src["kernel_src_blob"]) == 40
+    line = _latest_line()["roofline"]
+    if "traffic_source" in line:          # (lines printed since the fields are source-tagged)
+        assert line["traffic_source"]["file"].startswith("profiles/")
+        if line["traffic"] is not None:
+            assert line["traffic_source"]["current"] is True
