@@ -18,6 +18,11 @@ int cfun_conv_stem_fwd(const float*, const float*, const float*, const float*, f
 int cfun_conv_pointwise_supported(const CfunConv3dParams*);
 int cfun_conv_pointwise_fwd(const float*, const float*, const float*, const float*, const float*, float*,
                             const CfunConv3dParams*, hipStream_t);
+// conv3d_wino.hip
+int cfun_wino_supported(const CfunConv3dParams*);
+size_t cfun_wino_workspace_bytes(const CfunConv3dParams*);
+int cfun_wino_fwd(const float*, const float*, int, const float*, const float*, const float*, float*,
+                  const CfunConv3dParams*, void*, size_t, hipStream_t);
 // conv3d_wgrad_c1.hip
 int cfun_wgrad_c1_supported(const CfunConv3dParams*);
 size_t cfun_wgrad_c1_ws(const CfunConv3dParams*);
@@ -292,7 +297,9 @@ size_t cfun_conv3d_fwd_workspace_bytes(const CfunConv3dParams* p) {
   ConvMode md;
   int nsub;
   fwd_mode(p, s, &md, &nsub);
-  return cfun_align_up(s->fwd_ws(nsub, *p, md) + 256, 256);
+  size_t need = s->fwd_ws(nsub, *p, md);
+  if (cfun_wino_supported(p) && cfun_wino_workspace_bytes(p) > need) need = cfun_wino_workspace_bytes(p);
+  return cfun_align_up(need + 256, 256);
 }
 
 int cfun_conv3d_fwd(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
@@ -311,6 +318,8 @@ int cfun_conv3d_fwd(const float* x, const float* wp, const float* scale, const f
     int nsub;
     fwd_mode(p, s, &md, &nsub);
     if (ws && !cfun_aligned16(ws)) return CFUN_EALIGN;
+    if (ws && cfun_wino_supported(p) && ws_bytes >= cfun_wino_workspace_bytes(p))   // x axis in the Winograd F(2,3) domain
+      return cfun_wino_fwd(x, wp, 0, scale, shift, res, y, p, ws, ws_bytes, cfun_st(stream));
     return s->fwd(nsub, x, wp, scale, shift, res, y, *p, md, ws, ws ? ws_bytes : 0, cfun_st(stream));
   }
   if (p->algo == CFUN_ALGO_MFMA) return CFUN_EINVAL;
@@ -329,7 +338,9 @@ size_t cfun_conv3d_bwd_data_workspace_bytes(const CfunConv3dParams* p) {
     ConvMode md = kPlain;
     md.flip = 1;
     if (p->d2s) { md.in_s2d = 1; md.in_cqp = p->Co >> 3; md.in_cq = p->d2s_cq > 0 ? p->d2s_cq : md.in_cqp; }
-    return cfun_align_up(s->fwd_ws(pick_tile(s, q.Co, false), q, md) + 256, 256);   // split-K partials
+    size_t need = s->fwd_ws(pick_tile(s, q.Co, false), q, md);   // split-K partials
+    if (!p->d2s && cfun_wino_supported(&q) && cfun_wino_workspace_bytes(&q) > need) need = cfun_wino_workspace_bytes(&q);
+    return cfun_align_up(need + 256, 256);
   }
   return 256;
 }
@@ -361,6 +372,8 @@ int cfun_conv3d_bwd_data(const float* g, const float* wpT, float* dx, const Cfun
       md.in_cq = p->d2s_cq > 0 ? p->d2s_cq : md.in_cqp;
       md.tap_skip = p->tap_skip ? 2 : 0;
     }
+    if (!p->up2 && !p->d2s && cfun_aligned16(ws) && cfun_wino_supported(&q) && ws_bytes >= cfun_wino_workspace_bytes(&q))
+      return cfun_wino_fwd(g, wpT, 1, nullptr, nullptr, nullptr, dx, &q, ws, ws_bytes, cfun_st(stream));
     if (!p->up2) return s->fwd(nsub, g, wpT, nullptr, nullptr, nullptr, dx, q, md, ws, cfun_aligned16(ws) ? ws_bytes : 0, cfun_st(stream));
     if (ws_bytes < cfun_conv3d_bwd_data_workspace_bytes(p) || !cfun_aligned16(ws)) return CFUN_EWORKSPACE;
     const int rc = s->fwd(nsub, g, wpT, nullptr, nullptr, nullptr, (float*)ws, q, md, nullptr, 0, cfun_st(stream));

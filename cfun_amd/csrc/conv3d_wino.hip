@@ -1,0 +1,331 @@
+// 3x3x3 stride-1 convolution with the x axis in the Winograd F(2,3) domain, on the fp32 matrix cores.
+//
+// Along x every pair of outputs is computed from 4 transformed inputs and 4 transformed taps instead of 2 x 3
+// products (Lavin & Gray's minimal filtering, 1-D): the implicit GEMM runs 9 (dz,dy) x 4 points instead of 27 taps
+// per two output columns, i.e. 2/3 of the MFMAs of k_conv_mfma for the same result.  z and y stay direct.
+//   input transform  (while staging a chunk of 4 channels into LDS):  v = (d0-d2, d1+d2, d2-d1, d1-d3)
+//   weight transform (k_wino_weights, once per launch, from the packed [tap][Ci][CoP] weights):
+//                    u = (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2)
+//   output transform (registers, before the fused epilogue):          y_even = m0+m1+m2,  y_odd = m1-m2-m3
+// All coefficients are 0, +-1, 1/2: the result differs from the direct sum only by fp32 rounding order (measured in
+// tests/kernel_cases.py against the fp64 oracle next to the direct kernel).
+//
+//   block  = 256 threads (4 waves) -> 4(z) x 4(y) x 16(x) output voxels x (16*NSUB) output channels (same tile,
+//            raster and XCD remap as k_conv_mfma)
+//   wave w = z-plane w; MFMA columns = 2 rows x 8 x-pairs, 2 row groups; accumulators [2 row groups][4 points][NSUB]
+//   LDS    = V [4 ch][6 z][6 y][8 pairs] x float4 (the 4 points) + U [9 (dz,dy)][4 ch][16*NSUB] x float4: a fragment
+//            read is one ds_read_b128 per (dz,dy) for all 4 points (8 consecutive lanes = 128 contiguous bytes)
+#include <stdlib.h>
+
+#include "conv3d_mfma.h"
+
+namespace {
+
+using cfun_mfma::cdiv;
+
+constexpr int TD = 4, TH = 4, TW = 16, IZ = 6, IY = 6, NPAIR = 8;
+constexpr int VPLANE4 = IZ * IY * NPAIR;      // float4 (= the 4 points of one x-pair) per channel of the halo tile
+constexpr int X_ITEMS = IZ * IY * NPAIR, X_IT = cdiv(X_ITEMS, 256);
+
+// u[r9][ci][co][point] from wp[tap = r9*3 + dx][ci][co]  (flip: the data gradient reads tap 26 - t)
+__global__ void __launch_bounds__(256)
+k_wino_weights(const float* __restrict__ wp, float4* __restrict__ u, int Ci, int CoP, int flip) {
+  const int64_t per = (int64_t)Ci * CoP, total = 9 * per;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int r9 = (int)(i / per);
+  const int64_t e = i - r9 * per;
+  float g[3];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) {
+    const int tap = r9 * 3 + dx;
+    g[dx] = wp[(int64_t)(flip ? 26 - tap : tap) * per + e];
+  }
+  u[i] = make_float4(g[0], 0.5f * ((g[0] + g[2]) + g[1]), 0.5f * ((g[0] + g[2]) - g[1]), g[2]);
+}
+
+template <int NSUB>
+__global__ void __launch_bounds__(256)
+k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const float* __restrict__ scale,
+            const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y, CfunConv3dParams p,
+            int ntz, int nty, int ntx, int ncot, float* __restrict__ partial, int chunks_per_split) {
+  constexpr int NT = 16 * NSUB;
+  constexpr int W_ITEMS = 36 * NT;            // float4 (= 4 points of one output channel) items per chunk: 36 rows x NT
+  constexpr int W_LOADS = cdiv(W_ITEMS, 256);
+  CFUN_DYN_LDS(float4, smem);
+  float4* Vl = smem;                          // [4 ch][36 rows][8 pairs] x 4 points
+  float4* Ul = smem + 4 * VPLANE4;            // [9 (dz,dy)][4 ch][NT] x 4 points
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned lid = cfun_mfma::xcd_remap(blockIdx.x, gridDim.x);
+  const int cot = lid % ncot; lid /= ncot;
+  const unsigned per_n = (unsigned)(ntz * nty * ntx);
+  const int n = lid / per_n;
+  int tz, ty, tx;
+  cfun_mfma::tile_raster(lid - (unsigned)n * per_n, ntz, nty, ntx, tz, ty, tx);
+  const int z0 = tz * TD, y0 = ty * TH, x0 = tx * TW;
+  const int cobase = cot * NT;
+
+  // ---- staging descriptors.  X item = (z, y, x-pair j) of the halo tile -> 4 voxels x = 2j .. 2j+3 (4 channels each);
+  // out-of-volume voxels load element 0 and are zeroed by a select (no divergent branches in the chunk loop)
+  const float* in_ptr[X_IT][4];
+  unsigned in_ok = 0;
+#pragma unroll
+  for (int i = 0; i < X_IT; ++i) {
+    const int it = tid + i * 256;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) in_ptr[i][k] = x;
+    if (it < X_ITEMS) {
+      const int j = it & 7, yi = (it >> 3) % IY, zi = it / (NPAIR * IY);
+      const int vz = z0 - p.pd + zi, vy = y0 - p.ph + yi, vx = x0 - p.pw + 2 * j;
+      if (vz >= 0 && vz < p.Di && vy >= 0 && vy < p.Hi) {
+        const int64_t row = (((int64_t)n * p.Di + vz) * p.Hi + vy) * p.Wi;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (vx + k >= 0 && vx + k < p.Wi) { in_ok |= 1u << (i * 4 + k); in_ptr[i][k] = x + (row + vx + k) * p.Ci; }
+      }
+    }
+  }
+  int w_off[W_LOADS];      // float4 index into u for chunk 0, or -1
+#pragma unroll
+  for (int i = 0; i < W_LOADS; ++i) {
+    const int it = tid + i * 256, row = it / NT, co = it % NT;
+    w_off[i] = (it < W_ITEMS && cobase + co < p.CoP) ? (((row >> 2) * p.Ci + (row & 3)) * p.CoP + cobase + co) : -1;
+  }
+  const int w_step = 4 * p.CoP;
+  float4 xin[X_IT][4], win[W_LOADS];
+  auto prefetch = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(in_ptr[i][k] + c * 4);
+        xin[i][k] = ((in_ok >> (i * 4 + k)) & 1u) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+    for (int i = 0; i < W_LOADS; ++i) {
+      const float4 v = u[w_off[i] >= 0 ? w_off[i] + c * w_step : 0];
+      win[i] = w_off[i] >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i) {
+      const int it = tid + i * 256;
+      if (it < X_ITEMS) {
+        const float4 d0 = xin[i][0], d1 = xin[i][1], d2 = xin[i][2], d3 = xin[i][3];
+        Vl[it] = make_float4(d0.x - d2.x, d1.x + d2.x, d2.x - d1.x, d1.x - d3.x);
+        Vl[VPLANE4 + it] = make_float4(d0.y - d2.y, d1.y + d2.y, d2.y - d1.y, d1.y - d3.y);
+        Vl[2 * VPLANE4 + it] = make_float4(d0.z - d2.z, d1.z + d2.z, d2.z - d1.z, d1.z - d3.z);
+        Vl[3 * VPLANE4 + it] = make_float4(d0.w - d2.w, d1.w + d2.w, d2.w - d1.w, d1.w - d3.w);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < W_LOADS; ++i) {
+      const int it = tid + i * 256;
+      if (it < W_ITEMS) Ul[it] = win[i];
+    }
+  };
+
+  f32x4 acc[2][4][NSUB];
+#pragma unroll
+  for (int mg = 0; mg < 2; ++mg)
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+      for (int nn = 0; nn < NSUB; ++nn) acc[mg][pt][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment bases (float4 = the 4 points): B column (lane & 15) = (row (lane>>3)&1 of the row group, pair lane&7),
+  // k = channel lane>>4;  A row (lane & 15) = output channel
+  const float4* Vw = Vl + (lane >> 4) * VPLANE4 + (wv * IY + ((lane >> 3) & 1)) * NPAIR + (lane & 7);
+  const float4* Uw = Ul + (lane >> 4) * NT + (lane & 15);
+
+  const int nchunks = p.Ci >> 2;
+  const int c_begin = blockIdx.y * chunks_per_split;
+  const int c_end = (c_begin + chunks_per_split < nchunks) ? c_begin + chunks_per_split : nchunks;
+  if (c_begin < c_end) prefetch(c_begin);
+  for (int c = c_begin; c < c_end; ++c) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (c + 1 < c_end) prefetch(c + 1);
+    float4 a[NSUB], b[2];
+    auto frag = [&](int r9) {
+      const int dz = r9 / 3, dy = r9 - dz * 3;
+#pragma unroll
+      for (int nn = 0; nn < NSUB; ++nn) a[nn] = Uw[r9 * 4 * NT + nn * 16];
+#pragma unroll
+      for (int mg = 0; mg < 2; ++mg) b[mg] = Vw[(dz * IY + mg * 2 + dy) * NPAIR];
+    };
+    frag(0);
+#ifndef CFUN_HIP_EMULATION
+    __builtin_amdgcn_sched_group_barrier(0x100, NSUB + 2, 0);
+#endif
+#pragma unroll
+    for (int r9 = 0; r9 < 9; ++r9) {
+      float av[NSUB][4], bv[2][4];
+#pragma unroll
+      for (int nn = 0; nn < NSUB; ++nn) { av[nn][0] = a[nn].x; av[nn][1] = a[nn].y; av[nn][2] = a[nn].z; av[nn][3] = a[nn].w; }
+#pragma unroll
+      for (int mg = 0; mg < 2; ++mg) { bv[mg][0] = b[mg].x; bv[mg][1] = b[mg].y; bv[mg][2] = b[mg].z; bv[mg][3] = b[mg].w; }
+      if (r9 + 1 < 9) frag(r9 + 1);      // the next (dz,dy)'s fragments are in flight under this one's MFMAs
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+        for (int mg = 0; mg < 2; ++mg)
+#pragma unroll
+          for (int nn = 0; nn < NSUB; ++nn)
+            acc[mg][pt][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[nn][pt], bv[mg][pt], acc[mg][pt][nn], 0, 0, 0);
+#ifndef CFUN_HIP_EMULATION
+      // keep that order in the schedule: the LDS reads first, then the MFMA block that hides their latency
+      if (r9 + 1 < 9) __builtin_amdgcn_sched_group_barrier(0x100, NSUB + 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8 * NSUB, 0);
+#endif
+    }
+  }
+
+  // ---- output transform + epilogue: lane owns voxels (z0+wv, y0+2mg+r, x0+2j+{0,1}), channels nn*16+(lane>>4)*4..+3
+  const int oz = z0 + wv, oxe = x0 + 2 * (lane & 7);
+  if (oz >= p.Do) return;
+  auto emit = [&](int oy, int ox, int co, const f32x4& a4) {
+    if (oy >= p.Ho || ox >= p.Wo || co >= p.Co) return;
+    const int64_t v = (((int64_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox;
+    float4 r = make_float4(a4[0], a4[1], a4[2], a4[3]);
+    if (gridDim.y > 1) {
+      *reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.y * p.N * p.Do * p.Ho * p.Wo + v) * p.Co + co) = r;
+      return;
+    }
+    if (p.scale_mode) {
+      const float4 s4 = *reinterpret_cast<const float4*>(scale + (p.scale_mode == 2 ? n * p.Co : 0) + co);
+      r.x *= s4.x; r.y *= s4.y; r.z *= s4.z; r.w *= s4.w;
+    }
+    if (p.has_shift) {
+      const float4 t = *reinterpret_cast<const float4*>(shift + co);
+      r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+    }
+    if (p.res_mode) {
+      const float4 t = *reinterpret_cast<const float4*>(res + v * p.Co + co);
+      r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+    }
+    r.x = cfun_apply_act(r.x, p.act, p.slope); r.y = cfun_apply_act(r.y, p.act, p.slope);
+    r.z = cfun_apply_act(r.z, p.act, p.slope); r.w = cfun_apply_act(r.w, p.act, p.slope);
+    *reinterpret_cast<float4*>(y + v * p.Co + co) = r;
+  };
+#pragma unroll
+  for (int mg = 0; mg < 2; ++mg)
+#pragma unroll
+    for (int nn = 0; nn < NSUB; ++nn) {
+      const f32x4 m0 = acc[mg][0][nn], m1 = acc[mg][1][nn], m2 = acc[mg][2][nn], m3 = acc[mg][3][nn];
+      const int oy = y0 + mg * 2 + ((lane >> 3) & 1), co = cobase + nn * 16 + (lane >> 4) * 4;
+      emit(oy, oxe, co, (m0 + m1) + m2);
+      emit(oy, oxe + 1, co, (m1 - m2) - m3);
+    }
+}
+
+// 16-channel subtiles per block.  NSUB <= 3 keeps two waves per SIMD (134 VGPR + 96 accumulators); 80 = 5 x 16 runs
+// unpadded at one wave per SIMD, which measured faster than 48 + 32 (tools/bench_layers.py, profiles/round2_ab_layers.log)
+int wino_nsub(int co) {
+  static int mx = 0;      // tuning knob: CFUN_WINO_MAX_NSUB
+  if (!mx) {
+    const char* e = getenv("CFUN_WINO_MAX_NSUB");
+    mx = e ? atoi(e) : -1;
+    if (mx == 0 || mx > 5) mx = -1;
+  }
+  if (mx < 0 && co == 80) return 5;
+  const int cap = mx < 0 ? 3 : mx;
+  int best = 1, best_pad = 1 << 30;
+  for (int n = 1; n <= cap; ++n) {
+    const int nt = 16 * n, pad = (co + nt - 1) / nt * nt;
+    if (pad <= best_pad) { best_pad = pad; best = n; }
+  }
+  return best;
+}
+
+struct Plan {
+  int nsub, ntz, nty, ntx, ncot, ksplit, cps;
+  int64_t nblk;
+  size_t u_bytes, part_bytes;
+};
+
+Plan make_plan(const CfunConv3dParams& p, size_t ws_for_partials) {
+  Plan w;
+  w.nsub = wino_nsub(p.Co);
+  const int nt = 16 * w.nsub;
+  w.ntz = cdiv(p.Do, TD); w.nty = cdiv(p.Ho, TH); w.ntx = cdiv(p.Wo, TW); w.ncot = cdiv(p.Co, nt);
+  w.nblk = (int64_t)p.N * w.ntz * w.nty * w.ntx * w.ncot;
+  w.u_bytes = cfun_align_up((size_t)36 * p.Ci * p.CoP * sizeof(float), 256);
+  w.ksplit = cfun_mfma::splitk_factor(w.nblk, p.Ci >> 2, p, ws_for_partials);
+  w.cps = cdiv(p.Ci >> 2, w.ksplit);
+  w.part_bytes = w.ksplit > 1 ? (size_t)w.ksplit * p.N * p.Do * p.Ho * p.Wo * p.Co * sizeof(float) : 0;
+  return w;
+}
+
+template <int NSUB>
+int launch(const float* x, const float4* u, const float* scale, const float* shift, const float* res, float* y,
+           const CfunConv3dParams& p, const Plan& w, float* partial, hipStream_t st) {
+  const size_t lds = (size_t)(4 * VPLANE4 + 36 * 16 * NSUB) * sizeof(float4);
+  auto kern = k_conv_wino<NSUB>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)w.nblk, (unsigned)w.ksplit), dim3(256), lds, st, x, u, scale, shift, res, y, p,
+                     w.ntz, w.nty, w.ntx, w.ncot, partial, w.cps);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+}  // namespace
+
+// ---- entry points used by conv3d.hip
+
+// CFUN_WINO: 0 = never, 1 = every supported shape, unset = shapes where it measured faster (tools/bench_layers.py)
+static int wino_knob() {
+  static int v = -2;
+  if (v == -2) {
+    const char* e = getenv("CFUN_WINO");
+    v = e ? atoi(e) : -1;
+  }
+  return v;
+}
+
+int cfun_wino_supported(const CfunConv3dParams* p) {
+  const int knob = wino_knob();
+  if (knob == 0 || p->algo == CFUN_ALGO_DIRECT || p->algo == CFUN_ALGO_MFMA) return 0;
+  if (p->kd != 3 || p->kh != 3 || p->kw != 3 || p->stride != 1 || p->pd != 1 || p->ph != 1 || p->pw != 1) return 0;
+  if (p->up2 || p->d2s || p->tap_skip || p->res_up2 || (p->Ci & 3) || (p->Co & 3)) return 0;
+  if (p->Do != p->Di || p->Ho != p->Hi || p->Wo != p->Wi) return 0;
+  if ((int64_t)p->N * p->Do * p->Ho * p->Wo == 0) return 0;
+  if (knob == 1 || p->algo == CFUN_ALGO_WINO) return 1;
+  return p->Co >= 32 && p->Ci >= 16;
+}
+
+size_t cfun_wino_workspace_bytes(const CfunConv3dParams* p) {
+  const Plan w = make_plan(*p, (size_t)-1);
+  return w.u_bytes + cfun_align_up(w.part_bytes, 256);
+}
+
+// wp: packed weights [27][Ci][CoP] of the conv that is run (the data gradient passes the transposed pack and flip = 1)
+int cfun_wino_fwd(const float* x, const float* wp, int flip, const float* scale, const float* shift, const float* res,
+                  float* y, const CfunConv3dParams* p, void* ws, size_t ws_bytes, hipStream_t st) {
+  Plan w = make_plan(*p, 0);
+  if (!ws || ws_bytes < w.u_bytes) return CFUN_EWORKSPACE;
+  w = make_plan(*p, ws_bytes - w.u_bytes);
+  if (w.nblk > 0x7fffffffLL) return CFUN_EINVAL;
+  float4* u = (float4*)ws;
+  float* partial = (float*)((char*)ws + w.u_bytes);
+  const int64_t nu = (int64_t)9 * p->Ci * p->CoP;
+  hipLaunchKernelGGL(k_wino_weights, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, st, wp, u, p->Ci, p->CoP, flip);
+  CFUN_LAUNCH_CHECK();
+  int rc;
+  switch (w.nsub) {
+    case 1: rc = launch<1>(x, u, scale, shift, res, y, *p, w, partial, st); break;
+    case 2: rc = launch<2>(x, u, scale, shift, res, y, *p, w, partial, st); break;
+    case 3: rc = launch<3>(x, u, scale, shift, res, y, *p, w, partial, st); break;
+    case 4: rc = launch<4>(x, u, scale, shift, res, y, *p, w, partial, st); break;
+    default: rc = launch<5>(x, u, scale, shift, res, y, *p, w, partial, st); break;
+  }
+  if (rc) return rc;
+  if (w.ksplit > 1) return cfun_splitk_finish(partial, w.ksplit, scale, shift, res, y, p, st);
+  return CFUN_OK;
+}

@@ -7,7 +7,7 @@ import torch
 import torch.nn.functional as F
 
 from cfun_amd import ops
-from cfun_amd._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA
+from cfun_amd._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_WINO
 from oracle import cfun_oracle as orc
 
 RTOL = 2e-5
@@ -94,10 +94,19 @@ CONV_CASES = {
     "mfma_333_d2s_res": (2, (3, 4, 5), 8, 64, (3, 3, 3), dict(algo=ALGO_MFMA, d2s=True, res=True)),
     "auto_111_8_8_pointwise": (1, (16, 32, 64), 8, 8, (1, 1, 1), dict(algo=ALGO_AUTO, res=True, res_up2=True, shift=True, act=ACT_RELU, scale=True)),
     "direct_333_d2s_res_cq3": (1, (3, 4, 5), 3, 24, (3, 3, 3), dict(algo=ALGO_DIRECT, d2s=True, res=True, act=ACT_LRELU)),
+    # Winograd F(2,3) along x (conv3d_wino.hip): forward and data gradient; ragged tiles, odd widths, epilogue, split-K
+    "wino_333_8_48_ragged": (1, (5, 6, 18), 8, 48, (3, 3, 3), dict(algo=ALGO_WINO)),
+    "wino_333_epilogue_odd_w": (2, (4, 5, 7), 8, 40, (3, 3, 3), dict(algo=ALGO_WINO, act=ACT_LRELU, scale=True, per_n=True, res=True, shift=True)),
+    "wino_333_two_cotiles": (1, (3, 4, 5), 4, 96, (3, 3, 3), dict(algo=ALGO_WINO)),
+    "wino_333_splitk_epilogue": (2, (4, 4, 8), 32, 16, (3, 3, 3), dict(algo=ALGO_WINO, act=ACT_LRELU, scale=True, per_n=True, shift=True, res=True)),
+    "wino_333_40_40": (1, (4, 5, 19), 40, 40, (3, 3, 3), dict(algo=ALGO_WINO)),
 }
 # bigger shapes: many workgroups, several chunks per wgrad block, channel counts of the real nets (GPU tier)
 CONV_CASES_LARGE = {
     "mfma_333_40_40_32cube": (2, (32, 32, 32), 40, 40, (3, 3, 3), dict(algo=ALGO_MFMA, act=ACT_LRELU, res=True)),
+    "wino_333_40_40_32cube": (2, (32, 32, 32), 40, 40, (3, 3, 3), dict(algo=ALGO_WINO, act=ACT_LRELU, res=True)),
+    "wino_333_80_80_24cube": (2, (24, 24, 26), 80, 80, (3, 3, 3), dict(algo=ALGO_WINO, shift=True)),
+    "wino_333_128_256_fpn": (1, (8, 16, 16), 128, 256, (3, 3, 3), dict(algo=ALGO_WINO, shift=True, act=ACT_RELU)),
     "mfma_333_128_256_fpn": (1, (8, 16, 16), 128, 256, (3, 3, 3), dict(algo=ALGO_MFMA, shift=True, act=ACT_RELU)),
     "mfma_333_320_160_up2": (2, (6, 6, 6), 320, 160, (3, 3, 3), dict(algo=ALGO_MFMA, up2=True)),
     "mfma_333_s2_80_160": (2, (24, 24, 24), 80, 160, (3, 3, 3), dict(algo=ALGO_MFMA, stride=2)),
