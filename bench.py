@@ -56,8 +56,25 @@ def dominant_kernel_match(cfg):
     return match
 
 
-PMC_TRAFFIC_JSON = "profiles/round2_pmc_conv_l4_0.json"
-PMC_MFMA_JSON = "profiles/round2_pmc_mfma_conv_l4_0.json"
+PMC_TRAFFIC_JSON = "profiles/round2_pmc_wino_l4_0.json"
+PMC_MFMA_JSON = "profiles/round2_pmc_mfma_wino_l4_0.json"
+
+
+def dominant_kernel_info(cfg, n_roi):
+    """Which kernel the library runs for conv_norm_lrelu_l4.0 (cfun_conv3d_fwd_kernel) and the MFMA flops it actually
+    issues per launch: the Winograd kernel runs 9 (dz,dy) x 4 points instead of 27 taps per pair of x outputs (x 2/3),
+    on output-channel tiles padded to 16 * NSUB (40 -> 48)."""
+    import ctypes as C
+    from cfun_amd import _lib, ops
+    b, side = cfg.UNET_MASK_BRANCH_CHANNEL, tuple(cfg.MASK_POOL_SIZE)
+    spec = ops.ConvSpec(k=(3, 3, 3), co=2 * b, pad=(1, 1, 1))
+    p = ops._params(spec, (n_roi,) + side + (2 * b,), False, False, False)
+    kern = int(_lib.load().cfun_conv3d_fwd_kernel(C.byref(p)))
+    co_pad = (2 * b + 47) // 48 * 48 if 2 * b != 80 else 80
+    tiles = n_roi * -(-side[0] // 4) * -(-side[1] // 4) * -(-side[2] // 16)
+    macs_per_tile_ch = 256 * 27 * (2.0 / 3.0 if kern == 2 else 1.0)
+    executed = 2.0 * tiles * macs_per_tile_ch * (2 * b) * co_pad
+    return kern, executed
 
 
 def git_blob_sha1(path):
@@ -269,6 +286,9 @@ def main():
         flops = 2.0 * (2 * b) * (2 * b) * 27 * side[0] * side[1] * side[2] * n_roi_launch   # per launch
         durs = timer.durations_ms("mfma")
         durs_h = timer.durations_ms("hbm")
+        kern, executed = dominant_kernel_info(cfg, n_roi_launch)
+        kname = {2: "k_conv_wino<3> (x axis in the Winograd F(2,3) domain: 2/3 of the direct MACs on the MFMA pipe, "
+                    "incl. its k_wino_weights transform launch)", 1: "k_conv_mfma<3,3,3,1,3>"}.get(kern, "kernel code %d" % kern)
         t_k = sum(durs) / max(len(durs), 1) * 1e-3
         achieved = flops / t_k / 1e12 if t_k > 0 else 0.0
         result = {
@@ -295,11 +315,13 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": None, "mfma_util_pmc": None,
-                         "kernel": "k_conv_mfma<3,3,3,1,3> (conv_norm_lrelu_l4.0: 3x3x3 %d->%d @ %dx%d^3)"
-                                   % (2 * b, 2 * b, n_roi_launch, side[0]) if len(set(side)) == 1 else
-                                   "k_conv_mfma (conv_norm_lrelu_l4.0: 3x3x3 %d->%d @ %dx%s)"
-                                   % (2 * b, 2 * b, n_roi_launch, "x".join(map(str, side))),
-                         "flops_per_launch": flops, "avg_launch_ms": t_k * 1e3, "launches_timed": len(durs)},
+                         "kernel": "%s (conv_norm_lrelu_l4.0: 3x3x3 %d->%d @ %dx%s)"
+                                   % (kname, 2 * b, 2 * b, n_roi_launch, "x".join(map(str, side))),
+                         "flops_per_launch": flops, "flops_basis": "algorithmic: 2 * Ci * Co * 27 * voxels of the direct "
+                         "convolution (SURVEY.md section 8d), whatever the kernel executes",
+                         "mfma_flops_executed_per_launch": executed,
+                         "mfma_pipe_frac": executed / t_k / 1e12 / PEAK_FP32_MFMA_TFLOPS if t_k > 0 else 0.0,
+                         "avg_launch_ms": t_k * 1e3, "launches_timed": len(durs)},
         }
         if args.workload == "cfg2" and not b3:
             r = result["roofline"]

@@ -37,6 +37,7 @@ _SIGNATURES = {
     "cfun_version": (C.c_int, []),
     "cfun_error_string": (C.c_char_p, [C.c_int]),
     "cfun_conv3d_fwd_workspace_bytes": (_Z, [_PP]),
+    "cfun_conv3d_fwd_kernel": (_I, [_PP]),
     "cfun_conv3d_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _PP, _P, _Z, _P]),
     "cfun_conv3d_bwd_data_workspace_bytes": (_Z, [_PP]),
     "cfun_conv3d_bwd_data": (C.c_int, [_P, _P, _P, _PP, _P, _Z, _P]),

@@ -302,6 +302,14 @@ size_t cfun_conv3d_fwd_workspace_bytes(const CfunConv3dParams* p) {
   return cfun_align_up(need + 256, 256);
 }
 
+int cfun_conv3d_fwd_kernel(const CfunConv3dParams* p) {
+  if (!valid_params(p)) return CFUN_EINVAL;
+  if (p->algo == CFUN_ALGO_AUTO && cfun_conv_pointwise_supported(p)) return CFUN_KERNEL_POINTWISE;
+  if (p->algo != CFUN_ALGO_DIRECT && mfma_shape(p)) return cfun_wino_supported(p) ? CFUN_KERNEL_WINO : CFUN_KERNEL_MFMA;
+  if (p->algo != CFUN_ALGO_DIRECT && p->algo != CFUN_ALGO_MFMA && cfun_conv_stem_supported(p)) return CFUN_KERNEL_STEM;
+  return CFUN_KERNEL_DIRECT;
+}
+
 int cfun_conv3d_fwd(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
                     float* y, const CfunConv3dParams* p, void* ws, size_t ws_bytes, cfun_stream_t stream) {
   if (!valid_params(p)) return CFUN_EINVAL;

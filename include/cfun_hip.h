@@ -98,6 +98,13 @@ typedef struct CfunConv3dParams {
 /* ws: cfun_conv3d_fwd_workspace_bytes(p) bytes (split-K partials for volumes too small to fill the chip);
  * ws may be NULL -- the kernel then runs unsplit. */
 size_t cfun_conv3d_fwd_workspace_bytes(const CfunConv3dParams* p);
+/* Which kernel family cfun_conv3d_fwd runs for p when given that workspace (labels for profiles / bench.py). */
+#define CFUN_KERNEL_DIRECT 0      /* generic VALU direct conv (conv3d_direct.hip) */
+#define CFUN_KERNEL_MFMA 1        /* k_conv_mfma: implicit GEMM, every tap on the fp32 matrix cores */
+#define CFUN_KERNEL_WINO 2        /* k_conv_wino: 3x3x3 stride 1, x axis in the Winograd F(2,3) domain (2/3 of the MFMAs) */
+#define CFUN_KERNEL_STEM 3        /* k_conv_stem*: C_in = 1, HBM-bound */
+#define CFUN_KERNEL_POINTWISE 4   /* k_conv_pointwise: 1x1x1 -> 8 channels, streaming */
+int cfun_conv3d_fwd_kernel(const CfunConv3dParams* p);
 int cfun_conv3d_fwd(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
                     float* y, const CfunConv3dParams* p, void* ws, size_t ws_bytes, cfun_stream_t stream);
 /* dx[n,zi,yi,xi,ci] (stored-input resolution) = sum over outputs/taps that read it of g * W. g = dL/d(conv sum). */

@@ -2,7 +2,7 @@
 # MFMA-pipe utilisation of the dominant conv launch (conv_norm_lrelu_l4.0) from the SQ / GRBM counters
 # (MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (busy cycles * 256 CUs * 4 SIMDs); GRBM_GUI_ACTIVE comes back summed over
 # the 8 XCDs, so busy cycles = GRBM_GUI_ACTIVE / 8 -- it then equals kernel time x 2.4 GHz), one rocprofv3 --pmc pass
-# with --kernel-trace only.  Prints the JSON committed as profiles/round1_pmc_mfma_conv_l4_0.json.
+# with --kernel-trace only.  Prints the JSON committed as profiles/roundN_pmc_mfma_wino_l4_0.json.
 #   usage (on the GPU box, from the repo root):  bash tools/pmc_mfma.sh
 set -u
 REPO=$(cd "$(dirname "$0")/.." && pwd)
@@ -17,7 +17,7 @@ REPO="$REPO" python - "$REPO/gpurun_out/pmc_mfma.csv" <<'PY'
 import csv, json, os, sys
 sys.path.insert(0, os.path.join(os.environ["REPO"], "tools"))
 from pmc_traffic import git_blob_sha1, SRC
-K = os.environ.get("CFUN_PMC_KERNEL", "k_conv_mfma<3, 3, 3, 1, 3, false, 0>")
+K = os.environ.get("CFUN_PMC_KERNEL", "k_conv_wino<3>")
 acc = {}
 for row in csv.DictReader(open(sys.argv[1])):
     if K in row["Kernel_Name"]:
@@ -26,8 +26,8 @@ avg = {k: sum(v) / len(v) for k, v in acc.items()}
 cus = 256
 rec = {"what": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES (one pass, --kernel-trace only) "
                "around tools/bench_layers.py --filter l4.0 --iters 1 on MI355X (tools/pmc_mfma.sh)",
-       "kernel": "cfun_mfma::%s (3x3x3 40->40 @ 4x96^3, forward / data gradient)" % K,
-       "kernel_src": "cfun_amd/csrc/conv3d_mfma.h", "kernel_src_blob": git_blob_sha1(SRC),
+       "kernel": "%s (3x3x3 40->40 @ 4x96^3, forward / data gradient)" % K,
+       "kernel_src": "cfun_amd/csrc/" + os.path.basename(SRC), "kernel_src_blob": git_blob_sha1(SRC),
        "dispatches": len(next(iter(acc.values()))) if acc else 0, "counters_avg": avg}
 if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and "GRBM_GUI_ACTIVE" in avg and avg["GRBM_GUI_ACTIVE"] > 0:
     busy = avg["GRBM_GUI_ACTIVE"] / 8.0            # the counter is reported summed over the 8 XCDs

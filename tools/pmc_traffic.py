@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Parse the two rocprofv3 counter CSVs of tools/pmc_traffic.sh into the per-launch traffic record
-(profiles/round1_pmc_conv_l4_0.json).  FETCH_SIZE is doubled (gfx950 counts a wide coalesced read at half its
+(profiles/roundN_pmc_wino_l4_0.json).  FETCH_SIZE is doubled (gfx950 counts a wide coalesced read at half its
 bytes, MI355X_MICROARCH.md section HBM); WRITE_SIZE is taken as reported; both are in KB."""
 import csv
 import hashlib
@@ -8,7 +8,7 @@ import json
 import os
 import sys
 
-SRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cfun_amd", "csrc", "conv3d_mfma.h")
+SRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cfun_amd", "csrc", os.environ.get("CFUN_PMC_SRC", "conv3d_wino.hip"))
 
 
 def git_blob_sha1(path):
@@ -16,7 +16,7 @@ def git_blob_sha1(path):
     data = open(path, "rb").read()
     return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 
-KERNEL = os.environ.get("CFUN_PMC_KERNEL", "k_conv_mfma<3, 3, 3, 1, 3, false, 0>")
+KERNEL = os.environ.get("CFUN_PMC_KERNEL", "k_conv_wino<3>")
 
 
 def avg_counter(path, counter):
@@ -37,7 +37,7 @@ def main():
     rec = {
         "what": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) around "
                 "tools/bench_layers.py --filter l4.0 --iters 1 on MI355X (tools/pmc_traffic.sh)",
-        "kernel": "cfun_mfma::%s (conv_norm_lrelu_l4.0 forward / data gradient: 3x3x3 40->40 @ 4x96^3)" % KERNEL,
+        "kernel": "%s (conv_norm_lrelu_l4.0 forward / data gradient: 3x3x3 40->40 @ 4x96^3)" % KERNEL,
         "dispatches": n,
         "FETCH_SIZE_avg_KB": round(fetch, 1),
         "WRITE_SIZE_avg_KB": round(write, 1),
@@ -45,7 +45,7 @@ def main():
                       "on gfx950 -> doubled; WRITE_SIZE uncorrected",
         "traffic_bytes_per_launch": int(2 * fetch * 1024 + write * 1024),
         "algorithmic_bytes_per_launch": algorithmic,
-        "kernel_src": "cfun_amd/csrc/conv3d_mfma.h",
+        "kernel_src": "cfun_amd/csrc/" + os.path.basename(SRC),
         "kernel_src_blob": git_blob_sha1(SRC),      # bench.py reports `traffic` only while this still matches
     }
     print(json.dumps(rec, indent=2))

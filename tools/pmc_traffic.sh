@@ -2,7 +2,7 @@
 # HBM-side traffic of the dominant conv launch (conv_norm_lrelu_l4.0: 3x3x3 40->40 @ 4x96^3) from the TCC counters,
 # collected as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes with
 # --kernel-trace only.  Writes gpurun_out/pmc_{FETCH,WRITE}_SIZE.csv and prints the JSON that is committed as
-# profiles/round1_pmc_conv_l4_0.json (and read by bench.py for roofline.traffic).
+# profiles/roundN_pmc_wino_l4_0.json (and read by bench.py for roofline.traffic).
 #   usage (on the GPU box, from the repo root):  bash tools/pmc_traffic.sh
 set -u
 REPO=$(cd "$(dirname "$0")/.." && pwd)
