@@ -23,6 +23,9 @@ int cfun_wino_supported(const CfunConv3dParams*);
 size_t cfun_wino_workspace_bytes(const CfunConv3dParams*);
 int cfun_wino_fwd(const float*, const float*, int, const float*, const float*, const float*, float*,
                   const CfunConv3dParams*, void*, size_t, hipStream_t);
+int cfun_wino_wgrad_supported(const CfunConv3dParams*);
+size_t cfun_wino_wgrad_workspace_bytes(const CfunConv3dParams*);
+int cfun_wino_wgrad(const float*, const float*, float*, const CfunConv3dParams*, int*, hipStream_t);
 // conv3d_wgrad_c1.hip
 int cfun_wgrad_c1_supported(const CfunConv3dParams*);
 size_t cfun_wgrad_c1_ws(const CfunConv3dParams*);
@@ -403,6 +406,7 @@ size_t cfun_conv3d_bwd_weight_workspace_bytes(const CfunConv3dParams* p) {
   if (!valid_params(p)) return 0;
   if (p->algo != CFUN_ALGO_DIRECT && cfun_wgrad_c1_supported(p)) return cfun_align_up(cfun_wgrad_c1_ws(p), 256);
   const Shape* s = (p->algo == CFUN_ALGO_DIRECT || !wgrad_mfma_fits(p)) ? nullptr : mfma_shape(p);
+  if (s && cfun_wino_wgrad_supported(p)) return cfun_align_up(cfun_wino_wgrad_workspace_bytes(p), 256);
   if (s) {
     cfun_mfma::WgPlan w;
     s->plan(*p, wgrad_nsub(p, s), &w);
@@ -422,6 +426,13 @@ static int bwd_weight_any(const float* x, const float* g, CfunWgradDst dst, cons
   if (s) {
     if (!cfun_aligned16(x) || !cfun_aligned16(g)) return CFUN_EALIGN;
     if (ws_bytes < cfun_conv3d_bwd_weight_workspace_bytes(p)) return CFUN_EWORKSPACE;
+    if (cfun_wino_wgrad_supported(p)) {      // x axis in the Winograd F(2,3) domain
+      if (!cfun_aligned16(ws)) return CFUN_EALIGN;
+      int nparts = 0;
+      const int rc = cfun_wino_wgrad(x, g, (float*)ws, p, &nparts, cfun_st(stream));
+      if (rc) return rc;
+      return cfun_wgrad_finish((const float*)ws, dst, p, nparts, cfun_st(stream));
+    }
     cfun_mfma::WgPlan w;
     s->plan(*p, wgrad_nsub(p, s), &w);
     if (w.ntiles == 0) return cfun_wgrad_zero(dst, p, cfun_st(stream));

@@ -329,3 +329,236 @@ int cfun_wino_fwd(const float* x, const float* wp, int flip, const float* scale,
   if (w.ksplit > 1) return cfun_splitk_finish(partial, w.ksplit, scale, shift, res, y, p, st);
   return CFUN_OK;
 }
+
+// ================================================================================================ weight gradient
+// dW of the same convs with the x axis in the F(2,3) domain.  For every x-pair of outputs the four products
+//   dU_p[ci][co] += V_p[ci] * dM_p[co],   dM = (g_e, g_e + g_o, g_e - g_o, -g_o),   V as in the forward kernel
+// replace the 2 x 3 products of the direct sum; at the end dW = G^T dU:
+//   dw0 = dU0 + (dU1 + dU2)/2,  dw1 = (dU1 - dU2)/2,  dw2 = dU3 + (dU1 + dU2)/2.
+//   block  = 256 threads, one 16-channel ci subtile x (16*NSUB) co, a range of 2(z) x 4(y) x 16(x) voxel tiles
+//   wave w = Winograd point w: all 9 (dz,dy) offsets -> accumulators [9][NSUB]; MFMA k-step = 4 consecutive x-pairs
+//   LDS    = the raw halo tile [24 rows][x parity][9][16 ci] and gradient tile [8 rows][x parity][8][co]: V and dM are
+//            formed from two LDS reads each when the fragment is read (V_p = X[o1] + s*X[o2], dM_p = a*g_e + b*g_o with
+//            wave-uniform offsets / signs), so the tiles stay as small as the direct kernel's
+//   end    = per (dz,dy) the four waves' sums meet in LDS, G^T is applied and the 3 taps are written in the partial
+//            layout of k_wgrad_mfma ([chunk][tap][Ci][CoP]); cfun_wgrad_finish reduces the chunks as before.
+namespace {
+
+constexpr int WG_IY = 6, WG_XH = 9, WG_XROWS = 4 * WG_IY;      // halo rows (z,y); 9 columns per x parity
+constexpr int WG_XVOX = WG_XROWS * 2 * WG_XH;                  // 432 staged voxels x 16 channels
+constexpr int WG_GVOX = 2 * 4 * 16;                            // 128 gradient voxels
+constexpr int WG_XROW = 2 * WG_XH * 16;                        // floats per halo row
+
+template <int NSUB>
+__global__ void __launch_bounds__(256)
+k_wgrad_wino(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ partial, CfunConv3dParams p,
+             int ntz, int nty, int ntx, int ncisub, int ncot, int tiles_per_chunk, int ntiles) {
+  constexpr int NT = 16 * NSUB, GS = cfun_mfma::pad_row16(NT);
+  constexpr int X_ITEMS = WG_XVOX * 4, X_LOADS = cdiv(X_ITEMS, 256);
+  constexpr int G_ITEMS = WG_GVOX * (NT / 4), G_LOADS = cdiv(G_ITEMS, 256);
+  CFUN_DYN_LDS(float4, smem4);
+  float* Xl = reinterpret_cast<float*>(smem4);      // [row][parity][9][16]
+  float* Gl = Xl + WG_XVOX * 16;                    // [(lrow*2 + parity)*8 + j][GS]
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned lid = cfun_mfma::xcd_remap(blockIdx.x, gridDim.x);
+  const int cot = lid % ncot; lid /= ncot;
+  const int cis = lid % ncisub;
+  const int chunk = lid / ncisub;
+  const int ci0 = cis * 16, cobase = cot * NT;
+
+  f32x4 acc[9][NSUB];
+#pragma unroll
+  for (int r = 0; r < 9; ++r)
+#pragma unroll
+    for (int nn = 0; nn < NSUB; ++nn) acc[r][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // staging: unconditional loads (out-of-range items read offset 0), zero padding applied at commit time
+  float4 xin[X_LOADS], gin[G_LOADS];
+  unsigned xvalid = 0, gvalid = 0;
+  auto prefetch = [&](int tile) {
+    int t = tile;
+    const int tx = t % ntx; t /= ntx;
+    const int ty = t % nty; t /= nty;
+    const int tz = t % ntz;
+    const int n = t / ntz;
+    const int z0 = tz * 2, y0 = ty * 4, x0 = tx * 16;
+    xvalid = 0; gvalid = 0;
+#pragma unroll
+    for (int i = 0; i < X_LOADS; ++i) {
+      const int it = tid + i * 256;
+      const int idx = it >> 2, c = ci0 + (it & 3) * 4;
+      const int xh = idx % WG_XH, par = (idx / WG_XH) & 1, row = idx / (2 * WG_XH);
+      const int vz = z0 - 1 + row / WG_IY, vy = y0 - 1 + row % WG_IY, vx = x0 - 1 + 2 * xh + par;
+      const bool ok = (it < X_ITEMS) & (c < p.Ci) & (vz >= 0) & (vz < p.Di) & (vy >= 0) & (vy < p.Hi) & (vx >= 0) & (vx < p.Wi);
+      const unsigned off = ((((unsigned)n * p.Di + vz) * p.Hi + vy) * p.Wi + vx) * p.Ci + c;
+      xin[i] = *reinterpret_cast<const float4*>(x + (ok ? off : 0u));
+      xvalid |= (ok ? 1u : 0u) << i;
+    }
+#pragma unroll
+    for (int i = 0; i < G_LOADS; ++i) {
+      const int it = tid + i * 256;
+      const int slot = it / (NT / 4), col = (it % (NT / 4)) * 4;
+      const int j = slot & 7, par = (slot >> 3) & 1, lrow = slot >> 4;
+      const int oz = z0 + (lrow >> 2), oy = y0 + (lrow & 3), ox = x0 + 2 * j + par;
+      const bool ok = (it < G_ITEMS) & (cobase + col < p.Co) & (oz < p.Do) & (oy < p.Ho) & (ox < p.Wo);
+      const unsigned off = ((((unsigned)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * p.Co + cobase + col;
+      gin[i] = *reinterpret_cast<const float4*>(g + (ok ? off : 0u));
+      gvalid |= (ok ? 1u : 0u) << i;
+    }
+  };
+  auto commit = [&]() {
+    auto keep = [](unsigned bit, const float4& v) {
+      const float m = bit ? 1.f : 0.f;
+      return make_float4(bit ? v.x : m, bit ? v.y : m, bit ? v.z : m, bit ? v.w : m);
+    };
+#pragma unroll
+    for (int i = 0; i < X_LOADS; ++i) {
+      const int it = tid + i * 256;
+      if (it < X_ITEMS) *reinterpret_cast<float4*>(Xl + it * 4) = keep((xvalid >> i) & 1u, xin[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < G_LOADS; ++i) {
+      const int it = tid + i * 256;
+      if (it < G_ITEMS)
+        *reinterpret_cast<float4*>(Gl + (it / (NT / 4)) * GS + (it % (NT / 4)) * 4) = keep((gvalid >> i) & 1u, gin[i]);
+    }
+  };
+
+  // point of this wave: V_p = X[o1] + s2 * X[o2] over (E[j], O[j], E[j+1], O[j+1]) = float offsets (0, 144, 16, 160);
+  // dM_p = ce * g_e + cg * g_o
+  const int o1 = wv == 0 ? 0 : wv == 2 ? 16 : WG_XH * 16;
+  const int o2 = wv == 2 ? WG_XH * 16 : wv == 3 ? WG_XH * 16 + 16 : 16;
+  const float s2 = wv == 1 ? 1.f : -1.f;
+  const float ce = wv == 3 ? 0.f : 1.f, cg = wv == 0 ? 0.f : wv == 1 ? 1.f : -1.f;
+  // fragments: A row i = ci (lane & 15), k = x-pair lane >> 4 of the quad;  B col = co (lane & 15), same k
+  const float* Xa1 = Xl + o1 + (lane >> 4) * 16 + (lane & 15);
+  const float* Xa2 = Xl + o2 + (lane >> 4) * 16 + (lane & 15);
+  const float* Gw = Gl + (lane >> 4) * GS + (lane & 15);
+
+  const int t_begin = chunk * tiles_per_chunk;
+  const int t_end = (t_begin + tiles_per_chunk < ntiles) ? t_begin + tiles_per_chunk : ntiles;
+  if (t_begin < t_end) prefetch(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (tile + 1 < t_end) prefetch(tile + 1);
+#pragma unroll 1
+    for (int grp = 0; grp < 16; ++grp) {       // (output row lrow = (lz, ly), quad q of 4 x-pairs)
+      const int lrow = grp >> 1, q = grp & 1;
+      const int hrow = (lrow >> 2) * WG_IY + (lrow & 3);
+      float b[NSUB], a[9];
+#pragma unroll
+      for (int nn = 0; nn < NSUB; ++nn) {
+        const float* gp = Gw + ((lrow * 2) * 8 + q * 4) * GS + nn * 16;
+        b[nn] = ce * gp[0] + cg * gp[8 * GS];
+      }
+      const float* x1 = Xa1 + hrow * WG_XROW + q * 64;
+      const float* x2 = Xa2 + hrow * WG_XROW + q * 64;
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        const int o = ((r / 3) * WG_IY + (r % 3)) * WG_XROW;
+        a[r] = x1[o] + s2 * x2[o];
+      }
+#pragma unroll
+      for (int r = 0; r < 9; ++r)
+#pragma unroll
+        for (int nn = 0; nn < NSUB; ++nn)
+          acc[r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], b[nn], acc[r][nn], 0, 0, 0);
+    }
+  }
+
+  // ---- dW = G^T dU per (dz,dy): D[i = ci][j = co], lane -> co = lane & 15, rows (lane >> 4)*4 + r
+  float* S = Xl;                                   // [4 points][16 ci][NT]
+  float* out = partial + (int64_t)chunk * 27 * p.Ci * p.CoP;
+#pragma unroll
+  for (int r9 = 0; r9 < 9; ++r9) {
+    __syncthreads();
+#pragma unroll
+    for (int nn = 0; nn < NSUB; ++nn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        S[(wv * 16 + (lane >> 4) * 4 + r) * NT + nn * 16 + (lane & 15)] = acc[r9][nn][r];
+    __syncthreads();
+    for (int e = tid; e < 16 * NT; e += 256) {
+      const int ci = ci0 + e / NT, co = cobase + e % NT;
+      if (ci >= p.Ci || co >= p.CoP) continue;
+      const float u0 = S[e], u1 = S[16 * NT + e], u2 = S[2 * 16 * NT + e], u3 = S[3 * 16 * NT + e];
+      const float h = 0.5f * (u1 + u2);
+      float* o = out + ((int64_t)(r9 * 3) * p.Ci + ci) * p.CoP + co;
+      o[0] = u0 + h;
+      o[(int64_t)p.Ci * p.CoP] = 0.5f * (u1 - u2);
+      o[2 * (int64_t)p.Ci * p.CoP] = u3 + h;
+    }
+  }
+}
+
+struct WgPlanW {
+  int nsub, ntz, nty, ntx, ntiles, ncisub, ncot, nchunks, tiles_per_chunk;
+};
+
+WgPlanW make_wg_plan(const CfunConv3dParams& p) {
+  WgPlanW w;
+  w.nsub = p.CoP <= 16 ? 1 : ((p.CoP + 31) / 32 * 32 < (p.CoP + 47) / 48 * 48 ? 2 : 3);   // fewest padded columns, widest on ties
+  w.ntz = cdiv(p.Do, 2); w.nty = cdiv(p.Ho, 4); w.ntx = cdiv(p.Wo, 16);
+  w.ntiles = p.N * w.ntz * w.nty * w.ntx;
+  w.ncisub = cdiv(p.Ci, 16);
+  w.ncot = cdiv(p.CoP, 16 * w.nsub);
+  int want = 512 / (w.ncisub * w.ncot);       // ~2 workgroups per CU in total (as cfun_mfma::wgrad_plan)
+  if (want > w.ntiles) want = w.ntiles;
+  if (want < 1) want = 1;
+  w.tiles_per_chunk = cdiv(w.ntiles, want);
+  if (w.tiles_per_chunk < 1) w.tiles_per_chunk = 1;
+  w.nchunks = cdiv(w.ntiles, w.tiles_per_chunk);
+  if (w.nchunks < 1) w.nchunks = 1;
+  return w;
+}
+
+template <int NSUB>
+int launch_wg(const float* x, const float* g, float* partial, const CfunConv3dParams& p, const WgPlanW& w, hipStream_t st) {
+  constexpr int GS = cfun_mfma::pad_row16(16 * NSUB);
+  size_t lds = (size_t)(WG_XVOX * 16 + WG_GVOX * GS) * sizeof(float);
+  const size_t scratch = (size_t)4 * 16 * 16 * NSUB * sizeof(float);
+  if (lds < scratch) lds = scratch;
+  auto kern = k_wgrad_wino<NSUB>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(w.nchunks * w.ncisub * w.ncot)), dim3(256), lds, st, x, g, partial, p, w.ntz,
+                     w.nty, w.ntx, w.ncisub, w.ncot, w.tiles_per_chunk, w.ntiles);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+}  // namespace
+
+int cfun_wino_wgrad_supported(const CfunConv3dParams* p) {
+  static int knob = -2;       // CFUN_WINO_WGRAD: 0 = never, 1 = every supported shape
+  if (knob == -2) {
+    const char* e = getenv("CFUN_WINO_WGRAD");
+    knob = e ? atoi(e) : -1;
+  }
+  if (knob == 0 || !cfun_wino_supported(p)) return 0;
+  const int64_t lim = (int64_t)1 << 31;      // 32-bit element offsets
+  if ((int64_t)p->N * p->Di * p->Hi * p->Wi * p->Ci >= lim || (int64_t)p->N * p->Do * p->Ho * p->Wo * p->Co >= lim) return 0;
+  if (knob == 1 || p->algo == CFUN_ALGO_WINO) return 1;
+  return p->Ci >= 32 || p->Ci == 16;    // C_in = 20 keeps the fused plain + packed kernel (measured, tools/bench_layers.py)
+}
+
+size_t cfun_wino_wgrad_workspace_bytes(const CfunConv3dParams* p) {
+  const WgPlanW w = make_wg_plan(*p);
+  return (size_t)w.nchunks * 27 * p->Ci * p->CoP * sizeof(float);
+}
+
+// partial sums [nchunks][27][Ci][CoP] into ws; *nparts = nchunks (reduced by cfun_wgrad_finish)
+int cfun_wino_wgrad(const float* x, const float* g, float* ws, const CfunConv3dParams* p, int* nparts, hipStream_t st) {
+  const WgPlanW w = make_wg_plan(*p);
+  *nparts = w.nchunks;
+  switch (w.nsub) {
+    case 1: return launch_wg<1>(x, g, ws, *p, w, st);
+    case 2: return launch_wg<2>(x, g, ws, *p, w, st);
+    default: return launch_wg<3>(x, g, ws, *p, w, st);
+  }
+}
