@@ -21,7 +21,8 @@ int cfun_conv_pointwise_fwd(const float*, const float*, const float*, const floa
 // conv3d_wino.hip
 int cfun_wino_supported(const CfunConv3dParams*);
 size_t cfun_wino_workspace_bytes(const CfunConv3dParams*);
-int cfun_wino_fwd(const float*, const float*, int, const float*, const float*, const float*, float*,
+int cfun_wino_s2d_dgrad_supported(const CfunConv3dParams*, const CfunConv3dParams*);
+int cfun_wino_fwd(const float*, const float*, int, int, const float*, const float*, const float*, float*,
                   const CfunConv3dParams*, void*, size_t, hipStream_t);
 int cfun_wino_wgrad_supported(const CfunConv3dParams*);
 size_t cfun_wino_wgrad_workspace_bytes(const CfunConv3dParams*);
@@ -330,7 +331,7 @@ int cfun_conv3d_fwd(const float* x, const float* wp, const float* scale, const f
     fwd_mode(p, s, &md, &nsub);
     if (ws && !cfun_aligned16(ws)) return CFUN_EALIGN;
     if (ws && cfun_wino_supported(p) && ws_bytes >= cfun_wino_workspace_bytes(p))   // x axis in the Winograd F(2,3) domain
-      return cfun_wino_fwd(x, wp, 0, scale, shift, res, y, p, ws, ws_bytes, cfun_st(stream));
+      return cfun_wino_fwd(x, wp, 0, 0, scale, shift, res, y, p, ws, ws_bytes, cfun_st(stream));
     return s->fwd(nsub, x, wp, scale, shift, res, y, *p, md, ws, ws ? ws_bytes : 0, cfun_st(stream));
   }
   if (p->algo == CFUN_ALGO_MFMA) return CFUN_EINVAL;
@@ -350,7 +351,8 @@ size_t cfun_conv3d_bwd_data_workspace_bytes(const CfunConv3dParams* p) {
     md.flip = 1;
     if (p->d2s) { md.in_s2d = 1; md.in_cqp = p->Co >> 3; md.in_cq = p->d2s_cq > 0 ? p->d2s_cq : md.in_cqp; }
     size_t need = s->fwd_ws(pick_tile(s, q.Co, false), q, md);   // split-K partials
-    if (!p->d2s && cfun_wino_supported(&q) && cfun_wino_workspace_bytes(&q) > need) need = cfun_wino_workspace_bytes(&q);
+    if ((p->d2s ? cfun_wino_s2d_dgrad_supported(p, &q) : cfun_wino_supported(&q)) && cfun_wino_workspace_bytes(&q) > need)
+      need = cfun_wino_workspace_bytes(&q);
     return cfun_align_up(need + 256, 256);
   }
   return 256;
@@ -383,8 +385,9 @@ int cfun_conv3d_bwd_data(const float* g, const float* wpT, float* dx, const Cfun
       md.in_cq = p->d2s_cq > 0 ? p->d2s_cq : md.in_cqp;
       md.tap_skip = p->tap_skip ? 2 : 0;
     }
-    if (!p->up2 && !p->d2s && cfun_aligned16(ws) && cfun_wino_supported(&q) && ws_bytes >= cfun_wino_workspace_bytes(&q))
-      return cfun_wino_fwd(g, wpT, 1, nullptr, nullptr, nullptr, dx, &q, ws, ws_bytes, cfun_st(stream));
+    if (!p->up2 && cfun_aligned16(ws) && ws_bytes >= cfun_wino_workspace_bytes(&q) &&
+        (p->d2s ? cfun_wino_s2d_dgrad_supported(p, &q) : cfun_wino_supported(&q)))
+      return cfun_wino_fwd(g, wpT, 1, p->d2s ? (p->Co >> 3) : 0, nullptr, nullptr, nullptr, dx, &q, ws, ws_bytes, cfun_st(stream));
     if (!p->up2) return s->fwd(nsub, g, wpT, nullptr, nullptr, nullptr, dx, q, md, ws, cfun_aligned16(ws) ? ws_bytes : 0, cfun_st(stream));
     if (ws_bytes < cfun_conv3d_bwd_data_workspace_bytes(p) || !cfun_aligned16(ws)) return CFUN_EWORKSPACE;
     const int rc = s->fwd(nsub, g, wpT, nullptr, nullptr, nullptr, (float*)ws, q, md, nullptr, 0, cfun_st(stream));

@@ -44,11 +44,13 @@ k_wino_weights(const float* __restrict__ wp, float4* __restrict__ u, int Ci, int
   u[i] = make_float4(g[0], 0.5f * ((g[0] + g[2]) + g[1]), 0.5f * ((g[0] + g[2]) - g[1]), g[2]);
 }
 
-template <int NSUB>
+// S2D (data gradient of a depth-to-space conv): the logical input [N,Di,Hi,Wi,8*cq] is gathered from the hi-res gradient
+// [N,2Di,2Hi,2Wi,cq]; chunk c = 4 channels o4 of parity q = c / (cq/4), read at hi-res voxel 2*(z,y,x) + q.
+template <int NSUB, bool S2D>
 __global__ void __launch_bounds__(256)
 k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const float* __restrict__ scale,
             const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y, CfunConv3dParams p,
-            int ntz, int nty, int ntx, int ncot, float* __restrict__ partial, int chunks_per_split) {
+            int ntz, int nty, int ntx, int ncot, float* __restrict__ partial, int chunks_per_split, int s2d_cq) {
   constexpr int NT = 16 * NSUB;
   constexpr int W_ITEMS = 36 * NT;            // float4 (= 4 points of one output channel) items per chunk: 36 rows x NT
   constexpr int W_LOADS = cdiv(W_ITEMS, 256);
@@ -82,7 +84,11 @@ k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const flo
         const int64_t row = (((int64_t)n * p.Di + vz) * p.Hi + vy) * p.Wi;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          if (vx + k >= 0 && vx + k < p.Wi) { in_ok |= 1u << (i * 4 + k); in_ptr[i][k] = x + (row + vx + k) * p.Ci; }
+          if (vx + k >= 0 && vx + k < p.Wi) {
+            in_ok |= 1u << (i * 4 + k);
+            in_ptr[i][k] = S2D ? x + ((((int64_t)n * 2 * p.Di + 2 * vz) * 2 * p.Hi + 2 * vy) * 2 * p.Wi + 2 * (vx + k)) * s2d_cq
+                               : x + (row + vx + k) * p.Ci;
+          }
       }
     }
   }
@@ -94,12 +100,18 @@ k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const flo
   }
   const int w_step = 4 * p.CoP;
   float4 xin[X_IT][4], win[W_LOADS];
+  const int cpq = S2D ? (s2d_cq >> 2) : 1;       // chunks per parity
   auto prefetch = [&](int c) {
+    int64_t xo = c * 4;
+    if (S2D) {
+      const int q = c / cpq, o4 = c - q * cpq;
+      xo = ((int64_t)((q >> 2) * 2 * p.Hi + ((q >> 1) & 1)) * 2 * p.Wi + (q & 1)) * s2d_cq + o4 * 4;
+    }
 #pragma unroll
     for (int i = 0; i < X_IT; ++i)
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float4 v = *reinterpret_cast<const float4*>(in_ptr[i][k] + c * 4);
+        const float4 v = *reinterpret_cast<const float4*>(in_ptr[i][k] + xo);
         xin[i][k] = ((in_ok >> (i * 4 + k)) & 1u) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
@@ -203,13 +215,24 @@ k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const flo
       const float4 t = *reinterpret_cast<const float4*>(shift + co);
       r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
     }
+    // depth-to-space (parity-folded up-convs): channel co = parity q * CqP + oc goes to hi-res voxel 2*(oz,oy,ox) + q of a
+    // tensor with Cq channels; the residual is read at the low-res voxel
+    const int CqP = p.Co >> 3, Cq = p.d2s_cq > 0 ? p.d2s_cq : CqP;
+    const int q = p.d2s ? co / CqP : 0, oc = p.d2s ? co - q * CqP : co;
+    if (p.d2s && oc >= Cq) return;
     if (p.res_mode) {
-      const float4 t = *reinterpret_cast<const float4*>(res + v * p.Co + co);
+      const float4 t = *reinterpret_cast<const float4*>(res + v * (p.d2s ? Cq : p.Co) + oc);
       r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
     }
     r.x = cfun_apply_act(r.x, p.act, p.slope); r.y = cfun_apply_act(r.y, p.act, p.slope);
     r.z = cfun_apply_act(r.z, p.act, p.slope); r.w = cfun_apply_act(r.w, p.act, p.slope);
-    *reinterpret_cast<float4*>(y + v * p.Co + co) = r;
+    if (p.d2s) {
+      const int64_t hv = (((int64_t)n * 2 * p.Do + 2 * oz + (q >> 2)) * 2 * p.Ho + 2 * oy + ((q >> 1) & 1)) * 2 * p.Wo +
+                         2 * ox + (q & 1);
+      *reinterpret_cast<float4*>(y + hv * Cq + oc) = r;
+    } else {
+      *reinterpret_cast<float4*>(y + v * p.Co + co) = r;
+    }
   };
 #pragma unroll
   for (int mg = 0; mg < 2; ++mg)
@@ -262,15 +285,15 @@ Plan make_plan(const CfunConv3dParams& p, size_t ws_for_partials) {
 
 template <int NSUB>
 int launch(const float* x, const float4* u, const float* scale, const float* shift, const float* res, float* y,
-           const CfunConv3dParams& p, const Plan& w, float* partial, hipStream_t st) {
+           const CfunConv3dParams& p, const Plan& w, float* partial, int s2d_cq, hipStream_t st) {
   const size_t lds = (size_t)(4 * VPLANE4 + 36 * 16 * NSUB) * sizeof(float4);
-  auto kern = k_conv_wino<NSUB>;
+  auto kern = s2d_cq ? k_conv_wino<NSUB, true> : k_conv_wino<NSUB, false>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)w.nblk, (unsigned)w.ksplit), dim3(256), lds, st, x, u, scale, shift, res, y, p,
-                     w.ntz, w.nty, w.ntx, w.ncot, partial, w.cps);
+                     w.ntz, w.nty, w.ntx, w.ncot, partial, w.cps, s2d_cq);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }
@@ -293,11 +316,28 @@ int cfun_wino_supported(const CfunConv3dParams* p) {
   const int knob = wino_knob();
   if (knob == 0 || p->algo == CFUN_ALGO_DIRECT || p->algo == CFUN_ALGO_MFMA) return 0;
   if (p->kd != 3 || p->kh != 3 || p->kw != 3 || p->stride != 1 || p->pd != 1 || p->ph != 1 || p->pw != 1) return 0;
-  if (p->up2 || p->d2s || p->tap_skip || p->res_up2 || (p->Ci & 3) || (p->Co & 3)) return 0;
+  if (p->up2 || p->tap_skip || (p->res_up2 && !p->d2s) || (p->Ci & 3) || (p->Co & 3)) return 0;
+  if (p->d2s) {     // a lane's float4 stays inside one parity group; split-K partials have no depth-to-space finish
+    const int cqp = p->Co >> 3, cq = p->d2s_cq > 0 ? p->d2s_cq : cqp;
+    if ((cqp & 3) || (cq & 3)) return 0;
+  }
   if (p->Do != p->Di || p->Ho != p->Hi || p->Wo != p->Wi) return 0;
   if ((int64_t)p->N * p->Do * p->Ho * p->Wo == 0) return 0;
   if (knob == 1 || p->algo == CFUN_ALGO_WINO) return 1;
-  return p->Co >= 32 && p->Ci >= 16;
+  // (the folded 5x5x5 'finetune' conv -- d2s, C_in = 8 -- has two channel chunks and is bound by its stores: no gain measured)
+  return p->Co >= 32 && p->Ci >= 16 && !p->d2s;
+}
+
+// data gradient of a depth-to-space conv p (no tap skipping, no per-parity channel padding) as the Winograd conv q over
+// the gathered hi-res gradient
+int cfun_wino_s2d_dgrad_supported(const CfunConv3dParams* p, const CfunConv3dParams* q) {
+  if (wino_knob() == 0 || p->algo == CFUN_ALGO_DIRECT || p->algo == CFUN_ALGO_MFMA) return 0;
+  if (!p->d2s || p->tap_skip || p->up2) return 0;
+  const int cqp = p->Co >> 3, cq = p->d2s_cq > 0 ? p->d2s_cq : cqp;
+  if (cq != cqp || (cq & 3)) return 0;
+  if (q->kd != 3 || q->kh != 3 || q->kw != 3 || q->stride != 1 || q->pd != 1 || q->ph != 1 || q->pw != 1) return 0;
+  if (q->Do != q->Di || q->Ho != q->Hi || q->Wo != q->Wi || (q->Ci & 3) || (q->Co & 3)) return 0;
+  return (int64_t)q->N * q->Do * q->Ho * q->Wo > 0;
 }
 
 size_t cfun_wino_workspace_bytes(const CfunConv3dParams* p) {
@@ -306,8 +346,9 @@ size_t cfun_wino_workspace_bytes(const CfunConv3dParams* p) {
 }
 
 // wp: packed weights [27][Ci][CoP] of the conv that is run (the data gradient passes the transposed pack and flip = 1)
-int cfun_wino_fwd(const float* x, const float* wp, int flip, const float* scale, const float* shift, const float* res,
-                  float* y, const CfunConv3dParams* p, void* ws, size_t ws_bytes, hipStream_t st) {
+// s2d_cq > 0: x is the hi-res gradient of a depth-to-space conv with s2d_cq channels, p->Ci = 8 * s2d_cq (see k_conv_wino)
+int cfun_wino_fwd(const float* x, const float* wp, int flip, int s2d_cq, const float* scale, const float* shift,
+                  const float* res, float* y, const CfunConv3dParams* p, void* ws, size_t ws_bytes, hipStream_t st) {
   Plan w = make_plan(*p, 0);
   if (!ws || ws_bytes < w.u_bytes) return CFUN_EWORKSPACE;
   w = make_plan(*p, ws_bytes - w.u_bytes);
@@ -319,11 +360,11 @@ int cfun_wino_fwd(const float* x, const float* wp, int flip, const float* scale,
   CFUN_LAUNCH_CHECK();
   int rc;
   switch (w.nsub) {
-    case 1: rc = launch<1>(x, u, scale, shift, res, y, *p, w, partial, st); break;
-    case 2: rc = launch<2>(x, u, scale, shift, res, y, *p, w, partial, st); break;
-    case 3: rc = launch<3>(x, u, scale, shift, res, y, *p, w, partial, st); break;
-    case 4: rc = launch<4>(x, u, scale, shift, res, y, *p, w, partial, st); break;
-    default: rc = launch<5>(x, u, scale, shift, res, y, *p, w, partial, st); break;
+    case 1: rc = launch<1>(x, u, scale, shift, res, y, *p, w, partial, s2d_cq, st); break;
+    case 2: rc = launch<2>(x, u, scale, shift, res, y, *p, w, partial, s2d_cq, st); break;
+    case 3: rc = launch<3>(x, u, scale, shift, res, y, *p, w, partial, s2d_cq, st); break;
+    case 4: rc = launch<4>(x, u, scale, shift, res, y, *p, w, partial, s2d_cq, st); break;
+    default: rc = launch<5>(x, u, scale, shift, res, y, *p, w, partial, s2d_cq, st); break;
   }
   if (rc) return rc;
   if (w.ksplit > 1) return cfun_splitk_finish(partial, w.ksplit, scale, shift, res, y, p, st);
@@ -349,7 +390,7 @@ constexpr int WG_XVOX = WG_XROWS * 2 * WG_XH;                  // 432 staged vox
 constexpr int WG_GVOX = 2 * 4 * 16;                            // 128 gradient voxels
 constexpr int WG_XROW = 2 * WG_XH * 16;                        // floats per halo row
 
-template <int NSUB>
+template <int NSUB, bool D2S>
 __global__ void __launch_bounds__(256)
 k_wgrad_wino(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ partial, CfunConv3dParams p,
              int ntz, int nty, int ntx, int ncisub, int ncot, int tiles_per_chunk, int ntiles) {
@@ -401,8 +442,17 @@ k_wgrad_wino(const float* __restrict__ x, const float* __restrict__ g, float* __
       const int slot = it / (NT / 4), col = (it % (NT / 4)) * 4;
       const int j = slot & 7, par = (slot >> 3) & 1, lrow = slot >> 4;
       const int oz = z0 + (lrow >> 2), oy = y0 + (lrow & 3), ox = x0 + 2 * j + par;
-      const bool ok = (it < G_ITEMS) & (cobase + col < p.Co) & (oz < p.Do) & (oy < p.Ho) & (ox < p.Wo);
-      const unsigned off = ((((unsigned)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * p.Co + cobase + col;
+      bool ok = (it < G_ITEMS) & (cobase + col < p.Co) & (oz < p.Do) & (oy < p.Ho) & (ox < p.Wo);
+      unsigned off;
+      if (D2S) {   // g is the hi-res gradient of y [N,2Do,2Ho,2Wo,Cq]: gather parity q, channel o
+        const int CqP = p.Co >> 3, Cq = p.d2s_cq > 0 ? p.d2s_cq : CqP;
+        const int co = cobase + col, q = co / CqP, o = co - q * CqP;
+        ok = ok & (o < Cq);
+        off = ((((unsigned)n * 2 * p.Do + 2 * oz + (q >> 2)) * 2 * p.Ho + 2 * oy + ((q >> 1) & 1)) * 2 * p.Wo + 2 * ox +
+               (q & 1)) * Cq + o;
+      } else {
+        off = ((((unsigned)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * p.Co + cobase + col;
+      }
       gin[i] = *reinterpret_cast<const float4*>(g + (ok ? off : 0u));
       gvalid |= (ok ? 1u : 0u) << i;
     }
@@ -521,7 +571,7 @@ int launch_wg(const float* x, const float* g, float* partial, const CfunConv3dPa
   size_t lds = (size_t)(WG_XVOX * 16 + WG_GVOX * GS) * sizeof(float);
   const size_t scratch = (size_t)4 * 16 * 16 * NSUB * sizeof(float);
   if (lds < scratch) lds = scratch;
-  auto kern = k_wgrad_wino<NSUB>;
+  auto kern = p.d2s ? k_wgrad_wino<NSUB, true> : k_wgrad_wino<NSUB, false>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -544,6 +594,7 @@ int cfun_wino_wgrad_supported(const CfunConv3dParams* p) {
   const int64_t lim = (int64_t)1 << 31;      // 32-bit element offsets
   if ((int64_t)p->N * p->Di * p->Hi * p->Wi * p->Ci >= lim || (int64_t)p->N * p->Do * p->Ho * p->Wo * p->Co >= lim) return 0;
   if (knob == 1 || p->algo == CFUN_ALGO_WINO) return 1;
+  if (p->d2s) return 0;       // the folded 5x5x5 conv (C_in = 8): the direct kernel's packed tap pairs win (1.03 vs 1.29 ms)
   return p->Ci >= 32 || p->Ci == 16;    // C_in = 20 keeps the fused plain + packed kernel (measured, tools/bench_layers.py)
 }
 
