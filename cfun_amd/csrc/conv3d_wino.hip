@@ -595,7 +595,9 @@ int cfun_wino_wgrad_supported(const CfunConv3dParams* p) {
   if ((int64_t)p->N * p->Di * p->Hi * p->Wi * p->Ci >= lim || (int64_t)p->N * p->Do * p->Ho * p->Wo * p->Co >= lim) return 0;
   if (knob == 1 || p->algo == CFUN_ALGO_WINO) return 1;
   if (p->d2s) return 0;       // the folded 5x5x5 conv (C_in = 8): the direct kernel's packed tap pairs win (1.03 vs 1.29 ms)
-  return p->Ci >= 32 || p->Ci == 16;    // C_in = 20 keeps the fused plain + packed kernel (measured, tools/bench_layers.py)
+  // C_in <= 8 (packed tap groups: 7 / 14 fragment rows) and 17..20 (fused plain + packed rows) stay on the direct kernels:
+  // measured with tools/bench_layers.py (8->20 0.172 vs 0.191 ms, 20->20 1.17 vs 1.20; 12->20 0.251 -> 0.189, 40->40 3.41 -> 2.65)
+  return !(p->Ci <= 8 || (p->Ci > 16 && p->Ci <= 20));
 }
 
 size_t cfun_wino_wgrad_workspace_bytes(const CfunConv3dParams* p) {
