@@ -315,13 +315,14 @@ static int wino_knob() {
 int cfun_wino_supported(const CfunConv3dParams* p) {
   const int knob = wino_knob();
   if (knob == 0 || p->algo == CFUN_ALGO_DIRECT || p->algo == CFUN_ALGO_MFMA) return 0;
-  if (p->kd != 3 || p->kh != 3 || p->kw != 3 || p->stride != 1 || p->pd != 1 || p->ph != 1 || p->pw != 1) return 0;
+  // depth padding 0 / 1 / 2: depth-sharded slabs arrive with their halo planes (pd = 0; their data gradient has pd = 2)
+  if (p->kd != 3 || p->kh != 3 || p->kw != 3 || p->stride != 1 || p->pd < 0 || p->pd > 2 || p->ph != 1 || p->pw != 1) return 0;
   if (p->up2 || p->tap_skip || (p->res_up2 && !p->d2s) || (p->Ci & 3) || (p->Co & 3)) return 0;
   if (p->d2s) {     // a lane's float4 stays inside one parity group; split-K partials have no depth-to-space finish
     const int cqp = p->Co >> 3, cq = p->d2s_cq > 0 ? p->d2s_cq : cqp;
     if ((cqp & 3) || (cq & 3)) return 0;
   }
-  if (p->Do != p->Di || p->Ho != p->Hi || p->Wo != p->Wi) return 0;
+  if (p->Do != p->Di + 2 * p->pd - 2 || p->Ho != p->Hi || p->Wo != p->Wi) return 0;
   if ((int64_t)p->N * p->Do * p->Ho * p->Wo == 0) return 0;
   if (knob == 1 || p->algo == CFUN_ALGO_WINO) return 1;
   // (the folded 5x5x5 'finetune' conv -- d2s, C_in = 8 -- has two channel chunks and is bound by its stores: no gain measured)
@@ -335,8 +336,8 @@ int cfun_wino_s2d_dgrad_supported(const CfunConv3dParams* p, const CfunConv3dPar
   if (!p->d2s || p->tap_skip || p->up2) return 0;
   const int cqp = p->Co >> 3, cq = p->d2s_cq > 0 ? p->d2s_cq : cqp;
   if (cq != cqp || (cq & 3)) return 0;
-  if (q->kd != 3 || q->kh != 3 || q->kw != 3 || q->stride != 1 || q->pd != 1 || q->ph != 1 || q->pw != 1) return 0;
-  if (q->Do != q->Di || q->Ho != q->Hi || q->Wo != q->Wi || (q->Ci & 3) || (q->Co & 3)) return 0;
+  if (q->kd != 3 || q->kh != 3 || q->kw != 3 || q->stride != 1 || q->pd < 0 || q->pd > 2 || q->ph != 1 || q->pw != 1) return 0;
+  if (q->Do != q->Di + 2 * q->pd - 2 || q->Ho != q->Hi || q->Wo != q->Wi || (q->Ci & 3) || (q->Co & 3)) return 0;
   return (int64_t)q->N * q->Do * q->Ho * q->Wo > 0;
 }
 
@@ -430,7 +431,7 @@ k_wgrad_wino(const float* __restrict__ x, const float* __restrict__ g, float* __
       const int it = tid + i * 256;
       const int idx = it >> 2, c = ci0 + (it & 3) * 4;
       const int xh = idx % WG_XH, par = (idx / WG_XH) & 1, row = idx / (2 * WG_XH);
-      const int vz = z0 - 1 + row / WG_IY, vy = y0 - 1 + row % WG_IY, vx = x0 - 1 + 2 * xh + par;
+      const int vz = z0 - p.pd + row / WG_IY, vy = y0 - 1 + row % WG_IY, vx = x0 - 1 + 2 * xh + par;
       const bool ok = (it < X_ITEMS) & (c < p.Ci) & (vz >= 0) & (vz < p.Di) & (vy >= 0) & (vy < p.Hi) & (vx >= 0) & (vx < p.Wi);
       const unsigned off = ((((unsigned)n * p.Di + vz) * p.Hi + vy) * p.Wi + vx) * p.Ci + c;
       xin[i] = *reinterpret_cast<const float4*>(x + (ok ? off : 0u));

@@ -100,6 +100,7 @@ CONV_CASES = {
     "wino_333_two_cotiles": (1, (3, 4, 5), 4, 96, (3, 3, 3), dict(algo=ALGO_WINO)),
     "wino_333_splitk_epilogue": (2, (4, 4, 8), 32, 16, (3, 3, 3), dict(algo=ALGO_WINO, act=ACT_LRELU, scale=True, per_n=True, shift=True, res=True)),
     "wino_333_40_40": (1, (4, 5, 19), 40, 40, (3, 3, 3), dict(algo=ALGO_WINO)),
+    "wino_333_slab_pd0": (2, (7, 5, 9), 16, 32, (3, 3, 3), dict(algo=ALGO_WINO, pad=(0, 1, 1), shift=True)),   # a depth slab with its halo
     "wino_333_d2s_res": (2, (3, 4, 5), 8, 64, (3, 3, 3), dict(algo=ALGO_WINO, d2s=True, res=True, act=ACT_LRELU)),
 }
 # bigger shapes: many workgroups, several chunks per wgrad block, channel counts of the real nets (GPU tier)
