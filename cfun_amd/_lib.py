@@ -16,6 +16,7 @@ DEFAULT_LIB = os.path.join(_HERE, "libcfun_hip.so")
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = 0, 1, 2
 ALGO_WINO = 4    # every supported 3x3x3 stride-1 conv on the Winograd F(2,3)-along-x kernel (AUTO picks it per shape)
+ALGO_WINO2 = 5   # ... with y in the Winograd domain as well (forward / data gradient)
 ALGO_B3 = 3      # host-side only (opt-in): eligible 3x3x3 convs on the experimental 3xBF16 kernels, the rest as AUTO
 
 

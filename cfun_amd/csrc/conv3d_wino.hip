@@ -17,9 +17,16 @@
 //            read is one ds_read_b128 per (dz,dy) for all 4 points (8 consecutive lanes = 128 contiguous bytes)
 #include <stdlib.h>
 
+#include <utility>
+
 #include "conv3d_mfma.h"
 
 namespace {
+
+template <int... I, class F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
 
 using cfun_mfma::cdiv;
 
@@ -44,15 +51,45 @@ k_wino_weights(const float* __restrict__ wp, float4* __restrict__ u, int Ci, int
   u[i] = make_float4(g[0], 0.5f * ((g[0] + g[2]) + g[1]), 0.5f * ((g[0] + g[2]) - g[1]), g[2]);
 }
 
+// TWOD: u2[(dz*4 + py)][ci][co][px] = (G g G^T)[py][px] of the 3x3 (ky,kx) slice dz
+__global__ void __launch_bounds__(256)
+k_wino2_weights(const float* __restrict__ wp, float4* __restrict__ u, int Ci, int CoP, int flip) {
+  const int64_t per = (int64_t)Ci * CoP, total = 3 * per;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int dz = (int)(i / per);
+  const int64_t e = i - dz * per;
+  float t[4][3];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+    float g[3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int tap = (dz * 3 + ky) * 3 + kx;
+      g[ky] = wp[(int64_t)(flip ? 26 - tap : tap) * per + e];
+    }
+    t[0][kx] = g[0]; t[1][kx] = 0.5f * ((g[0] + g[2]) + g[1]); t[2][kx] = 0.5f * ((g[0] + g[2]) - g[1]); t[3][kx] = g[2];
+  }
+#pragma unroll
+  for (int py = 0; py < 4; ++py)
+    u[(int64_t)(dz * 4 + py) * per + e] = make_float4(t[py][0], 0.5f * ((t[py][0] + t[py][2]) + t[py][1]),
+                                                     0.5f * ((t[py][0] + t[py][2]) - t[py][1]), t[py][2]);
+}
+
 // S2D (data gradient of a depth-to-space conv): the logical input [N,Di,Hi,Wi,8*cq] is gathered from the hi-res gradient
 // [N,2Di,2Hi,2Wi,cq]; chunk c = 4 channels o4 of parity q = c / (cq/4), read at hi-res voxel 2*(z,y,x) + q.
-template <int NSUB, bool S2D>
+// TWOD: y is in the Winograd domain as well (F(2x2,3x3) per z tap): 3 (dz) x 16 points instead of 27 taps per 2x2 outputs =
+// 4/9 of the MFMAs.  Staging is unchanged (rows stay x-transformed in LDS); the y transform of the input is applied when
+// the fragment is read (two rows, one add per point), MFMA columns are the 2 x 8 tiles of the wave's 4 x 16 plane and the
+// accumulators are [4 py][4 px][NSUB].
+template <int NSUB, bool S2D, bool TWOD>
 __global__ void __launch_bounds__(256)
 k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const float* __restrict__ scale,
             const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y, CfunConv3dParams p,
             int ntz, int nty, int ntx, int ncot, float* __restrict__ partial, int chunks_per_split, int s2d_cq) {
   constexpr int NT = 16 * NSUB;
-  constexpr int W_ITEMS = 36 * NT;            // float4 (= 4 points of one output channel) items per chunk: 36 rows x NT
+  constexpr int UROWS = TWOD ? 12 : 9;        // (dz,py) or (dz,dy) groups of 4 channel rows
+  constexpr int W_ITEMS = UROWS * 4 * NT;     // float4 (= 4 x-points of one output channel) items per chunk
   constexpr int W_LOADS = cdiv(W_ITEMS, 256);
   CFUN_DYN_LDS(float4, smem);
   float4* Vl = smem;                          // [4 ch][36 rows][8 pairs] x 4 points
@@ -96,36 +133,48 @@ k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const flo
 #pragma unroll
   for (int i = 0; i < W_LOADS; ++i) {
     const int it = tid + i * 256, row = it / NT, co = it % NT;
-    w_off[i] = (it < W_ITEMS && cobase + co < p.CoP) ? (((row >> 2) * p.Ci + (row & 3)) * p.CoP + cobase + co) : -1;
+    // items past the tile's rows / the padded width re-read a valid element: their LDS slot is not written / their
+    // output channels are never stored, so no select is needed (selects made hipcc wrap every load in a branch)
+    w_off[i] = (it < W_ITEMS && cobase + co < p.CoP) ? (((row >> 2) * p.Ci + (row & 3)) * p.CoP + cobase + co) : 0;
   }
   const int w_step = 4 * p.CoP;
-  float4 xin[X_IT][4], win[W_LOADS];
+  float4 xa[X_IT][4], win[W_LOADS];
   const int cpq = S2D ? (s2d_cq >> 2) : 1;       // chunks per parity
-  auto prefetch = [&](int c) {
-    int64_t xo = c * 4;
-    if (S2D) {
-      const int q = c / cpq, o4 = c - q * cpq;
-      xo = ((int64_t)((q >> 2) * 2 * p.Hi + ((q >> 1) & 1)) * 2 * p.Wi + (q & 1)) * s2d_cq + o4 * 4;
-    }
+  auto chunk_xoff = [&](int c) -> int64_t {
+    if (!S2D) return (int64_t)c * 4;
+    const int q = c / cpq, o4 = c - q * cpq;
+    return ((int64_t)((q >> 2) * 2 * p.Hi + ((q >> 1) & 1)) * 2 * p.Wi + (q & 1)) * s2d_cq + o4 * 4;
+  };
+  auto prefetch_x = [&](int c, float4 (&xin)[X_IT][4]) {      // unconditional loads; padding is zeroed in commit()
+    const int64_t xo = chunk_xoff(c);
 #pragma unroll
     for (int i = 0; i < X_IT; ++i)
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float4 v = *reinterpret_cast<const float4*>(in_ptr[i][k] + xo);
-        xin[i][k] = ((in_ok >> (i * 4 + k)) & 1u) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        xin[i][k] = make_float4(v.x, v.y, v.z, v.w);
       }
+  };
+  auto prefetch_w = [&](int c) {
 #pragma unroll
-    for (int i = 0; i < W_LOADS; ++i) {
-      const float4 v = u[w_off[i] >= 0 ? w_off[i] + c * w_step : 0];
-      win[i] = w_off[i] >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < W_LOADS; ++i) {     // (columns >= CoP: never stored)
+      const float4 v = u[w_off[i] + c * w_step];
+      win[i] = make_float4(v.x, v.y, v.z, v.w);
     }
   };
-  auto commit = [&]() {
+  constexpr int LBUF = 4 * VPLANE4 + UROWS * 4 * NT;      // float4 per LDS buffer (TWOD runs two of them)
+  auto commit = [&](int buf, const float4 (&xin)[X_IT][4]) {
+    float4* Vl = smem + buf * LBUF;
+    float4* Ul = Vl + 4 * VPLANE4;
 #pragma unroll
     for (int i = 0; i < X_IT; ++i) {
       const int it = tid + i * 256;
       if (it < X_ITEMS) {
-        const float4 d0 = xin[i][0], d1 = xin[i][1], d2 = xin[i][2], d3 = xin[i][3];
+        auto keep = [](unsigned bit, const float4& v) {     // component-wise: a struct select would go through scratch
+          return make_float4(bit ? v.x : 0.f, bit ? v.y : 0.f, bit ? v.z : 0.f, bit ? v.w : 0.f);
+        };
+        const float4 d0 = keep((in_ok >> (i * 4)) & 1u, xin[i][0]), d1 = keep((in_ok >> (i * 4 + 1)) & 1u, xin[i][1]),
+                     d2 = keep((in_ok >> (i * 4 + 2)) & 1u, xin[i][2]), d3 = keep((in_ok >> (i * 4 + 3)) & 1u, xin[i][3]);
         Vl[it] = make_float4(d0.x - d2.x, d1.x + d2.x, d2.x - d1.x, d1.x - d3.x);
         Vl[VPLANE4 + it] = make_float4(d0.y - d2.y, d1.y + d2.y, d2.y - d1.y, d1.y - d3.y);
         Vl[2 * VPLANE4 + it] = make_float4(d0.z - d2.z, d1.z + d2.z, d2.z - d1.z, d1.z - d3.z);
@@ -139,9 +188,10 @@ k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const flo
     }
   };
 
-  f32x4 acc[2][4][NSUB];
+  constexpr int NMG = TWOD ? 4 : 2;           // row groups (1-D) / y points (2-D)
+  f32x4 acc[NMG][4][NSUB];
 #pragma unroll
-  for (int mg = 0; mg < 2; ++mg)
+  for (int mg = 0; mg < NMG; ++mg)
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt)
 #pragma unroll
@@ -149,50 +199,123 @@ k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const flo
 
   // fragment bases (float4 = the 4 points): B column (lane & 15) = (row (lane>>3)&1 of the row group, pair lane&7),
   // k = channel lane>>4;  A row (lane & 15) = output channel
-  const float4* Vw = Vl + (lane >> 4) * VPLANE4 + (wv * IY + ((lane >> 3) & 1)) * NPAIR + (lane & 7);
-  const float4* Uw = Ul + (lane >> 4) * NT + (lane & 15);
+  const float4* Vw0 = Vl + (lane >> 4) * VPLANE4 + (wv * IY + (TWOD ? 2 : 1) * ((lane >> 3) & 1)) * NPAIR + (lane & 7);
+  const float4* Uw0 = Ul + (lane >> 4) * NT + (lane & 15);
 
   const int nchunks = p.Ci >> 2;
   const int c_begin = blockIdx.y * chunks_per_split;
   const int c_end = (c_begin + chunks_per_split < nchunks) ? c_begin + chunks_per_split : nchunks;
-  if (c_begin < c_end) prefetch(c_begin);
+  if constexpr (TWOD) {
+  // TWOD runs one wave per SIMD (192 accumulator registers at NSUB = 3), so nothing else hides the staging: LDS is double
+  // buffered (2 x 55 KB) -- the next chunk is committed to the other buffer after this chunk's MFMAs were issued, one
+  // barrier per chunk
+  if (c_begin < c_end) { prefetch_x(c_begin, xa); prefetch_w(c_begin); commit(0, xa); __syncthreads(); }
   for (int c = c_begin; c < c_end; ++c) {
-    __syncthreads();
-    commit();
-    __syncthreads();
-    if (c + 1 < c_end) prefetch(c + 1);
-    float4 a[NSUB], b[2];
-    auto frag = [&](int r9) {
-      const int dz = r9 / 3, dy = r9 - dz * 3;
+    if (c + 1 < c_end) { prefetch_x(c + 1, xa); prefetch_w(c + 1); }
+    if constexpr (TWOD) {
+      const float4* Vw = Vw0 + ((c - c_begin) & 1) * LBUF;
+      const float4* Uw = Uw0 + ((c - c_begin) & 1) * LBUF;
+      // 12 steps (dz,py): the 4 x-transformed rows of the next dz and the next step's weight fragment are in flight
+      // under the current step's 4*NSUB MFMAs
+      float4 rows[2][4], a2[2][NSUB];
+      auto load_rows = [&](int dz, float4 (&r)[4]) {
 #pragma unroll
-      for (int nn = 0; nn < NSUB; ++nn) a[nn] = Uw[r9 * 4 * NT + nn * 16];
+        for (int k = 0; k < 4; ++k) r[k] = Vw[(dz * IY + k) * NPAIR];
+      };
+      auto load_a = [&](int st, float4 (&a)[NSUB]) {
 #pragma unroll
-      for (int mg = 0; mg < 2; ++mg) b[mg] = Vw[(dz * IY + mg * 2 + dy) * NPAIR];
-    };
-    frag(0);
+        for (int nn = 0; nn < NSUB; ++nn) a[nn] = Uw[st * 4 * NT + nn * 16];
+      };
+      load_rows(0, rows[0]);
+      load_a(0, a2[0]);
 #ifndef CFUN_HIP_EMULATION
-    __builtin_amdgcn_sched_group_barrier(0x100, NSUB + 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4 + NSUB, 0);
 #endif
+      auto step = [&](auto s_) {
+        constexpr int st = decltype(s_)::value, dz = st / 4, py = st % 4;
+        const float4(&r)[4] = rows[dz & 1];
+        // B^T d along y: (d0 - d2, d1 + d2, d2 - d1, d1 - d3)
+        constexpr int r1 = py == 0 ? 0 : py == 2 ? 2 : 1, r2 = py == 0 ? 2 : py == 1 ? 2 : py == 2 ? 1 : 3;
+        constexpr float sg = py == 1 ? 1.f : -1.f;
+        const float bv[4] = {r[r1].x + sg * r[r2].x, r[r1].y + sg * r[r2].y, r[r1].z + sg * r[r2].z, r[r1].w + sg * r[r2].w};
+        float av[NSUB][4];
 #pragma unroll
-    for (int r9 = 0; r9 < 9; ++r9) {
-      float av[NSUB][4], bv[2][4];
+        for (int nn = 0; nn < NSUB; ++nn) {
+          const float4 t = a2[st & 1][nn];
+          av[nn][0] = t.x; av[nn][1] = t.y; av[nn][2] = t.z; av[nn][3] = t.w;
+        }
+        if (st + 1 < 12) load_a(st + 1, a2[(st + 1) & 1]);
+        if (py == 3 && dz < 2) load_rows(dz + 1, rows[(dz + 1) & 1]);
+#ifdef CFUN_HIP_EMULATION
 #pragma unroll
-      for (int nn = 0; nn < NSUB; ++nn) { av[nn][0] = a[nn].x; av[nn][1] = a[nn].y; av[nn][2] = a[nn].z; av[nn][3] = a[nn].w; }
-#pragma unroll
-      for (int mg = 0; mg < 2; ++mg) { bv[mg][0] = b[mg].x; bv[mg][1] = b[mg].y; bv[mg][2] = b[mg].z; bv[mg][3] = b[mg].w; }
-      if (r9 + 1 < 9) frag(r9 + 1);      // the next (dz,dy)'s fragments are in flight under this one's MFMAs
-#pragma unroll
-      for (int pt = 0; pt < 4; ++pt)
-#pragma unroll
-        for (int mg = 0; mg < 2; ++mg)
+        for (int px = 0; px < 4; ++px)
 #pragma unroll
           for (int nn = 0; nn < NSUB; ++nn)
-            acc[mg][pt][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[nn][pt], bv[mg][pt], acc[mg][pt][nn], 0, 0, 0);
-#ifndef CFUN_HIP_EMULATION
-      // keep that order in the schedule: the LDS reads first, then the MFMA block that hides their latency
-      if (r9 + 1 < 9) __builtin_amdgcn_sched_group_barrier(0x100, NSUB + 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 8 * NSUB, 0);
+            acc[py][px][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[nn][px], bv[px], acc[py][px][nn], 0, 0, 0);
+#else
+        // The 16 * NSUB accumulators must live in AGPRs (they do not fit beside the staging registers in the 256
+        // architectural VGPRs); left to itself hipcc splits their live ranges across both files and copies them around
+        // every chunk (848 v_accvgpr moves in the loop).  The "+a" constraint pins them; the phases are fenced by hand.
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 1");          // VALU-written B operand -> MFMA read
+#pragma unroll
+        for (int px = 0; px < 4; ++px)
+#pragma unroll
+          for (int nn = 0; nn < NSUB; ++nn)
+            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[py][px][nn]) : "v"(av[nn][px]), "v"(bv[px]));
+        __builtin_amdgcn_sched_barrier(0);
 #endif
+      };
+      static_for(std::make_integer_sequence<int, 12>{}, step);
+      if (c + 1 < c_end) commit(((c - c_begin) & 1) ^ 1, xa);
+      __syncthreads();
+    }
+  }
+  } else {
+    auto mfma_phase = [&]() {
+      const float4* Vw = Vw0;
+      const float4* Uw = Uw0;
+    float4 a[NSUB], b[2];
+      auto frag = [&](int r9) {
+        const int dz = r9 / 3, dy = r9 - dz * 3;
+  #pragma unroll
+        for (int nn = 0; nn < NSUB; ++nn) a[nn] = Uw[r9 * 4 * NT + nn * 16];
+  #pragma unroll
+        for (int mg = 0; mg < 2; ++mg) b[mg] = Vw[(dz * IY + mg * 2 + dy) * NPAIR];
+      };
+      frag(0);
+  #ifndef CFUN_HIP_EMULATION
+      __builtin_amdgcn_sched_group_barrier(0x100, NSUB + 2, 0);
+  #endif
+  #pragma unroll
+      for (int r9 = 0; r9 < 9; ++r9) {
+        float av[NSUB][4], bv[2][4];
+  #pragma unroll
+        for (int nn = 0; nn < NSUB; ++nn) { av[nn][0] = a[nn].x; av[nn][1] = a[nn].y; av[nn][2] = a[nn].z; av[nn][3] = a[nn].w; }
+  #pragma unroll
+        for (int mg = 0; mg < 2; ++mg) { bv[mg][0] = b[mg].x; bv[mg][1] = b[mg].y; bv[mg][2] = b[mg].z; bv[mg][3] = b[mg].w; }
+        if (r9 + 1 < 9) frag(r9 + 1);      // the next (dz,dy)'s fragments are in flight under this one's MFMAs
+  #pragma unroll
+        for (int pt = 0; pt < 4; ++pt)
+  #pragma unroll
+          for (int mg = 0; mg < 2; ++mg)
+  #pragma unroll
+            for (int nn = 0; nn < NSUB; ++nn)
+              acc[mg][pt][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[nn][pt], bv[mg][pt], acc[mg][pt][nn], 0, 0, 0);
+  #ifndef CFUN_HIP_EMULATION
+        // keep that order in the schedule: the LDS reads first, then the MFMA block that hides their latency
+        if (r9 + 1 < 9) __builtin_amdgcn_sched_group_barrier(0x100, NSUB + 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8 * NSUB, 0);
+  #endif
+      }
+    };
+    if (c_begin < c_end) { prefetch_x(c_begin, xa); prefetch_w(c_begin); }
+    for (int c = c_begin; c < c_end; ++c) {
+      __syncthreads();
+      commit(0, xa);
+      __syncthreads();
+      if (c + 1 < c_end) { prefetch_x(c + 1, xa); prefetch_w(c + 1); }
+      mfma_phase();
     }
   }
 
@@ -234,28 +357,46 @@ k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const flo
       *reinterpret_cast<float4*>(y + v * p.Co + co) = r;
     }
   };
-#pragma unroll
-  for (int mg = 0; mg < 2; ++mg)
+  if constexpr (TWOD) {     // Y = A^T M A: lane owns the 2 x 2 outputs of tile (ty = (lane>>3)&1, j = lane&7)
+    const int oy = y0 + 2 * ((lane >> 3) & 1);
 #pragma unroll
     for (int nn = 0; nn < NSUB; ++nn) {
-      const f32x4 m0 = acc[mg][0][nn], m1 = acc[mg][1][nn], m2 = acc[mg][2][nn], m3 = acc[mg][3][nn];
-      const int oy = y0 + mg * 2 + ((lane >> 3) & 1), co = cobase + nn * 16 + (lane >> 4) * 4;
-      emit(oy, oxe, co, (m0 + m1) + m2);
-      emit(oy, oxe + 1, co, (m1 - m2) - m3);
+      f32x4 e[4], o[4];
+#pragma unroll
+      for (int py = 0; py < 4; ++py) {
+        e[py] = (acc[py][0][nn] + acc[py][1][nn]) + acc[py][2][nn];
+        o[py] = (acc[py][1][nn] - acc[py][2][nn]) - acc[py][3][nn];
+      }
+      const int co = cobase + nn * 16 + (lane >> 4) * 4;
+      emit(oy, oxe, co, (e[0] + e[1]) + e[2]);
+      emit(oy, oxe + 1, co, (o[0] + o[1]) + o[2]);
+      emit(oy + 1, oxe, co, (e[1] - e[2]) - e[3]);
+      emit(oy + 1, oxe + 1, co, (o[1] - o[2]) - o[3]);
     }
+  } else {
+#pragma unroll
+    for (int mg = 0; mg < 2; ++mg)
+#pragma unroll
+      for (int nn = 0; nn < NSUB; ++nn) {
+        const f32x4 m0 = acc[mg][0][nn], m1 = acc[mg][1][nn], m2 = acc[mg][2][nn], m3 = acc[mg][3][nn];
+        const int oy = y0 + mg * 2 + ((lane >> 3) & 1), co = cobase + nn * 16 + (lane >> 4) * 4;
+        emit(oy, oxe, co, (m0 + m1) + m2);
+        emit(oy, oxe + 1, co, (m1 - m2) - m3);
+      }
+  }
 }
 
 // 16-channel subtiles per block.  NSUB <= 3 keeps two waves per SIMD (134 VGPR + 96 accumulators); 80 = 5 x 16 runs
 // unpadded at one wave per SIMD, which measured faster than 48 + 32 (tools/bench_layers.py, profiles/round2_ab_layers.log)
-int wino_nsub(int co) {
+int wino_nsub(int co, int twod) {
   static int mx = 0;      // tuning knob: CFUN_WINO_MAX_NSUB
   if (!mx) {
     const char* e = getenv("CFUN_WINO_MAX_NSUB");
     mx = e ? atoi(e) : -1;
     if (mx == 0 || mx > 5) mx = -1;
   }
-  if (mx < 0 && co == 80) return 5;
-  const int cap = mx < 0 ? 3 : mx;
+  if (mx < 0 && co == 80 && !twod) return 5;
+  const int cap = (mx < 0 || twod) ? 3 : mx;
   int best = 1, best_pad = 1 << 30;
   for (int n = 1; n <= cap; ++n) {
     const int nt = 16 * n, pad = (co + nt - 1) / nt * nt;
@@ -264,19 +405,32 @@ int wino_nsub(int co) {
   return best;
 }
 
+// y in the Winograd domain as well?  CFUN_WINO_2D: 0 = never, 1 = every supported shape, unset = measured shapes
+int wino_2d(const CfunConv3dParams& p) {
+  static int knob = -2;
+  if (knob == -2) {
+    const char* e = getenv("CFUN_WINO_2D");
+    knob = e ? atoi(e) : -1;
+  }
+  if (p.algo == CFUN_ALGO_WINO) return 0;       // tests: the 1-D kernel
+  if (p.algo == CFUN_ALGO_WINO2 || knob == 1) return 1;
+  return 0;
+}
+
 struct Plan {
-  int nsub, ntz, nty, ntx, ncot, ksplit, cps;
+  int nsub, twod, ntz, nty, ntx, ncot, ksplit, cps;
   int64_t nblk;
   size_t u_bytes, part_bytes;
 };
 
 Plan make_plan(const CfunConv3dParams& p, size_t ws_for_partials) {
   Plan w;
-  w.nsub = wino_nsub(p.Co);
+  w.twod = wino_2d(p);
+  w.nsub = wino_nsub(p.Co, w.twod);
   const int nt = 16 * w.nsub;
   w.ntz = cdiv(p.Do, TD); w.nty = cdiv(p.Ho, TH); w.ntx = cdiv(p.Wo, TW); w.ncot = cdiv(p.Co, nt);
   w.nblk = (int64_t)p.N * w.ntz * w.nty * w.ntx * w.ncot;
-  w.u_bytes = cfun_align_up((size_t)36 * p.Ci * p.CoP * sizeof(float), 256);
+  w.u_bytes = cfun_align_up((size_t)(w.twod ? 48 : 36) * p.Ci * p.CoP * sizeof(float), 256);
   w.ksplit = cfun_mfma::splitk_factor(w.nblk, p.Ci >> 2, p, ws_for_partials);
   w.cps = cdiv(p.Ci >> 2, w.ksplit);
   w.part_bytes = w.ksplit > 1 ? (size_t)w.ksplit * p.N * p.Do * p.Ho * p.Wo * p.Co * sizeof(float) : 0;
@@ -286,8 +440,13 @@ Plan make_plan(const CfunConv3dParams& p, size_t ws_for_partials) {
 template <int NSUB>
 int launch(const float* x, const float4* u, const float* scale, const float* shift, const float* res, float* y,
            const CfunConv3dParams& p, const Plan& w, float* partial, int s2d_cq, hipStream_t st) {
-  const size_t lds = (size_t)(4 * VPLANE4 + 36 * 16 * NSUB) * sizeof(float4);
-  auto kern = s2d_cq ? k_conv_wino<NSUB, true> : k_conv_wino<NSUB, false>;
+  const size_t lds = (size_t)(w.twod ? 2 : 1) * (4 * VPLANE4 + (w.twod ? 48 : 36) * 16 * NSUB) * sizeof(float4);
+  auto kern = s2d_cq ? k_conv_wino<NSUB, true, false> : k_conv_wino<NSUB, false, false>;
+  if constexpr (NSUB <= 3) {     // 16 accumulator sets per wave: 64 * NSUB registers
+    if (w.twod) kern = s2d_cq ? k_conv_wino<NSUB, true, true> : k_conv_wino<NSUB, false, true>;
+  } else if (w.twod) {
+    return CFUN_EINVAL;
+  }
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -324,7 +483,7 @@ int cfun_wino_supported(const CfunConv3dParams* p) {
   }
   if (p->Do != p->Di + 2 * p->pd - 2 || p->Ho != p->Hi || p->Wo != p->Wi) return 0;
   if ((int64_t)p->N * p->Do * p->Ho * p->Wo == 0) return 0;
-  if (knob == 1 || p->algo == CFUN_ALGO_WINO) return 1;
+  if (knob == 1 || p->algo == CFUN_ALGO_WINO || p->algo == CFUN_ALGO_WINO2) return 1;
   // (the folded 5x5x5 'finetune' conv -- d2s, C_in = 8 -- has two channel chunks and is bound by its stores: no gain measured)
   return p->Co >= 32 && p->Ci >= 16 && !p->d2s;
 }
@@ -357,7 +516,10 @@ int cfun_wino_fwd(const float* x, const float* wp, int flip, int s2d_cq, const f
   float4* u = (float4*)ws;
   float* partial = (float*)((char*)ws + w.u_bytes);
   const int64_t nu = (int64_t)9 * p->Ci * p->CoP;
-  hipLaunchKernelGGL(k_wino_weights, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, st, wp, u, p->Ci, p->CoP, flip);
+  if (w.twod)
+    hipLaunchKernelGGL(k_wino2_weights, dim3((unsigned)((nu / 3 + 255) / 256)), dim3(256), 0, st, wp, u, p->Ci, p->CoP, flip);
+  else
+    hipLaunchKernelGGL(k_wino_weights, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, st, wp, u, p->Ci, p->CoP, flip);
   CFUN_LAUNCH_CHECK();
   int rc;
   switch (w.nsub) {
@@ -594,7 +756,7 @@ int cfun_wino_wgrad_supported(const CfunConv3dParams* p) {
   if (knob == 0 || !cfun_wino_supported(p)) return 0;
   const int64_t lim = (int64_t)1 << 31;      // 32-bit element offsets
   if ((int64_t)p->N * p->Di * p->Hi * p->Wi * p->Ci >= lim || (int64_t)p->N * p->Do * p->Ho * p->Wo * p->Co >= lim) return 0;
-  if (knob == 1 || p->algo == CFUN_ALGO_WINO) return 1;
+  if (knob == 1 || p->algo == CFUN_ALGO_WINO || p->algo == CFUN_ALGO_WINO2) return 1;
   if (p->d2s) return 0;       // the folded 5x5x5 conv (C_in = 8): the direct kernel's packed tap pairs win (1.03 vs 1.29 ms)
   // C_in <= 8 (packed tap groups: 7 / 14 fragment rows) and 17..20 (fused plain + packed rows) stay on the direct kernels:
   // measured with tools/bench_layers.py (8->20 0.172 vs 0.191 ms, 20->20 1.17 vs 1.20; 12->20 0.251 -> 0.189, 40->40 3.41 -> 2.65)

@@ -44,6 +44,7 @@ typedef void* cfun_stream_t;
 #define CFUN_ALGO_DIRECT 1        /* generic VALU direct convolution (any shape) */
 #define CFUN_ALGO_MFMA 2          /* LDS-tiled implicit GEMM on v_mfma_f32_16x16x4_f32 (Ci%4==0, Co%4==0) */
 #define CFUN_ALGO_WINO 4          /* as AUTO, but every supported 3x3x3 stride-1 conv runs the F(2,3)-along-x MFMA kernel */
+#define CFUN_ALGO_WINO2 5         /* as WINO with y in the Winograd domain as well (F(2x2,3x3) per z tap) in forward / dgrad */
 
 int cfun_version(void);
 const char* cfun_error_string(int code);

@@ -7,7 +7,7 @@ import torch
 import torch.nn.functional as F
 
 from cfun_amd import ops
-from cfun_amd._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_WINO
+from cfun_amd._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_WINO, ALGO_WINO2
 from oracle import cfun_oracle as orc
 
 RTOL = 2e-5
@@ -100,6 +100,10 @@ CONV_CASES = {
     "wino_333_two_cotiles": (1, (3, 4, 5), 4, 96, (3, 3, 3), dict(algo=ALGO_WINO)),
     "wino_333_splitk_epilogue": (2, (4, 4, 8), 32, 16, (3, 3, 3), dict(algo=ALGO_WINO, act=ACT_LRELU, scale=True, per_n=True, shift=True, res=True)),
     "wino_333_40_40": (1, (4, 5, 19), 40, 40, (3, 3, 3), dict(algo=ALGO_WINO)),
+    "wino2_333_8_48_ragged": (1, (5, 6, 18), 8, 48, (3, 3, 3), dict(algo=ALGO_WINO2)),
+    "wino2_333_epilogue_odd_w": (2, (4, 5, 7), 8, 40, (3, 3, 3), dict(algo=ALGO_WINO2, act=ACT_LRELU, scale=True, per_n=True, res=True, shift=True)),
+    "wino2_333_two_cotiles_splitk": (2, (4, 4, 8), 32, 96, (3, 3, 3), dict(algo=ALGO_WINO2, shift=True)),
+    "wino2_333_d2s_slab": (1, (6, 4, 5), 8, 64, (3, 3, 3), dict(algo=ALGO_WINO2, d2s=True, res=True, pad=(0, 1, 1))),
     "wino_333_slab_pd0": (2, (7, 5, 9), 16, 32, (3, 3, 3), dict(algo=ALGO_WINO, pad=(0, 1, 1), shift=True)),   # a depth slab with its halo
     "wino_333_d2s_res": (2, (3, 4, 5), 8, 64, (3, 3, 3), dict(algo=ALGO_WINO, d2s=True, res=True, act=ACT_LRELU)),
 }
@@ -108,6 +112,8 @@ CONV_CASES_LARGE = {
     "mfma_333_40_40_32cube": (2, (32, 32, 32), 40, 40, (3, 3, 3), dict(algo=ALGO_MFMA, act=ACT_LRELU, res=True)),
     "wino_333_40_40_32cube": (2, (32, 32, 32), 40, 40, (3, 3, 3), dict(algo=ALGO_WINO, act=ACT_LRELU, res=True)),
     "wino_333_80_80_24cube": (2, (24, 24, 26), 80, 80, (3, 3, 3), dict(algo=ALGO_WINO, shift=True)),
+    "wino2_333_40_40_32cube": (2, (32, 32, 32), 40, 40, (3, 3, 3), dict(algo=ALGO_WINO2, act=ACT_LRELU, res=True)),
+    "wino2_333_160_160_24cube": (1, (24, 24, 26), 160, 160, (3, 3, 3), dict(algo=ALGO_WINO2, shift=True)),
     "wino_333_128_256_fpn": (1, (8, 16, 16), 128, 256, (3, 3, 3), dict(algo=ALGO_WINO, shift=True, act=ACT_RELU)),
     "mfma_333_128_256_fpn": (1, (8, 16, 16), 128, 256, (3, 3, 3), dict(algo=ALGO_MFMA, shift=True, act=ACT_RELU)),
     "mfma_333_320_160_up2": (2, (6, 6, 6), 320, 160, (3, 3, 3), dict(algo=ALGO_MFMA, up2=True)),
