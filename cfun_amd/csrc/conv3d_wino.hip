@@ -32,7 +32,6 @@ using cfun_mfma::cdiv;
 
 constexpr int TD = 4, TH = 4, TW = 16, IZ = 6, IY = 6, NPAIR = 8;
 constexpr int VPLANE4 = IZ * IY * NPAIR;      // float4 (= the 4 points of one x-pair) per channel of the halo tile
-constexpr int X_ITEMS = IZ * IY * NPAIR, X_IT = cdiv(X_ITEMS, 256);
 
 // u[r9][ci][co][point] from wp[tap = r9*3 + dx][ci][co]  (flip: the data gradient reads tap 26 - t)
 __global__ void __launch_bounds__(256)
@@ -105,24 +104,30 @@ k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const flo
   const int z0 = tz * TD, y0 = ty * TH, x0 = tx * TW;
   const int cobase = cot * NT;
 
-  // ---- staging descriptors.  X item = (z, y, x-pair j) of the halo tile -> 4 voxels x = 2j .. 2j+3 (4 channels each);
-  // out-of-volume voxels load element 0 and are zeroed by a select (no divergent branches in the chunk loop)
-  const float* in_ptr[X_IT][4];
+  // ---- staging descriptors.  X item = (halo row r = (z, y), column pair jj of 9): the two voxels x = 2jj, 2jj+1 for TWO
+  // consecutive channel chunks (each 16-byte piece; both come out of the same 64-byte sector, so issued back to back
+  // the second merges with the first's miss instead of fetching the sector from L2 again one chunk later -- the tile's
+  // 104 KB footprint does not survive in the L1 between chunks).  A wave owns 7 whole rows per pass (lane = 9*row + jj,
+  // lane 63 idle), so the two voxels an x-pair needs from the next column pair are one lane away (__shfl).  Loads are
+  // unconditional (out-of-volume voxels read element 0) and the zero padding is applied in commit(): selects at load time
+  // made hipcc wrap every load in a branch.
+  constexpr int X_PASSES = 2;                   // 4 waves x 7 rows x 2 passes = 56 >= 36 halo rows
+  const int xrow0 = wv * 7 + lane / 9, xjj = lane % 9;
+  const float* in_ptr[X_PASSES][2];
   unsigned in_ok = 0;
 #pragma unroll
-  for (int i = 0; i < X_IT; ++i) {
-    const int it = tid + i * 256;
+  for (int i = 0; i < X_PASSES; ++i) {
+    const int r = i * 28 + xrow0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) in_ptr[i][k] = x;
-    if (it < X_ITEMS) {
-      const int j = it & 7, yi = (it >> 3) % IY, zi = it / (NPAIR * IY);
-      const int vz = z0 - p.pd + zi, vy = y0 - p.ph + yi, vx = x0 - p.pw + 2 * j;
+    for (int k = 0; k < 2; ++k) in_ptr[i][k] = x;
+    if (lane < 63 && r < IZ * IY) {
+      const int vz = z0 - p.pd + r / IY, vy = y0 - p.ph + r % IY, vx = x0 - p.pw + 2 * xjj;
       if (vz >= 0 && vz < p.Di && vy >= 0 && vy < p.Hi) {
         const int64_t row = (((int64_t)n * p.Di + vz) * p.Hi + vy) * p.Wi;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < 2; ++k)
           if (vx + k >= 0 && vx + k < p.Wi) {
-            in_ok |= 1u << (i * 4 + k);
+            in_ok |= 1u << (i * 2 + k);
             in_ptr[i][k] = S2D ? x + ((((int64_t)n * 2 * p.Di + 2 * vz) * 2 * p.Hi + 2 * vy) * 2 * p.Wi + 2 * (vx + k)) * s2d_cq
                                : x + (row + vx + k) * p.Ci;
           }
@@ -138,21 +143,23 @@ k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const flo
     w_off[i] = (it < W_ITEMS && cobase + co < p.CoP) ? (((row >> 2) * p.Ci + (row & 3)) * p.CoP + cobase + co) : 0;
   }
   const int w_step = 4 * p.CoP;
-  float4 xa[X_IT][4], win[W_LOADS];
+  float4 xp[X_PASSES][2][2], win[W_LOADS];      // [pass][voxel][chunk of the pair]
   const int cpq = S2D ? (s2d_cq >> 2) : 1;       // chunks per parity
   auto chunk_xoff = [&](int c) -> int64_t {
     if (!S2D) return (int64_t)c * 4;
     const int q = c / cpq, o4 = c - q * cpq;
     return ((int64_t)((q >> 2) * 2 * p.Hi + ((q >> 1) & 1)) * 2 * p.Wi + (q & 1)) * s2d_cq + o4 * 4;
   };
-  auto prefetch_x = [&](int c, float4 (&xin)[X_IT][4]) {      // unconditional loads; padding is zeroed in commit()
-    const int64_t xo = chunk_xoff(c);
+  auto prefetch_x = [&](int c, int c1) {          // chunks c and c1 (= c + 1, or c again at the end) of this thread's voxels
+    const int64_t xo = chunk_xoff(c), xo1 = chunk_xoff(c1);
 #pragma unroll
-    for (int i = 0; i < X_IT; ++i)
+    for (int i = 0; i < X_PASSES; ++i)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < 2; ++k) {
         const float4 v = *reinterpret_cast<const float4*>(in_ptr[i][k] + xo);
-        xin[i][k] = make_float4(v.x, v.y, v.z, v.w);
+        const float4 w = *reinterpret_cast<const float4*>(in_ptr[i][k] + xo1);
+        xp[i][k][0] = make_float4(v.x, v.y, v.z, v.w);
+        xp[i][k][1] = make_float4(w.x, w.y, w.z, w.w);
       }
   };
   auto prefetch_w = [&](int c) {
@@ -163,22 +170,29 @@ k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const flo
     }
   };
   constexpr int LBUF = 4 * VPLANE4 + UROWS * 4 * NT;      // float4 per LDS buffer (TWOD runs two of them)
-  auto commit = [&](int buf, const float4 (&xin)[X_IT][4]) {
+  auto commit = [&](int buf, int half) {           // half: which chunk of the prefetched pair
     float4* Vl = smem + buf * LBUF;
     float4* Ul = Vl + 4 * VPLANE4;
 #pragma unroll
-    for (int i = 0; i < X_IT; ++i) {
-      const int it = tid + i * 256;
-      if (it < X_ITEMS) {
-        auto keep = [](unsigned bit, const float4& v) {     // component-wise: a struct select would go through scratch
-          return make_float4(bit ? v.x : 0.f, bit ? v.y : 0.f, bit ? v.z : 0.f, bit ? v.w : 0.f);
-        };
-        const float4 d0 = keep((in_ok >> (i * 4)) & 1u, xin[i][0]), d1 = keep((in_ok >> (i * 4 + 1)) & 1u, xin[i][1]),
-                     d2 = keep((in_ok >> (i * 4 + 2)) & 1u, xin[i][2]), d3 = keep((in_ok >> (i * 4 + 3)) & 1u, xin[i][3]);
-        Vl[it] = make_float4(d0.x - d2.x, d1.x + d2.x, d2.x - d1.x, d1.x - d3.x);
-        Vl[VPLANE4 + it] = make_float4(d0.y - d2.y, d1.y + d2.y, d2.y - d1.y, d1.y - d3.y);
-        Vl[2 * VPLANE4 + it] = make_float4(d0.z - d2.z, d1.z + d2.z, d2.z - d1.z, d1.z - d3.z);
-        Vl[3 * VPLANE4 + it] = make_float4(d0.w - d2.w, d1.w + d2.w, d2.w - d1.w, d1.w - d3.w);
+    for (int i = 0; i < X_PASSES; ++i) {
+      float d[4][4];                                // [voxel 0..3 of the x-pair][channel]
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const bool ok = (in_ok >> (i * 2 + k)) & 1u;
+        const float4 lo = xp[i][k][0], hi = xp[i][k][1];
+        d[k][0] = ok ? (half ? hi.x : lo.x) : 0.f; d[k][1] = ok ? (half ? hi.y : lo.y) : 0.f;
+        d[k][2] = ok ? (half ? hi.z : lo.z) : 0.f; d[k][3] = ok ? (half ? hi.w : lo.w) : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) d[2 + k][cc] = __shfl(d[k][cc], (lane + 1) & 63, 64);     // voxels 2jj+2, 2jj+3
+      const int r = i * 28 + xrow0;
+      if (lane < 63 && r < IZ * IY && xjj < NPAIR) {
+        float4* v = Vl + r * NPAIR + xjj;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+          v[cc * VPLANE4] = make_float4(d[0][cc] - d[2][cc], d[1][cc] + d[2][cc], d[2][cc] - d[1][cc], d[1][cc] - d[3][cc]);
       }
     }
 #pragma unroll
@@ -209,9 +223,14 @@ k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const flo
   // TWOD runs one wave per SIMD (192 accumulator registers at NSUB = 3), so nothing else hides the staging: LDS is double
   // buffered (2 x 55 KB) -- the next chunk is committed to the other buffer after this chunk's MFMAs were issued, one
   // barrier per chunk
-  if (c_begin < c_end) { prefetch_x(c_begin, xa); prefetch_w(c_begin); commit(0, xa); __syncthreads(); }
+  if (c_begin < c_end) {
+    prefetch_x(c_begin, c_begin + 1 < c_end ? c_begin + 1 : c_begin);
+    prefetch_w(c_begin);
+    commit(0, 0);
+    __syncthreads();
+  }
   for (int c = c_begin; c < c_end; ++c) {
-    if (c + 1 < c_end) { prefetch_x(c + 1, xa); prefetch_w(c + 1); }
+    if (c + 1 < c_end) prefetch_w(c + 1);
     if constexpr (TWOD) {
       const float4* Vw = Vw0 + ((c - c_begin) & 1) * LBUF;
       const float4* Uw = Uw0 + ((c - c_begin) & 1) * LBUF;
@@ -267,7 +286,11 @@ k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const flo
 #endif
       };
       static_for(std::make_integer_sequence<int, 12>{}, step);
-      if (c + 1 < c_end) commit(((c - c_begin) & 1) ^ 1, xa);
+      if (c + 1 < c_end) {
+        const int half = (c + 1 - c_begin) & 1;
+        commit(((c - c_begin) & 1) ^ 1, half);
+        if (half && c + 2 < c_end) prefetch_x(c + 2, c + 3 < c_end ? c + 3 : c + 2);     // both halves consumed: next pair
+      }
       __syncthreads();
     }
   }
@@ -309,12 +332,14 @@ k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const flo
   #endif
       }
     };
-    if (c_begin < c_end) { prefetch_x(c_begin, xa); prefetch_w(c_begin); }
+    if (c_begin < c_end) { prefetch_x(c_begin, c_begin + 1 < c_end ? c_begin + 1 : c_begin); prefetch_w(c_begin); }
     for (int c = c_begin; c < c_end; ++c) {
       __syncthreads();
-      commit(0, xa);
+      const int half = (c - c_begin) & 1;
+      commit(0, half);
       __syncthreads();
-      if (c + 1 < c_end) { prefetch_x(c + 1, xa); prefetch_w(c + 1); }
+      if (c + 1 < c_end) prefetch_w(c + 1);
+      if (half && c + 1 < c_end) prefetch_x(c + 1, c + 2 < c_end ? c + 2 : c + 1);        // both halves consumed: next pair
       mfma_phase();
     }
   }
