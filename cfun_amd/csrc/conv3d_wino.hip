@@ -411,8 +411,9 @@ k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const flo
   }
 }
 
-// 16-channel subtiles per block.  NSUB <= 3 keeps two waves per SIMD (134 VGPR + 96 accumulators); 80 = 5 x 16 runs
-// unpadded at one wave per SIMD, which measured faster than 48 + 32 (tools/bench_layers.py, profiles/round2_ab_layers.log)
+// 16-channel subtiles per block: fewest padded channels, widest on ties, at most 3 (two waves per SIMD: 134 VGPR + 96
+// accumulators).  80 channels = 5 tiles of 16 measured as fast as one 80-wide tile at one wave per SIMD on 48^3 and 10 %
+// faster on 24^3 (tools/bench_layers.py, profiles/round2_ab_layers.log)
 int wino_nsub(int co, int twod) {
   static int mx = 0;      // tuning knob: CFUN_WINO_MAX_NSUB
   if (!mx) {
@@ -420,7 +421,6 @@ int wino_nsub(int co, int twod) {
     mx = e ? atoi(e) : -1;
     if (mx == 0 || mx > 5) mx = -1;
   }
-  if (mx < 0 && co == 80 && !twod) return 5;
   const int cap = (mx < 0 || twod) ? 3 : mx;
   int best = 1, best_pad = 1 << 30;
   for (int n = 1; n <= cap; ++n) {
