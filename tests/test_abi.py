@@ -87,3 +87,30 @@ def test_input_formatting_helpers():
     iid, shape, window, active = utils.parse_image_meta(meta)
     assert int(iid[0]) == 7 and list(shape[0]) == [1, 32, 64, 64] and list(window[0]) == [0, 0, 0, 32, 64, 64]
     assert active.shape == (1, 8)
+
+
+def test_conv_kernel_selection(emu):
+    """Which kernel family AUTO picks for the benchmarked shapes (cfun_conv3d_fwd_kernel): the measured per-shape rules of
+    DESIGN section 3.9 must not drift silently.  Host-side logic only (no launch)."""
+    import ctypes as C
+    from cfun_amd import _lib, ops
+    lib = _lib.load()
+    DIRECT, MFMA, WINO, STEM, POINTWISE = 0, 1, 2, 3, 4
+
+    def kern(shape, **spec):
+        p = ops._params(ops.ConvSpec(**spec), shape, False, False, False)
+        return int(lib.cfun_conv3d_fwd_kernel(C.byref(p)))
+
+    k3 = dict(k=(3, 3, 3), pad=(1, 1, 1))
+    assert kern((4, 96, 96, 96, 40), co=40, **k3) == WINO                      # conv_norm_lrelu_l4.0, the dominant launch
+    assert kern((4, 48, 48, 48, 80), co=80, **k3) == WINO
+    assert kern((1, 16, 32, 32, 128), co=256, **k3) == WINO                    # rpn.conv_shared
+    assert kern((2, 8, 8, 8, 40), co=40, k=(3, 3, 3), pad=(0, 1, 1)) == WINO   # a depth slab that arrives with its halo
+    assert kern((4, 96, 96, 96, 20), co=20, **k3) == MFMA                      # 32-wide tile would pad C_out = 20 by 37 %
+    assert kern((4, 96, 96, 96, 40), co=40, algo=_lib.ALGO_MFMA, **k3) == MFMA
+    assert kern((4, 96, 96, 96, 20), co=40, stride=2, **k3) == MFMA            # stride 2
+    assert kern((4, 48, 48, 48, 40), co=8 * 32, d2s=True, d2s_cq=20, tap_skip=True, **k3) == MFMA   # parity-folded up-conv
+    assert kern((4, 96, 96, 96, 8), co=64, d2s=True, **k3) == MFMA             # folded 5x5x5 conv: forward stays direct
+    assert kern((4, 96, 96, 96, 1), co=20, **k3) == STEM
+    assert kern((4, 96, 96, 96, 40), co=8, k=(1, 1, 1), pad=(0, 0, 0)) == POINTWISE
+    assert kern((1, 8, 8, 8, 3), co=5, **k3) == DIRECT                         # channel counts the MFMA tiles cannot take
