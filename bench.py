@@ -70,11 +70,16 @@ def dominant_kernel_info(cfg, n_roi):
     spec = ops.ConvSpec(k=(3, 3, 3), co=2 * b, pad=(1, 1, 1))
     p = ops._params(spec, (n_roi,) + side + (2 * b,), False, False, False)
     kern = int(_lib.load().cfun_conv3d_fwd_kernel(C.byref(p)))
-    co_pad = (2 * b + 47) // 48 * 48 if 2 * b != 80 else 80
+    nsub, best_pad = 1, 1 << 30      # conv3d_wino.hip wino_nsub(): fewest padded channels, widest on ties, at most 3
+    for n_ in (1, 2, 3):
+        pad = -(-2 * b // (16 * n_)) * 16 * n_
+        if pad <= best_pad:
+            nsub, best_pad = n_, pad
+    co_pad = best_pad if kern == 2 else -(-2 * b // 16) * 16
     tiles = n_roi * -(-side[0] // 4) * -(-side[1] // 4) * -(-side[2] // 16)
     macs_per_tile_ch = 256 * 27 * (2.0 / 3.0 if kern == 2 else 1.0)
     executed = 2.0 * tiles * macs_per_tile_ch * (2 * b) * co_pad
-    return kern, executed
+    return kern, executed, nsub
 
 
 def git_blob_sha1(path):
@@ -286,8 +291,8 @@ def main():
         flops = 2.0 * (2 * b) * (2 * b) * 27 * side[0] * side[1] * side[2] * n_roi_launch   # per launch
         durs = timer.durations_ms("mfma")
         durs_h = timer.durations_ms("hbm")
-        kern, executed = dominant_kernel_info(cfg, n_roi_launch)
-        kname = {2: "k_conv_wino<3> (x axis in the Winograd F(2,3) domain: 2/3 of the direct MACs on the MFMA pipe, "
+        kern, executed, nsub_w = dominant_kernel_info(cfg, n_roi_launch)
+        kname = {2: "k_conv_wino<%d> (x axis" % nsub_w + " in the Winograd F(2,3) domain: 2/3 of the direct MACs on the MFMA pipe, "
                     "incl. its k_wino_weights transform launch)", 1: "k_conv_mfma<3,3,3,1,3>"}.get(kern, "kernel code %d" % kern)
         t_k = sum(durs) / max(len(durs), 1) * 1e-3
         achieved = flops / t_k / 1e12 if t_k > 0 else 0.0
