@@ -73,6 +73,25 @@ def main():
         yr = conv(xr)
         (yr * gys).sum().backward()
         res.update(ref_conv_y=yr.detach().numpy(), ref_conv_gx=xr.grad.numpy(), ref_conv_gw=conv.weight.grad.numpy())
+    # 3b) the same with channel counts for which AUTO picks the Winograd kernels (16 -> 32): the slabs run them with depth
+    #     padding 0 on their halo planes (interior / edge launches of halo_conv), the data gradient with depth padding 2
+    torch.manual_seed(2)
+    convw = Conv3dParams(16, 32, 3, padding=1)
+    xw = torch.randn(1, 8, 4, 6, 16, generator=g)
+    gyw = torch.randn(1, 8, 4, 6, 32, generator=g)
+    with cdist.depth_sharded():
+        xlw = cdist.slab(xw, dim=1).clone().requires_grad_(True)
+        ylw = convw(xlw)
+        (ylw * cdist.slab(gyw, dim=1)).sum().backward()
+        wgw = convw.weight.grad.clone()
+        dist.all_reduce(wgw)
+    res["wconv_y"], res["wconv_gx"], res["wconv_gw"] = ylw.detach().numpy(), xlw.grad.numpy(), wgw.numpy()
+    if rank == 0:
+        convw.weight.grad = None
+        xrw = xw.clone().requires_grad_(True)
+        yrw = convw(xrw)
+        (yrw * gyw).sum().backward()
+        res.update(ref_wconv_y=yrw.detach().numpy(), ref_wconv_gx=xrw.grad.numpy(), ref_wconv_gw=convw.weight.grad.numpy())
     # 4) data-parallel replicas: bucketed gradient averaging overlapped with backward (hooks), incl. a parameter that
     #    gets no gradient and a weight used twice (one accumulate, one hook call)
     torch.manual_seed(2)

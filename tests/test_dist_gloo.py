@@ -58,6 +58,10 @@ def test_depth_sharding_world2(emu_lib, tmp_path):
     np.testing.assert_allclose(np.concatenate([r[0]["conv_y"], r[1]["conv_y"]], axis=1), ref["ref_conv_y"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(np.concatenate([r[0]["conv_gx"], r[1]["conv_gx"]], axis=1), ref["ref_conv_gx"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(r[0]["conv_gw"], ref["ref_conv_gw"], rtol=1e-4, atol=1e-5)
+    # ... and through the Winograd kernels (16 -> 32 channels: slabs with depth padding 0, data gradient with padding 2)
+    np.testing.assert_allclose(np.concatenate([r[0]["wconv_y"], r[1]["wconv_y"]], axis=1), ref["ref_wconv_y"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(np.concatenate([r[0]["wconv_gx"], r[1]["wconv_gx"]], axis=1), ref["ref_wconv_gx"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(r[0]["wconv_gw"], ref["ref_wconv_gw"], rtol=1e-4, atol=2e-5)
 
     # bucketed data-parallel gradient averaging: every rank ends with the mean of the per-rank gradients
     mean = 0.5 * (r[0]["dp_local"] + r[1]["dp_local"])
