@@ -19,7 +19,7 @@ for r in rows:
     d[r["Counter_Name"]] = float(r["Counter_Value"])
 agg = collections.OrderedDict()
 for (_, name), v in disp.items():
-    if "mfma" not in name and "wgrad" not in name:
+    if "mfma" not in name and "wgrad" not in name and "wino" not in name:
         continue
     m = re.search(r"(k_\w+<[^>]*>)", name)
     a = agg.setdefault((m.group(1) if m else name[:60], v["grid"], v["vgpr"]), [0.0, 0.0, 0])
