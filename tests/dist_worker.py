@@ -199,7 +199,7 @@ def main():
     #    all-reduced InstanceNorm statistics, the lower levels folded onto both ranks): logits slabs and the summed
     #    parameter gradients equal the single-process U-Net, in both stages, with Dropout3d active
     from cfun_amd.mask_branch import Modified3DUNet
-    for stage7 in ("finetune",):           # ('finetune' = 'beginning' + the folded 5^3 up-scaling conv on slabs)
+    for stage7 in ("beginning", "finetune"):
         torch.manual_seed(7)
         unet = Modified3DUNet(1, 8, stage7, 4)
         unet.train()

@@ -86,8 +86,8 @@ CONV_CASES = {
     "auto_lits_stem_wgrad_mfma": (1, (6, 8, 8), 1, 24, (5, 7, 7), dict(stride=2, pad=(2, 3, 3), algo=ALGO_AUTO)),
     "mfma_333_splitk_epilogue": (2, (4, 4, 8), 32, 16, (3, 3, 3), dict(algo=ALGO_MFMA, act=ACT_LRELU, scale=True, per_n=True, shift=True, res=True)),
     "mfma_111_splitk_res_up2": (1, (4, 4, 8), 64, 8, (1, 1, 1), dict(algo=ALGO_MFMA, res=True, res_up2=True)),
-    "mfma_333_rem_20_20": (1, (4, 5, 17), 20, 20, (3, 3, 3), dict(algo=ALGO_MFMA, act=ACT_LRELU, res=True, scale=True, per_n=True)),
-    "mfma_333_rem_40_40": (1, (4, 5, 7), 40, 40, (3, 3, 3), dict(algo=ALGO_MFMA)),
+    "mfma_333_rem_20_20": (1, (5, 6, 18), 20, 20, (3, 3, 3), dict(algo=ALGO_MFMA, act=ACT_LRELU, res=True, scale=True, per_n=True)),
+    "mfma_333_rem_40_40": (2, (4, 5, 7), 40, 40, (3, 3, 3), dict(algo=ALGO_MFMA)),
     "mfma_333_rem_16_8": (1, (4, 5, 17), 16, 8, (3, 3, 3), dict(algo=ALGO_MFMA, shift=True)),
     "mfma_111_rem_40_8_res_up2": (1, (4, 6, 18), 40, 8, (1, 1, 1), dict(algo=ALGO_MFMA, res=True, res_up2=True)),
     "mfma_333_s2_rem_20_40": (1, (8, 8, 10), 20, 40, (3, 3, 3), dict(algo=ALGO_MFMA, stride=2)),
@@ -99,11 +99,14 @@ CONV_CASES = {
     "wino_333_epilogue_odd_w": (2, (4, 5, 7), 8, 40, (3, 3, 3), dict(algo=ALGO_WINO, act=ACT_LRELU, scale=True, per_n=True, res=True, shift=True)),
     "wino_333_two_cotiles": (1, (3, 4, 5), 4, 96, (3, 3, 3), dict(algo=ALGO_WINO)),
     "wino_333_splitk_epilogue": (2, (4, 4, 8), 32, 16, (3, 3, 3), dict(algo=ALGO_WINO, act=ACT_LRELU, scale=True, per_n=True, shift=True, res=True)),
-    "wino_333_40_40": (1, (3, 5, 17), 40, 40, (3, 3, 3), dict(algo=ALGO_WINO)),
+    "wino_333_40_40": (1, (4, 5, 19), 40, 40, (3, 3, 3), dict(algo=ALGO_WINO)),
     "wino2_333_8_48_ragged": (1, (5, 6, 18), 8, 48, (3, 3, 3), dict(algo=ALGO_WINO2)),
     "wino2_333_epilogue_odd_w": (2, (4, 5, 7), 8, 40, (3, 3, 3), dict(algo=ALGO_WINO2, act=ACT_LRELU, scale=True, per_n=True, res=True, shift=True)),
     "wino2_333_two_cotiles_splitk": (2, (4, 4, 8), 32, 96, (3, 3, 3), dict(algo=ALGO_WINO2, shift=True)),
     "wino2_333_d2s_slab": (1, (6, 4, 5), 8, 64, (3, 3, 3), dict(algo=ALGO_WINO2, d2s=True, res=True, pad=(0, 1, 1))),
+    "wino_333_80_80_nsub1_tiles": (1, (5, 4, 10), 80, 80, (3, 3, 3), dict(algo=ALGO_WINO, act=ACT_LRELU)),      # 5 co tiles of 16, 5 ci subtiles
+    "wino_333_12_20_small_ci": (1, (4, 6, 9), 12, 20, (3, 3, 3), dict(algo=ALGO_WINO)),                        # C_in = 12: one half-empty ci subtile
+    "wino2_333_40_40": (1, (4, 5, 19), 40, 40, (3, 3, 3), dict(algo=ALGO_WINO2, res=True)),
     "wino_333_slab_pd0": (2, (7, 5, 9), 16, 32, (3, 3, 3), dict(algo=ALGO_WINO, pad=(0, 1, 1), shift=True)),   # a depth slab with its halo
     "wino_333_d2s_res": (2, (3, 4, 5), 8, 64, (3, 3, 3), dict(algo=ALGO_WINO, d2s=True, res=True, act=ACT_LRELU)),
 }

@@ -92,7 +92,7 @@ def test_depth_sharding_world2(emu_lib, tmp_path):
         assert np.linalg.norm(a - b) / den < 2e-3 or np.abs(a - b).max() < 1e-6, (str(name), np.linalg.norm(a - b) / den)
 
     # z-sharded per-RoI U-Net: slabs of the logits and summed gradients equal the single-process U-Net
-    for stage in ("finetune",):
+    for stage in ("beginning", "finetune"):
         y = np.concatenate([r[0]["zu_y_" + stage], r[1]["zu_y_" + stage]], axis=1)
         assert y.shape == ref["zu_ref_y_" + stage].shape
         assert np.abs(y - ref["zu_ref_y_" + stage]).max() < 1e-4 * max(1.0, np.abs(ref["zu_ref_y_" + stage]).max())

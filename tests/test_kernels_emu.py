@@ -101,8 +101,8 @@ def test_conv_b3_experimental(emu):
     kc.check_conv_b3(emu, 1, (4, 5, 9), 20, 12)                        # K padded 20 -> 24, data gradient K 12 -> 16
 
 
-# (the opt-in 3xBF16 kernels' parity-folded 5^3 modes run on the GPU tier only -- test_kernels_gpu.py::test_fold5_b3_experimental;
-#  9 s of emulated bf16 MFMAs for an experimental path does not fit the CPU tier's budget)
+def test_fold5_b3_experimental(emu):
+    kc.check_fold5_b3(emu)
 
 
 def test_mask_losses_lits_golden(emu):

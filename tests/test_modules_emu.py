@@ -106,6 +106,11 @@ def test_b3_module_path(emu):
     mc.check_b3_module_path(emu)
 
 
+def test_training_step_lits_finetune(emu_direct):
+    """LiTS fork 'finetune': class-weighted mask CE + raw-Sobel edge loss through the whole step vs the oracle."""
+    mc.check_training_step_vs_oracle(emu_direct, mc.tiny_lits_config("finetune"), n_pos=1, fp64_bound=False)
+
+
 def test_lits_detector_phase_inference_masks_are_zero(emu_direct):
     """LiTS fork, stage 'beginning': predict('inference') has no mask branch yet and returns zero masks
     (LiTS_2017/model.py:1485-1489)."""
@@ -127,8 +132,7 @@ def test_fpn_rpn_lits_golden(emu_direct):
 
 
 def test_unet_lits_noncubic_golden(emu_direct):
-    # logits only here: the gradient check (fp64 bound + kink-flip fit, ~15 s of oracle work) runs on the GPU tier
-    mc.check_unet_golden(emu_direct, "unet_lits_noncubic", check_grads=False)
+    mc.check_unet_golden(emu_direct, "unet_lits_noncubic")
 
 
 def test_detection_target_layer_lits_golden(emu):
