@@ -338,6 +338,20 @@ def tiny_config(stage="finetune"):
     return cfg
 
 
+def tiny_wino_config(stage="beginning"):
+    """tiny_config with channel counts at which CFUN_ALGO_AUTO takes the Winograd kernels (C_out >= 32, C_in >= 16): U-Net
+    b = 8 (levels 3-5: 32 / 64 / 128 channels), FPN / RPN 3x3x3 convs at 32 channels."""
+    from cfun_amd import config
+    cls = type("TinyHeartWino", (config.HeartConfig,), dict(
+        IMAGE_MAX_DIM=32, IMAGE_MIN_DIM=16, MASK_POOL_SIZE=[32, 32, 32], POOL_SIZE=[4, 4, 4],
+        UNET_MASK_BRANCH_CHANNEL=8, TOP_DOWN_PYRAMID_SIZE=32, RPN_CONV_CHANNELS=32, FPN_CLASSIFY_FC_LAYERS_SIZE=16,
+        RPN_ANCHOR_SCALES=(16, 32), PRE_NMS_LIMIT=64, POST_NMS_ROIS_TRAINING=16))
+    cfg = cls(stage)
+    side = 64 if stage == "finetune" else 32
+    cfg.MASK_SHAPE = cfg.MINI_MASK_SHAPE = (side, side, side)
+    return cfg
+
+
 def tiny_lits_config(stage="beginning", max_dim=32, min_dim=16):
     """The LiTS fork's shapes (BASELINE.json configs[4]) shrunk: P3D35 ([4,5] blocks, 5x7x7 stem), 3 classes,
     channel counts in the fork's 3:6 ratios, no dropout, non-cubic mask crops."""

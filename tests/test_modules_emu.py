@@ -61,6 +61,15 @@ def test_training_step_vs_oracle(emu_direct, stage):
     assert all(l == l for l in r["losses"])   # finite
 
 
+def test_training_step_winograd_channels_vs_oracle(emu):
+    """A whole step (FPN/RPN, heads, U-Net b = 8, six losses, backward) on the kernels AUTO picks -- MFMA and, at these
+    channel counts, the Winograd forward / data-gradient / weight-gradient kernels -- against the oracle."""
+    # (blanket gradient tolerances here: with b = 8 the 32^3 crop holds more LeakyReLU kink flips than flip_fit's 96-voxel basis
+    # absorbs -- the direct kernels show the same residual; the measured bound is applied at b = 4 and, on the GPU tier, at b = 20)
+    r = mc.check_training_step_vs_oracle(emu, mc.tiny_wino_config("beginning"), n_pos=1, fp64_bound=False)
+    assert all(l == l for l in r["losses"])
+
+
 def test_training_step_lits_shapes(emu_direct):
     """LiTS fork shapes: P3D35, (5,7,7) stem, 3 classes (C % 4 != 0 heads on the direct kernels), no dropout."""
     mc.check_training_step_vs_oracle(emu_direct, mc.tiny_lits_config(), n_pos=1, fp64_bound=False)
