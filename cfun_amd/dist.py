@@ -146,23 +146,53 @@ class _HaloExchange(torch.autograd.Function):
         return gx, None, None, None
 
 
-class _HaloEdges(torch.autograd.Function):
-    """The two EDGE inputs of a depth-coupled conv on a slab: (lo halo planes from the previous rank ++ the slab's first
-    ``n_lo`` planes, the slab's last ``n_hi`` planes ++ hi halo planes from the next rank); zeros stand in for a
-    neighbour at the volume boundary (= the conv's zero padding).  The transfers run on a side HIP stream: the caller
-    launches the interior conv -- which needs no halo -- before it touches these outputs (``wait`` makes the current
-    stream wait for the transfer).  Backward: the halo planes' gradients travel back to the ranks that own the planes."""
+class _HaloStart(torch.autograd.Function):
+    """First half of the edge exchange of ``halo_conv``: pack this slab's boundary planes and START their transfer on the
+    side HIP stream; nothing here waits for it.  Returns an alias of x that every consumer (the interior conv, the edge
+    tensors of ``_HaloFinish``) must read, so that this node's backward runs LAST: it waits for the gradient exchange that
+    ``_HaloFinish.backward`` started and adds the neighbours' contributions for the planes they used as halos.
+    ``state`` (a dict shared by the two halves) carries the receive buffers and the stream hand-over."""
 
     @staticmethod
-    def forward(ctx, x, lo, hi, n_lo, n_hi, shard):
+    def forward(ctx, x, lo, hi, shard, state):
         n, d, h, w, c = x.shape
         send_next = ops.halo_pack(x, d - lo, lo) if lo > 0 else None      # my top planes are next's low halo
         send_prev = ops.halo_pack(x, 0, hi) if hi > 0 else None           # my bottom planes are prev's high halo
-        from_prev, from_next, wait = _exchange_async(shard, send_prev, send_next, (n, lo, h, w, c) if lo > 0 else None,
-                                                     (n, hi, h, w, c) if hi > 0 else None, x)
-        ctx.shard, ctx.dims, ctx.xshape = shard, (lo, hi, n_lo, n_hi), tuple(x.shape)
+        state["fp"], state["fn"], state["wait"] = _exchange_async(
+            shard, send_prev, send_next, (n, lo, h, w, c) if lo > 0 else None, (n, hi, h, w, c) if hi > 0 else None, x)
+        ctx.state, ctx.dims = state, (lo, hi, d)
+        return x.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, gx_in):
+        lo, hi, d = ctx.dims
+        st = ctx.state
+        if "bwait" not in st:           # autograd must have run _HaloFinish.backward first (it is the later forward call)
+            raise RuntimeError("halo_conv: the edge gradients were not exchanged before the slab's gradient was finalised")
+        st["bwait"]()
+        gx = gx_in.clone()
+        if st["bfp"] is not None:      # prev used my bottom `hi` planes as its high halo
+            gx[:, :hi] += st["bfp"]
+        if st["bfn"] is not None:      # next used my top `lo` planes as its low halo
+            gx[:, d - lo:] += st["bfn"]
+        return gx, None, None, None, None
+
+
+class _HaloFinish(torch.autograd.Function):
+    """Second half: called AFTER the interior conv has been enqueued.  Makes the current stream wait for the transfer and
+    builds the two EDGE inputs of the depth-coupled conv: (lo halo planes from the previous rank ++ the slab's first
+    ``n_lo`` planes, the slab's last ``n_hi`` planes ++ hi halo planes from the next rank); zeros stand in for a
+    neighbour at the volume boundary (= the conv's zero padding).  Backward (it runs BEFORE the interior conv's backward:
+    later forward call, higher autograd sequence number): the halo planes' gradients start travelling back to the ranks
+    that own the planes on the side stream, the wait is left to ``_HaloStart.backward``."""
+
+    @staticmethod
+    def forward(ctx, x, lo, hi, n_lo, n_hi, shard, state):
+        n, d, h, w, c = x.shape
+        ctx.shard, ctx.dims, ctx.xshape, ctx.state = shard, (lo, hi, n_lo, n_hi), tuple(x.shape), state
         head, tail = x[:, :n_lo], x[:, d - n_hi:]
-        wait()
+        state["wait"]()
+        from_prev, from_next = state.pop("fp"), state.pop("fn")
         zl = from_prev if from_prev is not None else x.new_zeros((n, lo, h, w, c))
         zh = from_next if from_next is not None else x.new_zeros((n, hi, h, w, c))
         return torch.cat([zl, head], dim=1), torch.cat([tail, zh], dim=1)
@@ -170,22 +200,17 @@ class _HaloEdges(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_lo, g_hi):
         lo, hi, n_lo, n_hi = ctx.dims
-        shard = ctx.shard
+        shard, st = ctx.shard, ctx.state
         n, d, h, w, c = ctx.xshape
         g_lo, g_hi = g_lo.contiguous(), g_hi.contiguous()
         send_prev = g_lo[:, :lo].contiguous() if lo > 0 else None         # gradient of prev's top planes
         send_next = g_hi[:, n_hi:].contiguous() if hi > 0 else None       # gradient of next's bottom planes
-        from_prev, from_next, wait = _exchange_async(shard, send_prev, send_next, (n, hi, h, w, c) if hi > 0 else None,
-                                                     (n, lo, h, w, c) if lo > 0 else None, g_lo)
+        st["bfp"], st["bfn"], st["bwait"] = _exchange_async(
+            shard, send_prev, send_next, (n, hi, h, w, c) if hi > 0 else None, (n, lo, h, w, c) if lo > 0 else None, g_lo)
         gx = g_lo.new_zeros(ctx.xshape)
         gx[:, :n_lo] += g_lo[:, lo:]
         gx[:, d - n_hi:] += g_hi[:, :n_hi]
-        wait()
-        if from_prev is not None:      # prev used my bottom `hi` planes as its high halo
-            gx[:, :hi] += from_prev
-        if from_next is not None:      # next used my top `lo` planes as its low halo
-            gx[:, d - lo:] += from_next
-        return gx, None, None, None, None, None
+        return gx, None, None, None, None, None, None
 
 
 def _exchange_async(ctx, send_prev, send_next, recv_prev_shape, recv_next_shape, like):
@@ -232,11 +257,15 @@ def halo_conv(x, run, kd, stride, pd, out_tail, shard=None):
     n_tail = d - first_hi if j_hi + 1 < do else 0
     if n_head > d or n_tail > d or first_hi < 0:
         return None
-    edge_lo, edge_hi = _HaloEdges.apply(x, lo, hi, max(n_head, 0), max(n_tail, 0), shard)
+    state = {}
+    x = _HaloStart.apply(x.contiguous(), lo, hi, shard, state)        # planes packed, transfer started on the side stream
     buf = x.new_empty((1, do) + tuple(out_tail))
     parts = []
-    # interior first: it needs no halo, so it is enqueued while the transfer is in flight
+    # interior first: it needs no halo, so it is enqueued on the main stream while the transfer is in flight ...
     mid = run(x[:, j_lo * stride - pd:j_hi * stride - pd + kd], buf[:, j_lo:j_hi + 1], j_lo, j_hi + 1)
+    # ... and only now does the main stream wait for the halo planes (backward mirrors this: the gradient planes are sent
+    # before the interior conv's backward is enqueued and awaited after it)
+    edge_lo, edge_hi = _HaloFinish.apply(x, lo, hi, max(n_head, 0), max(n_tail, 0), shard, state)
     if j_lo > 0:
         parts.append(run(edge_lo, buf[:, 0:j_lo], 0, j_lo))
     parts.append(mid)

@@ -1,5 +1,8 @@
-"""Worker for the world_size-2 gloo tests (spawned by tests/test_dist_gloo.py).  Runs on CPU tensors through the
-HIP emulator build of the kernels (CFUN_LIB_PATH) -- the exchange logic is what is under test."""
+"""Worker for the world_size-2 gloo tests.  tests/test_dist_gloo.py (CPU tier) runs it on CPU tensors through the HIP
+emulator build of the kernels (CFUN_LIB_PATH) -- the exchange logic is what is under test; tests/test_dist_gpu.py (GPU
+tier) runs the SAME sections with device "cuda:0" on the real library: two processes share the one GPU of the test box,
+the collectives go through gloo (RCCL refuses two ranks on one device), the kernels, streams and side-stream halo
+overlap are the product's.  argv: rank world port out-pattern [device] [extra]"""
 import os
 import sys
 
@@ -14,9 +17,16 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    dev = torch.device(sys.argv[5] if len(sys.argv) > 5 else "cpu")
+    extra = sys.argv[6] if len(sys.argv) > 6 else ""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = port
-    os.environ["CFUN_CONV_ALGO"] = "direct"
+    if dev.type == "cpu":
+        os.environ["CFUN_CONV_ALGO"] = "direct"
+    else:                       # GPU tier: the real library, AUTO algorithm (Winograd / MFMA as the product picks them)
+        os.environ.pop("CFUN_LIB_PATH", None)
+        os.environ.pop("CFUN_CONV_ALGO", None)
+        torch.cuda.set_device(dev)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from cfun_amd import dist as cdist
     from cfun_amd import ops, step
@@ -25,93 +35,93 @@ def main():
     res = {}
     # 1) halo exchange forward + backward against plain padding of the full tensor
     g = torch.Generator().manual_seed(0)
-    full = torch.randn(1, 8, 3, 4, 4, generator=g)
-    gy_full = torch.randn(1, 8 + 2 * world, 3, 4, 4, generator=g)     # per-rank padded slabs, concatenated
+    full = torch.randn(1, 8, 3, 4, 4, generator=g).to(dev)
+    gy_full = torch.randn(1, 8 + 2 * world, 3, 4, 4, generator=g).to(dev)     # per-rank padded slabs, concatenated
     with cdist.depth_sharded() as sh:
         x = cdist.slab(full, dim=1).clone().requires_grad_(True)
         y = cdist.halo_exchange(x, 1, 1)
         dl = full.shape[1] // world
         gy = gy_full[:, rank * (dl + 2):(rank + 1) * (dl + 2)]
         (y * gy).sum().backward()
-    res["halo_y"] = y.detach().numpy()
-    res["halo_gx"] = x.grad.numpy()
+    res["halo_y"] = y.detach().cpu().numpy()
+    res["halo_gx"] = x.grad.cpu().numpy()
 
     # 2) depth-sharded FPN -> RPN -> proposals == single-rank result
     cfg = mc.tiny_config("beginning")
     cfg.IMAGE_SHAPE = np.array([32, 32, 32, 1])           # D = 32: 16 planes per rank, 1 p3 plane per rank
     torch.manual_seed(0)
-    net = step.CFUNHotPath(cfg).eval()
-    image = torch.randn(1, 1, 32, 32, 32, generator=g)
+    net = step.CFUNHotPath(cfg).to(dev).eval()
+    image = torch.randn(1, 1, 32, 32, 32, generator=g).to(dev)
     with torch.no_grad():
         with cdist.depth_sharded():
             p2, p3, logits, probs, bbox, rois = cdist.sharded_backbone_rpn(net, cdist.slab(image, dim=2))
         if rank == 0:
             rp2, rp3, rlogits, rprobs, rbbox = net.backbone_rpn(image)
             rrois = net.proposals(rprobs, rbbox, "inference")
-            res.update(ref_p2=rp2.numpy(), ref_p3=rp3.numpy(), ref_logits=rlogits.numpy(), ref_bbox=rbbox.numpy(),
-                       ref_rois=rrois.numpy())
-    res.update(p2=p2.numpy(), p3=p3.numpy(), logits=logits.numpy(), bbox=bbox.numpy(), rois=rois.numpy())
+            res.update(ref_p2=rp2.cpu().numpy(), ref_p3=rp3.cpu().numpy(), ref_logits=rlogits.cpu().numpy(), ref_bbox=rbbox.cpu().numpy(),
+                       ref_rois=rrois.cpu().numpy())
+    res.update(p2=p2.cpu().numpy(), p3=p3.cpu().numpy(), logits=logits.cpu().numpy(), bbox=bbox.cpu().numpy(), rois=rois.cpu().numpy())
 
     # 3) a depth-coupled conv trains through the halo exchange: gradients equal the unsharded ones
     from cfun_amd.layers import Conv3dParams
     torch.manual_seed(1)
-    conv = Conv3dParams(4, 8, 3, padding=1)
-    xs = torch.randn(1, 8, 4, 4, 4, generator=g)
-    gys = torch.randn(1, 8, 4, 4, 8, generator=g)
+    conv = Conv3dParams(4, 8, 3, padding=1).to(dev)
+    xs = torch.randn(1, 8, 4, 4, 4, generator=g).to(dev)
+    gys = torch.randn(1, 8, 4, 4, 8, generator=g).to(dev)
     with cdist.depth_sharded():
         xl = cdist.slab(xs, dim=1).clone().requires_grad_(True)
         yl = conv(xl)
         (yl * cdist.slab(gys, dim=1)).sum().backward()
         wg = conv.weight.grad.clone()
         dist.all_reduce(wg)                                  # data-parallel style sum of the slabs' contributions
-    res["conv_y"] = yl.detach().numpy()
-    res["conv_gx"] = xl.grad.numpy()
-    res["conv_gw"] = wg.numpy()
+    res["conv_y"] = yl.detach().cpu().numpy()
+    res["conv_gx"] = xl.grad.cpu().numpy()
+    res["conv_gw"] = wg.cpu().numpy()
     if rank == 0:
         conv.weight.grad = None
         xr = xs.clone().requires_grad_(True)
         yr = conv(xr)
         (yr * gys).sum().backward()
-        res.update(ref_conv_y=yr.detach().numpy(), ref_conv_gx=xr.grad.numpy(), ref_conv_gw=conv.weight.grad.numpy())
+        res.update(ref_conv_y=yr.detach().cpu().numpy(), ref_conv_gx=xr.grad.cpu().numpy(), ref_conv_gw=conv.weight.grad.cpu().numpy())
     # 3b) the same with channel counts for which AUTO picks the Winograd kernels (16 -> 32): the slabs run them with depth
     #     padding 0 on their halo planes (interior / edge launches of halo_conv), the data gradient with depth padding 2
     torch.manual_seed(2)
-    convw = Conv3dParams(16, 32, 3, padding=1)
-    xw = torch.randn(1, 8, 4, 6, 16, generator=g)
-    gyw = torch.randn(1, 8, 4, 6, 32, generator=g)
+    convw = Conv3dParams(16, 32, 3, padding=1).to(dev)
+    xw = torch.randn(1, 8, 4, 6, 16, generator=g).to(dev)
+    gyw = torch.randn(1, 8, 4, 6, 32, generator=g).to(dev)
     with cdist.depth_sharded():
         xlw = cdist.slab(xw, dim=1).clone().requires_grad_(True)
         ylw = convw(xlw)
         (ylw * cdist.slab(gyw, dim=1)).sum().backward()
         wgw = convw.weight.grad.clone()
         dist.all_reduce(wgw)
-    res["wconv_y"], res["wconv_gx"], res["wconv_gw"] = ylw.detach().numpy(), xlw.grad.numpy(), wgw.numpy()
+    res["wconv_y"], res["wconv_gx"], res["wconv_gw"] = ylw.detach().cpu().numpy(), xlw.grad.cpu().numpy(), wgw.cpu().numpy()
     if rank == 0:
         convw.weight.grad = None
         xrw = xw.clone().requires_grad_(True)
         yrw = convw(xrw)
         (yrw * gyw).sum().backward()
-        res.update(ref_wconv_y=yrw.detach().numpy(), ref_wconv_gx=xrw.grad.numpy(), ref_wconv_gw=convw.weight.grad.numpy())
+        res.update(ref_wconv_y=yrw.detach().cpu().numpy(), ref_wconv_gx=xrw.grad.cpu().numpy(), ref_wconv_gw=convw.weight.grad.cpu().numpy())
     # 4) data-parallel replicas: bucketed gradient averaging overlapped with backward (hooks), incl. a parameter that
     #    gets no gradient and a weight used twice (one accumulate, one hook call)
     torch.manual_seed(2)
-    c1, c2, unused = Conv3dParams(4, 8, 3, padding=1), Conv3dParams(8, 8, 1), Conv3dParams(8, 4, 1)
+    c1, c2, unused = [m.to(dev) for m in (Conv3dParams(4, 8, 3, padding=1), Conv3dParams(8, 8, 1), Conv3dParams(8, 4, 1))]
     plist = list(c1.parameters()) + list(c2.parameters()) + list(unused.parameters())
     red = cdist.GradientReducer(plist, bucket_bytes=300)           # several buckets
     assert len(red.buckets) > 2
-    xr = torch.randn(1, 4, 4, 4, 4, generator=torch.Generator().manual_seed(10 + rank))
+    xr = torch.randn(1, 4, 4, 4, 4, generator=torch.Generator().manual_seed(10 + rank)).to(dev)
     for it in range(2):                                             # buckets are reusable across steps
         red.zero_grad()
         y = c2(c2(c1(xr)))
         (y * y).sum().backward()
         red.finish()
-    res["dp_grads"] = np.concatenate([p.grad.reshape(-1).numpy() for p in plist])
+    res["dp_grads"] = np.concatenate([p.grad.reshape(-1).cpu().numpy() for p in plist])
     for p in plist:
         p.grad = None
     red.remove()
     y = c2(c2(c1(xr)))
     (y * y).sum().backward()
-    res["dp_local"] = np.concatenate([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).numpy()
+    res["dp_local"] = np.concatenate([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).cpu().numpy()
                                       for p in plist])
     # 5) ONE volume over 2 ranks: depth-sharded FPN/RPN + round-robin head RoIs; the ranks' loss shares add up to
     #    the single-process losses and the summed gradients equal the single-process gradients
@@ -123,8 +133,8 @@ def main():
     cfg5 = cls("beginning")
     cfg5.MASK_SHAPE = cfg5.MINI_MASK_SHAPE = (32, 32, 32)
     torch.manual_seed(4)
-    net5 = step.CFUNHotPath(cfg5)
-    s5 = step.synthetic_inputs(cfg5, torch.device("cpu"), 0)
+    net5 = step.CFUNHotPath(cfg5).to(dev)
+    s5 = step.synthetic_inputs(cfg5, dev, 0)
     s5["p_rois"], s5["mask_labels"] = s5["p_rois"][:2], s5["mask_labels"][:2]      # 2 positives + 4 negatives
     s5["n_rois"] = s5["n_rois"][:4]
     keep = [0, 1, 4, 5, 6, 7]
@@ -142,15 +152,15 @@ def main():
     flat5 = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
                        for k, p in net5.named_parameters() if p.requires_grad])
     dist.all_reduce(flat5)
-    res["sh_losses"], res["sh_grads"], res["sh_rois"] = lv.numpy(), flat5.numpy(), rois5.detach().numpy()
+    res["sh_losses"], res["sh_grads"], res["sh_rois"] = lv.cpu().numpy(), flat5.cpu().numpy(), rois5.detach().cpu().numpy()
     if rank == 0:
         net5.mask.modified_u_net.dropout_masks = masks5
         net5.zero_grad(set_to_none=True)
         out_r, losses_r, total_r = step.training_step(net5, s5)
         res["ref_losses"] = np.array([float(l.detach()) for l in losses_r], np.float32)
         res["ref_grads"] = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
-                                      for k, p in net5.named_parameters() if p.requires_grad]).numpy()
-        res["ref_rois5"] = out_r["rpn_rois"].detach().numpy()
+                                      for k, p in net5.named_parameters() if p.requires_grad]).cpu().numpy()
+        res["ref_rois5"] = out_r["rpn_rois"].detach().cpu().numpy()
         sizes = [int(p.numel()) for k, p in net5.named_parameters() if p.requires_grad]
         res["grad_sizes"] = np.array(sizes)
         res["grad_names"] = np.array(names5)
@@ -173,15 +183,15 @@ def main():
     red6.remove()
     lv6 = torch.stack([l.detach().float() for l in losses6])
     dist.all_reduce(lv6)
-    res["sh6_losses"] = lv6.numpy()
-    res["sh6_grads"] = torch.cat([p.grad.reshape(-1) for k, p in net5.named_parameters() if p.requires_grad]).numpy()
+    res["sh6_losses"] = lv6.cpu().numpy()
+    res["sh6_grads"] = torch.cat([p.grad.reshape(-1) for k, p in net5.named_parameters() if p.requires_grad]).cpu().numpy()
     if rank == 0:
         for p in net5.parameters():
             p.grad = None
         _, losses_r6, _ = step.training_step(net5, s6)
         res["ref6_losses"] = np.array([float(l.detach()) for l in losses_r6], np.float32)
         res["ref6_grads"] = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
-                                       for k, p in net5.named_parameters() if p.requires_grad]).numpy()
+                                       for k, p in net5.named_parameters() if p.requires_grad]).cpu().numpy()
     # 6b) the same 1 + 1 RoI step with the positive RoI's U-Net z-sharded over BOTH ranks (more ranks than positive RoIs):
     #     loss shares and summed gradients again equal the single-process step
     for p in net5.parameters():
@@ -193,7 +203,7 @@ def main():
     flat6b = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
                         for k, p in net5.named_parameters() if p.requires_grad])
     dist.all_reduce(flat6b)
-    res["sh6b_losses"], res["sh6b_grads"] = lv6b.numpy(), flat6b.numpy()
+    res["sh6b_losses"], res["sh6b_grads"] = lv6b.cpu().numpy(), flat6b.cpu().numpy()
 
     # 7) ONE RoI's U-Net z-sharded over the 2 ranks (levels at full and half resolution on depth slabs with halos and
     #    all-reduced InstanceNorm statistics, the lower levels folded onto both ranks): logits slabs and the summed
@@ -201,13 +211,13 @@ def main():
     from cfun_amd.mask_branch import Modified3DUNet
     for stage7 in ("beginning", "finetune"):
         torch.manual_seed(7)
-        unet = Modified3DUNet(1, 8, stage7, 4)
+        unet = Modified3DUNet(1, 8, stage7, 4).to(dev)
         unet.train()
         g7 = torch.Generator().manual_seed(17)
         unet.dropout_masks = [torch.empty(1, c).bernoulli_(0.4, generator=g7) / 0.4 for c in (4, 8, 16, 32, 64)]
-        x7 = torch.randn(1, 32, 32, 32, 1, generator=g7)
+        x7 = torch.randn(1, 32, 32, 32, 1, generator=g7).to(dev)
         side = 64 if stage7 == "finetune" else 32
-        gy7 = torch.randn(1, side, side, side, 8, generator=g7)
+        gy7 = torch.randn(1, side, side, side, 8, generator=g7).to(dev)
         zs = cdist.ShardContext()
         for p_ in unet.parameters():
             p_.grad = None
@@ -215,17 +225,79 @@ def main():
         (y7 * cdist.slab(gy7, dim=1, shard=zs)).sum().backward()
         flat7 = torch.cat([(p_.grad if p_.grad is not None else torch.zeros_like(p_)).reshape(-1) for p_ in unet.parameters()])
         dist.all_reduce(flat7)
-        res["zu_y_" + stage7], res["zu_g_" + stage7] = y7.detach().numpy(), flat7.numpy()
+        res["zu_y_" + stage7], res["zu_g_" + stage7] = y7.detach().cpu().numpy(), flat7.cpu().numpy()
         if rank == 0:
             for p_ in unet.parameters():
                 p_.grad = None
             yr7 = unet.forward_ndhwc(x7)
             (yr7 * gy7).sum().backward()
-            res["zu_ref_y_" + stage7] = yr7.detach().numpy()
+            res["zu_ref_y_" + stage7] = yr7.detach().cpu().numpy()
             res["zu_ref_g_" + stage7] = torch.cat([(p_.grad if p_.grad is not None else torch.zeros_like(p_)).reshape(-1)
-                                                   for p_ in unet.parameters()]).numpy()
+                                                   for p_ in unet.parameters()]).cpu().numpy()
             res["zu_sizes"] = np.array([int(p_.numel()) for p_ in unet.parameters()])
             res["zu_names"] = np.array([k for k, _ in unet.named_parameters()])
+    # 8) (GPU tier, "cfg0") BASELINE configs[0]'s volume (64x64x32) with the REAL channel counts, stage 'finetune' (edge
+    #    loss), 4 + 8 RoIs, 96^3 -> 192^3 masks -- the shapes of the benchmarked step -- as ONE volume over 2 ranks:
+    #    (a) depth-sharded FPN/RPN (halo_conv: interior planes overlapped with the side-stream exchange; Winograd /
+    #    MFMA kernels on slabs) + round-robin heads, gradients summed by the ordered GradientReducer; (b) 1 positive RoI
+    #    whose U-Net is z-sharded over both ranks (b = 20, slabs of 48 / 24 planes, all-reduced InstanceNorm statistics).
+    #    Both against the single-process step of rank 0.
+    if "cfg0" in extra:
+        cfg8 = ccfg.heart_config("finetune", 64, 64, 32)
+        torch.manual_seed(8)
+        net8 = step.CFUNHotPath(cfg8).to(dev)
+        s8 = step.synthetic_inputs(cfg8, dev, 0)
+        b8 = cfg8.UNET_MASK_BRANCH_CHANNEL
+        g8 = torch.Generator().manual_seed(19)
+        masks8 = [torch.empty(4, c).bernoulli_(0.4, generator=g8) / 0.4 for c in (b8, 2 * b8, 4 * b8, 8 * b8, 16 * b8)]
+        pnames = [k for k, p in net8.named_parameters() if p.requires_grad]
+
+        def flat_grads():
+            return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                              for k, p in net8.named_parameters() if p.requires_grad])
+        # (a)
+        net8.mask.modified_u_net.dropout_masks = [mk[rank::world] for mk in masks8]
+        for p in net8.parameters():
+            p.grad = None
+        red8 = cdist.GradientReducer(net8.parameters(), average=False)
+        red8.zero_grad()
+        with cdist.depth_sharded():
+            losses8, _, rois8 = cdist.sharded_training_step(net8, s8)
+        red8.finish()
+        red8.remove()
+        lv8 = torch.stack([l.detach().float() for l in losses8])
+        dist.all_reduce(lv8)
+        res["c0_losses"], res["c0_grads"], res["c0_rois"] = lv8.cpu().numpy(), flat_grads().cpu().numpy(), rois8.detach().cpu().numpy()
+        # (b)
+        s9 = dict(s8)
+        s9["p_rois"], s9["mask_labels"], s9["n_rois"] = s8["p_rois"][:1], s8["mask_labels"][:1], s8["n_rois"][:1]
+        s9["target_class_ids"], s9["target_deltas"] = s8["target_class_ids"][[0, 4]], s8["target_deltas"][[0, 4]]
+        net8.mask.modified_u_net.dropout_masks = [mk[:1] for mk in masks8]
+        for p in net8.parameters():
+            p.grad = None
+        with cdist.depth_sharded():
+            losses9, _, _ = cdist.sharded_training_step(net8, s9, zshard_unet=True)
+        lv9 = torch.stack([l.detach().float() for l in losses9])
+        dist.all_reduce(lv9)
+        fg9 = flat_grads()
+        dist.all_reduce(fg9)
+        res["c0z_losses"], res["c0z_grads"] = lv9.cpu().numpy(), fg9.cpu().numpy()
+        if rank == 0:
+            net8.mask.modified_u_net.dropout_masks = masks8
+            for p in net8.parameters():
+                p.grad = None
+            out_r8, losses_r8, _ = step.training_step(net8, s8)
+            res["c0_ref_losses"] = np.array([float(l.detach()) for l in losses_r8], np.float32)
+            res["c0_ref_grads"] = flat_grads().cpu().numpy()
+            res["c0_ref_rois"] = out_r8["rpn_rois"].detach().cpu().numpy()
+            net8.mask.modified_u_net.dropout_masks = [mk[:1] for mk in masks8]
+            for p in net8.parameters():
+                p.grad = None
+            _, losses_r9, _ = step.training_step(net8, s9)
+            res["c0z_ref_losses"] = np.array([float(l.detach()) for l in losses_r9], np.float32)
+            res["c0z_ref_grads"] = flat_grads().cpu().numpy()
+            res["c0_sizes"] = np.array([int(p.numel()) for k, p in net8.named_parameters() if p.requires_grad])
+            res["c0_names"] = np.array(pnames)
     np.savez(out % rank, **res)
     dist.barrier()
     dist.destroy_process_group()

@@ -19,16 +19,33 @@ def _free_port():
     return str(p)
 
 
-def test_depth_sharding_world2(emu_lib, tmp_path):
+def run_world2(tmp_path, env, worker_args=(), timeout=900):
+    """Spawn tests/dist_worker.py as 2 ranks over gloo and return the two result dicts."""
     port = _free_port()
     out = str(tmp_path / "rank%d.npz")
-    env = dict(os.environ, CFUN_LIB_PATH=emu_lib, PYTHONPATH=ROOT)
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(r), "2", port, out],
-                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
-    logs = [p.communicate(timeout=900)[0].decode() for p in procs]
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(r), "2", port, out]
+                              + list(worker_args), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=timeout)[0].decode())
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
     for p, log in zip(procs, logs):
         assert p.returncode == 0, log[-3000:]
-    r = [dict(np.load(out % k)) for k in range(2)]
+    return [dict(np.load(out % k)) for k in range(2)]
+
+
+def test_depth_sharding_world2(emu_lib, tmp_path):
+    env = dict(os.environ, CFUN_LIB_PATH=emu_lib, PYTHONPATH=ROOT)
+    check_world2(run_world2(tmp_path, env))
+
+
+def check_world2(r, conv_tol=1.0):
+    """The assertions shared by the CPU tier (emulator kernels) and the GPU tier (tests/test_dist_gpu.py, real kernels)."""
 
     # halo exchange: rank k's padded slab = planes [8k-1, 8k+5) of the zero-padded full tensor
     import torch
