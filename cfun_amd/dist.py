@@ -79,31 +79,49 @@ def slab_local():
         _CTX = old
 
 
+def _host_staged(ctx, like):
+    """gloo moves host memory and is not stream-ordered: handed a device tensor, its send/recv read and write the raw
+    pointer from the host at once, whatever the stream still has queued (the 2-rank GPU-tier test caught exactly that: stale
+    halo planes once the GPU ran behind the host).  Device tensors on a gloo group -- only the single-GPU test set-up,
+    tests/test_dist_gpu.py and CFUN_BENCH_BACKEND=gloo -- are therefore staged through host copies, which ARE ordered on
+    the current stream.  RCCL ("nccl") enqueues on the current stream and takes the device buffers as they are."""
+    return like.is_cuda and dist.get_backend(ctx.group) == "gloo"
+
+
 def _exchange(ctx, send_prev, send_next, recv_prev_shape, recv_next_shape, like):
     """Ring-neighbour exchange of packed plane buffers.  Returns (from_prev, from_next); None at the volume
     boundary.  Global ranks are resolved through the group so sub-groups work."""
     reqs, from_prev, from_next = [], None, None
+    staged = _host_staged(ctx, like)
+    rdev = torch.device("cpu") if staged else like.device
 
     def peer(r):
         return dist.get_global_rank(ctx.group, r) if ctx.group is not None else r
 
+    def out(t):
+        t = t.contiguous()
+        return t.cpu() if staged else t      # (.cpu() waits for the current stream: the planes are complete)
+
     opsl = []
     if ctx.prev is not None:
         if recv_prev_shape is not None:
-            from_prev = torch.empty(recv_prev_shape, dtype=like.dtype, device=like.device)
+            from_prev = torch.empty(recv_prev_shape, dtype=like.dtype, device=rdev)
             opsl.append(dist.P2POp(dist.irecv, from_prev, peer(ctx.prev), ctx.group))
         if send_prev is not None:
-            opsl.append(dist.P2POp(dist.isend, send_prev.contiguous(), peer(ctx.prev), ctx.group))
+            opsl.append(dist.P2POp(dist.isend, out(send_prev), peer(ctx.prev), ctx.group))
     if ctx.next is not None:
         if send_next is not None:
-            opsl.append(dist.P2POp(dist.isend, send_next.contiguous(), peer(ctx.next), ctx.group))
+            opsl.append(dist.P2POp(dist.isend, out(send_next), peer(ctx.next), ctx.group))
         if recv_next_shape is not None:
-            from_next = torch.empty(recv_next_shape, dtype=like.dtype, device=like.device)
+            from_next = torch.empty(recv_next_shape, dtype=like.dtype, device=rdev)
             opsl.append(dist.P2POp(dist.irecv, from_next, peer(ctx.next), ctx.group))
     if opsl:
         reqs = dist.batch_isend_irecv(opsl)
         for r in reqs:
             r.wait()
+    if staged:
+        from_prev = None if from_prev is None else from_prev.to(like.device)
+        from_next = None if from_next is None else from_next.to(like.device)
     return from_prev, from_next
 
 

@@ -22,7 +22,7 @@ def main():
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = port
     if dev.type == "cpu":
-        os.environ["CFUN_CONV_ALGO"] = "direct"
+        os.environ["CFUN_CONV_ALGO"] = os.environ.get("CFUN_DIST_WORKER_ALGO", "direct")
     else:                       # GPU tier: the real library, AUTO algorithm (Winograd / MFMA as the product picks them)
         os.environ.pop("CFUN_LIB_PATH", None)
         os.environ.pop("CFUN_CONV_ALGO", None)

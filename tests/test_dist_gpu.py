@@ -44,7 +44,10 @@ def test_two_ranks_on_real_kernels(gpu, tmp_path):
     np.testing.assert_array_equal(r[0]["c0_grads"], r[1]["c0_grads"])
     assert r[0]["c0_rois"].shape == ref["c0_ref_rois"].shape
     np.testing.assert_allclose(r[0]["c0_rois"], ref["c0_ref_rois"], rtol=0, atol=1e-5)
-    w = _grads_close(ref["c0_names"], ref["c0_sizes"], r[0]["c0_grads"], ref["c0_ref_grads"], 2e-3, 2e-3)
+    # U-Net tensors: the ranks run 2 RoIs each instead of 4 in one batch (other partial-sum orders in the weight
+    # gradients) and at b = 20 / 96^3 the reference's own fp32-vs-fp64 deviation of these gradients is 2e-4 ... 7e-3
+    # (DESIGN section 6, table printed by test_training_step_finetune_b20_vs_oracle): held to 1e-2, everything else 2e-3
+    w = _grads_close(ref["c0_names"], ref["c0_sizes"], r[0]["c0_grads"], ref["c0_ref_grads"], 2e-3, 1e-2)
     print("cfg0 sharded step, worst gradient rel-L2 vs single process:", w)
     # (b) one positive RoI's U-Net (b = 20, 96^3) z-sharded over both ranks: the slab-wise InstanceNorm statistics are
     # combined in a different order than the single-process sums (deep levels: 6^3 voxels), hence the looser mask bound
