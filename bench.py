@@ -82,6 +82,36 @@ def dominant_kernel_info(cfg, n_roi):
     return kern, executed, nsub
 
 
+def stem_back_to_back(cfg, net, n_roi, dev, launches=64):
+    """conv3d_c1_1 (the HBM-bound 3x3x3 conv of the path: C_in = 1) exactly as the step calls it -- same entry point,
+    shapes, weight -- `launches` times back to back between one pair of HIP events.  Returns (seconds per launch, launches,
+    the name of the kernel the library runs for it)."""
+    import ctypes as C
+    from cfun_amd import _lib, ops
+    conv = net.mask.modified_u_net.conv3d_c1_1
+    side = tuple(cfg.MASK_POOL_SIZE)
+    x = torch.randn((n_roi,) + side + (1,), device=dev)
+    spec = ops.ConvSpec(k=tuple(conv.kernel_size), co=conv.out_channels, pad=tuple(conv.padding))
+    p = ops._params(spec, x.shape, False, False, False)
+    kern = int(_lib.load().cfun_conv3d_fwd_kernel(C.byref(p)))
+    zpt = os.environ.get("CFUN_STEM_ZPT", "2")
+    name = {3: "k_conv_stem333z<%d, %s>" % (conv.out_channels, zpt if zpt in ("2", "4") else "-"),
+            1: "k_conv_mfma", 0: "k_conv_fwd_direct"}.get(kern, "kernel code %d" % kern)
+    if kern == 3 and zpt not in ("2", "4"):
+        name = "k_conv_stem<3,3,3,1,%d>" % conv.out_channels
+    with torch.no_grad():
+        for _ in range(4):
+            ops.conv3d_w(x, conv.weight, spec)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(launches):
+            ops.conv3d_w(x, conv.weight, spec)
+        e1.record()
+        torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / launches, launches, name
+
+
 def git_blob_sha1(path):
     """= `git hash-object path` (works without a .git directory, as on the GPU box)."""
     import hashlib
@@ -108,7 +138,37 @@ def pmc_record(rel_path, field):
         return None, src
 
 
-def cpu_baseline(cfg, net, sample, threads, iters=1):
+def physical_cores():
+    """(physical cores, logical CPUs) of the host from /proc/cpuinfo (unique (physical id, core id) pairs)."""
+    logical = os.cpu_count() or 1
+    try:
+        pairs, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if core is not None:
+                    pairs.add((phys, core))
+                phys = core = None
+        if core is not None:
+            pairs.add((phys, core))
+        return (len(pairs) or logical), logical
+    except OSError:
+        return logical, logical
+
+
+def parity_dropout_masks(cfg, n_pos):
+    """The Dropout3d masks BOTH legs of the loss-parity step use (generator seed 1; None when the config has no dropout)."""
+    if getattr(cfg, "UNET_DROPOUT", 0.6) <= 0:
+        return None
+    b = cfg.UNET_MASK_BRANCH_CHANNEL
+    gen = torch.Generator().manual_seed(1)
+    return [torch.empty(n_pos, ch).bernoulli_(0.4, generator=gen) / 0.4 for ch in (b, 2 * b, 4 * b, 8 * b, 16 * b)]
+
+
+def cpu_baseline(cfg, net, sample, threads, iters=1, small_iters=3):
     """The reference's CPU path timed beside the GPU run: the oracle (oracle/cfun_oracle.py -- the plain fp32 torch-CPU
     restatement of the reference, pinned to it by tests/golden) runs THE SAME training step -- this run's weights, image,
     4 + 8 injected RoIs, targets, all six losses incl. the 3-D Sobel edge loss, forward + backward -- on the host cores.
@@ -125,11 +185,7 @@ def cpu_baseline(cfg, net, sample, threads, iters=1):
         sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype == torch.float32 and "running" not in k)
               for k, v in net_i.state_dict().items()}
         c = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in s.items()}
-        b = cfg_i.UNET_MASK_BRANCH_CHANNEL
-        gen = torch.Generator().manual_seed(1)
-        masks = [torch.empty(n_pos, ch).bernoulli_(0.4, generator=gen) / 0.4 for ch in (b, 2 * b, 4 * b, 8 * b, 16 * b)]
-        if getattr(cfg_i, "UNET_DROPOUT", 0.6) <= 0:
-            masks = None
+        masks = parity_dropout_masks(cfg_i, n_pos)
         keep = list(range(n_pos)) + list(range(4, 4 + 2 * n_pos))
         onehot = torch.stack([(c["mask_labels"][:n_pos] == k) for k in range(cfg_i.NUM_CLASSES)], dim=1).double()
         t0 = time.perf_counter()
@@ -147,24 +203,33 @@ def cpu_baseline(cfg, net, sample, threads, iters=1):
         ref["total"].backward()
         return time.perf_counter() - t0, [float(l) for l in ref["losses"]]
 
-    # warm-up: the same code path at the smallest configuration
+    # warm-up: the same code path at the smallest configuration (BASELINE configs[0]'s 64x64x32 volume, 1 + 2 RoIs), then
+    # `small_iters` timed iterations of it: the cfg0 figure SURVEY.md section 8(d) asks for beside cfg2's
     wcfg = ccfg.heart_config(cfg.STAGE, 64, 64, 32) if not hasattr(cfg, "BACKBONE_LAYERS") else None
+    small = None
     if wcfg is not None:
         wnet = step.CFUNHotPath(wcfg)
-        one(wcfg, wnet, step.synthetic_inputs(wcfg, torch.device("cpu"), 0), 1)
+        ws_ = step.synthetic_inputs(wcfg, torch.device("cpu"), 0)
+        one(wcfg, wnet, ws_, 1)
+        st = sorted(one(wcfg, wnet, ws_, 1)[0] for _ in range(max(1, small_iters)))
+        small = {"workload": "64x64x32 volume, stage '%s', 1 positive + 2 negative RoIs, same step" % cfg.STAGE,
+                 "value": 1.0 / st[len(st) // 2], "unit": "volumes/s", "iters": len(st), "median_s": st[len(st) // 2]}
     times, losses = [], None
     for _ in range(max(1, iters)):
         t, losses = one(cfg, net, sample, 4)
         times.append(t)
     med = sorted(times)[len(times) // 2]
     d, h, w = cfg.image_dhw
-    return dict(value=1.0 / med, unit="volumes/s", cores=threads, kind="port",
-                sample="oracle (torch %s CPU fp32, torch.get_num_threads() = %d of os.cpu_count() = %d): the identical "
-                       "%dx%dx%d '%s' training step -- same weights, image, 4 + 8 RoIs, targets, six losses, forward + "
-                       "backward; %d timed full iteration(s) after one warm-up at 64x64x32: %s s (median %.1f s); "
-                       "nothing extrapolated" % (torch.__version__, torch.get_num_threads(), os.cpu_count() or 0, h, w, d,
-                                                 cfg.STAGE, len(times), ", ".join("%.1f" % t for t in times), med),
-                losses=losses)
+    phys, logical = physical_cores()
+    return dict(value=1.0 / med, unit="volumes/s", cores=threads, kind="port", physical_cores=phys, logical_cpus=logical,
+                sample="oracle (torch %s CPU fp32, torch.get_num_threads() = %d threads on a host with %d physical cores / "
+                       "%d logical CPUs -- one thread per physical core, capped at 64: past that torch's CPU conv3d / "
+                       "instance-norm kernels stop scaling): the identical %dx%dx%d '%s' training step -- same "
+                       "weights, image, 4 + 8 RoIs, targets, Dropout3d masks (seed 1), six losses, forward + backward; %d "
+                       "timed full iteration(s) after a warm-up at 64x64x32: %s s (median %.1f s); nothing extrapolated"
+                       % (torch.__version__, torch.get_num_threads(), phys, logical, h, w, d, cfg.STAGE, len(times),
+                          ", ".join("%.1f" % t for t in times), med),
+                losses=losses, small_config=small)
 
 
 def main():
@@ -341,19 +406,46 @@ def main():
         if alt is not None:
             result["alt_3xbf16"] = alt
         if durs_h:   # north_star's "HBM roofline on the 3x3x3 conv kernel": the C_in = 1 stem, algorithmic bytes / time
-            t_h = sum(durs_h) / len(durs_h) * 1e-3
+            t_step = sum(durs_h) / len(durs_h) * 1e-3       # one event pair per launch inside the step (~10 us of overhead)
+            t_h, nb2b, hname = stem_back_to_back(cfg, net, n_roi_launch, dev)
             vox = n_roi_launch * side[0] * side[1] * side[2]
             nbytes = 4.0 * (vox + vox * b + 27 * b)
             result["roofline_hbm"] = {
                 "bound": "hbm", "achieved": nbytes / t_h / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": nbytes / t_h / 1e9 / PEAK_HBM_GBS, "traffic": None,
-                "kernel": "k_conv_stem<3,3,3,1,%d> (conv3d_c1_1: 3x3x3 1->%d @ %dx%d^3)" % (b, b, n_roi_launch, side[0]),
-                "bytes_per_launch": nbytes, "avg_launch_ms": t_h * 1e3, "launches_timed": len(durs_h)}
+                "kernel": "%s (conv3d_c1_1: 3x3x3 1->%d @ %dx%d^3)" % (hname, b, n_roi_launch, side[0]),
+                "bytes_per_launch": nbytes, "avg_launch_ms": t_h * 1e3, "launches_timed": nb2b,
+                "timing": "%d back-to-back launches of the step's own call between ONE pair of HIP events on the launch "
+                          "stream (an event pair around a single ~80 us launch adds ~10 %%)" % nb2b,
+                "avg_launch_ms_in_step": t_step * 1e3, "launches_timed_in_step": len(durs_h)}
+        parity_fail = None
         if world == 1 and not args.no_cpu_baseline:
+            # full-size parity check: ONE more (untimed) GPU step with the Dropout3d masks the oracle leg uses, so that the
+            # six losses of the two legs are the same computation and must agree
+            unet = net.mask.modified_u_net
+            prev_masks = unet.dropout_masks
+            unet.dropout_masks = parity_dropout_masks(cfg, 4)
+            try:
+                gl = [float(l.detach()) for l in one_step()]
+            finally:
+                unet.dropout_masks = prev_masks
+            torch.cuda.synchronize()
             torch.cuda.empty_cache()
-            result["cpu_baseline"] = cpu_baseline(cfg, net, sample, threads=min(os.cpu_count() or 1, 64),
-                                                  iters=args.cpu_baseline_iters)
+            phys, _ = physical_cores()
+            cb = cpu_baseline(cfg, net, sample, threads=max(1, min(phys, 64)), iters=args.cpu_baseline_iters)
+            result["cpu_baseline"] = cb
+            rel = [abs(g - c) / max(abs(c), 1e-12) for g, c in zip(gl, cb["losses"])]
+            tol = 1e-4
+            result["loss_parity"] = {"what": "the six losses of one extra, untimed GPU step vs the oracle's CPU step at the "
+                                             "benchmarked size -- same weights, inputs, RoIs and Dropout3d masks (seed 1)",
+                                     "gpu": gl, "cpu_oracle": cb["losses"], "rel_diff": rel, "tolerance_rel": tol,
+                                     "ok": bool(max(rel) <= tol)}
+            if max(rel) > tol:
+                parity_fail = "loss parity FAILED at full size: rel diff %s > %g" % (rel, tol)
         print(json.dumps(result), flush=True)
+        if parity_fail:
+            sys.stderr.write(parity_fail + "\n")
+            sys.exit(3)
     if world > 1:
         dist.destroy_process_group()
 

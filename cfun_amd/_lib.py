@@ -27,12 +27,21 @@ class ConvParams(C.Structure):
                [(n, C.c_int32) for n in ("scale_mode", "has_shift", "res_mode", "res_up2", "d2s", "d2s_cq", "tap_skip", "algo")]
 
 
+class ConvFusion(C.Structure):
+    """CfunConvFusion (include/cfun_hip.h): InstanceNorm / LeakyReLU hooks of the conv kernels."""
+    _fields_ = [("in_stats", C.c_void_p), ("in_act", C.c_int32), ("in_slope", C.c_float), ("out_stats", C.c_void_p),
+                ("out_eps", C.c_float)]
+
+
+FUSE_OUT_STATS, FUSE_IN_NORM, FUSE_IN_NORM_WGRAD = 1, 2, 4
+
 _P = C.c_void_p
 _I = C.c_int32
 _L = C.c_int64
 _F = C.c_float
 _Z = C.c_size_t
 _PP = C.POINTER(ConvParams)
+_PF = C.POINTER(ConvFusion)
 
 _SIGNATURES = {
     "cfun_version": (C.c_int, []),
@@ -40,6 +49,9 @@ _SIGNATURES = {
     "cfun_conv3d_fwd_workspace_bytes": (_Z, [_PP]),
     "cfun_conv3d_fwd_kernel": (_I, [_PP]),
     "cfun_conv3d_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _PP, _P, _Z, _P]),
+    "cfun_conv3d_fused_support": (C.c_int, [_PP]),
+    "cfun_conv3d_fwd_fused_workspace_bytes": (_Z, [_PP, _PF]),
+    "cfun_conv3d_fwd_fused": (C.c_int, [_P, _P, _P, _P, _P, _P, _PP, _PF, _P, _Z, _P]),
     "cfun_conv3d_bwd_data_workspace_bytes": (_Z, [_PP]),
     "cfun_conv3d_bwd_data": (C.c_int, [_P, _P, _P, _PP, _P, _Z, _P]),
     "cfun_conv3d_bwd_weight_workspace_bytes": (_Z, [_PP]),

@@ -23,7 +23,10 @@ int cfun_wino_supported(const CfunConv3dParams*);
 size_t cfun_wino_workspace_bytes(const CfunConv3dParams*);
 int cfun_wino_s2d_dgrad_supported(const CfunConv3dParams*, const CfunConv3dParams*);
 int cfun_wino_fwd(const float*, const float*, int, int, const float*, const float*, const float*, float*,
-                  const CfunConv3dParams*, void*, size_t, hipStream_t);
+                  const CfunConv3dParams*, void*, size_t, const cfun_mfma::ConvMode*, hipStream_t);
+int cfun_wino_stat_slots(const CfunConv3dParams*, size_t);
+// elementwise.hip: (mean, rstd) per (n, channel) from per-slot fp64 sums [N][slots][2][C]
+int cfun_stats_finalize(const double* part, float* stats, int N, int slots, int C, int64_t V, float eps, hipStream_t st);
 int cfun_wino_wgrad_supported(const CfunConv3dParams*);
 size_t cfun_wino_wgrad_workspace_bytes(const CfunConv3dParams*);
 int cfun_wino_wgrad(const float*, const float*, float*, const CfunConv3dParams*, int*, hipStream_t);
@@ -64,7 +67,7 @@ const Shape* find_shape(int kd, int kh, int kw, int s) {
 }
 
 using cfun_mfma::ConvMode;
-const ConvMode kPlain = {0, 0, 0, 0, 0};
+const ConvMode kPlain = {0, 0, 0, 0, 0, nullptr, 0, 0.f, nullptr, 0};
 
 // tap skipping needs every output-channel tile inside one parity group: largest tile that divides Co/8
 int pick_nsub_parity(int cqp, int max_nsub) {
@@ -249,10 +252,99 @@ k_splitk_finish(const float4* __restrict__ partial, int ksplit, const float* __r
   }
 }
 
+// the same epilogue organised as a per-(sample, channel) reduction: thread = (voxel lane, 4-channel group) of sample
+// blockIdx.y, so that the sums of y and y*y per channel (InstanceNorm statistics of the conv's output) come out of the
+// pass that writes y -- fp64 accumulators, one partial per block in k_channel_finalize's layout [n][block][2][Co]
+__global__ void __launch_bounds__(256)
+k_splitk_finish_stats(const float4* __restrict__ partial, int ksplit, const float* __restrict__ scale,
+                      const float* __restrict__ shift, const float* __restrict__ res, float4* __restrict__ y,
+                      CfunConv3dParams p, int64_t V, int lanes, double* __restrict__ part) {
+  __shared__ double sm[256 * 8];
+  const int C4 = p.Co >> 2, tid = threadIdx.x;
+  const int cg = tid % C4, vl = tid / C4, n = blockIdx.y, co = cg * 4;
+  const int64_t total4 = (int64_t)p.N * V * C4;
+  double acc[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+  if (vl < lanes) {
+    float4 s4 = make_float4(1.f, 1.f, 1.f, 1.f), t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.scale_mode) s4 = *reinterpret_cast<const float4*>(scale + (p.scale_mode == 2 ? n * p.Co : 0) + co);
+    if (p.has_shift) t4 = *reinterpret_cast<const float4*>(shift + co);
+    for (int64_t vv = (int64_t)blockIdx.x * lanes + vl; vv < V; vv += (int64_t)gridDim.x * lanes) {
+      const int64_t v = (int64_t)n * V + vv, i = v * C4 + cg;
+      float4 a = partial[i];
+      for (int k = 1; k < ksplit; ++k) {
+        const float4 b = partial[(int64_t)k * total4 + i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      }
+      if (p.scale_mode) { a.x *= s4.x; a.y *= s4.y; a.z *= s4.z; a.w *= s4.w; }
+      if (p.has_shift) { a.x += t4.x; a.y += t4.y; a.z += t4.z; a.w += t4.w; }
+      if (p.res_mode) {
+        int64_t rv = v;
+        if (p.res_up2) {
+          int64_t t = vv;
+          const int ox = (int)(t % p.Wo); t /= p.Wo;
+          const int oy = (int)(t % p.Ho);
+          const int oz = (int)(t / p.Ho);
+          rv = (((int64_t)n * (p.Do >> 1) + (oz >> 1)) * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
+        }
+        const float4 r4 = *reinterpret_cast<const float4*>(res + rv * p.Co + co);
+        a.x += r4.x; a.y += r4.y; a.z += r4.z; a.w += r4.w;
+      }
+      a.x = cfun_apply_act(a.x, p.act, p.slope); a.y = cfun_apply_act(a.y, p.act, p.slope);
+      a.z = cfun_apply_act(a.z, p.act, p.slope); a.w = cfun_apply_act(a.w, p.act, p.slope);
+      y[i] = a;
+      acc[0][0] += a.x; acc[0][1] += a.y; acc[0][2] += a.z; acc[0][3] += a.w;
+      acc[1][0] += (double)a.x * a.x; acc[1][1] += (double)a.y * a.y; acc[1][2] += (double)a.z * a.z; acc[1][3] += (double)a.w * a.w;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sm[(tid * 2 + q) * 4 + j] = acc[q][j];
+  __syncthreads();
+  if (vl == 0) {
+    for (int l = 1; l < lanes; ++l) {
+      const int t2 = l * C4 + cg;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[q][j] += sm[(t2 * 2 + q) * 4 + j];
+    }
+    double* out = part + ((int64_t)n * gridDim.x + blockIdx.x) * 2 * p.Co;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) out[(int64_t)q * p.Co + co + j] = acc[q][j];
+  }
+}
+
+// blocks per sample of k_splitk_finish_stats (= statistics slots per sample), 0 when the shape does not fit it
+int splitk_stats_blocks(const CfunConv3dParams* p, int* lanes_out) {
+  const int C4 = p->Co >> 2;
+  if ((p->Co & 3) || C4 > 256 || C4 < 1) return 0;
+  const int lanes = 256 / C4;
+  const int64_t V = (int64_t)p->Do * p->Ho * p->Wo;
+  int64_t want = (1024 + p->N - 1) / (p->N > 0 ? p->N : 1);
+  int64_t maxb = (V + (int64_t)lanes * 16 - 1) / ((int64_t)lanes * 16);
+  if (maxb < 1) maxb = 1;
+  if (lanes_out) *lanes_out = lanes;
+  return (int)(want < maxb ? want : maxb);
+}
+
 }  // namespace
 
+int cfun_splitk_stat_slots(const CfunConv3dParams* p) { return splitk_stats_blocks(p, nullptr); }
+
 int cfun_splitk_finish(const float* partial, int ksplit, const float* scale, const float* shift, const float* res,
-                       float* y, const CfunConv3dParams* p, hipStream_t st) {
+                       float* y, const CfunConv3dParams* p, double* stat_part, hipStream_t st) {
+  if (stat_part) {
+    int lanes = 0;
+    const int blocks = splitk_stats_blocks(p, &lanes);
+    if (blocks <= 0) return CFUN_EINVAL;
+    hipLaunchKernelGGL(k_splitk_finish_stats, dim3((unsigned)blocks, (unsigned)p->N), dim3(256), 0, st, (const float4*)partial,
+                       ksplit, scale, shift, res, (float4*)y, *p, (int64_t)p->Do * p->Ho * p->Wo, lanes, stat_part);
+    CFUN_LAUNCH_CHECK();
+    return CFUN_OK;
+  }
   const int64_t total4 = (int64_t)p->N * p->Do * p->Ho * p->Wo * (p->Co >> 2);
   int64_t blocks = (total4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
@@ -314,12 +406,15 @@ int cfun_conv3d_fwd_kernel(const CfunConv3dParams* p) {
   return CFUN_KERNEL_DIRECT;
 }
 
-int cfun_conv3d_fwd(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
-                    float* y, const CfunConv3dParams* p, void* ws, size_t ws_bytes, cfun_stream_t stream) {
+// fz: the fusion hooks (null / kPlain: none); main_bytes of ws are the plain call's workspace
+static int conv_fwd_impl(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
+                         float* y, const CfunConv3dParams* p, const ConvMode* fz, void* ws, size_t ws_bytes,
+                         int* stat_slots, cfun_stream_t stream) {
   if (!valid_params(p)) return CFUN_EINVAL;
   if ((p->scale_mode && !scale) || (p->has_shift && !shift) || (p->res_mode && !res)) return CFUN_EINVAL;
   if (p->scale_mode < 0 || p->scale_mode > 2 || p->res_mode < 0 || p->res_mode > 1) return CFUN_EINVAL;
-  if (p->algo == CFUN_ALGO_AUTO && cfun_conv_pointwise_supported(p) && cfun_aligned16(x) && cfun_aligned16(y))
+  const bool fused = fz && (fz->in_stats || fz->in_act || fz->out_part);
+  if (!fused && p->algo == CFUN_ALGO_AUTO && cfun_conv_pointwise_supported(p) && cfun_aligned16(x) && cfun_aligned16(y))
     return cfun_conv_pointwise_fwd(x, wp, scale, shift, res, y, p, cfun_st(stream));   // 1x1x1 -> 8: streaming
   const Shape* s = p->algo == CFUN_ALGO_DIRECT ? nullptr : mfma_shape(p);
   if (s) {
@@ -329,15 +424,67 @@ int cfun_conv3d_fwd(const float* x, const float* wp, const float* scale, const f
     ConvMode md;
     int nsub;
     fwd_mode(p, s, &md, &nsub);
+    if (fused) { md.in_stats = fz->in_stats; md.in_act = fz->in_act; md.in_slope = fz->in_slope; md.out_part = fz->out_part; }
     if (ws && !cfun_aligned16(ws)) return CFUN_EALIGN;
-    if (ws && cfun_wino_supported(p) && ws_bytes >= cfun_wino_workspace_bytes(p))   // x axis in the Winograd F(2,3) domain
-      return cfun_wino_fwd(x, wp, 0, 0, scale, shift, res, y, p, ws, ws_bytes, cfun_st(stream));
+    if (ws && cfun_wino_supported(p) && ws_bytes >= cfun_wino_workspace_bytes(p)) {   // x axis in the Winograd F(2,3) domain
+      if (stat_slots) *stat_slots = cfun_wino_stat_slots(p, ws_bytes);
+      return cfun_wino_fwd(x, wp, 0, 0, scale, shift, res, y, p, ws, ws_bytes, &md, cfun_st(stream));
+    }
+    if (stat_slots) *stat_slots = cfun_mfma::fwd_stat_slots(nsub, *p, md, ws ? ws_bytes : 0);
     return s->fwd(nsub, x, wp, scale, shift, res, y, *p, md, ws, ws ? ws_bytes : 0, cfun_st(stream));
   }
+  if (fused) return CFUN_EINVAL;      // the fusion hooks live in the MFMA / Winograd kernels (cfun_conv3d_fused_support)
   if (p->algo == CFUN_ALGO_MFMA) return CFUN_EINVAL;
   if (p->algo != CFUN_ALGO_DIRECT && cfun_conv_stem_supported(p) && cfun_aligned16(y))
     return cfun_conv_stem_fwd(x, wp, scale, shift, y, p, cfun_st(stream));    // C_in = 1: LDS-tiled, write-bound
   return cfun_conv_fwd_direct(x, wp, scale, shift, res, y, p, cfun_st(stream));
+}
+
+int cfun_conv3d_fwd(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
+                    float* y, const CfunConv3dParams* p, void* ws, size_t ws_bytes, cfun_stream_t stream) {
+  return conv_fwd_impl(x, wp, scale, shift, res, y, p, nullptr, ws, ws_bytes, nullptr, stream);
+}
+
+int cfun_conv3d_fused_support(const CfunConv3dParams* p) {
+  if (!valid_params(p) || p->algo == CFUN_ALGO_DIRECT || !mfma_shape(p)) return 0;
+  return CFUN_FUSE_OUT_STATS;
+}
+
+static size_t stat_part_bytes(const CfunConv3dParams* p) {
+  const int tiles = cfun_mfma::cdiv(p->Do, 4) * cfun_mfma::cdiv(p->Ho, 4) * cfun_mfma::cdiv(p->Wo, 16) * (p->d2s ? 8 : 1);
+  const int sk = cfun_splitk_stat_slots(p);
+  const int cy = p->d2s ? (p->d2s_cq > 0 ? p->d2s_cq : (p->Co >> 3)) : p->Co;
+  return cfun_align_up((size_t)p->N * (tiles > sk ? tiles : sk) * 2 * cy * sizeof(double), 256);
+}
+
+size_t cfun_conv3d_fwd_fused_workspace_bytes(const CfunConv3dParams* p, const CfunConvFusion* f) {
+  const size_t main_bytes = cfun_conv3d_fwd_workspace_bytes(p);
+  if (!main_bytes || !f || !f->out_stats) return main_bytes;
+  return main_bytes + stat_part_bytes(p);
+}
+
+int cfun_conv3d_fwd_fused(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
+                          float* y, const CfunConv3dParams* p, const CfunConvFusion* f, void* ws, size_t ws_bytes,
+                          cfun_stream_t stream) {
+  if (!f || (!f->in_stats && !f->in_act && !f->out_stats))
+    return conv_fwd_impl(x, wp, scale, shift, res, y, p, nullptr, ws, ws_bytes, nullptr, stream);
+  const int have = cfun_conv3d_fused_support(p);
+  const int want = (f->out_stats ? CFUN_FUSE_OUT_STATS : 0) | ((f->in_stats || f->in_act) ? CFUN_FUSE_IN_NORM : 0);
+  if ((want & have) != want) return CFUN_EINVAL;
+  ConvMode fz = kPlain;
+  fz.in_stats = f->in_stats; fz.in_act = f->in_act; fz.in_slope = f->in_slope;
+  const size_t main_bytes = cfun_conv3d_fwd_workspace_bytes(p);
+  if (f->out_stats) {
+    if (!ws || !cfun_aligned16(ws) || ws_bytes < main_bytes + stat_part_bytes(p)) return CFUN_EWORKSPACE;
+    fz.out_part = (double*)((char*)ws + main_bytes);
+  }
+  int slots = 0;
+  const int rc = conv_fwd_impl(x, wp, scale, shift, res, y, p, &fz, ws, f->out_stats ? main_bytes : ws_bytes, &slots, stream);
+  if (rc || !f->out_stats) return rc;
+  if (slots <= 0) return CFUN_EINVAL;
+  const int cy = p->d2s ? (p->d2s_cq > 0 ? p->d2s_cq : (p->Co >> 3)) : p->Co;
+  return cfun_stats_finalize(fz.out_part, f->out_stats, p->N, slots, cy, (int64_t)p->Do * p->Ho * p->Wo * (p->d2s ? 8 : 1),
+                             f->out_eps, cfun_st(stream));
 }
 
 size_t cfun_conv3d_bwd_data_workspace_bytes(const CfunConv3dParams* p) {
@@ -387,7 +534,7 @@ int cfun_conv3d_bwd_data(const float* g, const float* wpT, float* dx, const Cfun
     }
     if (!p->up2 && cfun_aligned16(ws) && ws_bytes >= cfun_wino_workspace_bytes(&q) &&
         (p->d2s ? cfun_wino_s2d_dgrad_supported(p, &q) : cfun_wino_supported(&q)))
-      return cfun_wino_fwd(g, wpT, 1, p->d2s ? (p->Co >> 3) : 0, nullptr, nullptr, nullptr, dx, &q, ws, ws_bytes, cfun_st(stream));
+      return cfun_wino_fwd(g, wpT, 1, p->d2s ? (p->Co >> 3) : 0, nullptr, nullptr, nullptr, dx, &q, ws, ws_bytes, nullptr, cfun_st(stream));
     if (!p->up2) return s->fwd(nsub, g, wpT, nullptr, nullptr, nullptr, dx, q, md, ws, cfun_aligned16(ws) ? ws_bytes : 0, cfun_st(stream));
     if (ws_bytes < cfun_conv3d_bwd_data_workspace_bytes(p) || !cfun_aligned16(ws)) return CFUN_EWORKSPACE;
     const int rc = s->fwd(nsub, g, wpT, nullptr, nullptr, nullptr, (float*)ws, q, md, nullptr, 0, cfun_st(stream));

@@ -292,7 +292,7 @@ int launch_b3(const float* x, const void* wb3, const float* scale, const float* 
                      (size_t)2 * 3 * kB3Plane, st, x, (const b3_u32x4*)wb3, scale, shift, res, y, p, ntz, nty, ntx, ncot,
                      nsub_total, cq, (float*)ws, cps);
   CFUN_LAUNCH_CHECK();
-  if (ksplit > 1) return cfun_splitk_finish((const float*)ws, ksplit, scale, shift, res, y, &p, st);
+  if (ksplit > 1) return cfun_splitk_finish((const float*)ws, ksplit, scale, shift, res, y, &p, nullptr, st);
   return CFUN_OK;
 }
 

@@ -23,9 +23,11 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// conv3d.hip: sums split-K partials in order and applies the fused epilogue
+// conv3d.hip: sums split-K partials in order and applies the fused epilogue; with stat_part also the per-(sample, block)
+// sums of y and y*y per channel (cfun_splitk_stat_slots(p) slots per sample, k_channel_finalize's layout)
 int cfun_splitk_finish(const float* partial, int ksplit, const float* scale, const float* shift, const float* res,
-                       float* y, const CfunConv3dParams* p, hipStream_t st);
+                       float* y, const CfunConv3dParams* p, double* stat_part, hipStream_t st);
+int cfun_splitk_stat_slots(const CfunConv3dParams* p);
 
 namespace cfun_mfma {
 
@@ -70,7 +72,65 @@ struct ConvMode {
                  // (the output gradient of a depth-to-space conv); weight rows of parity q start at q*in_cqp
   int in_cq, in_cqp;
   int tap_skip;  // 0 none | 1 by the output-channel tile's parity | 2 by the input chunk's parity (flipped taps)
+  // ---- InstanceNorm / LeakyReLU folded into the conv (CfunConvFusion, include/cfun_hip.h)
+  const float* in_stats;  // [N][Ci][2] {mean, rstd} or null: the staged input is in_act((x - mean) * rstd)
+  int in_act;             // CFUN_ACT_* applied to the (normalised) input at commit time; zero padding stays zero
+  float in_slope;
+  double* out_part;       // null, or per-(sample, slot) sums of y and y*y per channel: [N][slots][2][Cy] (k_channel_finalize's
+  int out_slots;          // layout); slots = tiles per sample (x 8 parities for depth-to-space outputs)
 };
+
+// Per-tile, per-channel sums of the tile's final outputs (InstanceNorm statistics from the producer's epilogue).  A lane
+// arrives with fp32 sums over ITS voxels for one channel quad; quad_sums_16: the 16 lanes with equal lane>>4 share the
+// quad (16-wide MFMA subtiles: channel c0 + (lane>>4)*4 + j), quad_sums_wave: all 64 lanes do (remainder quads).  Lanes are
+// combined by xor-shuffles and parked in LDS (red: 4 waves x NT x 2 floats -- the main loop's tiles are dead: the caller
+// has passed a __syncthreads() after it); tile_sums_write then adds the 4 wave sums in fp64 in a fixed order and writes
+// one slot of the fp64 partial buffer.  Taken one quad at a time so that only 8 registers of sums are live beside the
+// accumulators.
+__device__ __forceinline__ void quad_sums_16(const float (&sa)[4], const float (&sb)[4], float* red, int wv, int lane, int nt, int c0) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float u = sa[j], v = sb[j];
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { u += __shfl_xor(u, o, 64); v += __shfl_xor(v, o, 64); }
+    if ((lane & 15) == 0) {
+      float* r = red + (wv * nt + c0 + (lane >> 4) * 4 + j) * 2;
+      r[0] = u; r[1] = v;
+    }
+  }
+}
+__device__ __forceinline__ void quad_sums_wave(const float (&sa)[4], const float (&sb)[4], float* red, int wv, int lane, int nt, int c0) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float u = cfun_wave_sum(sa[j]), v = cfun_wave_sum(sb[j]);
+    if (lane == 0) {
+      float* r = red + (wv * nt + c0 + j) * 2;
+      r[0] = u; r[1] = v;
+    }
+  }
+}
+template <int NT>
+__device__ __forceinline__ void tile_sums_write(const float* red, int tid, int cobase, int n, int tile, const CfunConv3dParams& p,
+                                                const ConvMode& md) {
+  __syncthreads();
+  if (tid < 2 * NT) {
+    const int c = tid >> 1, qn = tid & 1, co = cobase + c;
+    if (co < p.Co) {
+      double sum = 0.0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) sum += (double)red[(w * NT + c) * 2 + qn];
+      int slot = tile, ch = co, cy = p.Co;
+      if (p.d2s) {
+        const int CqP = p.Co >> 3;
+        cy = p.d2s_cq > 0 ? p.d2s_cq : CqP;
+        const int q = co / CqP;
+        ch = co - q * CqP;
+        slot = tile * 8 + q;
+      }
+      if (ch < cy) md.out_part[(((int64_t)n * md.out_slots + slot) * 2 + qn) * cy + ch] = sum;
+    }
+  }
+}
 
 // taps of a parity-folded "nearest x2 -> 3x3x3" kernel that are non-zero for output parity q = (pz,py,px):
 // per axis the 2 low-resolution taps {p, p+1} of {0,1,2}
@@ -106,7 +166,9 @@ struct FwdTile {
 // v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 outer products: lane 4b+j supplies voxel j of block b, lane 4b+i the
 // weight of channel i; result lane = voxel, 4 registers = 4 channels -- measured with tools/probe_mfma.py), so
 // Co = 20 / 40 / 8 tiles carry no channel padding (a 16-wide MFMA subtile would be 75 % / 50 % / 50 % idle).
-template <int KD, int KH, int KW, int S, int NSUB, bool SPECIAL, int REM>
+// STATS: the epilogue also produces the per-tile sums of y and y*y per channel (md.out_part) -- an instantiation of its
+// own, so that the plain kernels keep their register budget (the sums cost the 64-channel tile a resident wave)
+template <int KD, int KH, int KW, int S, int NSUB, bool SPECIAL, int REM, bool STATS = false>
 __global__ void __launch_bounds__(256)
 k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale,
             const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
@@ -268,9 +330,12 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
   // ---- epilogue.  16-wide subtiles: lane owns voxel (z0+wv, y0+m, x0+(lane&15)), channels nn*16 + (lane>>4)*4..+3;
   // remainder quads: lane owns voxel (z0+wv, y0+(lane>>4), x0+(lane&15)), channels 16*NSUB + 4q..+3
   const int oz = z0 + wv, ox = x0 + (lane & 15);
-  if (oz >= p.Do || ox >= p.Wo) return;
-  auto emit = [&](int oy, int co, const f32x4& a4) {
-    if (oy >= p.Ho || co >= p.Co) return;
+  constexpr bool stats_on = STATS;
+  const bool vox_ok = oz < p.Do && ox < p.Wo;
+  if (!stats_on && !vox_ok) return;
+  if (stats_on) __syncthreads();      // every wave has left the main loop: its LDS tiles are dead, `smem` becomes `red`
+  auto emit = [&](int oy, int co, const f32x4& a4, float (&sa)[4], float (&sb)[4]) {
+    if (!vox_ok || oy >= p.Ho || co >= p.Co) return;
     const int64_t v = (((int64_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox;
     float4 r = make_float4(a4[0], a4[1], a4[2], a4[3]);
     if (gridDim.y > 1) {       // split-K partial: raw sums, plain layout
@@ -297,6 +362,10 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
     }
     r.x = cfun_apply_act(r.x, p.act, p.slope); r.y = cfun_apply_act(r.y, p.act, p.slope);
     r.z = cfun_apply_act(r.z, p.act, p.slope); r.w = cfun_apply_act(r.w, p.act, p.slope);
+    if (stats_on) {
+      sa[0] += r.x; sa[1] += r.y; sa[2] += r.z; sa[3] += r.w;
+      sb[0] += r.x * r.x; sb[1] += r.y * r.y; sb[2] += r.z * r.z; sb[3] += r.w * r.w;
+    }
     if (p.d2s) {
       const int64_t hv = (((int64_t)n * 2 * p.Do + 2 * oz + (q >> 2)) * 2 * p.Ho + 2 * oy + ((q >> 1) & 1)) * 2 * p.Wo +
                          2 * ox + (q & 1);
@@ -307,14 +376,22 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
   };
   if constexpr (NSUB > 0) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int nn = 0; nn < NSUB; ++nn) {
+      float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int nn = 0; nn < NSUB; ++nn) emit(y0 + m, cobase + nn * 16 + (lane >> 4) * 4, acc[m][nn]);
+      for (int m = 0; m < 4; ++m) emit(y0 + m, cobase + nn * 16 + (lane >> 4) * 4, acc[m][nn], sa, sb);
+      if (stats_on) quad_sums_16(sa, sb, smem, wv, lane, NT, nn * 16);
+    }
   }
   if constexpr (REM > 0) {
 #pragma unroll
-    for (int q = 0; q < REM; ++q) emit(y0 + (lane >> 4), cobase + 16 * NSUB + 4 * q, accr[q]);
+    for (int q = 0; q < REM; ++q) {
+      float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+      emit(y0 + (lane >> 4), cobase + 16 * NSUB + 4 * q, accr[q], sa, sb);
+      if (stats_on) quad_sums_wave(sa, sb, smem, wv, lane, NT, 16 * NSUB + 4 * q);
+    }
   }
+  if (stats_on) tile_sums_write<NT>(smem, tid, cobase, n, (int)(lid - (unsigned)n * per_n), p, md);
 }
 
 // how many ways to split the channel chunks so that a small volume still fills the chip (0 workspace => 1)
@@ -347,22 +424,35 @@ int launch_conv_mfma(const float* x, const float* wp, const float* scale, const 
   constexpr bool kHasSpecial = (KD == 3 && KH == 3 && KW == 3 && S == 1);
   const bool special = md.in_s2d || md.tap_skip;
   if (special && !kHasSpecial) return CFUN_EINVAL;
-  auto kern = k_conv_mfma<KD, KH, KW, S, NSUB, false, REM>;
+  const int nchunks = md.in_s2d ? 8 * (md.in_cq >> 2) : (p.Ci >> 2);
+  const int ksplit = splitk_factor(nblk, nchunks, p, ws_bytes);
+  const bool stats = md.out_part != nullptr && ksplit == 1;      // (split-K: the finish pass takes the statistics)
+  auto kern = stats ? k_conv_mfma<KD, KH, KW, S, NSUB, false, REM, true> : k_conv_mfma<KD, KH, KW, S, NSUB, false, REM, false>;
   if constexpr (kHasSpecial) {
-    if (special) kern = k_conv_mfma<KD, KH, KW, S, NSUB, true, REM>;
+    if (special) kern = stats ? k_conv_mfma<KD, KH, KW, S, NSUB, true, REM, true> : k_conv_mfma<KD, KH, KW, S, NSUB, true, REM, false>;
   }
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  const int nchunks = md.in_s2d ? 8 * (md.in_cq >> 2) : (p.Ci >> 2);
-  const int ksplit = splitk_factor(nblk, nchunks, p, ws_bytes);
   const int cps = cdiv(nchunks, ksplit);
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)ksplit), dim3(256), lds, st, x, wp, scale, shift, res, y, p, md,
+  ConvMode mk = md;                // epilogue statistics: by this kernel's tiles, or by the split-K finish
+  mk.out_slots = ntz * nty * ntx * (p.d2s ? 8 : 1);
+  if (ksplit > 1) mk.out_part = nullptr;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)ksplit), dim3(256), lds, st, x, wp, scale, shift, res, y, p, mk,
                      ntz, nty, ntx, ncot, (float*)ws, cps);
   CFUN_LAUNCH_CHECK();
-  if (ksplit > 1) return cfun_splitk_finish((const float*)ws, ksplit, scale, shift, res, y, &p, st);
+  if (ksplit > 1) return cfun_splitk_finish((const float*)ws, ksplit, scale, shift, res, y, &p, md.out_part, st);
   return CFUN_OK;
+}
+
+// statistics slots per sample that launch_conv_mfma fills for (p, tile code nsub) given ws_bytes of split-K workspace
+inline int fwd_stat_slots(int nsub, const CfunConv3dParams& p, const ConvMode& md, size_t ws_bytes) {
+  const int nt = 16 * (nsub & 7) + 4 * (nsub >> 3);
+  const int tiles = cdiv(p.Do, 4) * cdiv(p.Ho, 4) * cdiv(p.Wo, 16);
+  const int64_t nblk = (int64_t)p.N * tiles * cdiv(p.Co, nt);
+  const int nchunks = md.in_s2d ? 8 * (md.in_cq >> 2) : (p.Ci >> 2);
+  return splitk_factor(nblk, nchunks, p, ws_bytes) > 1 ? cfun_splitk_stat_slots(&p) : tiles * (p.d2s ? 8 : 1);
 }
 
 template <int KD, int KH, int KW, int S>

@@ -81,11 +81,12 @@ k_wino2_weights(const float* __restrict__ wp, float4* __restrict__ u, int Ci, in
 // 4/9 of the MFMAs.  Staging is unchanged (rows stay x-transformed in LDS); the y transform of the input is applied when
 // the fragment is read (two rows, one add per point), MFMA columns are the 2 x 8 tiles of the wave's 4 x 16 plane and the
 // accumulators are [4 py][4 px][NSUB].
-template <int NSUB, bool S2D, bool TWOD>
+template <int NSUB, bool S2D, bool TWOD, bool STATS = false>
 __global__ void __launch_bounds__(256)
 k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const float* __restrict__ scale,
             const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y, CfunConv3dParams p,
-            int ntz, int nty, int ntx, int ncot, float* __restrict__ partial, int chunks_per_split, int s2d_cq) {
+            int ntz, int nty, int ntx, int ncot, float* __restrict__ partial, int chunks_per_split, int s2d_cq,
+            cfun_mfma::ConvMode md) {
   constexpr int NT = 16 * NSUB;
   constexpr int UROWS = TWOD ? 12 : 9;        // (dz,py) or (dz,dy) groups of 4 channel rows
   constexpr int W_ITEMS = UROWS * 4 * NT;     // float4 (= 4 x-points of one output channel) items per chunk
@@ -346,9 +347,12 @@ k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const flo
 
   // ---- output transform + epilogue: lane owns voxels (z0+wv, y0+2mg+r, x0+2j+{0,1}), channels nn*16+(lane>>4)*4..+3
   const int oz = z0 + wv, oxe = x0 + 2 * (lane & 7);
-  if (oz >= p.Do) return;
-  auto emit = [&](int oy, int ox, int co, const f32x4& a4) {
-    if (oy >= p.Ho || ox >= p.Wo || co >= p.Co) return;
+  constexpr bool stats_on = STATS;      // the per-tile sums of y, y*y per channel (md.out_part): its own instantiation
+  if (!stats_on && oz >= p.Do) return;
+  float* red = reinterpret_cast<float*>(smem);
+  if (stats_on) __syncthreads();      // every wave has left the main loop: the LDS tiles are dead, smem becomes `red`
+  auto emit = [&](int oy, int ox, int co, const f32x4& a4, float (&sa)[4], float (&sb)[4]) {
+    if (oz >= p.Do || oy >= p.Ho || ox >= p.Wo || co >= p.Co) return;
     const int64_t v = (((int64_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox;
     float4 r = make_float4(a4[0], a4[1], a4[2], a4[3]);
     if (gridDim.y > 1) {
@@ -374,6 +378,10 @@ k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const flo
     }
     r.x = cfun_apply_act(r.x, p.act, p.slope); r.y = cfun_apply_act(r.y, p.act, p.slope);
     r.z = cfun_apply_act(r.z, p.act, p.slope); r.w = cfun_apply_act(r.w, p.act, p.slope);
+    if (stats_on) {
+      sa[0] += r.x; sa[1] += r.y; sa[2] += r.z; sa[3] += r.w;
+      sb[0] += r.x * r.x; sb[1] += r.y * r.y; sb[2] += r.z * r.z; sb[3] += r.w * r.w;
+    }
     if (p.d2s) {
       const int64_t hv = (((int64_t)n * 2 * p.Do + 2 * oz + (q >> 2)) * 2 * p.Ho + 2 * oy + ((q >> 1) & 1)) * 2 * p.Wo +
                          2 * ox + (q & 1);
@@ -386,6 +394,7 @@ k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const flo
     const int oy = y0 + 2 * ((lane >> 3) & 1);
 #pragma unroll
     for (int nn = 0; nn < NSUB; ++nn) {
+      float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
       f32x4 e[4], o[4];
 #pragma unroll
       for (int py = 0; py < 4; ++py) {
@@ -393,22 +402,27 @@ k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const flo
         o[py] = (acc[py][1][nn] - acc[py][2][nn]) - acc[py][3][nn];
       }
       const int co = cobase + nn * 16 + (lane >> 4) * 4;
-      emit(oy, oxe, co, (e[0] + e[1]) + e[2]);
-      emit(oy, oxe + 1, co, (o[0] + o[1]) + o[2]);
-      emit(oy + 1, oxe, co, (e[1] - e[2]) - e[3]);
-      emit(oy + 1, oxe + 1, co, (o[1] - o[2]) - o[3]);
+      emit(oy, oxe, co, (e[0] + e[1]) + e[2], sa, sb);
+      emit(oy, oxe + 1, co, (o[0] + o[1]) + o[2], sa, sb);
+      emit(oy + 1, oxe, co, (e[1] - e[2]) - e[3], sa, sb);
+      emit(oy + 1, oxe + 1, co, (o[1] - o[2]) - o[3], sa, sb);
+      if (stats_on) cfun_mfma::quad_sums_16(sa, sb, red, wv, lane, NT, nn * 16);
     }
   } else {
 #pragma unroll
-    for (int mg = 0; mg < 2; ++mg)
+    for (int nn = 0; nn < NSUB; ++nn) {
+      float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int nn = 0; nn < NSUB; ++nn) {
+      for (int mg = 0; mg < 2; ++mg) {
         const f32x4 m0 = acc[mg][0][nn], m1 = acc[mg][1][nn], m2 = acc[mg][2][nn], m3 = acc[mg][3][nn];
         const int oy = y0 + mg * 2 + ((lane >> 3) & 1), co = cobase + nn * 16 + (lane >> 4) * 4;
-        emit(oy, oxe, co, (m0 + m1) + m2);
-        emit(oy, oxe + 1, co, (m1 - m2) - m3);
+        emit(oy, oxe, co, (m0 + m1) + m2, sa, sb);
+        emit(oy, oxe + 1, co, (m1 - m2) - m3, sa, sb);
       }
+      if (stats_on) cfun_mfma::quad_sums_16(sa, sb, red, wv, lane, NT, nn * 16);
+    }
   }
+  if (stats_on) cfun_mfma::tile_sums_write<NT>(red, tid, cobase, n, (int)(lid - (unsigned)n * per_n), p, md);
 }
 
 // 16-channel subtiles per block: fewest padded channels, widest on ties, at most 3 (two waves per SIMD: 134 VGPR + 96
@@ -464,7 +478,7 @@ Plan make_plan(const CfunConv3dParams& p, size_t ws_for_partials) {
 
 template <int NSUB>
 int launch(const float* x, const float4* u, const float* scale, const float* shift, const float* res, float* y,
-           const CfunConv3dParams& p, const Plan& w, float* partial, int s2d_cq, hipStream_t st) {
+           const CfunConv3dParams& p, const Plan& w, float* partial, int s2d_cq, const cfun_mfma::ConvMode& md, hipStream_t st) {
   const size_t lds = (size_t)(w.twod ? 2 : 1) * (4 * VPLANE4 + (w.twod ? 48 : 36) * 16 * NSUB) * sizeof(float4);
   auto kern = s2d_cq ? k_conv_wino<NSUB, true, false> : k_conv_wino<NSUB, false, false>;
   if constexpr (NSUB <= 3) {     // 16 accumulator sets per wave: 64 * NSUB registers
@@ -472,12 +486,19 @@ int launch(const float* x, const float4* u, const float* scale, const float* shi
   } else if (w.twod) {
     return CFUN_EINVAL;
   }
+  if (md.out_part) {             // epilogue statistics (forward only: never with the s2d gather)
+    if (s2d_cq) return CFUN_EINVAL;
+    kern = k_conv_wino<NSUB, false, false, true>;
+    if constexpr (NSUB <= 3) {
+      if (w.twod) kern = k_conv_wino<NSUB, false, true, true>;
+    }
+  }
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)w.nblk, (unsigned)w.ksplit), dim3(256), lds, st, x, u, scale, shift, res, y, p,
-                     w.ntz, w.nty, w.ntx, w.ncot, partial, w.cps, s2d_cq);
+                     w.ntz, w.nty, w.ntx, w.ncot, partial, w.cps, s2d_cq, md);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }
@@ -536,8 +557,17 @@ size_t cfun_wino_workspace_bytes(const CfunConv3dParams* p) {
 
 // wp: packed weights [27][Ci][CoP] of the conv that is run (the data gradient passes the transposed pack and flip = 1)
 // s2d_cq > 0: x is the hi-res gradient of a depth-to-space conv with s2d_cq channels, p->Ci = 8 * s2d_cq (see k_conv_wino)
+// statistics slots per sample a launch with ws_bytes of workspace fills (fz->out_part)
+int cfun_wino_stat_slots(const CfunConv3dParams* p, size_t ws_bytes) {
+  Plan w = make_plan(*p, 0);
+  if (ws_bytes < w.u_bytes) return 0;
+  w = make_plan(*p, ws_bytes - w.u_bytes);
+  return w.ksplit > 1 ? cfun_splitk_stat_slots(p) : w.ntz * w.nty * w.ntx * (p->d2s ? 8 : 1);
+}
+
 int cfun_wino_fwd(const float* x, const float* wp, int flip, int s2d_cq, const float* scale, const float* shift,
-                  const float* res, float* y, const CfunConv3dParams* p, void* ws, size_t ws_bytes, hipStream_t st) {
+                  const float* res, float* y, const CfunConv3dParams* p, void* ws, size_t ws_bytes,
+                  const cfun_mfma::ConvMode* fz, hipStream_t st) {
   Plan w = make_plan(*p, 0);
   if (!ws || ws_bytes < w.u_bytes) return CFUN_EWORKSPACE;
   w = make_plan(*p, ws_bytes - w.u_bytes);
@@ -550,15 +580,20 @@ int cfun_wino_fwd(const float* x, const float* wp, int flip, int s2d_cq, const f
   else
     hipLaunchKernelGGL(k_wino_weights, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, st, wp, u, p->Ci, p->CoP, flip);
   CFUN_LAUNCH_CHECK();
+  cfun_mfma::ConvMode md = {0, 0, 0, 0, 0, nullptr, 0, 0.f, nullptr, 0};
+  if (fz) { md.in_stats = fz->in_stats; md.in_act = fz->in_act; md.in_slope = fz->in_slope; md.out_part = fz->out_part; }
+  md.out_slots = w.ntz * w.nty * w.ntx * (p->d2s ? 8 : 1);
+  double* finish_part = md.out_part;
+  if (w.ksplit > 1) md.out_part = nullptr;     // statistics by the split-K finish instead
   int rc;
   switch (w.nsub) {
-    case 1: rc = launch<1>(x, u, scale, shift, res, y, *p, w, partial, s2d_cq, st); break;
-    case 2: rc = launch<2>(x, u, scale, shift, res, y, *p, w, partial, s2d_cq, st); break;
-    case 3: rc = launch<3>(x, u, scale, shift, res, y, *p, w, partial, s2d_cq, st); break;
-    case 4: rc = launch<4>(x, u, scale, shift, res, y, *p, w, partial, s2d_cq, st); break;
-    default: rc = launch<5>(x, u, scale, shift, res, y, *p, w, partial, s2d_cq, st); break;
+    case 1: rc = launch<1>(x, u, scale, shift, res, y, *p, w, partial, s2d_cq, md, st); break;
+    case 2: rc = launch<2>(x, u, scale, shift, res, y, *p, w, partial, s2d_cq, md, st); break;
+    case 3: rc = launch<3>(x, u, scale, shift, res, y, *p, w, partial, s2d_cq, md, st); break;
+    case 4: rc = launch<4>(x, u, scale, shift, res, y, *p, w, partial, s2d_cq, md, st); break;
+    default: rc = launch<5>(x, u, scale, shift, res, y, *p, w, partial, s2d_cq, md, st); break;
   }
   if (rc) return rc;
-  if (w.ksplit > 1) return cfun_splitk_finish(partial, w.ksplit, scale, shift, res, y, p, st);
+  if (w.ksplit > 1) return cfun_splitk_finish(partial, w.ksplit, scale, shift, res, y, p, finish_part, st);
   return CFUN_OK;
 }

@@ -529,6 +529,16 @@ k_sgd_momentum_step(float* __restrict__ p, const float* __restrict__ g, float* _
 }  // namespace
 
 // ====================================================================== C ABI
+// (mean, rstd) per (n, channel) from per-slot fp64 sums of x and x*x, part[n][slot][2][C] (conv epilogues, conv3d.hip)
+int cfun_stats_finalize(const double* part, float* stats, int N, int slots, int C, int64_t V, float eps, hipStream_t st) {
+  const int NC = N * C;
+  if (NC <= 0) return CFUN_OK;
+  hipLaunchKernelGGL(k_channel_finalize, dim3((unsigned)((NC * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, part, stats, NC, C,
+                     slots, 2, V, eps, 0);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
 extern "C" {
 
 int cfun_lrelu_fwd(const float* x, float* y, int64_t n, float slope, cfun_stream_t stream) {

@@ -45,9 +45,10 @@ class Conv3dParams(nn.Module):
     def packed(self):
         return ops.pack_weight(self.weight)
 
-    def forward(self, x, act=ops.ACT_NONE, bn=None, bn_eps=None, res=None, up2=False, res_up2=False, scale=None):
+    def forward(self, x, act=ops.ACT_NONE, bn=None, bn_eps=None, res=None, up2=False, res_up2=False, scale=None, stats=None):
         """NDHWC in / out.  bn: a frozen nn.BatchNorm3d folded into the epilogue (SURVEY.md App. A-1);
-        scale: per-(n, channel) multiplier (Dropout3d mask) -- mutually exclusive with bn."""
+        scale: per-(n, channel) multiplier (Dropout3d mask) -- mutually exclusive with bn; stats: an ``ops.StatsSlot`` that
+        receives the output's InstanceNorm statistics from the conv's epilogue (left empty on depth slabs)."""
         shift = self.bias
         per_n = False
         pad = None
@@ -63,7 +64,8 @@ class Conv3dParams(nn.Module):
                 raise NotImplementedError("depth sharding of unfolded up-sampling convs: use mask_branch._up_conv")
             return sharded_conv(x, self.weight, self.spec(act, False, res_up2, per_n, (0, self.padding[1], self.padding[2])),
                                 self.kernel_size[0], self.stride, self.padding[0], scale, shift, res, shard)
-        return ops.conv3d_w(x, self.weight, self.spec(act, up2, res_up2, per_n, pad), scale=scale, shift=shift, res=res)
+        return ops.conv3d_w(x, self.weight, self.spec(act, up2, res_up2, per_n, pad), scale=scale, shift=shift, res=res,
+                            stats=stats)
 
     def extra_repr(self):
         return "%d, %d, kernel_size=%s, stride=%d, padding=%s, bias=%s" % (

@@ -115,16 +115,18 @@ class Modified3DUNet(nn.Module):
             om += m.numel() + p
         return out
 
-    def _dropout_pair(self, src, head, conv1, conv2, drop_cpu, pre2):
+    def _dropout_pair(self, src, head, conv1, conv2, drop_cpu, pre2, out_stats=None):
         """One level's ``(a, res) = head(src); out = conv2(pre2(Dropout3d(conv1(a)))) + res``: conv1 / conv2 are the
         level's 3x3x3 Conv3dParams (conv1: Ci -> C, conv2: C -> Co), drop_cpu = (device mask [N,C] (keep / (1-p)),
         per-sample kept-channel index tensors) from ``_upload_dropout`` or None, ``head`` the ops that produce the
-        pair's input and residual from ``src`` [N,...]."""
+        pair's input and residual from ``src`` [N,...].  ``pre2(t, stats)`` gets the ``ops.StatsSlot`` conv1's epilogue
+        filled with t's InstanceNorm statistics; ``out_stats`` (a slot of N samples) receives those of the result."""
         n = src.shape[0]
         c = conv1.out_channels
         if drop_cpu is None:
             a, res = head(src)
-            return conv2(pre2(conv1(a)), res=res)
+            s1 = ops.StatsSlot(n)
+            return conv2(pre2(conv1(a, stats=s1), s1), res=res, stats=out_stats)
         drop, idxs = drop_cpu
         s2 = getattr(head, "stride", 1)
         vox = (src.shape[1] // s2) * (src.shape[2] // s2) * (src.shape[3] // s2)
@@ -132,7 +134,8 @@ class Modified3DUNet(nn.Module):
                   and conv1.in_channels % 4 == 0 and conv1.bias is None and conv2.bias is None)
         if not sparse:
             a, res = head(src)
-            return conv2(pre2(conv1(a, scale=drop)), res=res)
+            s1 = ops.StatsSlot(n)
+            return conv2(pre2(conv1(a, scale=drop, stats=s1), s1), res=res, stats=out_stats)
         algo = default_algo()
         # the level's head ops stay batched (per-sample heads measured no better); batched <-> per-sample hand-overs are
         # zero-copy in both directions (ops.split_batch / join_batch: results and gradients are written in place)
@@ -153,19 +156,21 @@ class Modified3DUNet(nn.Module):
                 spec1 = ops.ConvSpec(k=conv1.kernel_size, co=idx.numel(), pad=p1, scale_per_n=True, algo=algo)
                 t = sharded_conv(a, w1, spec1, conv1.kernel_size[0], 1, conv1.padding[0], sc1, None, None, zs)
                 spec2 = ops.ConvSpec(k=conv2.kernel_size, co=conv2.out_channels, pad=p2, algo=algo)
-                outs.append(sharded_conv(pre2(t), w2s[i], spec2, conv2.kernel_size[0], 1, conv2.padding[0], None, None, res, zs))
+                outs.append(sharded_conv(pre2(t, None), w2s[i], spec2, conv2.kernel_size[0], 1, conv2.padding[0], None, None, res, zs))
                 continue
             spec1 = ops.ConvSpec(k=conv1.kernel_size, co=idx.numel(), pad=conv1.padding, scale_per_n=True, algo=algo)
-            t = ops.conv3d_w(a, w1, spec1, scale=sc1, dx_slot=(gbuf, i))
+            s1 = ops.StatsSlot(1)
+            t = ops.conv3d_w(a, w1, spec1, scale=sc1, dx_slot=(gbuf, i), stats=s1)
             w2 = w2s[i]
             spec2 = ops.ConvSpec(k=conv2.kernel_size, co=conv2.out_channels, pad=conv2.padding, algo=algo)
-            outs.append(ops.conv3d_w(pre2(t), w2, spec2, res=res, out=(ybuf, i)))
+            outs.append(ops.conv3d_w(pre2(t, s1), w2, spec2, res=res, out=(ybuf, i),
+                                     stats=None if out_stats is None else (out_stats, i)))
         if zs is not None:
             return outs[0] if n == 1 else torch.cat(outs, dim=0)
         return ops.join_batch(ybuf, outs)
 
     @staticmethod
-    def _up_conv(h, conv, depth_padded=False):
+    def _up_conv(h, conv, depth_padded=False, stats=None):
         """conv3x3x3(nearest_up2(h)).  On the up-sampled grid each output parity only sees 2x2x2 distinct
         low-resolution voxels, so the weights are folded per parity (ops.fold_up2_weight, differentiable) and the
         conv runs on the LOW-resolution tensor with a depth-to-space epilogue, skipping the 19 folded-zero taps:
@@ -174,12 +179,12 @@ class Modified3DUNet(nn.Module):
         if ci % 4 or co % 4:
             if depth_padded:
                 raise NotImplementedError("z-sharded up-conv needs C % 4 == 0 (the folded form)")
-            return conv(h, up2=True)
+            return conv(h, up2=True, stats=stats)
         cqp = (co + 15) // 16 * 16
         # depth_padded: h already carries one low-resolution halo plane on each side (z-sharded RoI) -> depth-VALID
         spec = ops.ConvSpec(k=(3, 3, 3), co=8 * cqp, pad=(0 if depth_padded else 1, 1, 1), d2s=True, d2s_cq=co,
                             tap_skip=True, algo=default_algo())
-        return ops.conv3d_w(h, ops.fold_up2_weight(conv.weight, cqp), spec)
+        return ops.conv3d_w(h, ops.fold_up2_weight(conv.weight, cqp), spec, stats=None if depth_padded else stats)
 
     def forward_ndhwc(self, x, zshard=None):
         """x [N,D,H,W,in]: the RoI crops.  ``zshard`` (a ``dist.ShardContext`` over the RoI's sub-group of ranks, N == 1):
@@ -192,17 +197,25 @@ class Modified3DUNet(nn.Module):
         sharded = (lambda: dist.depth_sharded_as(zs)) if zs is not None else dist.nullcontext
         folded = dist.slab_local if zs is not None else dist.nullcontext
 
-        def nl(t, out=None, rep=False):      # rep: t is a replicated (folded) tensor -> plain local statistics
-            return ops.instnorm_lrelu(t, out=out, shard=None if rep else zs)
+        def nl(t, out=None, rep=False, stats=None):      # rep: t is a replicated (folded) tensor -> plain local statistics
+            # stats: the StatsSlot t's producer conv filled from its epilogue (empty on depth slabs: own pass then)
+            return ops.instnorm_lrelu(t, out=out, shard=None if rep else zs, stats=stats)
+
+        def slot(t_or_n):
+            return ops.StatsSlot(t_or_n if isinstance(t_or_n, int) else t_or_n.shape[0])
+
+        nb = x.shape[0]
 
         drop = self._upload_dropout(self._drop_masks(x.shape[0], x.device), x.device)
 
-        def nluc(h, holder, out=None, src="same"):
+        def nluc(h, holder, out=None, src="same", stats=None):
             """norm -> lrelu -> nearest x2 -> 3x3x3 conv -> norm -> lrelu (mask_branch.py:108-116).  src: where h lives --
-            'same' (no sharding, or sharded in and out), 'rep' (replicated in and out) or 'enter' (replicated in, sharded out)."""
-            a = nl(h, rep=src != "same")
+            'same' (no sharding, or sharded in and out), 'rep' (replicated in and out) or 'enter' (replicated in, sharded out).
+            stats: the slot h's producer filled."""
+            a = nl(h, rep=src != "same", stats=stats)
             if zs is None or src == "rep":
-                return nl(self._up_conv(a, holder[3]), out=out, rep=src == "rep")
+                su = slot(nb)
+                return nl(self._up_conv(a, holder[3], stats=su), out=out, rep=src == "rep", stats=su)
             a = dist.enter_slab(a, zs, 1, 1) if src == "enter" else dist.halo_exchange(a, 1, 1, zs)
             return nl(self._up_conv(a, holder[3], depth_padded=True), out=out)
 
@@ -211,54 +224,65 @@ class Modified3DUNet(nn.Module):
             def head1(xp):
                 res = self.conv3d_c1_1(xp)
                 return ops.lrelu(res), res
-            out = self._dropout_pair(x, head1, self.conv3d_c1_2, self.lrelu_conv_c1[1], drop[0], ops.lrelu)
+            s_out = slot(nb)
+            out = self._dropout_pair(x, head1, self.conv3d_c1_2, self.lrelu_conv_c1[1], drop[0], lambda t, st: ops.lrelu(t),
+                                     out_stats=s_out)
             # context_1 is only ever read by the level-1 concat (mask_branch.py:203): it is written straight into the
             # second half of that concat's buffer, the decoder later writes the first half -- no torch.cat, no copies
             b1 = self.base_n_filter
             cat1 = ops.ConcatBuffer(out, 2 * b1) if b1 % 4 == 0 else None
             ctx = [ops.lrelu(out, out=None if cat1 is None else cat1.slot(b1, 2 * b1))]
-            h = nl(out)
+            h = nl(out, stats=s_out)
         # levels 2..5: stride-2 conv, then the SAME norm_lrelu_conv weights twice around the dropout
         for lvl in (2, 3, 4, 5):
             down = getattr(self, "conv3d_c%d" % lvl)
             rep = zs is not None and lvl >= 3          # folded levels
 
             def head(hp, down=down, lvl=lvl, rep=rep):
+                sd = None
                 if zs is not None and lvl == 3:        # the fold: slabs of the 1/4-resolution tensor -> every rank
                     with dist.depth_sharded_as(zs):
                         res = down(hp)
                     res = dist.gather_replicated(res, zs)
                 else:
-                    res = down(hp)
-                return nl(res, rep=rep), res
+                    sd = slot(nb)
+                    res = down(hp, stats=sd)
+                return nl(res, rep=rep, stats=sd), res
             head.stride = 2
             conv = getattr(self, "norm_lrelu_conv_c%d" % lvl)[2]
             with (folded() if rep else sharded()):
-                out = self._dropout_pair(h, head, conv, conv, drop[lvl - 1], lambda t, rep=rep: nl(t, rep=rep))
+                s_out = slot(nb)
+                out = self._dropout_pair(h, head, conv, conv, drop[lvl - 1], lambda t, st, rep=rep: nl(t, rep=rep, stats=st),
+                                         out_stats=s_out)
                 if lvl < 5:
-                    h = nl(out, rep=rep)
+                    h = nl(out, rep=rep, stats=s_out)
                     ctx.append(h)
         R = zs is not None       # decoder: replicated up to 1/4 resolution, sharded from 1/2
         with folded():
-            h = nluc(out, self.norm_lrelu_upscale_conv_norm_lrelu_l0, src="rep" if R else "same")
-            h = nl(self.conv3d_l0(h), rep=R)
-            h = nl(self.conv_norm_lrelu_l1[0](torch.cat([h, ctx[3]], dim=-1)), rep=R)
-            h = nluc(self.conv3d_l1(h), self.norm_lrelu_upscale_conv_norm_lrelu_l1, src="rep" if R else "same")
-            ds2 = nl(self.conv_norm_lrelu_l2[0](torch.cat([h, ctx[2]], dim=-1)), rep=R)
-            h_l2 = self.conv3d_l2(ds2)
+            h = nluc(out, self.norm_lrelu_upscale_conv_norm_lrelu_l0, src="rep" if R else "same", stats=s_out)
+            sa, sb, sc, sd_ = slot(nb), slot(nb), slot(nb), slot(nb)
+            h = nl(self.conv3d_l0(h, stats=sa), rep=R, stats=sa)
+            h = nl(self.conv_norm_lrelu_l1[0](torch.cat([h, ctx[3]], dim=-1), stats=sb), rep=R, stats=sb)
+            h = nluc(self.conv3d_l1(h, stats=sc), self.norm_lrelu_upscale_conv_norm_lrelu_l1, src="rep" if R else "same",
+                     stats=sc)
+            ds2 = nl(self.conv_norm_lrelu_l2[0](torch.cat([h, ctx[2]], dim=-1), stats=sd_), rep=R, stats=sd_)
+            s_l2 = slot(nb)
+            h_l2 = self.conv3d_l2(ds2, stats=s_l2)
             ds2_out = self.ds2_1x1_conv3d(ds2)
-        h = nluc(h_l2, self.norm_lrelu_upscale_conv_norm_lrelu_l2, src="enter" if R else "same")
+        h = nluc(h_l2, self.norm_lrelu_upscale_conv_norm_lrelu_l2, src="enter" if R else "same", stats=s_l2)
         if R:
             ds2_out = dist.enter_slab(ds2_out, zs)
         with sharded():
-            ds3 = nl(self.conv_norm_lrelu_l3[0](torch.cat([h, ctx[1]], dim=-1)))
+            s3, s_l3, s4 = slot(nb), slot(nb), slot(nb)
+            ds3 = nl(self.conv_norm_lrelu_l3[0](torch.cat([h, ctx[1]], dim=-1), stats=s3), stats=s3)
             if cat1 is None:
-                h = nluc(self.conv3d_l3(ds3), self.norm_lrelu_upscale_conv_norm_lrelu_l3)
+                h = nluc(self.conv3d_l3(ds3, stats=s_l3), self.norm_lrelu_upscale_conv_norm_lrelu_l3, stats=s_l3)
                 joined = torch.cat([h, ctx[0]], dim=-1)
             else:
-                h = nluc(self.conv3d_l3(ds3), self.norm_lrelu_upscale_conv_norm_lrelu_l3, out=cat1.slot(0, b1))
+                h = nluc(self.conv3d_l3(ds3, stats=s_l3), self.norm_lrelu_upscale_conv_norm_lrelu_l3, out=cat1.slot(0, b1),
+                         stats=s_l3)
                 joined = cat1.join(h, ctx[0])
-            h = nl(self.conv_norm_lrelu_l4[0](joined))
+            h = nl(self.conv_norm_lrelu_l4[0](joined, stats=s4), stats=s4)
             # deep supervision: up(up(ds2_1x1) + ds3_1x1) + out_pred, each add is a conv epilogue
             s = self.ds3_1x1_conv3d(ds3, res=ds2_out, res_up2=True)
             out = self.conv3d_l4(h, res=s, res_up2=True)

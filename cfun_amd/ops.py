@@ -203,9 +203,33 @@ def _b3_wgrad_wanted(lib, p):
     return bool(lib.cfun_conv3d_b3_wgrad_preferred(C.byref(p)))
 
 
+class StatsSlot:
+    """Receives InstanceNorm statistics (mean, rstd) [N,C,2] of a conv's OUTPUT from the epilogue that writes it
+    (cfun_conv3d_fwd_fused, CfunConvFusion.out_stats) -- ``conv3d_w(..., stats=slot)`` fills it, ``instnorm_lrelu(y,
+    stats=slot)`` then skips its own statistics pass over y.  Per-sample convs of one batch fill one row each:
+    ``stats=(slot, i)``.  ``stats`` stays None when the kernel that ran has no statistics epilogue (the norm then runs
+    its own pass): nothing downstream depends on whether the fusion happened."""
+
+    def __init__(self, n=1, eps=1e-5):
+        self.n, self.eps, self.stats, self.filled = n, eps, None, 0
+
+    def row(self, i, c, like):
+        if self.stats is None:
+            self.stats = torch.empty((self.n, c, 2), dtype=torch.float32, device=like.device)
+        if self.stats.shape[1] != c:
+            raise RuntimeError("StatsSlot: %d channels, the slot holds %d" % (c, self.stats.shape[1]))
+        return self.stats[i:i + 1]
+
+    def get(self, n, c):
+        """The finished [n,c,2] tensor, or None if not every row was filled by a fused epilogue."""
+        if self.stats is None or self.filled != self.n or tuple(self.stats.shape) != (n, c, 2):
+            return None
+        return self.stats
+
+
 class _Conv3d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, wp, scale, shift, res, spec, out=None, dx_slot=None, w_src=None):
+    def forward(ctx, x, wp, scale, shift, res, spec, out=None, dx_slot=None, w_src=None, stats=None):
         lib = _lib.load()
         x = _c(x)
         wpT = None
@@ -246,6 +270,21 @@ class _Conv3d(torch.autograd.Function):
             ws = workspace(lib.cfun_conv3d_b3_fwd_workspace_bytes(C.byref(p)), x)
             check(lib.cfun_conv3d_b3_fwd(ptr(x), ptr(wb3), ptr(scale), ptr(shift), ptr(res), ptr(y), C.byref(p), ptr(ws),
                                          ws.numel(), stream(x)), "conv3d_b3_fwd")
+        elif stats is not None and (lib.cfun_conv3d_fused_support(C.byref(p)) & _lib.FUSE_OUT_STATS):
+            # InstanceNorm statistics of y from this epilogue (the norm that follows skips its pass over y)
+            slot, i = stats if isinstance(stats, tuple) else (stats, None)
+            if (i is None and slot.n != p.N) or (i is not None and p.N != 1):
+                raise RuntimeError("conv3d: stats slot of %d samples does not fit a conv over %d" % (slot.n, p.N))
+            if i is None:
+                slot.stats = torch.empty((p.N, y.shape[-1], 2), dtype=torch.float32, device=x.device)
+                dst, slot.filled = slot.stats, slot.n
+            else:
+                dst = slot.row(i, y.shape[-1], x)
+                slot.filled += 1
+            fz = _lib.ConvFusion(None, 0, 0.0, dst.data_ptr(), float(slot.eps))
+            ws = workspace(lib.cfun_conv3d_fwd_fused_workspace_bytes(C.byref(p), C.byref(fz)), x)
+            check(lib.cfun_conv3d_fwd_fused(ptr(x), ptr(wp), ptr(scale), ptr(shift), ptr(res), ptr(y), C.byref(p),
+                                            C.byref(fz), ptr(ws), ws.numel(), stream(x)), "conv3d_fwd_fused")
         else:
             ws = workspace(lib.cfun_conv3d_fwd_workspace_bytes(C.byref(p)), x)
             check(lib.cfun_conv3d_fwd(ptr(x), ptr(wp), ptr(scale), ptr(shift), ptr(res), ptr(y), C.byref(p), ptr(ws),
@@ -347,21 +386,22 @@ class _Conv3d(torch.autograd.Function):
                       "upsample2_bwd")
             else:
                 dres = gp
-        return dx, dwp, None, dshift, dres, None, None, None, dw
+        return dx, dwp, None, dshift, dres, None, None, None, dw, None
 
 
-def conv3d(x, wp, spec, scale=None, shift=None, res=None, out=None, dx_slot=None):
+def conv3d(x, wp, spec, scale=None, shift=None, res=None, out=None, dx_slot=None, stats=None):
     """y = act(scale * conv(x) + shift + res); see include/cfun_hip.h (cfun_conv3d_fwd).  ``out`` / ``dx_slot``:
-    (BatchBuffer, i) -- write y / the input gradient into sample i of a shared batch buffer (per-sample convs)."""
-    return _Conv3d.apply(x, wp, scale, shift, res, spec, out, dx_slot, None)
+    (BatchBuffer, i) -- write y / the input gradient into sample i of a shared batch buffer (per-sample convs).
+    ``stats``: a ``StatsSlot`` (or (slot, i) for per-sample convs) that receives y's InstanceNorm statistics."""
+    return _Conv3d.apply(x, wp, scale, shift, res, spec, out, dx_slot, None, stats)
 
 
-def conv3d_w(x, w, spec, scale=None, shift=None, res=None, out=None, dx_slot=None):
+def conv3d_w(x, w, spec, scale=None, shift=None, res=None, out=None, dx_slot=None, stats=None):
     """``conv3d`` on an OIDHW weight [Co,Ci,kd,kh,kw] (a parameter, a gathered slice of one, a folded up-conv
     weight): packed inside the op, and the weight gradient is produced directly in OIDHW -- the reduction of the
     wgrad kernel's per-chunk partial sums and the un-packing are one kernel (cfun_conv3d_bwd_weight_oidhw) instead
     of conv3d(x, pack_weight(w))'s reduce + un-pack launches.  Same values bit for bit."""
-    return _Conv3d.apply(x, None, scale, shift, res, spec, out, dx_slot, w)
+    return _Conv3d.apply(x, None, scale, shift, res, spec, out, dx_slot, w, stats)
 
 
 # ---- EXPERIMENTAL: 3x3x3 conv with fp32 emulated on the bf16 matrix cores (conv3d_b3.hip; not used by the modules) ----
@@ -663,7 +703,7 @@ def _combine_stats_over_ranks(stats, eps, shard):
 
 class _InstNormLReLU(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, eps, out=None, shard=None):
+    def forward(ctx, x, eps, out=None, shard=None, pre=None):
         lib = _lib.load()
         x = _c(x)
         n, c = x.shape[0], x.shape[-1]
@@ -672,10 +712,12 @@ class _InstNormLReLU(torch.autograd.Function):
         if v * (shard.world if zs else 1) <= 1:
             raise ValueError("Expected more than 1 spatial element when training, got input size %s"
                              % (tuple(x.shape),))  # InstanceNorm3d behaviour, SURVEY.md App. A-3
-        stats = torch.empty((n, c, 2), dtype=torch.float32, device=x.device)
-        ws = workspace(lib.cfun_instnorm_workspace_bytes(n, v, c), x)
         st = stream(x)
-        check(lib.cfun_instnorm_stats(ptr(x), ptr(stats), n, v, c, eps, ptr(ws), ws.numel(), st), "instnorm_stats")
+        stats = pre.get(n, c) if (pre is not None and pre.eps == eps) else None      # from the producer conv's epilogue
+        if stats is None:
+            stats = torch.empty((n, c, 2), dtype=torch.float32, device=x.device)
+            ws = workspace(lib.cfun_instnorm_workspace_bytes(n, v, c), x)
+            check(lib.cfun_instnorm_stats(ptr(x), ptr(stats), n, v, c, eps, ptr(ws), ws.numel(), st), "instnorm_stats")
         if zs:
             stats = _combine_stats_over_ranks(stats, eps, shard)
         if out is None:
@@ -714,15 +756,16 @@ class _InstNormLReLU(torch.autograd.Function):
             means /= ctx.shard.world
             check(lib.cfun_instnorm_lrelu_bwd_apply(ptr(x), ptr(stats), ptr(means), ptr_raw(dy), ptr(dx), n, v, c, rs,
                                                     LRELU_SLOPE, stream(x)), "instnorm_lrelu_bwd_apply")
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 
-def instnorm_lrelu(x, eps=1e-5, out=None, shard=None):
+def instnorm_lrelu(x, eps=1e-5, out=None, shard=None, stats=None):
     """LeakyReLU(InstanceNorm3d(x)) (affine=False, biased variance), mask_branch.py:28-116.  ``out``: a
     ``ConcatBuffer.slot`` to write the result into (zero-copy concat).  ``shard``: x is this rank's equal depth slab of
     a volume z-sharded over ``shard``'s ranks -- the statistics (forward) and the two gradient means (backward) are
-    combined with one small all-reduce each."""
-    return _InstNormLReLU.apply(x, eps, out, shard)
+    combined with one small all-reduce each.  ``stats``: a ``StatsSlot`` the conv that produced x filled from its
+    epilogue (this rank's slab for a sharded x) -- the statistics pass over x is then skipped."""
+    return _InstNormLReLU.apply(x, eps, out, shard, stats)
 
 
 class _LReLU(torch.autograd.Function):

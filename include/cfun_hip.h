@@ -108,6 +108,32 @@ size_t cfun_conv3d_fwd_workspace_bytes(const CfunConv3dParams* p);
 int cfun_conv3d_fwd_kernel(const CfunConv3dParams* p);
 int cfun_conv3d_fwd(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
                     float* y, const CfunConv3dParams* p, void* ws, size_t ws_bytes, cfun_stream_t stream);
+/* InstanceNorm3d(affine=False) + LeakyReLU folded into the convolutions around it (mask_branch.py:23-25,91-116: every
+ * "conv -> [Dropout3d] -> InstanceNorm3d -> LeakyReLU -> conv" chain of the U-Net).  All hooks are optional:
+ *   out_stats  [N][Cy][2] {mean, rstd} of the conv's OUTPUT y per (sample, channel), biased variance + out_eps (what
+ *              cfun_instnorm_stats computes in a pass of its own), taken from the epilogue that writes y: per-tile fp32
+ *              sums combined in fp64 in a fixed order (deterministic).  Cy = Co, or d2s_cq for depth-to-space outputs.
+ *   in_stats   [N][Ci][2] {mean, rstd}: the conv reads in_act((x - mean) * rstd) in place of x, applied while the input
+ *              tile is staged (zero padding stays zero) -- the normalised tensor is never written to memory.
+ *   in_act     CFUN_ACT_* applied to the (normalised) input; in_slope its LeakyReLU slope.  in_act without in_stats
+ *              folds a plain LeakyReLU (mask_branch.py:18) into the consumer.
+ * cfun_conv3d_fused_support(p): which hooks the kernel that runs p implements (CFUN_FUSE_* bits; 0 = none, the caller
+ * then keeps the separate cfun_instnorm_* passes).  Workspace: cfun_conv3d_fwd_fused_workspace_bytes. */
+typedef struct CfunConvFusion {
+  const float* in_stats;
+  int32_t in_act;
+  float in_slope;
+  float* out_stats;
+  float out_eps;
+} CfunConvFusion;
+#define CFUN_FUSE_OUT_STATS 1
+#define CFUN_FUSE_IN_NORM 2       /* in_stats / in_act in cfun_conv3d_fwd_fused */
+#define CFUN_FUSE_IN_NORM_WGRAD 4 /* ... and in cfun_conv3d_bwd_weight_fused (the weight gradient needs the same input) */
+int cfun_conv3d_fused_support(const CfunConv3dParams* p);
+size_t cfun_conv3d_fwd_fused_workspace_bytes(const CfunConv3dParams* p, const CfunConvFusion* f);
+int cfun_conv3d_fwd_fused(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
+                          float* y, const CfunConv3dParams* p, const CfunConvFusion* f, void* ws, size_t ws_bytes,
+                          cfun_stream_t stream);
 /* dx[n,zi,yi,xi,ci] (stored-input resolution) = sum over outputs/taps that read it of g * W. g = dL/d(conv sum). */
 size_t cfun_conv3d_bwd_data_workspace_bytes(const CfunConv3dParams* p);
 int cfun_conv3d_bwd_data(const float* g, const float* wpT, float* dx, const CfunConv3dParams* p, void* ws,

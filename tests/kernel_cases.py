@@ -173,6 +173,22 @@ def check_conv(device, n, dhw, ci, co, k, stride=1, pad=None, up2=False, act=ACT
     yw.backward(gy.to(device))
     assert torch.equal(yw, y) and torch.equal(xw.grad, xd.grad), "conv3d_w: y / dx differ from the packed path"
     assert torch.equal(ww.grad, wd.grad), "conv3d_w: fused OIDHW weight gradient differs from reduce + unpack"
+    # InstanceNorm statistics of y from the conv's epilogue (CfunConvFusion.out_stats): same y, and (mean, rstd) per
+    # (sample, channel) equal to the two-pass fp64 statistics of the reference output
+    slot = ops.StatsSlot(n)
+    with torch.no_grad():
+        ys = ops.conv3d_w(xw.detach(), ww.detach(), spec, None if sc is None else sc.to(device),
+                          None if sfw is None else sfw.detach(), None if rsw is None else rsw.detach(), stats=slot)
+    assert torch.equal(ys, y), "conv3d_w(stats=...): y differs from the plain call"
+    st = slot.get(n, y.shape[-1])
+    if algo != ALGO_DIRECT and ci % 4 == 0 and co % 4 == 0 and ci > 1:
+        assert st is not None, "the MFMA / Winograd kernels must deliver epilogue statistics"
+    if st is not None:
+        y64 = yr.detach().double().reshape(n, -1, yr.shape[-1])
+        mean = y64.mean(dim=1)
+        rstd = 1.0 / torch.sqrt(y64.var(dim=1, unbiased=False) + 1e-5)
+        assert_close(st[..., 0], mean.float(), "epilogue mean", 2e-5)
+        assert_close(st[..., 1], rstd.float(), "epilogue rstd", 2e-5)
 
 
 # ------------------------------------------------------------------------------------------ norm / act / pool
