@@ -447,6 +447,7 @@ int cfun_conv3d_fwd(const float* x, const float* wp, const float* scale, const f
 
 int cfun_conv3d_fused_support(const CfunConv3dParams* p) {
   if (!valid_params(p) || p->algo == CFUN_ALGO_DIRECT || !mfma_shape(p)) return 0;
+  if (p->algo == CFUN_ALGO_AUTO && cfun_conv_pointwise_supported(p)) return 0;    // the streaming 1x1x1 -> 8 kernel has no hooks
   return CFUN_FUSE_OUT_STATS;
 }
 

@@ -80,45 +80,46 @@ struct ConvMode {
   int out_slots;          // layout); slots = tiles per sample (x 8 parities for depth-to-space outputs)
 };
 
-// Per-tile, per-channel sums of the tile's final outputs (InstanceNorm statistics from the producer's epilogue).  A lane
-// arrives with fp32 sums over ITS voxels for one channel quad; quad_sums_16: the 16 lanes with equal lane>>4 share the
-// quad (16-wide MFMA subtiles: channel c0 + (lane>>4)*4 + j), quad_sums_wave: all 64 lanes do (remainder quads).  Lanes are
-// combined by xor-shuffles and parked in LDS (red: 4 waves x NT x 2 floats -- the main loop's tiles are dead: the caller
-// has passed a __syncthreads() after it); tile_sums_write then adds the 4 wave sums in fp64 in a fixed order and writes
-// one slot of the fp64 partial buffer.  Taken one quad at a time so that only 8 registers of sums are live beside the
-// accumulators.
-__device__ __forceinline__ void quad_sums_16(const float (&sa)[4], const float (&sb)[4], float* red, int wv, int lane, int nt, int c0) {
+// Per-tile, per-channel sums of the tile's final outputs (InstanceNorm statistics from the producer's epilogue), as
+// accurate as the stand-alone fp64 pass: a lane sums ITS (at most 4) voxels per channel in fp32, parks the pair (sum,
+// sum of squares) in LDS -- entry e = wave*16 + (lane & 15), `es` floats per entry -- and one thread per (channel, quantity)
+// adds the 64 entries in fp64 in a fixed order and writes one slot of the fp64 partial buffer.  `red` reuses the main
+// loop's tiles (the caller has passed a __syncthreads() after the loop); channels are taken in rounds of at most
+// STAT_ROUND so that 64 * (2 * STAT_ROUND + 8) floats fit every kernel's LDS.
+constexpr int STAT_ROUND = 32;
+constexpr int stat_es(int chans) { return 2 * chans + 8; }            // (+8: the 16 x-lanes of a quad land on different banks)
+constexpr int stat_lds_floats(int nt) { return 64 * stat_es(nt < STAT_ROUND ? nt : STAT_ROUND); }
+// the 16 lanes with equal lane>>4 share the quad (16-wide MFMA subtiles): local channel cl + (lane>>4)*4 + j
+__device__ __forceinline__ void quad_park_16(const float (&sa)[4], const float (&sb)[4], float* red, int es, int wv, int lane, int cl) {
+  float* r = red + (wv * 16 + (lane & 15)) * es + (cl + (lane >> 4) * 4) * 2;
+  *reinterpret_cast<float4*>(r) = make_float4(sa[0], sb[0], sa[1], sb[1]);
+  *reinterpret_cast<float4*>(r + 4) = make_float4(sa[2], sb[2], sa[3], sb[3]);
+}
+// all 64 lanes share the quad (remainder quads: lane = voxel (row lane>>4, x = lane&15)): the 4 rows are added first
+__device__ __forceinline__ void quad_park_wave(const float (&sa)[4], const float (&sb)[4], float* red, int es, int wv, int lane, int cl) {
+  float u[4], v[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    float u = sa[j], v = sb[j];
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) { u += __shfl_xor(u, o, 64); v += __shfl_xor(v, o, 64); }
-    if ((lane & 15) == 0) {
-      float* r = red + (wv * nt + c0 + (lane >> 4) * 4 + j) * 2;
-      r[0] = u; r[1] = v;
-    }
+    u[j] = sa[j]; v[j] = sb[j];
+    u[j] += __shfl_xor(u[j], 16, 64); v[j] += __shfl_xor(v[j], 16, 64);
+    u[j] += __shfl_xor(u[j], 32, 64); v[j] += __shfl_xor(v[j], 32, 64);
+  }
+  if ((lane >> 4) == 0) {
+    float* r = red + (wv * 16 + (lane & 15)) * es + cl * 2;
+    *reinterpret_cast<float4*>(r) = make_float4(u[0], v[0], u[1], v[1]);
+    *reinterpret_cast<float4*>(r + 4) = make_float4(u[2], v[2], u[3], v[3]);
   }
 }
-__device__ __forceinline__ void quad_sums_wave(const float (&sa)[4], const float (&sb)[4], float* red, int wv, int lane, int nt, int c0) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float u = cfun_wave_sum(sa[j]), v = cfun_wave_sum(sb[j]);
-    if (lane == 0) {
-      float* r = red + (wv * nt + c0 + j) * 2;
-      r[0] = u; r[1] = v;
-    }
-  }
-}
-template <int NT>
-__device__ __forceinline__ void tile_sums_write(const float* red, int tid, int cobase, int n, int tile, const CfunConv3dParams& p,
-                                                const ConvMode& md) {
+// one round: tile-local channels [c0, c0 + nch) are parked; sum them and write the slot.  All 256 threads call it.
+__device__ __forceinline__ void stat_round_flush(const float* red, int es, int tid, int c0, int nch, int cobase, int n, int tile,
+                                                 const CfunConv3dParams& p, const ConvMode& md) {
   __syncthreads();
-  if (tid < 2 * NT) {
-    const int c = tid >> 1, qn = tid & 1, co = cobase + c;
+  if (tid < 2 * nch) {
+    const int cl = tid >> 1, qn = tid & 1, co = cobase + c0 + cl;
     if (co < p.Co) {
       double sum = 0.0;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) sum += (double)red[(w * NT + c) * 2 + qn];
+#pragma unroll 8
+      for (int e = 0; e < 64; ++e) sum += (double)red[e * es + cl * 2 + qn];
       int slot = tile, ch = co, cy = p.Co;
       if (p.d2s) {
         const int CqP = p.Co >> 3;
@@ -130,6 +131,7 @@ __device__ __forceinline__ void tile_sums_write(const float* red, int tid, int c
       if (ch < cy) md.out_part[(((int64_t)n * md.out_slots + slot) * 2 + qn) * cy + ch] = sum;
     }
   }
+  __syncthreads();
 }
 
 // taps of a parity-folded "nearest x2 -> 3x3x3" kernel that are non-zero for output parity q = (pz,py,px):
@@ -374,13 +376,20 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
       *reinterpret_cast<float4*>(y + v * p.Co + co) = r;
     }
   };
+  // statistics rounds: subtiles [g*GRP, (g+1)*GRP) of 16 channels, then the remainder quads in a round of their own
+  constexpr int GRP = STAT_ROUND / 16, ES = stat_es(NT < STAT_ROUND ? NT : STAT_ROUND);
+  const int tile = (int)(lid - (unsigned)n * per_n);
   if constexpr (NSUB > 0) {
 #pragma unroll
     for (int nn = 0; nn < NSUB; ++nn) {
       float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int m = 0; m < 4; ++m) emit(y0 + m, cobase + nn * 16 + (lane >> 4) * 4, acc[m][nn], sa, sb);
-      if (stats_on) quad_sums_16(sa, sb, smem, wv, lane, NT, nn * 16);
+      if constexpr (stats_on) {
+        quad_park_16(sa, sb, smem, ES, wv, lane, (nn % GRP) * 16);
+        if ((nn + 1) % GRP == 0 || nn + 1 == NSUB)
+          stat_round_flush(smem, ES, tid, (nn / GRP) * GRP * 16, (nn % GRP + 1) * 16, cobase, n, tile, p, md);
+      }
     }
   }
   if constexpr (REM > 0) {
@@ -388,10 +397,10 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
     for (int q = 0; q < REM; ++q) {
       float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
       emit(y0 + (lane >> 4), cobase + 16 * NSUB + 4 * q, accr[q], sa, sb);
-      if (stats_on) quad_sums_wave(sa, sb, smem, wv, lane, NT, 16 * NSUB + 4 * q);
+      if constexpr (stats_on) quad_park_wave(sa, sb, smem, ES, wv, lane, 4 * q);
     }
+    if constexpr (stats_on) stat_round_flush(smem, ES, tid, 16 * NSUB, 4 * REM, cobase, n, tile, p, md);
   }
-  if (stats_on) tile_sums_write<NT>(smem, tid, cobase, n, (int)(lid - (unsigned)n * per_n), p, md);
 }
 
 // how many ways to split the channel chunks so that a small volume still fills the chip (0 workspace => 1)
@@ -431,15 +440,17 @@ int launch_conv_mfma(const float* x, const float* wp, const float* scale, const 
   if constexpr (kHasSpecial) {
     if (special) kern = stats ? k_conv_mfma<KD, KH, KW, S, NSUB, true, REM, true> : k_conv_mfma<KD, KH, KW, S, NSUB, true, REM, false>;
   }
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  size_t lds_k = lds;
+  if (stats && lds_k < stat_lds_floats(NT) * sizeof(float)) lds_k = stat_lds_floats(NT) * sizeof(float);
+  if (lds_k > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);
     if (e != hipSuccess) return (int)e;
   }
   const int cps = cdiv(nchunks, ksplit);
   ConvMode mk = md;                // epilogue statistics: by this kernel's tiles, or by the split-K finish
   mk.out_slots = ntz * nty * ntx * (p.d2s ? 8 : 1);
   if (ksplit > 1) mk.out_part = nullptr;
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)ksplit), dim3(256), lds, st, x, wp, scale, shift, res, y, p, mk,
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)ksplit), dim3(256), lds_k, st, x, wp, scale, shift, res, y, p, mk,
                      ntz, nty, ntx, ncot, (float*)ws, cps);
   CFUN_LAUNCH_CHECK();
   if (ksplit > 1) return cfun_splitk_finish((const float*)ws, ksplit, scale, shift, res, y, &p, md.out_part, st);

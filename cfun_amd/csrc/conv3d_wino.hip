@@ -390,6 +390,13 @@ k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const flo
       *reinterpret_cast<float4*>(y + v * p.Co + co) = r;
     }
   };
+  constexpr int GRP = cfun_mfma::STAT_ROUND / 16, ES = cfun_mfma::stat_es(NT < cfun_mfma::STAT_ROUND ? NT : cfun_mfma::STAT_ROUND);
+  const int tile = (int)(lid - (unsigned)n * per_n);
+  auto park = [&](int nn, const float (&sa)[4], const float (&sb)[4]) {      // statistics rounds of GRP subtiles
+    cfun_mfma::quad_park_16(sa, sb, red, ES, wv, lane, (nn % GRP) * 16);
+    if ((nn + 1) % GRP == 0 || nn + 1 == NSUB)
+      cfun_mfma::stat_round_flush(red, ES, tid, (nn / GRP) * GRP * 16, (nn % GRP + 1) * 16, cobase, n, tile, p, md);
+  };
   if constexpr (TWOD) {     // Y = A^T M A: lane owns the 2 x 2 outputs of tile (ty = (lane>>3)&1, j = lane&7)
     const int oy = y0 + 2 * ((lane >> 3) & 1);
 #pragma unroll
@@ -406,7 +413,7 @@ k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const flo
       emit(oy, oxe + 1, co, (o[0] + o[1]) + o[2], sa, sb);
       emit(oy + 1, oxe, co, (e[1] - e[2]) - e[3], sa, sb);
       emit(oy + 1, oxe + 1, co, (o[1] - o[2]) - o[3], sa, sb);
-      if (stats_on) cfun_mfma::quad_sums_16(sa, sb, red, wv, lane, NT, nn * 16);
+      if constexpr (stats_on) park(nn, sa, sb);
     }
   } else {
 #pragma unroll
@@ -419,10 +426,9 @@ k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const flo
         emit(oy, oxe, co, (m0 + m1) + m2, sa, sb);
         emit(oy, oxe + 1, co, (m1 - m2) - m3, sa, sb);
       }
-      if (stats_on) cfun_mfma::quad_sums_16(sa, sb, red, wv, lane, NT, nn * 16);
+      if constexpr (stats_on) park(nn, sa, sb);
     }
   }
-  if (stats_on) cfun_mfma::tile_sums_write<NT>(red, tid, cobase, n, (int)(lid - (unsigned)n * per_n), p, md);
 }
 
 // 16-channel subtiles per block: fewest padded channels, widest on ties, at most 3 (two waves per SIMD: 134 VGPR + 96

@@ -181,7 +181,7 @@ def check_conv(device, n, dhw, ci, co, k, stride=1, pad=None, up2=False, act=ACT
                           None if sfw is None else sfw.detach(), None if rsw is None else rsw.detach(), stats=slot)
     assert torch.equal(ys, y), "conv3d_w(stats=...): y differs from the plain call"
     st = slot.get(n, y.shape[-1])
-    if algo != ALGO_DIRECT and ci % 4 == 0 and co % 4 == 0 and ci > 1:
+    if algo in (ALGO_MFMA, ALGO_WINO, ALGO_WINO2) and ci % 4 == 0 and co % 4 == 0:
         assert st is not None, "the MFMA / Winograd kernels must deliver epilogue statistics"
     if st is not None:
         y64 = yr.detach().double().reshape(n, -1, yr.shape[-1])
