@@ -26,7 +26,7 @@ int cfun_wino_fwd(const float*, const float*, int, int, const float*, const floa
                   const CfunConv3dParams*, void*, size_t, const cfun_mfma::ConvMode*, hipStream_t);
 int cfun_wino_stat_slots(const CfunConv3dParams*, size_t);
 // elementwise.hip: (mean, rstd) per (n, channel) from per-slot fp64 sums [N][slots][2][C]
-int cfun_stats_finalize(const double* part, float* stats, int N, int slots, int C, int64_t V, float eps, hipStream_t st);
+int cfun_stats_finalize(const double* part, float* stats, int N, int slots, int C, int64_t V, float eps, int slot_minor, hipStream_t st);
 int cfun_wino_wgrad_supported(const CfunConv3dParams*);
 size_t cfun_wino_wgrad_workspace_bytes(const CfunConv3dParams*);
 int cfun_wino_wgrad(const float*, const float*, float*, const CfunConv3dParams*, int*, hipStream_t);
@@ -268,6 +268,7 @@ k_splitk_finish_stats(const float4* __restrict__ partial, int ksplit, const floa
     float4 s4 = make_float4(1.f, 1.f, 1.f, 1.f), t4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.scale_mode) s4 = *reinterpret_cast<const float4*>(scale + (p.scale_mode == 2 ? n * p.Co : 0) + co);
     if (p.has_shift) t4 = *reinterpret_cast<const float4*>(shift + co);
+#pragma unroll 4
     for (int64_t vv = (int64_t)blockIdx.x * lanes + vl; vv < V; vv += (int64_t)gridDim.x * lanes) {
       const int64_t v = (int64_t)n * V + vv, i = v * C4 + cg;
       float4 a = partial[i];
@@ -323,8 +324,9 @@ int splitk_stats_blocks(const CfunConv3dParams* p, int* lanes_out) {
   if ((p->Co & 3) || C4 > 256 || C4 < 1) return 0;
   const int lanes = 256 / C4;
   const int64_t V = (int64_t)p->Do * p->Ho * p->Wo;
-  int64_t want = (1024 + p->N - 1) / (p->N > 0 ? p->N : 1);
-  int64_t maxb = (V + (int64_t)lanes * 16 - 1) / ((int64_t)lanes * 16);
+  int64_t want = (4096 + p->N - 1) / (p->N > 0 ? p->N : 1);
+  // (4 voxels per thread: these are the small, latency-bound volumes -- every load of a thread waits for the previous one)
+  int64_t maxb = (V + (int64_t)lanes * 4 - 1) / ((int64_t)lanes * 4);
   if (maxb < 1) maxb = 1;
   if (lanes_out) *lanes_out = lanes;
   return (int)(want < maxb ? want : maxb);
@@ -409,7 +411,7 @@ int cfun_conv3d_fwd_kernel(const CfunConv3dParams* p) {
 // fz: the fusion hooks (null / kPlain: none); main_bytes of ws are the plain call's workspace
 static int conv_fwd_impl(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
                          float* y, const CfunConv3dParams* p, const ConvMode* fz, void* ws, size_t ws_bytes,
-                         int* stat_slots, cfun_stream_t stream) {
+                         int* stat_slots, cfun_stream_t stream) {      // *stat_slots < 0: -(slots), k_channel_finalize's layout
   if (!valid_params(p)) return CFUN_EINVAL;
   if ((p->scale_mode && !scale) || (p->has_shift && !shift) || (p->res_mode && !res)) return CFUN_EINVAL;
   if (p->scale_mode < 0 || p->scale_mode > 2 || p->res_mode < 0 || p->res_mode > 1) return CFUN_EINVAL;
@@ -427,7 +429,7 @@ static int conv_fwd_impl(const float* x, const float* wp, const float* scale, co
     if (fused) { md.in_stats = fz->in_stats; md.in_act = fz->in_act; md.in_slope = fz->in_slope; md.out_part = fz->out_part; }
     if (ws && !cfun_aligned16(ws)) return CFUN_EALIGN;
     if (ws && cfun_wino_supported(p) && ws_bytes >= cfun_wino_workspace_bytes(p)) {   // x axis in the Winograd F(2,3) domain
-      if (stat_slots) *stat_slots = cfun_wino_stat_slots(p, ws_bytes);
+      if (stat_slots) *stat_slots = cfun_wino_stat_slots(p, ws_bytes);      // (negative: by the split-K finish)
       return cfun_wino_fwd(x, wp, 0, 0, scale, shift, res, y, p, ws, ws_bytes, &md, cfun_st(stream));
     }
     if (stat_slots) *stat_slots = cfun_mfma::fwd_stat_slots(nsub, *p, md, ws ? ws_bytes : 0);
@@ -482,10 +484,10 @@ int cfun_conv3d_fwd_fused(const float* x, const float* wp, const float* scale, c
   int slots = 0;
   const int rc = conv_fwd_impl(x, wp, scale, shift, res, y, p, &fz, ws, f->out_stats ? main_bytes : ws_bytes, &slots, stream);
   if (rc || !f->out_stats) return rc;
-  if (slots <= 0) return CFUN_EINVAL;
+  if (slots == 0) return CFUN_EINVAL;
   const int cy = p->d2s ? (p->d2s_cq > 0 ? p->d2s_cq : (p->Co >> 3)) : p->Co;
-  return cfun_stats_finalize(fz.out_part, f->out_stats, p->N, slots, cy, (int64_t)p->Do * p->Ho * p->Wo * (p->d2s ? 8 : 1),
-                             f->out_eps, cfun_st(stream));
+  return cfun_stats_finalize(fz.out_part, f->out_stats, p->N, slots < 0 ? -slots : slots, cy,
+                             (int64_t)p->Do * p->Ho * p->Wo * (p->d2s ? 8 : 1), f->out_eps, slots > 0, cfun_st(stream));
 }
 
 size_t cfun_conv3d_bwd_data_workspace_bytes(const CfunConv3dParams* p) {

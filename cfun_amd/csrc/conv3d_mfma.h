@@ -76,8 +76,8 @@ struct ConvMode {
   const float* in_stats;  // [N][Ci][2] {mean, rstd} or null: the staged input is in_act((x - mean) * rstd)
   int in_act;             // CFUN_ACT_* applied to the (normalised) input at commit time; zero padding stays zero
   float in_slope;
-  double* out_part;       // null, or per-(sample, slot) sums of y and y*y per channel: [N][slots][2][Cy] (k_channel_finalize's
-  int out_slots;          // layout); slots = tiles per sample (x 8 parities for depth-to-space outputs)
+  double* out_part;       // null, or per-(sample, slot) sums of y and y*y per channel, slot-minor: [N][2][Cy][slots] (the
+  int out_slots;          // finalize reads a channel's slots contiguously); slots = tiles per sample (x 8 parities for d2s)
 };
 
 // Per-tile, per-channel sums of the tile's final outputs (InstanceNorm statistics from the producer's epilogue), as
@@ -128,7 +128,7 @@ __device__ __forceinline__ void stat_round_flush(const float* red, int es, int t
         ch = co - q * CqP;
         slot = tile * 8 + q;
       }
-      if (ch < cy) md.out_part[(((int64_t)n * md.out_slots + slot) * 2 + qn) * cy + ch] = sum;
+      if (ch < cy) md.out_part[(((int64_t)n * 2 + qn) * cy + ch) * md.out_slots + slot] = sum;
     }
   }
   __syncthreads();
@@ -376,8 +376,8 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
       *reinterpret_cast<float4*>(y + v * p.Co + co) = r;
     }
   };
-  // statistics rounds: subtiles [g*GRP, (g+1)*GRP) of 16 channels, then the remainder quads in a round of their own
-  constexpr int GRP = STAT_ROUND / 16, ES = stat_es(NT < STAT_ROUND ? NT : STAT_ROUND);
+  // statistics rounds: the tile's channels (16-wide subtiles, then the remainder quads) in windows of STAT_ROUND
+  constexpr int ES = stat_es(NT < STAT_ROUND ? NT : STAT_ROUND);
   const int tile = (int)(lid - (unsigned)n * per_n);
   if constexpr (NSUB > 0) {
 #pragma unroll
@@ -386,20 +386,23 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
 #pragma unroll
       for (int m = 0; m < 4; ++m) emit(y0 + m, cobase + nn * 16 + (lane >> 4) * 4, acc[m][nn], sa, sb);
       if constexpr (stats_on) {
-        quad_park_16(sa, sb, smem, ES, wv, lane, (nn % GRP) * 16);
-        if ((nn + 1) % GRP == 0 || nn + 1 == NSUB)
-          stat_round_flush(smem, ES, tid, (nn / GRP) * GRP * 16, (nn % GRP + 1) * 16, cobase, n, tile, p, md);
+        const int base = (nn * 16 / STAT_ROUND) * STAT_ROUND;
+        quad_park_16(sa, sb, smem, ES, wv, lane, nn * 16 - base);
+        const int end = (nn + 1) * 16;                    // window complete, or the tile's last channel parked
+        if (end % STAT_ROUND == 0 || end == NT) stat_round_flush(smem, ES, tid, base, end - base, cobase, n, tile, p, md);
       }
     }
   }
   if constexpr (REM > 0) {
+    constexpr int RBASE = (16 * NSUB / STAT_ROUND) * STAT_ROUND;      // the window the remainder quads fall into
+    static_assert(16 * NSUB + 4 * REM - RBASE <= STAT_ROUND, "remainder quads must fit the last window");
 #pragma unroll
     for (int q = 0; q < REM; ++q) {
       float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
       emit(y0 + (lane >> 4), cobase + 16 * NSUB + 4 * q, accr[q], sa, sb);
-      if constexpr (stats_on) quad_park_wave(sa, sb, smem, ES, wv, lane, 4 * q);
+      if constexpr (stats_on) quad_park_wave(sa, sb, smem, ES, wv, lane, 16 * NSUB + 4 * q - RBASE);
     }
-    if constexpr (stats_on) stat_round_flush(smem, ES, tid, 16 * NSUB, 4 * REM, cobase, n, tile, p, md);
+    if constexpr (stats_on) stat_round_flush(smem, ES, tid, RBASE, NT - RBASE, cobase, n, tile, p, md);
   }
 }
 
@@ -457,13 +460,14 @@ int launch_conv_mfma(const float* x, const float* wp, const float* scale, const 
   return CFUN_OK;
 }
 
-// statistics slots per sample that launch_conv_mfma fills for (p, tile code nsub) given ws_bytes of split-K workspace
+// statistics slots per sample that launch_conv_mfma fills for (p, tile code nsub) given ws_bytes of split-K workspace:
+// > 0 by the conv's tiles (slot-minor layout), < 0 by the split-K finish (-(blocks), k_channel_finalize's layout)
 inline int fwd_stat_slots(int nsub, const CfunConv3dParams& p, const ConvMode& md, size_t ws_bytes) {
   const int nt = 16 * (nsub & 7) + 4 * (nsub >> 3);
   const int tiles = cdiv(p.Do, 4) * cdiv(p.Ho, 4) * cdiv(p.Wo, 16);
   const int64_t nblk = (int64_t)p.N * tiles * cdiv(p.Co, nt);
   const int nchunks = md.in_s2d ? 8 * (md.in_cq >> 2) : (p.Ci >> 2);
-  return splitk_factor(nblk, nchunks, p, ws_bytes) > 1 ? cfun_splitk_stat_slots(&p) : tiles * (p.d2s ? 8 : 1);
+  return splitk_factor(nblk, nchunks, p, ws_bytes) > 1 ? -cfun_splitk_stat_slots(&p) : tiles * (p.d2s ? 8 : 1);
 }
 
 template <int KD, int KH, int KW, int S>

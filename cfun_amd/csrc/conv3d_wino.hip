@@ -390,12 +390,12 @@ k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const flo
       *reinterpret_cast<float4*>(y + v * p.Co + co) = r;
     }
   };
-  constexpr int GRP = cfun_mfma::STAT_ROUND / 16, ES = cfun_mfma::stat_es(NT < cfun_mfma::STAT_ROUND ? NT : cfun_mfma::STAT_ROUND);
+  constexpr int SR = cfun_mfma::STAT_ROUND, ES = cfun_mfma::stat_es(NT < SR ? NT : SR);
   const int tile = (int)(lid - (unsigned)n * per_n);
-  auto park = [&](int nn, const float (&sa)[4], const float (&sb)[4]) {      // statistics rounds of GRP subtiles
-    cfun_mfma::quad_park_16(sa, sb, red, ES, wv, lane, (nn % GRP) * 16);
-    if ((nn + 1) % GRP == 0 || nn + 1 == NSUB)
-      cfun_mfma::stat_round_flush(red, ES, tid, (nn / GRP) * GRP * 16, (nn % GRP + 1) * 16, cobase, n, tile, p, md);
+  auto park = [&](int nn, const float (&sa)[4], const float (&sb)[4]) {      // statistics rounds: windows of SR channels
+    const int base = (nn * 16 / SR) * SR, end = (nn + 1) * 16;
+    cfun_mfma::quad_park_16(sa, sb, red, ES, wv, lane, nn * 16 - base);
+    if (end % SR == 0 || end == NT) cfun_mfma::stat_round_flush(red, ES, tid, base, end - base, cobase, n, tile, p, md);
   };
   if constexpr (TWOD) {     // Y = A^T M A: lane owns the 2 x 2 outputs of tile (ty = (lane>>3)&1, j = lane&7)
     const int oy = y0 + 2 * ((lane >> 3) & 1);
@@ -568,7 +568,7 @@ int cfun_wino_stat_slots(const CfunConv3dParams* p, size_t ws_bytes) {
   Plan w = make_plan(*p, 0);
   if (ws_bytes < w.u_bytes) return 0;
   w = make_plan(*p, ws_bytes - w.u_bytes);
-  return w.ksplit > 1 ? cfun_splitk_stat_slots(p) : w.ntz * w.nty * w.ntx * (p->d2s ? 8 : 1);
+  return w.ksplit > 1 ? -cfun_splitk_stat_slots(p) : w.ntz * w.nty * w.ntx * (p->d2s ? 8 : 1);
 }
 
 int cfun_wino_fwd(const float* x, const float* wp, int flip, int s2d_cq, const float* scale, const float* shift,

@@ -240,6 +240,30 @@ k_channel_finalize(const double* __restrict__ partial, float* __restrict__ out, 
   }
 }
 
+// block i = (n, c): rows part[n][q][c][0..slots) for q = 0, 1; fixed summation order (thread-strided, then a tree)
+__global__ void __launch_bounds__(kBlock)
+k_stats_finalize_rows(const double* __restrict__ part, float* __restrict__ stats, int C, int slots, int64_t V, float eps) {
+  __shared__ double sm[2][kBlock / 64];
+  const int i = blockIdx.x, n = i / C, c = i - n * C, tid = threadIdx.x;
+  const double* r0 = part + (((int64_t)n * 2 + 0) * C + c) * slots;
+  const double* r1 = part + (((int64_t)n * 2 + 1) * C + c) * slots;
+  double s0 = 0.0, s1 = 0.0;
+  for (int b = tid; b < slots; b += kBlock) { s0 += r0[b]; s1 += r1[b]; }
+  s0 = cfun_wave_sum_d(s0);
+  s1 = cfun_wave_sum_d(s1);
+  if ((tid & 63) == 0) { sm[0][tid >> 6] = s0; sm[1][tid >> 6] = s1; }
+  __syncthreads();
+  if (tid == 0) {
+    double a = 0.0, b = 0.0;
+    for (int w = 0; w < kBlock / 64; ++w) { a += sm[0][w]; b += sm[1][w]; }
+    const double mean = a / (double)V;
+    double var = b / (double)V - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[(int64_t)i * 2] = (float)mean;
+    stats[(int64_t)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
 struct ReducePlan {
   int lanes, blocks;
 };
@@ -529,12 +553,18 @@ k_sgd_momentum_step(float* __restrict__ p, const float* __restrict__ g, float* _
 }  // namespace
 
 // ====================================================================== C ABI
-// (mean, rstd) per (n, channel) from per-slot fp64 sums of x and x*x, part[n][slot][2][C] (conv epilogues, conv3d.hip)
-int cfun_stats_finalize(const double* part, float* stats, int N, int slots, int C, int64_t V, float eps, hipStream_t st) {
+// (mean, rstd) per (n, channel) from per-slot fp64 sums of x and x*x (conv epilogues, conv3d.hip).  slot_minor = 0:
+// part[n][slot][2][C] (k_channel_finalize's layout: few slots); slot_minor = 1: part[n][2][C][slots] -- the tile kernels'
+// thousands of slots, one 256-thread block per (n, channel) reads its two rows contiguously
+int cfun_stats_finalize(const double* part, float* stats, int N, int slots, int C, int64_t V, float eps, int slot_minor,
+                        hipStream_t st) {
   const int NC = N * C;
   if (NC <= 0) return CFUN_OK;
-  hipLaunchKernelGGL(k_channel_finalize, dim3((unsigned)((NC * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, part, stats, NC, C,
-                     slots, 2, V, eps, 0);
+  if (slot_minor)
+    hipLaunchKernelGGL(k_stats_finalize_rows, dim3((unsigned)NC), dim3(kBlock), 0, st, part, stats, C, slots, V, eps);
+  else
+    hipLaunchKernelGGL(k_channel_finalize, dim3((unsigned)((NC * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, part, stats, NC,
+                       C, slots, 2, V, eps, 0);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }

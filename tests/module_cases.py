@@ -377,7 +377,7 @@ GRAD_FP64_FACTOR = 3.0
 GRAD_FP64_FLOOR = 2e-5
 
 
-def flip_fit(taps64, taps32, params64, got, ref32, max_basis=96, max_params=3_000_000):
+def flip_fit(taps64, taps32, params64, got, ref32, max_basis=None, max_params=3_000_000):
     """LeakyReLU is not differentiable at 0: a pre-activation that sits within fp32 rounding of 0 can land on either
     side in two correct fp32 evaluations (torch's, ours) and in fp64, and the one voxel's slope (1 vs 0.01) moves every
     gradient upstream of it by up to ~1e-2 in the small test configurations.  This separates that effect from real
@@ -387,6 +387,9 @@ def flip_fit(taps64, taps32, params64, got, ref32, max_basis=96, max_params=3_00
     partial backward each).  ``got`` - fp64 and ``ref32`` - fp64 (dicts name -> array over ``params64``'s keys) are
     least-squares fitted on that basis; returned are the residual dicts (what no combination of kink flips explains)
     and the number of basis voxels.  None when the configuration is too large for the dense fit."""
+    import os
+    if max_basis is None:
+        max_basis = int(os.environ.get("CFUN_TEST_FLIP_BASIS", "96"))
     names = list(params64)
     plist = [params64[k] for k in names]
     if sum(p.numel() for p in plist) > max_params:
