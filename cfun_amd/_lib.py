@@ -52,6 +52,7 @@ _SIGNATURES = {
     "cfun_conv3d_fused_support": (C.c_int, [_PP]),
     "cfun_conv3d_fwd_fused_workspace_bytes": (_Z, [_PP, _PF]),
     "cfun_conv3d_fwd_fused": (C.c_int, [_P, _P, _P, _P, _P, _P, _PP, _PF, _P, _Z, _P]),
+    "cfun_conv3d_bwd_weight_fused": (C.c_int, [_P, _P, _P, _I, _PP, _PF, _P, _Z, _P]),
     "cfun_conv3d_bwd_data_workspace_bytes": (_Z, [_PP]),
     "cfun_conv3d_bwd_data": (C.c_int, [_P, _P, _P, _PP, _P, _Z, _P]),
     "cfun_conv3d_bwd_weight_workspace_bytes": (_Z, [_PP]),

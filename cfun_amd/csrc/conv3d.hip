@@ -16,8 +16,9 @@ int cfun_wgrad_zero(CfunWgradDst, const CfunConv3dParams*, hipStream_t);
 int cfun_conv_stem_supported(const CfunConv3dParams*);
 int cfun_conv_stem_fwd(const float*, const float*, const float*, const float*, float*, const CfunConv3dParams*, hipStream_t);
 int cfun_conv_pointwise_supported(const CfunConv3dParams*);
+int cfun_conv_pointwise_in_supported(const CfunConv3dParams*);
 int cfun_conv_pointwise_fwd(const float*, const float*, const float*, const float*, const float*, float*,
-                            const CfunConv3dParams*, hipStream_t);
+                            const CfunConv3dParams*, const float*, int, float, hipStream_t);
 // conv3d_wino.hip
 int cfun_wino_supported(const CfunConv3dParams*);
 size_t cfun_wino_workspace_bytes(const CfunConv3dParams*);
@@ -416,8 +417,11 @@ static int conv_fwd_impl(const float* x, const float* wp, const float* scale, co
   if ((p->scale_mode && !scale) || (p->has_shift && !shift) || (p->res_mode && !res)) return CFUN_EINVAL;
   if (p->scale_mode < 0 || p->scale_mode > 2 || p->res_mode < 0 || p->res_mode > 1) return CFUN_EINVAL;
   const bool fused = fz && (fz->in_stats || fz->in_act || fz->out_part);
-  if (!fused && p->algo == CFUN_ALGO_AUTO && cfun_conv_pointwise_supported(p) && cfun_aligned16(x) && cfun_aligned16(y))
-    return cfun_conv_pointwise_fwd(x, wp, scale, shift, res, y, p, cfun_st(stream));   // 1x1x1 -> 8: streaming
+  if (p->algo == CFUN_ALGO_AUTO && cfun_conv_pointwise_supported(p) && cfun_aligned16(x) && cfun_aligned16(y)) {
+    if (fused && (fz->out_part || !cfun_conv_pointwise_in_supported(p))) return CFUN_EINVAL;
+    return cfun_conv_pointwise_fwd(x, wp, scale, shift, res, y, p, fused ? fz->in_stats : nullptr, fused ? fz->in_act : 0,
+                                   fused ? fz->in_slope : 0.f, cfun_st(stream));   // 1x1x1 -> 8: streaming
+  }
   const Shape* s = p->algo == CFUN_ALGO_DIRECT ? nullptr : mfma_shape(p);
   if (s) {
     if (!cfun_aligned16(x) || !cfun_aligned16(wp) || !cfun_aligned16(y) || (scale && !cfun_aligned16(scale)) ||
@@ -429,6 +433,7 @@ static int conv_fwd_impl(const float* x, const float* wp, const float* scale, co
     if (fused) { md.in_stats = fz->in_stats; md.in_act = fz->in_act; md.in_slope = fz->in_slope; md.out_part = fz->out_part; }
     if (ws && !cfun_aligned16(ws)) return CFUN_EALIGN;
     if (ws && cfun_wino_supported(p) && ws_bytes >= cfun_wino_workspace_bytes(p)) {   // x axis in the Winograd F(2,3) domain
+      if (md.in_stats || md.in_act) return CFUN_EINVAL;       // (no input prologue in k_conv_wino: cfun_conv3d_fused_support)
       if (stat_slots) *stat_slots = cfun_wino_stat_slots(p, ws_bytes);      // (negative: by the split-K finish)
       return cfun_wino_fwd(x, wp, 0, 0, scale, shift, res, y, p, ws, ws_bytes, &md, cfun_st(stream));
     }
@@ -447,10 +452,16 @@ int cfun_conv3d_fwd(const float* x, const float* wp, const float* scale, const f
   return conv_fwd_impl(x, wp, scale, shift, res, y, p, nullptr, ws, ws_bytes, nullptr, stream);
 }
 
+// the weight gradient of p runs on k_wgrad_mfma / k_wgrad_fused (which carry the input prologue)?
+static bool wgrad_takes_prologue(const CfunConv3dParams* p);
+
 int cfun_conv3d_fused_support(const CfunConv3dParams* p) {
   if (!valid_params(p) || p->algo == CFUN_ALGO_DIRECT || !mfma_shape(p)) return 0;
-  if (p->algo == CFUN_ALGO_AUTO && cfun_conv_pointwise_supported(p)) return 0;    // the streaming 1x1x1 -> 8 kernel has no hooks
-  return CFUN_FUSE_OUT_STATS;
+  const int wg = wgrad_takes_prologue(p) ? CFUN_FUSE_IN_NORM_WGRAD : 0;
+  if (p->algo == CFUN_ALGO_AUTO && cfun_conv_pointwise_supported(p))      // the streaming 1x1x1 -> 8 kernel: prologue only
+    return cfun_conv_pointwise_in_supported(p) ? (CFUN_FUSE_IN_NORM | wg) : 0;
+  if (cfun_wino_supported(p)) return CFUN_FUSE_OUT_STATS;                 // k_conv_wino: epilogue statistics only
+  return CFUN_FUSE_OUT_STATS | CFUN_FUSE_IN_NORM | wg;
 }
 
 static size_t stat_part_bytes(const CfunConv3dParams* p) {
@@ -568,9 +579,16 @@ size_t cfun_conv3d_bwd_weight_workspace_bytes(const CfunConv3dParams* p) {
   return cfun_align_up(cfun_direct_wgrad_ws(p), 256);
 }
 
-static int bwd_weight_any(const float* x, const float* g, CfunWgradDst dst, const CfunConv3dParams* p, void* ws,
-                          size_t ws_bytes, cfun_stream_t stream) {
+static bool wgrad_takes_prologue(const CfunConv3dParams* p) {
+  if (p->algo == CFUN_ALGO_DIRECT || !wgrad_mfma_fits(p) || !mfma_shape(p)) return false;
+  return !cfun_wgrad_c1_supported(p) && !cfun_wino_wgrad_supported(p);
+}
+
+static int bwd_weight_any(const float* x, const float* g, CfunWgradDst dst, const CfunConv3dParams* p,
+                          const CfunConvFusion* f, void* ws, size_t ws_bytes, cfun_stream_t stream) {
   if (!valid_params(p)) return CFUN_EINVAL;
+  const bool pro = f && (f->in_stats || f->in_act);
+  if (pro && !wgrad_takes_prologue(p)) return CFUN_EINVAL;
   if (p->algo != CFUN_ALGO_DIRECT && cfun_wgrad_c1_supported(p) && (int64_t)p->N * p->Do * p->Ho * p->Wo > 0) {
     if (!cfun_aligned16(g) || !cfun_aligned16(ws)) return CFUN_EALIGN;
     return cfun_wgrad_c1(x, g, dst, p, ws, ws_bytes, cfun_st(stream));
@@ -588,6 +606,7 @@ static int bwd_weight_any(const float* x, const float* g, CfunWgradDst dst, cons
     }
     cfun_mfma::WgPlan w;
     s->plan(*p, wgrad_nsub(p, s), &w);
+    if (pro) { w.in_stats = f->in_stats; w.in_act = f->in_act; w.in_slope = f->in_slope; }
     if (w.ntiles == 0) return cfun_wgrad_zero(dst, p, cfun_st(stream));
     const int rc = s->wgrad(x, g, (float*)ws, *p, w, cfun_st(stream));
     if (rc) return rc;
@@ -599,12 +618,17 @@ static int bwd_weight_any(const float* x, const float* g, CfunWgradDst dst, cons
 
 int cfun_conv3d_bwd_weight(const float* x, const float* g, float* dwp, const CfunConv3dParams* p, void* ws,
                            size_t ws_bytes, cfun_stream_t stream) {
-  return bwd_weight_any(x, g, CfunWgradDst{dwp, 0}, p, ws, ws_bytes, stream);
+  return bwd_weight_any(x, g, CfunWgradDst{dwp, 0}, p, nullptr, ws, ws_bytes, stream);
 }
 
 int cfun_conv3d_bwd_weight_oidhw(const float* x, const float* g, float* dw, const CfunConv3dParams* p, void* ws,
                                  size_t ws_bytes, cfun_stream_t stream) {
-  return bwd_weight_any(x, g, CfunWgradDst{dw, 1}, p, ws, ws_bytes, stream);
+  return bwd_weight_any(x, g, CfunWgradDst{dw, 1}, p, nullptr, ws, ws_bytes, stream);
+}
+
+int cfun_conv3d_bwd_weight_fused(const float* x, const float* g, float* dw, int32_t oidhw, const CfunConv3dParams* p,
+                                 const CfunConvFusion* f, void* ws, size_t ws_bytes, cfun_stream_t stream) {
+  return bwd_weight_any(x, g, CfunWgradDst{dw, oidhw ? 1 : 0}, p, f, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

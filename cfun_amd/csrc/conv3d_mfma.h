@@ -19,6 +19,8 @@
 //     accumulated in registers over all tiles of the block, written as a partial; a second kernel sums the
 //     partials (deterministic, no atomics).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -79,6 +81,19 @@ struct ConvMode {
   double* out_part;       // null, or per-(sample, slot) sums of y and y*y per channel, slot-minor: [N][2][Cy][slots] (the
   int out_slots;          // finalize reads a channel's slots contiguously); slots = tiles per sample (x 8 parities for d2s)
 };
+
+// The input prologue (CfunConvFusion.in_stats / in_act): what the conv reads in place of a staged value v of a channel
+// with statistics (mean, rstd) -- the arithmetic of k_instnorm_lrelu_fwd / k_lrelu_fwd, so that the fused and the
+// materialised paths agree bit for bit.
+__device__ __forceinline__ float norm_act_in(float v, float mean, float rstd, int act, float slope) {
+  const float xh = (v - mean) * rstd;
+  return cfun_apply_act(xh, act, slope);
+}
+__device__ __forceinline__ float4 norm_act_in4(const float4& v, const float4& s01, const float4& s23, int act, float slope) {
+  // s01 = (mean0, rstd0, mean1, rstd1), s23 = (mean2, rstd2, mean3, rstd3): a row of stats[n][c..c+3][2]
+  return make_float4(norm_act_in(v.x, s01.x, s01.y, act, slope), norm_act_in(v.y, s01.z, s01.w, act, slope),
+                     norm_act_in(v.z, s23.x, s23.y, act, slope), norm_act_in(v.w, s23.z, s23.w, act, slope));
+}
 
 // Per-tile, per-channel sums of the tile's final outputs (InstanceNorm statistics from the producer's epilogue), as
 // accurate as the stand-alone fp64 pass: a lane sums ITS (at most 4) voxels per channel in fp32, parks the pair (sum,
@@ -228,9 +243,16 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
     return q * md.in_cqp + o4 * 4;
   };
   float4 xin[T::IN_LOADS], win[W_LOADS];
+  // input prologue: the chunk's 4 channels carry (mean, rstd) of sample n -- wave-uniform, fetched with the chunk
+  const bool in_fused = md.in_stats != nullptr || md.in_act != CFUN_ACT_NONE;
+  float4 ns01 = make_float4(0.f, 1.f, 0.f, 1.f), ns23 = make_float4(0.f, 1.f, 0.f, 1.f);
   auto prefetch = [&](int c) {
     const int64_t xo = chunk_xoff(c);
     const int wrow = chunk_wrow(c);
+    if (md.in_stats) {
+      const float4* sp = reinterpret_cast<const float4*>(md.in_stats + ((int64_t)n * p.Ci + c * 4) * 2);
+      ns01 = sp[0]; ns23 = sp[1];
+    }
 #pragma unroll
     for (int i = 0; i < T::IN_LOADS; ++i)
       xin[i] = in_off[i] >= 0 ? *reinterpret_cast<const float4*>(x + in_off[i] + xo) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -248,6 +270,11 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
     }
   };
   auto commit = [&]() {
+    if (in_fused) {       // (padded voxels were fetched as zeros and must stay zeros: the conv pads the NORMALISED tensor)
+#pragma unroll
+      for (int i = 0; i < T::IN_LOADS; ++i)
+        if (in_off[i] >= 0) xin[i] = norm_act_in4(xin[i], ns01, ns23, md.in_act, md.in_slope);
+    }
 #pragma unroll
     for (int i = 0; i < T::IN_LOADS; ++i) {
       const int idx = tid + i * 256;
@@ -513,6 +540,12 @@ int dispatch_nsub(int nsub, const float* x, const float* wp, const float* scale,
 }
 
 // ============================================================================================ weight gradient
+struct WgIn {          // input prologue of the weight-gradient kernels (kernel argument; see WgPlan)
+  const float* stats;
+  int act;
+  float slope;
+};
+
 template <int KD, int KH, int KW, int S>
 struct WgTile {
   static constexpr int TD = (S == 1) ? 2 : 1, TH = 4, TW = 16;   // stride 2: smaller tile, the halo tile is 4x larger
@@ -537,11 +570,14 @@ struct WgTile {
 // PACK > 1 (27-tap shapes whose C_in <= R = 16/PACK, i.e. <= 8): the 16 rows of the A fragment carry PACK taps x R
 // channels instead of 1 tap x 16 (mostly zero) channels -- row i reads tap group*PACK + i/R, channel i%R -- so the
 // block runs ceil(27/PACK) instead of 27 tap rows of MFMA work.
-template <int KD, int KH, int KW, int S, int NSUB, bool TSKIP, int PACK>
+// IN: the input prologue (WgIn) -- x is staged as in_act((x - mean) * rstd).  The (mean, rstd) rows of the committed
+// tile's sample sit in a small LDS table behind the tiles (refilled when the sample changes, by the prefetch that runs
+// between two commits), so the plain instantiation keeps its registers and the prologue costs two LDS reads per item.
+template <int KD, int KH, int KW, int S, int NSUB, bool TSKIP, int PACK, bool IN>
 __device__ __forceinline__ void
 wgrad_body(float* smem, const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ partial,
            const CfunConv3dParams& p, int ntz, int nty, int ntx, int cot, int cis, int chunk, int tiles_per_chunk,
-           int ntiles) {
+           int ntiles, const WgIn& fin) {
   using T = WgTile<KD, KH, KW, S>;
   constexpr int TAPS = T::TAPS, NT = 16 * NSUB, GS = pad_row16(NT);
   constexpr int NLIVE = TSKIP ? 8 : TAPS;                         // taps this block accumulates
@@ -551,6 +587,7 @@ wgrad_body(float* smem, const float* __restrict__ x, const float* __restrict__ g
   constexpr int G_LOADS = cdiv(G_ITEMS, 256);
   float* Xl = smem;                       // [IVOX][16]
   float* Gl = smem + T::IVOX * T::XS;     // [TVOX][GS]
+  float4* Sl = reinterpret_cast<float4*>(Gl + T::TVOX * GS);      // IN: [4 channel quads of the subtile][2] stats rows
 
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform
   const int ci0 = cis * 16;
@@ -578,6 +615,7 @@ wgrad_body(float* smem, const float* __restrict__ x, const float* __restrict__ g
   // commit time -- exec-masked loads made hipcc wrap each one in nested branches and wait (vmcnt(0)) mid-way.
   float4 xin[T::X_LOADS], gin[G_LOADS];
   unsigned xvalid = 0, gvalid = 0;
+  int n_table = -1;      // IN: the sample whose statistics the LDS table holds
   auto prefetch = [&](int tile) {
     int t = tile;
     const int tx = t % ntx; t /= ntx;
@@ -586,6 +624,16 @@ wgrad_body(float* smem, const float* __restrict__ x, const float* __restrict__ g
     const int n = t / ntz;
     const int z0 = tz * T::TD, y0 = ty * T::TH, x0 = tx * T::TW;
     xvalid = 0; gvalid = 0;
+    if constexpr (IN) {
+      if (n != n_table) {      // (wave-uniform; the previous commit is done with the table: we are past its barrier)
+        n_table = n;
+        if (tid < 8) {
+          const int cs = ci0 + (tid >> 1) * 4;
+          Sl[tid] = (fin.stats && cs < p.Ci) ? reinterpret_cast<const float4*>(fin.stats + ((int64_t)n * p.Ci + cs) * 2)[tid & 1]
+                                             : make_float4(0.f, 1.f, 0.f, 1.f);
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < T::X_LOADS; ++i) {
       const int it = tid + i * 256;
@@ -632,7 +680,8 @@ wgrad_body(float* smem, const float* __restrict__ x, const float* __restrict__ g
     for (int i = 0; i < T::X_LOADS; ++i) {
       const int it = tid + i * 256;
       if (it < T::IVOX * 4)
-        *reinterpret_cast<float4*>(Xl + (it >> 2) * T::XS + (it & 3) * 4) = keep((xvalid >> i) & 1u, xin[i]);
+        *reinterpret_cast<float4*>(Xl + (it >> 2) * T::XS + (it & 3) * 4) =
+            keep((xvalid >> i) & 1u, IN ? norm_act_in4(xin[i], Sl[(it & 3) * 2], Sl[(it & 3) * 2 + 1], fin.act, fin.slope) : xin[i]);
     }
 #pragma unroll
     for (int i = 0; i < G_LOADS; ++i) {
@@ -732,17 +781,17 @@ wgrad_body(float* smem, const float* __restrict__ x, const float* __restrict__ g
 // Packing the remainder subtile of C_in = 20 / 40 beside plain subtiles was measured and dropped: the dispatcher
 // deals workgroups round-robin over the CUs (tools/probe_dispatch.py), the light packed workgroups finish early
 // and the kernel time stays that of the plain ones; rebalancing by tile count lost to the per-tile staging cost.
-template <int KD, int KH, int KW, int S, int NSUB, bool TSKIP, int PACK>
+template <int KD, int KH, int KW, int S, int NSUB, bool TSKIP, int PACK, bool IN = false>
 __global__ void __launch_bounds__(256)
 k_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ partial,
-             CfunConv3dParams p, int ntz, int nty, int ntx, int ncisub, int ncot, int tiles_per_chunk, int ntiles) {
+             CfunConv3dParams p, int ntz, int nty, int ntx, int ncisub, int ncot, int tiles_per_chunk, int ntiles, WgIn fin) {
   CFUN_DYN_LDS(float, smem);
   unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
   const int cot = lid % ncot; lid /= ncot;
   const int cis = lid % ncisub;
   const int chunk = lid / ncisub;
-  wgrad_body<KD, KH, KW, S, NSUB, TSKIP, PACK>(smem, x, g, partial, p, ntz, nty, ntx, cot, cis, chunk,
-                                               tiles_per_chunk, ntiles);
+  wgrad_body<KD, KH, KW, S, NSUB, TSKIP, PACK, IN>(smem, x, g, partial, p, ntz, nty, ntx, cot, cis, chunk,
+                                                   tiles_per_chunk, ntiles, fin);
 }
 
 // ---- C_in = 16*NPL + R with R = 16/PACK <= 8 remainder channels and 27 taps (the level-1 U-Net convs: C_in = 20 ->
@@ -762,10 +811,10 @@ inline int wgrad_fused_mode(const CfunConv3dParams& p, int nsub) {
   return 0;
 }
 
-template <int KD, int KH, int KW, int S, int NSUB, int NPL, int PACK>
+template <int KD, int KH, int KW, int S, int NSUB, int NPL, int PACK, bool IN = false>
 __global__ void __launch_bounds__(256)
 k_wgrad_fused(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ partial, CfunConv3dParams p,
-              int ntz, int nty, int ntx, int ncot, int tiles_per_chunk, int ntiles) {
+              int ntz, int nty, int ntx, int ncot, int tiles_per_chunk, int ntiles, WgIn fin) {
   using T = WgTile<KD, KH, KW, S>;
   constexpr int TAPS = T::TAPS, NT = 16 * NSUB, GS = pad_row16(NT);
   constexpr int R = 16 / PACK, CH = 16 * NPL + R, C4 = CH / 4;
@@ -778,6 +827,7 @@ k_wgrad_fused(const float* __restrict__ x, const float* __restrict__ g, float* _
   CFUN_DYN_LDS(float, smem);
   float* Xl = smem;                      // [IVOX][XS]
   float* Gl = smem + T::IVOX * XS;       // [TVOX][GS]
+  float4* Sl = reinterpret_cast<float4*>(Gl + T::TVOX * GS);      // IN: [C4 channel quads][2] stats rows (see wgrad_body)
 
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -800,12 +850,23 @@ k_wgrad_fused(const float* __restrict__ x, const float* __restrict__ g, float* _
 
   float4 xin[X_LOADS], gin[G_LOADS];
   unsigned xvalid = 0, gvalid = 0;
+  int n_table = -1;      // IN: the sample whose statistics the LDS table holds
   auto prefetch = [&](int tile) {   // unconditional loads + validity bits, as in wgrad_body
     int t = tile;
     const int tx = t % ntx; t /= ntx;
     const int ty = t % nty; t /= nty;
     const int tz = t % ntz;
     const int n = t / ntz;
+    if constexpr (IN) {
+      if (n != n_table) {
+        n_table = n;
+        if (tid < 2 * C4) {
+          const int cs = (tid >> 1) * 4;
+          Sl[tid] = (fin.stats && cs < p.Ci) ? reinterpret_cast<const float4*>(fin.stats + ((int64_t)n * p.Ci + cs) * 2)[tid & 1]
+                                             : make_float4(0.f, 1.f, 0.f, 1.f);
+        }
+      }
+    }
     const int z0 = tz * T::TD, y0 = ty * T::TH, x0 = tx * T::TW;
     xvalid = 0; gvalid = 0;
 #pragma unroll
@@ -850,7 +911,8 @@ k_wgrad_fused(const float* __restrict__ x, const float* __restrict__ g, float* _
       const int it = tid + i * 256;
       if (it < X_ITEMS) {
         const int idx = it / C4, c = (it - idx * C4) * 4;
-        *reinterpret_cast<float4*>(Xl + idx * XS + c) = keep((xvalid >> i) & 1u, xin[i]);
+        *reinterpret_cast<float4*>(Xl + idx * XS + c) =
+            keep((xvalid >> i) & 1u, IN ? norm_act_in4(xin[i], Sl[(c >> 2) * 2], Sl[(c >> 2) * 2 + 1], fin.act, fin.slope) : xin[i]);
       }
     }
 #pragma unroll
@@ -943,7 +1005,12 @@ k_wgrad_fused(const float* __restrict__ x, const float* __restrict__ g, float* _
 
 struct WgPlan {
   int ntz, nty, ntx, ntiles, ncisub, ncot, nchunks, tiles_per_chunk, nsub, kslots;
+  // input prologue (CfunConvFusion): x is read as in_act((x - mean) * rstd); set by the caller after wgrad_plan
+  const float* in_stats;
+  int in_act;
+  float in_slope;
 };
+
 
 template <int KD, int KH, int KW, int S>
 WgPlan wgrad_plan(const CfunConv3dParams& p, int nsub) {
@@ -963,6 +1030,7 @@ WgPlan wgrad_plan(const CfunConv3dParams& p, int nsub) {
   w.nchunks = cdiv(w.ntiles, w.tiles_per_chunk);
   if (w.nchunks < 1) w.nchunks = 1;
   w.kslots = T::KSPLIT;
+  w.in_stats = nullptr; w.in_act = 0; w.in_slope = 0.f;
   return w;
 }
 
@@ -971,7 +1039,7 @@ int launch_wgrad_mfma(const float* x, const float* g, float* partial, const Cfun
                       hipStream_t st) {
   using T = WgTile<KD, KH, KW, S>;
   constexpr int NT = 16 * NSUB, GS = pad_row16(NT);
-  const size_t lds = (size_t)(T::IVOX * T::XS + T::TVOX * GS) * sizeof(float);
+  const size_t lds = (size_t)(T::IVOX * T::XS + T::TVOX * GS) * sizeof(float) + 8 * sizeof(float4);      // (+ stats table)
   // the kernel addresses x and g with 32-bit element offsets
   const int64_t lim = (int64_t)1 << 31;
   if ((int64_t)p.N * p.Di * p.Hi * p.Wi * p.Ci >= lim || (int64_t)p.N * p.Do * p.Ho * p.Wo * p.Co >= lim) return CFUN_EINVAL;
@@ -979,42 +1047,49 @@ int launch_wgrad_mfma(const float* x, const float* g, float* partial, const Cfun
     const int mode = wgrad_fused_mode(p, NSUB);
     if (mode) {
       const int xs = (mode & 15) == 1 ? 24 : 40;
-      const size_t ldsf = (size_t)(T::IVOX * xs + T::TVOX * GS) * sizeof(float);
-      void (*kf)(const float*, const float*, float*, CfunConv3dParams, int, int, int, int, int, int) =
-          k_wgrad_fused<KD, KH, KW, S, NSUB, 1, 4>;
+      const size_t ldsf = (size_t)(T::IVOX * xs + T::TVOX * GS) * sizeof(float) + 2 * (xs / 4) * sizeof(float4);   // (+ stats table)
+      const bool in = w.in_stats != nullptr || w.in_act != CFUN_ACT_NONE;
+      void (*kf)(const float*, const float*, float*, CfunConv3dParams, int, int, int, int, int, int, WgIn) =
+          in ? k_wgrad_fused<KD, KH, KW, S, NSUB, 1, 4, true> : k_wgrad_fused<KD, KH, KW, S, NSUB, 1, 4, false>;
       if constexpr (S == 1) {
-        if ((mode & 15) == 2) kf = k_wgrad_fused<KD, KH, KW, S, NSUB, 2, 2>;
+        if ((mode & 15) == 2) kf = in ? k_wgrad_fused<KD, KH, KW, S, NSUB, 2, 2, true> : k_wgrad_fused<KD, KH, KW, S, NSUB, 2, 2, false>;
       }
       if (ldsf > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
         if (e != hipSuccess) return (int)e;
       }
       hipLaunchKernelGGL(kf, dim3((unsigned)(w.nchunks * w.ncot)), dim3(256), ldsf, st, x, g, partial, p, w.ntz, w.nty,
-                         w.ntx, w.ncot, w.tiles_per_chunk, w.ntiles);
+                         w.ntx, w.ncot, w.tiles_per_chunk, w.ntiles, WgIn{w.in_stats, w.in_act, w.in_slope});
       CFUN_LAUNCH_CHECK();
       return CFUN_OK;
     }
   }
-  auto kern = k_wgrad_mfma<KD, KH, KW, S, NSUB, false, 1>;
-  if constexpr (KD * KH * KW == 27) {   // C_in <= 8: PACK taps per A fragment
-    const int pack = w.ncisub > 1 ? 1 : p.Ci <= 4 ? 4 : p.Ci <= 8 ? 2 : 1;
-    const bool ts = S == 1 && p.d2s && p.tap_skip;
-    if constexpr (S == 1) {
-      if (ts) kern = pack == 4 ? k_wgrad_mfma<KD, KH, KW, S, NSUB, true, 4>
-                   : pack == 2 ? k_wgrad_mfma<KD, KH, KW, S, NSUB, true, 2>
-                               : k_wgrad_mfma<KD, KH, KW, S, NSUB, true, 1>;
+  const bool in = w.in_stats != nullptr || w.in_act != CFUN_ACT_NONE;
+  auto kern = k_wgrad_mfma<KD, KH, KW, S, NSUB, false, 1, false>;
+  auto pick = [&](auto in_c) {
+    constexpr bool I = decltype(in_c)::value;
+    kern = k_wgrad_mfma<KD, KH, KW, S, NSUB, false, 1, I>;
+    if constexpr (KD * KH * KW == 27) {   // C_in <= 8: PACK taps per A fragment
+      const int pack = w.ncisub > 1 ? 1 : p.Ci <= 4 ? 4 : p.Ci <= 8 ? 2 : 1;
+      const bool ts = S == 1 && p.d2s && p.tap_skip;
+      if constexpr (S == 1) {
+        if (ts) kern = pack == 4 ? k_wgrad_mfma<KD, KH, KW, S, NSUB, true, 4, I>
+                     : pack == 2 ? k_wgrad_mfma<KD, KH, KW, S, NSUB, true, 2, I>
+                                 : k_wgrad_mfma<KD, KH, KW, S, NSUB, true, 1, I>;
+      }
+      if (!ts) kern = pack == 4 ? k_wgrad_mfma<KD, KH, KW, S, NSUB, false, 4, I>
+                    : pack == 2 ? k_wgrad_mfma<KD, KH, KW, S, NSUB, false, 2, I>
+                                : k_wgrad_mfma<KD, KH, KW, S, NSUB, false, 1, I>;
     }
-    if (!ts) kern = pack == 4 ? k_wgrad_mfma<KD, KH, KW, S, NSUB, false, 4>
-                  : pack == 2 ? k_wgrad_mfma<KD, KH, KW, S, NSUB, false, 2>
-                              : k_wgrad_mfma<KD, KH, KW, S, NSUB, false, 1>;
-  }
+  };
+  if (in) pick(std::true_type{}); else pick(std::false_type{});
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   const int64_t nblk = (int64_t)w.nchunks * w.ncisub * w.ncot;
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, x, g, partial, p, w.ntz, w.nty, w.ntx, w.ncisub,
-                     w.ncot, w.tiles_per_chunk, w.ntiles);
+                     w.ncot, w.tiles_per_chunk, w.ntiles, WgIn{w.in_stats, w.in_act, w.in_slope});
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }

@@ -9,7 +9,7 @@
 //     contiguous floats as float4s, so a wave writes one contiguous 64*C_out*4-byte span.
 // The generic direct kernel computed 8 channels per thread in 3 passes over the input with 32-byte scattered
 // stores (0.35 ms per stem = 0.85 TB/s); this one is write-bound.
-#include "common.h"
+#include "conv3d_mfma.h"
 #include <stdlib.h>
 
 namespace {
@@ -276,19 +276,31 @@ int cfun_conv_stem_fwd(const float* x, const float* wp, const float* scale, cons
 // barrier per 4-channel chunk on 4 KB of input here and runs at 1.5 TB/s.
 namespace {
 
-template <int CO>
+// IN: the input prologue (CfunConvFusion.in_stats / in_act) -- x is read as in_act((x - mean) * rstd); the (mean, rstd)
+// table [N][Ci][2] of the whole launch sits in LDS (a thread's sample is not wave-uniform at sample boundaries)
+template <int CO, bool IN>
 __global__ void __launch_bounds__(256)
 k_conv_pointwise(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale,
                  const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
-                 CfunConv3dParams p, int64_t total) {
+                 CfunConv3dParams p, int64_t total, const float* __restrict__ in_stats, int in_act, float in_slope) {
+  CFUN_DYN_LDS(float4, stab);       // IN: [N * Ci / 4][2] float4 rows (mean0, rstd0, mean1, rstd1 | mean2, ...)
+  if constexpr (IN) {
+    const int rows = p.N * (p.Ci >> 2) * 2;
+    for (int i = threadIdx.x; i < rows; i += 256)
+      stab[i] = in_stats ? reinterpret_cast<const float4*>(in_stats)[i] : make_float4(0.f, 1.f, 0.f, 1.f);
+    __syncthreads();
+  }
+  const int64_t per_n_in = (int64_t)p.Do * p.Ho * p.Wo;
   for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
     const float4* xr = reinterpret_cast<const float4*>(x + v * p.Ci);
+    const float4* srow = stab + (IN ? (v / per_n_in) * (p.Ci >> 2) * 2 : 0);
     float acc[CO];
 #pragma unroll
     for (int j = 0; j < CO; ++j) acc[j] = 0.f;
 #pragma unroll 2
     for (int c = 0; c < p.Ci; c += 4) {
-      const float4 xv = xr[c >> 2];
+      float4 xv = xr[c >> 2];
+      if constexpr (IN) xv = cfun_mfma::norm_act_in4(xv, srow[(c >> 2) * 2], srow[(c >> 2) * 2 + 1], in_act, in_slope);
       const float* w = wp + (int64_t)c * p.CoP;          // wave-uniform: scalar loads
 #pragma unroll
       for (int j = 0; j < CO; ++j) {
@@ -333,13 +345,27 @@ int cfun_conv_pointwise_supported(const CfunConv3dParams* p) {
   return (int64_t)p->N * p->Do * p->Ho * p->Wo >= 32768;      // small volumes: the split-K MFMA path
 }
 
+// the (mean, rstd) table of the input prologue must fit LDS: N * Ci * 2 floats
+int cfun_conv_pointwise_in_supported(const CfunConv3dParams* p) {
+  return cfun_conv_pointwise_supported(p) && (size_t)p->N * p->Ci * 2 * sizeof(float) <= 48 * 1024;
+}
+
 int cfun_conv_pointwise_fwd(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
-                            float* y, const CfunConv3dParams* p, hipStream_t st) {
+                            float* y, const CfunConv3dParams* p, const float* in_stats, int in_act, float in_slope,
+                            hipStream_t st) {
   const int64_t total = (int64_t)p->N * p->Do * p->Ho * p->Wo;
   if (total <= 0) return CFUN_OK;
   int64_t blocks = (total + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;
-  hipLaunchKernelGGL(k_conv_pointwise<8>, dim3((unsigned)blocks), dim3(256), 0, st, x, wp, scale, shift, res, y, *p, total);
+  if (in_stats || in_act != CFUN_ACT_NONE) {
+    if (!cfun_conv_pointwise_in_supported(p)) return CFUN_EINVAL;
+    const size_t lds = (size_t)p->N * p->Ci * 2 * sizeof(float);
+    hipLaunchKernelGGL((k_conv_pointwise<8, true>), dim3((unsigned)blocks), dim3(256), lds, st, x, wp, scale, shift, res, y, *p,
+                       total, in_stats, in_act, in_slope);
+  } else {
+    hipLaunchKernelGGL((k_conv_pointwise<8, false>), dim3((unsigned)blocks), dim3(256), 0, st, x, wp, scale, shift, res, y, *p,
+                       total, nullptr, 0, 0.f);
+  }
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }

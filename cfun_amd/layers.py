@@ -46,7 +46,7 @@ class Conv3dParams(nn.Module):
         return ops.pack_weight(self.weight)
 
     def forward(self, x, act=ops.ACT_NONE, bn=None, bn_eps=None, res=None, up2=False, res_up2=False, scale=None, stats=None):
-        """NDHWC in / out.  bn: a frozen nn.BatchNorm3d folded into the epilogue (SURVEY.md App. A-1);
+        """NDHWC in / out (x may be an ``ops.NormedInput``).  bn: a frozen nn.BatchNorm3d folded into the epilogue (SURVEY.md App. A-1);
         scale: per-(n, channel) multiplier (Dropout3d mask) -- mutually exclusive with bn; stats: an ``ops.StatsSlot`` that
         receives the output's InstanceNorm statistics from the conv's epilogue (left empty on depth slabs)."""
         shift = self.bias
@@ -58,6 +58,8 @@ class Conv3dParams(nn.Module):
         elif scale is not None:
             per_n = True
         shard = dist.current()
+        if shard is not None and shard.world > 1 and isinstance(x, ops.NormedInput):
+            x = x.materialize()          # depth slabs: the split / padded launches take a real tensor
         if shard is not None and shard.world > 1 and self.kernel_size[0] > 1:
             # depth-sharded volume: the conv runs depth-VALID with the halo planes of the ring neighbours
             if up2:

@@ -9,6 +9,8 @@ mask_branch.py:11-220, but runs as NDHWC HIP kernels:
   * residual / deep-supervision adds, the Dropout3d channel mask and the 'finetune' skip are conv epilogues;
   * InstanceNorm3d + LeakyReLU is one fused statistics pass + one apply pass.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -140,7 +142,8 @@ class Modified3DUNet(nn.Module):
         # the level's head ops stay batched (per-sample heads measured no better); batched <-> per-sample hand-overs are
         # zero-copy in both directions (ops.split_batch / join_batch: results and gradients are written in place)
         a_all, res_all = head(src)
-        a_parts, res_parts = ops.split_batch(a_all), ops.split_batch(res_all)
+        a_parts = a_all.samples() if isinstance(a_all, ops.NormedInput) else ops.split_batch(a_all)
+        res_parts = ops.split_batch(res_all)
         ybuf, gbuf = ops.BatchBuffer(n), ops.BatchBuffer(n)     # outputs / conv1 input gradients, written in place
         outs = []
         w1s, w2s = ops.gather_slices(conv1.weight, 0, idxs), ops.gather_slices(conv2.weight, 1, idxs)
@@ -197,9 +200,13 @@ class Modified3DUNet(nn.Module):
         sharded = (lambda: dist.depth_sharded_as(zs)) if zs is not None else dist.nullcontext
         folded = dist.slab_local if zs is not None else dist.nullcontext
 
-        def nl(t, out=None, rep=False, stats=None):      # rep: t is a replicated (folded) tensor -> plain local statistics
+        def nl(t, out=None, rep=False, stats=None, lazy=False):      # rep: t is a replicated (folded) tensor -> plain local statistics
             # stats: the StatsSlot t's producer conv filled from its epilogue (empty on depth slabs: own pass then)
-            return ops.instnorm_lrelu(t, out=out, shard=None if rep else zs, stats=stats)
+            # lazy: every consumer is a conv -> no apply pass, they stage t through the norm (ops.NormedInput)
+            return ops.instnorm_lrelu(t, out=out, shard=None if rep else zs, stats=stats, lazy=lazy and zs is None and LAZY)
+
+        LAZY = os.environ.get("CFUN_FUSE_NORM", "1") != "0"      # (A/B switch: 0 = every norm / activation as its own pass)
+        lz = zs is None and LAZY
 
         def slot(t_or_n):
             return ops.StatsSlot(t_or_n if isinstance(t_or_n, int) else t_or_n.shape[0])
@@ -208,14 +215,14 @@ class Modified3DUNet(nn.Module):
 
         drop = self._upload_dropout(self._drop_masks(x.shape[0], x.device), x.device)
 
-        def nluc(h, holder, out=None, src="same", stats=None):
+        def nluc(h, holder, out=None, src="same", stats=None, lazy_out=False):
             """norm -> lrelu -> nearest x2 -> 3x3x3 conv -> norm -> lrelu (mask_branch.py:108-116).  src: where h lives --
             'same' (no sharding, or sharded in and out), 'rep' (replicated in and out) or 'enter' (replicated in, sharded out).
-            stats: the slot h's producer filled."""
-            a = nl(h, rep=src != "same", stats=stats)
+            stats: the slot h's producer filled; lazy_out: the result feeds convs only."""
+            a = nl(h, rep=src != "same", stats=stats, lazy=True)       # -> the folded up-conv
             if zs is None or src == "rep":
                 su = slot(nb)
-                return nl(self._up_conv(a, holder[3], stats=su), out=out, rep=src == "rep", stats=su)
+                return nl(self._up_conv(a, holder[3], stats=su), out=out, rep=src == "rep", stats=su, lazy=lazy_out)
             a = dist.enter_slab(a, zs, 1, 1) if src == "enter" else dist.halo_exchange(a, 1, 1, zs)
             return nl(self._up_conv(a, holder[3], depth_padded=True), out=out)
 
@@ -223,16 +230,16 @@ class Modified3DUNet(nn.Module):
             # level 1: residual is the pre-activation stem output, context_1 is taken before the norm
             def head1(xp):
                 res = self.conv3d_c1_1(xp)
-                return ops.lrelu(res), res
+                return ops.lrelu(res, lazy=lz), res
             s_out = slot(nb)
-            out = self._dropout_pair(x, head1, self.conv3d_c1_2, self.lrelu_conv_c1[1], drop[0], lambda t, st: ops.lrelu(t),
-                                     out_stats=s_out)
+            out = self._dropout_pair(x, head1, self.conv3d_c1_2, self.lrelu_conv_c1[1], drop[0],
+                                     lambda t, st: ops.lrelu(t, lazy=lz), out_stats=s_out)
             # context_1 is only ever read by the level-1 concat (mask_branch.py:203): it is written straight into the
             # second half of that concat's buffer, the decoder later writes the first half -- no torch.cat, no copies
             b1 = self.base_n_filter
             cat1 = ops.ConcatBuffer(out, 2 * b1) if b1 % 4 == 0 else None
             ctx = [ops.lrelu(out, out=None if cat1 is None else cat1.slot(b1, 2 * b1))]
-            h = nl(out, stats=s_out)
+            h = nl(out, stats=s_out, lazy=True)      # -> conv3d_c2 only
         # levels 2..5: stride-2 conv, then the SAME norm_lrelu_conv weights twice around the dropout
         for lvl in (2, 3, 4, 5):
             down = getattr(self, "conv3d_c%d" % lvl)
@@ -247,25 +254,25 @@ class Modified3DUNet(nn.Module):
                 else:
                     sd = slot(nb)
                     res = down(hp, stats=sd)
-                return nl(res, rep=rep, stats=sd), res
+                return nl(res, rep=rep, stats=sd, lazy=True), res
             head.stride = 2
             conv = getattr(self, "norm_lrelu_conv_c%d" % lvl)[2]
             with (folded() if rep else sharded()):
                 s_out = slot(nb)
-                out = self._dropout_pair(h, head, conv, conv, drop[lvl - 1], lambda t, st, rep=rep: nl(t, rep=rep, stats=st),
-                                         out_stats=s_out)
+                out = self._dropout_pair(h, head, conv, conv, drop[lvl - 1],
+                                         lambda t, st, rep=rep: nl(t, rep=rep, stats=st, lazy=True), out_stats=s_out)
                 if lvl < 5:
                     h = nl(out, rep=rep, stats=s_out)
                     ctx.append(h)
         R = zs is not None       # decoder: replicated up to 1/4 resolution, sharded from 1/2
         with folded():
-            h = nluc(out, self.norm_lrelu_upscale_conv_norm_lrelu_l0, src="rep" if R else "same", stats=s_out)
+            h = nluc(out, self.norm_lrelu_upscale_conv_norm_lrelu_l0, src="rep" if R else "same", stats=s_out, lazy_out=True)
             sa, sb, sc, sd_ = slot(nb), slot(nb), slot(nb), slot(nb)
             h = nl(self.conv3d_l0(h, stats=sa), rep=R, stats=sa)
-            h = nl(self.conv_norm_lrelu_l1[0](torch.cat([h, ctx[3]], dim=-1), stats=sb), rep=R, stats=sb)
+            h = nl(self.conv_norm_lrelu_l1[0](torch.cat([h, ctx[3]], dim=-1), stats=sb), rep=R, stats=sb, lazy=True)
             h = nluc(self.conv3d_l1(h, stats=sc), self.norm_lrelu_upscale_conv_norm_lrelu_l1, src="rep" if R else "same",
                      stats=sc)
-            ds2 = nl(self.conv_norm_lrelu_l2[0](torch.cat([h, ctx[2]], dim=-1), stats=sd_), rep=R, stats=sd_)
+            ds2 = nl(self.conv_norm_lrelu_l2[0](torch.cat([h, ctx[2]], dim=-1), stats=sd_), rep=R, stats=sd_, lazy=True)
             s_l2 = slot(nb)
             h_l2 = self.conv3d_l2(ds2, stats=s_l2)
             ds2_out = self.ds2_1x1_conv3d(ds2)
@@ -274,7 +281,7 @@ class Modified3DUNet(nn.Module):
             ds2_out = dist.enter_slab(ds2_out, zs)
         with sharded():
             s3, s_l3, s4 = slot(nb), slot(nb), slot(nb)
-            ds3 = nl(self.conv_norm_lrelu_l3[0](torch.cat([h, ctx[1]], dim=-1), stats=s3), stats=s3)
+            ds3 = nl(self.conv_norm_lrelu_l3[0](torch.cat([h, ctx[1]], dim=-1), stats=s3), stats=s3, lazy=True)
             if cat1 is None:
                 h = nluc(self.conv3d_l3(ds3, stats=s_l3), self.norm_lrelu_upscale_conv_norm_lrelu_l3, stats=s_l3)
                 joined = torch.cat([h, ctx[0]], dim=-1)
@@ -282,7 +289,7 @@ class Modified3DUNet(nn.Module):
                 h = nluc(self.conv3d_l3(ds3, stats=s_l3), self.norm_lrelu_upscale_conv_norm_lrelu_l3, out=cat1.slot(0, b1),
                          stats=s_l3)
                 joined = cat1.join(h, ctx[0])
-            h = nl(self.conv_norm_lrelu_l4[0](joined, stats=s4), stats=s4)
+            h = nl(self.conv_norm_lrelu_l4[0](joined, stats=s4), stats=s4, lazy=True)      # -> conv3d_l4 only
             # deep supervision: up(up(ds2_1x1) + ds3_1x1) + out_pred, each add is a conv epilogue
             s = self.ds3_1x1_conv3d(ds3, res=ds2_out, res_up2=True)
             out = self.conv3d_l4(h, res=s, res_up2=True)

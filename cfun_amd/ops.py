@@ -229,7 +229,8 @@ class StatsSlot:
 
 class _Conv3d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, wp, scale, shift, res, spec, out=None, dx_slot=None, w_src=None, stats=None):
+    def forward(ctx, x, wp, scale, shift, res, spec, out=None, dx_slot=None, w_src=None, stats=None, pro=None):
+        # pro = (stats [N,Ci,2] or None, act, slope): the conv reads act((x - mean) * rstd) in place of x (NormedInput)
         lib = _lib.load()
         x = _c(x)
         wpT = None
@@ -270,18 +271,26 @@ class _Conv3d(torch.autograd.Function):
             ws = workspace(lib.cfun_conv3d_b3_fwd_workspace_bytes(C.byref(p)), x)
             check(lib.cfun_conv3d_b3_fwd(ptr(x), ptr(wb3), ptr(scale), ptr(shift), ptr(res), ptr(y), C.byref(p), ptr(ws),
                                          ws.numel(), stream(x)), "conv3d_b3_fwd")
-        elif stats is not None and (lib.cfun_conv3d_fused_support(C.byref(p)) & _lib.FUSE_OUT_STATS):
-            # InstanceNorm statistics of y from this epilogue (the norm that follows skips its pass over y)
-            slot, i = stats if isinstance(stats, tuple) else (stats, None)
-            if (i is None and slot.n != p.N) or (i is not None and p.N != 1):
-                raise RuntimeError("conv3d: stats slot of %d samples does not fit a conv over %d" % (slot.n, p.N))
-            if i is None:
-                slot.stats = torch.empty((p.N, y.shape[-1], 2), dtype=torch.float32, device=x.device)
-                dst, slot.filled = slot.stats, slot.n
-            else:
-                dst = slot.row(i, y.shape[-1], x)
-                slot.filled += 1
-            fz = _lib.ConvFusion(None, 0, 0.0, dst.data_ptr(), float(slot.eps))
+        elif pro is not None or (stats is not None and (lib.cfun_conv3d_fused_support(C.byref(p)) & _lib.FUSE_OUT_STATS)):
+            # InstanceNorm statistics of y from this epilogue (the norm that follows skips its pass over y) and / or the
+            # norm + activation in front of this conv applied while x is staged
+            dst = None
+            if stats is not None and (lib.cfun_conv3d_fused_support(C.byref(p)) & _lib.FUSE_OUT_STATS):
+                slot, i = stats if isinstance(stats, tuple) else (stats, None)
+                if (i is None and slot.n != p.N) or (i is not None and p.N != 1):
+                    raise RuntimeError("conv3d: stats slot of %d samples does not fit a conv over %d" % (slot.n, p.N))
+                if i is None:
+                    slot.stats = torch.empty((p.N, y.shape[-1], 2), dtype=torch.float32, device=x.device)
+                    dst, slot.filled = slot.stats, slot.n
+                else:
+                    dst = slot.row(i, y.shape[-1], x)
+                    slot.filled += 1
+            fz = _lib.ConvFusion(None, 0, 0.0, None if dst is None else dst.data_ptr(), float(slot.eps) if dst is not None else 0.0)
+            if pro is not None:
+                pst = None if pro[0] is None else _c(pro[0])
+                if pst is not None and tuple(pst.shape) != (p.N, p.Ci, 2):
+                    raise RuntimeError("conv3d: input statistics %s do not fit x %s" % (tuple(pst.shape), tuple(x.shape)))
+                fz.in_stats, fz.in_act, fz.in_slope = (None if pst is None else pst.data_ptr()), int(pro[1]), float(pro[2])
             ws = workspace(lib.cfun_conv3d_fwd_fused_workspace_bytes(C.byref(p), C.byref(fz)), x)
             check(lib.cfun_conv3d_fwd_fused(ptr(x), ptr(wp), ptr(scale), ptr(shift), ptr(res), ptr(y), C.byref(p),
                                             C.byref(fz), ptr(ws), ws.numel(), stream(x)), "conv3d_fwd_fused")
@@ -298,15 +307,20 @@ class _Conv3d(torch.autograd.Function):
         ctx.dx_slot = dx_slot
         ctx.wshape = None if w_src is None else tuple(w_src.shape)
         ctx.b3 = b3
+        ctx.pro = None if pro is None else (int(pro[1]), float(pro[2]))
         ctx.save_for_backward(x, wp, scale, y if spec.act != ACT_NONE else None, wpT,
-                              w_src.detach() if b3 and ctx.needs_input_grad[0] else None)
+                              w_src.detach() if b3 and ctx.needs_input_grad[0] else None,
+                              None if pro is None or pro[0] is None else _c(pro[0]))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        x, wp, scale, y, wpT, w_b3 = ctx.saved_tensors
+        x, wp, scale, y, wpT, w_b3, pst = ctx.saved_tensors
         spec, p = ctx.spec, ctx.p
+        fz = None
+        if ctx.pro is not None:      # the weight gradient stages x through the same prologue as the forward did
+            fz = _lib.ConvFusion(None if pst is None else pst.data_ptr(), ctx.pro[0], ctx.pro[1], None, 0.0)
         need_x, need_w, need_scale, need_shift, need_res = ctx.needs_input_grad[:5]
         need_wsrc = ctx.needs_input_grad[8]
         if need_scale:
@@ -360,14 +374,22 @@ class _Conv3d(torch.autograd.Function):
             dwp = torch.empty_like(wp)
             nb = lib.cfun_conv3d_bwd_weight_workspace_bytes(C.byref(p))
             ws = workspace(nb, x)
-            check(lib.cfun_conv3d_bwd_weight(ptr(x), ptr(g), ptr(dwp), C.byref(p), ptr(ws), ws.numel(), st),
-                  "conv3d_bwd_weight")
+            if fz is not None:
+                check(lib.cfun_conv3d_bwd_weight_fused(ptr(x), ptr(g), ptr(dwp), 0, C.byref(p), C.byref(fz), ptr(ws),
+                                                       ws.numel(), st), "conv3d_bwd_weight_fused")
+            else:
+                check(lib.cfun_conv3d_bwd_weight(ptr(x), ptr(g), ptr(dwp), C.byref(p), ptr(ws), ws.numel(), st),
+                      "conv3d_bwd_weight")
         if need_wsrc:
             dw = torch.empty(ctx.wshape, dtype=torch.float32, device=dy.device)
             if spec.algo == ALGO_B3 and _b3_wgrad_wanted(lib, p):      # opt-in 3xBF16 weight gradient
                 ws = workspace(lib.cfun_conv3d_b3_wgrad_workspace_bytes(C.byref(p)), x)
                 check(lib.cfun_conv3d_b3_wgrad_oidhw(ptr(x), ptr(g), ptr(dw), C.byref(p), ptr(ws), ws.numel(), st),
                       "conv3d_b3_wgrad_oidhw")
+            elif fz is not None:
+                ws = workspace(lib.cfun_conv3d_bwd_weight_workspace_bytes(C.byref(p)), x)
+                check(lib.cfun_conv3d_bwd_weight_fused(ptr(x), ptr(g), ptr(dw), 1, C.byref(p), C.byref(fz), ptr(ws),
+                                                       ws.numel(), st), "conv3d_bwd_weight_fused(oidhw)")
             else:
                 nb = lib.cfun_conv3d_bwd_weight_workspace_bytes(C.byref(p))
                 ws = workspace(nb, x)
@@ -386,14 +408,92 @@ class _Conv3d(torch.autograd.Function):
                       "upsample2_bwd")
             else:
                 dres = gp
-        return dx, dwp, None, dshift, dres, None, None, None, dw, None
+        return dx, dwp, None, dshift, dres, None, None, None, dw, None, None
+
+
+class NormedInput:
+    """A tensor that exists only as "act((raw - mean) * rstd)": the InstanceNorm3d + LeakyReLU (or the plain LeakyReLU)
+    between a producer and the conv that consumes it (mask_branch.py:23-25,91-116), not written to memory.  ``token``
+    aliases the RAW tensor and carries the norm's backward in the autograd graph (``instnorm_lrelu(..., lazy=True)``,
+    ``lrelu(..., lazy=True)``); a conv whose kernel has the input prologue (cfun_conv3d_fused_support) stages the raw
+    values through it, every other consumer gets ``materialize()`` -- the stand-alone apply pass, run at most once.
+    Either way the gradient reaches the producer through the token's one backward node."""
+
+    def __init__(self, token, stats, act, slope):
+        self.token, self.stats, self.act, self.slope = token, stats, act, slope
+        self._mat = None
+
+    @property
+    def shape(self):
+        return self.token.shape
+
+    @property
+    def device(self):
+        return self.token.device
+
+    def pro(self):
+        return (self.stats, self.act, self.slope)
+
+    def materialize(self):
+        if self._mat is None:
+            self._mat = _Materialize.apply(self.token, self.stats, self.act, self.slope)
+        return self._mat
+
+    def samples(self):
+        """Per-sample NormedInputs [1,...] (zero-copy split, gradients rejoin without a copy: split_batch)."""
+        parts = split_batch(self.token)
+        return [NormedInput(t, None if self.stats is None else self.stats[i:i + 1], self.act, self.slope)
+                for i, t in enumerate(parts)]
+
+
+class _Materialize(torch.autograd.Function):
+    """token -> the normalised + activated tensor (the stand-alone apply pass); the gradient passes through unchanged to
+    the token, whose backward node is the norm's."""
+
+    @staticmethod
+    def forward(ctx, token, stats, act, slope):
+        lib = _lib.load()
+        x = _c(token)
+        y = torch.empty_like(x)
+        if stats is not None:
+            if act != ACT_LRELU:
+                raise RuntimeError("materialize: InstanceNorm is fused with LeakyReLU only")
+            n, c = x.shape[0], x.shape[-1]
+            check(lib.cfun_instnorm_lrelu_fwd(ptr(x), ptr(_c(stats)), ptr(y), n, x.numel() // (n * c), c, slope, stream(x)),
+                  "instnorm_lrelu_fwd")
+        else:
+            check(lib.cfun_lrelu_fwd(ptr(x), ptr(y), x.numel(), slope, stream(x)), "lrelu_fwd")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None, None, None
+
+
+def _fusable_input(x, spec, scale, shift, res, need_wgrad):
+    """Can the conv (spec) stage the NormedInput x through its prologue -- forward kernel and, when the weight needs a
+    gradient, the weight-gradient kernel?"""
+    if spec.algo == ALGO_B3 or spec.up2:
+        return False
+    lib = _lib.load()
+    p = _params(spec, x.shape, scale is not None, shift is not None, res is not None)
+    have = lib.cfun_conv3d_fused_support(C.byref(p))
+    want = _lib.FUSE_IN_NORM | (_lib.FUSE_IN_NORM_WGRAD if need_wgrad else 0)
+    return (have & want) == want
 
 
 def conv3d(x, wp, spec, scale=None, shift=None, res=None, out=None, dx_slot=None, stats=None):
     """y = act(scale * conv(x) + shift + res); see include/cfun_hip.h (cfun_conv3d_fwd).  ``out`` / ``dx_slot``:
     (BatchBuffer, i) -- write y / the input gradient into sample i of a shared batch buffer (per-sample convs).
-    ``stats``: a ``StatsSlot`` (or (slot, i) for per-sample convs) that receives y's InstanceNorm statistics."""
-    return _Conv3d.apply(x, wp, scale, shift, res, spec, out, dx_slot, None, stats)
+    ``stats``: a ``StatsSlot`` (or (slot, i) for per-sample convs) that receives y's InstanceNorm statistics.
+    x may be a ``NormedInput``."""
+    pro = None
+    if isinstance(x, NormedInput):
+        if _fusable_input(x, spec, scale, shift, res, wp.requires_grad):
+            x, pro = x.token, x.pro()
+        else:
+            x = x.materialize()
+    return _Conv3d.apply(x, wp, scale, shift, res, spec, out, dx_slot, None, stats, pro)
 
 
 def conv3d_w(x, w, spec, scale=None, shift=None, res=None, out=None, dx_slot=None, stats=None):
@@ -401,7 +501,13 @@ def conv3d_w(x, w, spec, scale=None, shift=None, res=None, out=None, dx_slot=Non
     weight): packed inside the op, and the weight gradient is produced directly in OIDHW -- the reduction of the
     wgrad kernel's per-chunk partial sums and the un-packing are one kernel (cfun_conv3d_bwd_weight_oidhw) instead
     of conv3d(x, pack_weight(w))'s reduce + un-pack launches.  Same values bit for bit."""
-    return _Conv3d.apply(x, None, scale, shift, res, spec, out, dx_slot, w, stats)
+    pro = None
+    if isinstance(x, NormedInput):
+        if _fusable_input(x, spec, scale, shift, res, w.requires_grad):
+            x, pro = x.token, x.pro()
+        else:
+            x = x.materialize()
+    return _Conv3d.apply(x, None, scale, shift, res, spec, out, dx_slot, w, stats, pro)
 
 
 # ---- EXPERIMENTAL: 3x3x3 conv with fp32 emulated on the bf16 matrix cores (conv3d_b3.hip; not used by the modules) ----
@@ -703,7 +809,8 @@ def _combine_stats_over_ranks(stats, eps, shard):
 
 class _InstNormLReLU(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, eps, out=None, shard=None, pre=None):
+    def forward(ctx, x, eps, out=None, shard=None, pre=None, lazy=None):
+        # lazy: a list that receives the statistics -- no apply pass, the result aliases x (see NormedInput)
         lib = _lib.load()
         x = _c(x)
         n, c = x.shape[0], x.shape[-1]
@@ -720,7 +827,12 @@ class _InstNormLReLU(torch.autograd.Function):
             check(lib.cfun_instnorm_stats(ptr(x), ptr(stats), n, v, c, eps, ptr(ws), ws.numel(), st), "instnorm_stats")
         if zs:
             stats = _combine_stats_over_ranks(stats, eps, shard)
-        if out is None:
+        if lazy is not None:
+            if out is not None:
+                raise RuntimeError("instnorm_lrelu: lazy and out= are exclusive")
+            lazy.append(stats)
+            y = x.view(x.shape)
+        elif out is None:
             y = torch.empty_like(x)
             check(lib.cfun_instnorm_lrelu_fwd(ptr(x), ptr(stats), ptr(y), n, v, c, LRELU_SLOPE, st), "instnorm_lrelu_fwd")
         else:                                        # write into a channel range of a ConcatBuffer
@@ -756,24 +868,31 @@ class _InstNormLReLU(torch.autograd.Function):
             means /= ctx.shard.world
             check(lib.cfun_instnorm_lrelu_bwd_apply(ptr(x), ptr(stats), ptr(means), ptr_raw(dy), ptr(dx), n, v, c, rs,
                                                     LRELU_SLOPE, stream(x)), "instnorm_lrelu_bwd_apply")
-        return dx, None, None, None, None
+        return dx, None, None, None, None, None
 
 
-def instnorm_lrelu(x, eps=1e-5, out=None, shard=None, stats=None):
+def instnorm_lrelu(x, eps=1e-5, out=None, shard=None, stats=None, lazy=False):
     """LeakyReLU(InstanceNorm3d(x)) (affine=False, biased variance), mask_branch.py:28-116.  ``out``: a
     ``ConcatBuffer.slot`` to write the result into (zero-copy concat).  ``shard``: x is this rank's equal depth slab of
     a volume z-sharded over ``shard``'s ranks -- the statistics (forward) and the two gradient means (backward) are
     combined with one small all-reduce each.  ``stats``: a ``StatsSlot`` the conv that produced x filled from its
-    epilogue (this rank's slab for a sharded x) -- the statistics pass over x is then skipped."""
-    return _InstNormLReLU.apply(x, eps, out, shard, stats)
+    epilogue (this rank's slab for a sharded x) -- the statistics pass over x is then skipped.  ``lazy``: return a
+    ``NormedInput`` instead of running the apply pass -- the consumer convs stage x through the norm themselves."""
+    if not lazy:
+        return _InstNormLReLU.apply(x, eps, out, shard, stats)
+    got = []
+    token = _InstNormLReLU.apply(x, eps, None, shard, stats, got)
+    return NormedInput(token, got[0], ACT_LRELU, LRELU_SLOPE)
 
 
 class _LReLU(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, out=None):
+    def forward(ctx, x, out=None, lazy=False):
         lib = _lib.load()
         x = _c(x)
-        if out is None:
+        if lazy:                      # no pass: the result aliases x, the consumer conv applies the activation (NormedInput)
+            y = x.view(x.shape)
+        elif out is None:
             y = torch.empty_like(x)
             check(lib.cfun_lrelu_fwd(ptr(x), ptr(y), x.numel(), LRELU_SLOPE, stream(x)), "lrelu_fwd")
         else:
@@ -799,10 +918,12 @@ class _LReLU(torch.autograd.Function):
         else:
             check(lib.cfun_lrelu_bwd_strided(ptr(x), ptr_raw(dy), ptr(dx), x.numel() // c, c, rs, LRELU_SLOPE,
                                              stream(x)), "lrelu_bwd_strided")
-        return dx, None
+        return dx, None, None
 
 
-def lrelu(x, out=None):
+def lrelu(x, out=None, lazy=False):
+    if lazy:
+        return NormedInput(_LReLU.apply(x, None, True), None, ACT_LRELU, LRELU_SLOPE)
     return _LReLU.apply(x, out)
 
 

@@ -134,6 +134,11 @@ size_t cfun_conv3d_fwd_fused_workspace_bytes(const CfunConv3dParams* p, const Cf
 int cfun_conv3d_fwd_fused(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
                           float* y, const CfunConv3dParams* p, const CfunConvFusion* f, void* ws, size_t ws_bytes,
                           cfun_stream_t stream);
+/* The weight gradient of a conv whose forward ran with in_stats / in_act: x is the RAW tensor the forward read, the
+ * kernel applies the same prologue while staging it (only f->in_* are used).  oidhw: 0 = dw in the packed layout of
+ * cfun_conv3d_bwd_weight, 1 = torch's OIDHW (cfun_conv3d_bwd_weight_oidhw).  Same workspace as the plain calls. */
+int cfun_conv3d_bwd_weight_fused(const float* x, const float* g, float* dw, int32_t oidhw, const CfunConv3dParams* p,
+                                 const CfunConvFusion* f, void* ws, size_t ws_bytes, cfun_stream_t stream);
 /* dx[n,zi,yi,xi,ci] (stored-input resolution) = sum over outputs/taps that read it of g * W. g = dL/d(conv sum). */
 size_t cfun_conv3d_bwd_data_workspace_bytes(const CfunConv3dParams* p);
 int cfun_conv3d_bwd_data(const float* g, const float* wpT, float* dx, const CfunConv3dParams* p, void* ws,

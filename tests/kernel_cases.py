@@ -189,6 +189,25 @@ def check_conv(device, n, dhw, ci, co, k, stride=1, pad=None, up2=False, act=ACT
         rstd = 1.0 / torch.sqrt(y64.var(dim=1, unbiased=False) + 1e-5)
         assert_close(st[..., 0], mean.float(), "epilogue mean", 2e-5)
         assert_close(st[..., 1], rstd.float(), "epilogue rstd", 2e-5)
+    # the input prologue (CfunConvFusion.in_stats / in_act): the conv reads lrelu((x - mean) * rstd) while staging x,
+    # forward and weight gradient; the returned input gradient is the one w.r.t. the NORMALISED input
+    if not up2 and ops._fusable_input(ops.NormedInput(xw.detach(), None, ACT_LRELU, 0.01), spec, sc, sfw, rsw, True):
+        ist = torch.stack([randn(gen, n, ci) * 0.5, torch.rand(n, ci, generator=gen) + 0.5], dim=-1)
+        for stats_t in (ist, None):          # InstanceNorm + LeakyReLU, then the plain LeakyReLU
+            xn = x if stats_t is None else (x - stats_t[..., 0].view(n, 1, 1, 1, ci)) * stats_t[..., 1].view(n, 1, 1, 1, ci)
+            xn = F.leaky_relu(xn, 0.01).detach().requires_grad_(True)
+            _, wr2, sfr2, rsr2 = leafs("cpu")
+            yn = ref_conv(xn, wr2, spec, sc, sfr2, rsr2)
+            yn.backward(gy)
+            xp, wp2, sfp, rsp = leafs(device)
+            tok = xp.detach().requires_grad_(True)
+            yp = ops.conv3d_w(ops.NormedInput(tok, None if stats_t is None else stats_t.to(device), ACT_LRELU, 0.01), wp2, spec,
+                              None if sc is None else sc.to(device), sfp, rsp)
+            yp.backward(gy.to(device))
+            tag = "prologue(norm)" if stats_t is not None else "prologue(lrelu)"
+            assert_close(yp, yn, tag + " y", tol)
+            assert_close(tok.grad, xn.grad, tag + " dx", tol)
+            assert_close(wp2.grad, wr2.grad, tag + " dw", tol)
 
 
 # ------------------------------------------------------------------------------------------ norm / act / pool

@@ -389,7 +389,7 @@ def flip_fit(taps64, taps32, params64, got, ref32, max_basis=None, max_params=3_
     and the number of basis voxels.  None when the configuration is too large for the dense fit."""
     import os
     if max_basis is None:
-        max_basis = int(os.environ.get("CFUN_TEST_FLIP_BASIS", "96"))
+        max_basis = int(os.environ.get("CFUN_TEST_FLIP_BASIS", "192"))
     names = list(params64)
     plist = [params64[k] for k in names]
     if sum(p.numel() for p in plist) > max_params:
