@@ -485,8 +485,11 @@ int cfun_conv3d_fwd_fused(const float* x, const float* wp, const float* scale, c
   const int have = cfun_conv3d_fused_support(p);
   const int want = (f->out_stats ? CFUN_FUSE_OUT_STATS : 0) | ((f->in_stats || f->in_act) ? CFUN_FUSE_IN_NORM : 0);
   if ((want & have) != want) return CFUN_EINVAL;
+  if (f->in_act != CFUN_ACT_NONE && (f->in_act != CFUN_ACT_LRELU || f->in_slope < 0.f || f->in_slope > 1.f)) return CFUN_EINVAL;
   ConvMode fz = kPlain;
-  fz.in_stats = f->in_stats; fz.in_act = f->in_act; fz.in_slope = f->in_slope;
+  fz.in_stats = f->in_stats;
+  fz.in_act = (f->in_stats || f->in_act) ? CFUN_ACT_LRELU : CFUN_ACT_NONE;      // kernels: max(xh, xh * slope), slope 1 = none
+  fz.in_slope = f->in_act == CFUN_ACT_LRELU ? f->in_slope : 1.f;
   const size_t main_bytes = cfun_conv3d_fwd_workspace_bytes(p);
   if (f->out_stats) {
     if (!ws || !cfun_aligned16(ws) || ws_bytes < main_bytes + stat_part_bytes(p)) return CFUN_EWORKSPACE;
@@ -606,7 +609,10 @@ static int bwd_weight_any(const float* x, const float* g, CfunWgradDst dst, cons
     }
     cfun_mfma::WgPlan w;
     s->plan(*p, wgrad_nsub(p, s), &w);
-    if (pro) { w.in_stats = f->in_stats; w.in_act = f->in_act; w.in_slope = f->in_slope; }
+    if (pro) {
+      if (f->in_act != CFUN_ACT_NONE && (f->in_act != CFUN_ACT_LRELU || f->in_slope < 0.f || f->in_slope > 1.f)) return CFUN_EINVAL;
+      w.in_stats = f->in_stats; w.in_act = CFUN_ACT_LRELU; w.in_slope = f->in_act == CFUN_ACT_LRELU ? f->in_slope : 1.f;
+    }
     if (w.ntiles == 0) return cfun_wgrad_zero(dst, p, cfun_st(stream));
     const int rc = s->wgrad(x, g, (float*)ws, *p, w, cfun_st(stream));
     if (rc) return rc;

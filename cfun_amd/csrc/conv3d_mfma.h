@@ -85,9 +85,11 @@ struct ConvMode {
 // The input prologue (CfunConvFusion.in_stats / in_act): what the conv reads in place of a staged value v of a channel
 // with statistics (mean, rstd) -- the arithmetic of k_instnorm_lrelu_fwd / k_lrelu_fwd, so that the fused and the
 // materialised paths agree bit for bit.
-__device__ __forceinline__ float norm_act_in(float v, float mean, float rstd, int act, float slope) {
+// (act is NONE or LRELU with 0 <= slope <= 1: max(xh, xh * slope) == (xh > 0 ? xh : xh * slope), two instructions
+// instead of the compare / select chains of the generic cfun_apply_act; slope = 1 encodes "no activation")
+__device__ __forceinline__ float norm_act_in(float v, float mean, float rstd, int, float slope) {
   const float xh = (v - mean) * rstd;
-  return cfun_apply_act(xh, act, slope);
+  return fmaxf(xh, xh * slope);
 }
 __device__ __forceinline__ float4 norm_act_in4(const float4& v, const float4& s01, const float4& s23, int act, float slope) {
   // s01 = (mean0, rstd0, mean1, rstd1), s23 = (mean2, rstd2, mean3, rstd3): a row of stats[n][c..c+3][2]

@@ -17,7 +17,7 @@ REPO="$REPO" python - "$REPO/gpurun_out/pmc_mfma.csv" <<'PY'
 import csv, json, os, sys
 sys.path.insert(0, os.path.join(os.environ["REPO"], "tools"))
 from pmc_traffic import git_blob_sha1, SRC
-K = os.environ.get("CFUN_PMC_KERNEL", "k_conv_wino<3, false, false>")
+K = os.environ.get("CFUN_PMC_KERNEL", "k_conv_wino<3, false, false, false>")
 acc = {}
 for row in csv.DictReader(open(sys.argv[1])):
     if K in row["Kernel_Name"]:

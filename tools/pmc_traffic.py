@@ -16,7 +16,7 @@ def git_blob_sha1(path):
     data = open(path, "rb").read()
     return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 
-KERNEL = os.environ.get("CFUN_PMC_KERNEL", "k_conv_wino<3, false, false>")
+KERNEL = os.environ.get("CFUN_PMC_KERNEL", "k_conv_wino<3, false, false, false>")
 
 
 def avg_counter(path, counter):
