@@ -68,6 +68,8 @@ _SIGNATURES = {
     "cfun_lrelu_fwd": (C.c_int, [_P, _P, _L, _F, _P]),
     "cfun_lrelu_bwd": (C.c_int, [_P, _P, _P, _L, _F, _P]),
     "cfun_add": (C.c_int, [_P, _P, _P, _L, _P]),
+    "cfun_lrelu_bwd_add": (C.c_int, [_P, _P, _P, _P, _L, _I, _L, _F, _P]),
+    "cfun_instnorm_lrelu_bwd_add": (C.c_int, [_P, _P, _P, _P, _P, _I, _L, _I, _L, _F, _P, _Z, _P]),
     "cfun_upsample2_bwd": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "cfun_instnorm_workspace_bytes": (_Z, [_I, _L, _I]),
     "cfun_instnorm_stats": (C.c_int, [_P, _P, _I, _L, _I, _F, _P, _Z, _P]),

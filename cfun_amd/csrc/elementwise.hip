@@ -36,12 +36,14 @@ __global__ void k_lrelu_fwd_tail(const float* x, float* y, int64_t from, int64_t
   if (i < n) y[i] = x[i] > 0.f ? x[i] : x[i] * slope;
 }
 __global__ void __launch_bounds__(kBlock)
-k_lrelu_bwd(const float4* x, const float4* dy, float4* dx, int64_t n4, float slope) {
+k_lrelu_bwd(const float4* x, const float4* dy, float4* dx, int64_t n4, float slope, const float4* add) {
+  // add: a second gradient of x (x also feeds a residual / another branch), summed here instead of by a pass of its own
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
     const float4 v = x[i];
     float4 g = dy[i];
     g.x = v.x > 0.f ? g.x : g.x * slope; g.y = v.y > 0.f ? g.y : g.y * slope;
     g.z = v.z > 0.f ? g.z : g.z * slope; g.w = v.w > 0.f ? g.w : g.w * slope;
+    if (add) { const float4 a = add[i]; g.x += a.x; g.y += a.y; g.z += a.z; g.w += a.w; }
     dx[i] = g;
   }
 }
@@ -65,7 +67,7 @@ k_lrelu_fwd_s(const float4* x, float4* y, int64_t nvox, int cg, int64_t xg, int6
   }
 }
 __global__ void __launch_bounds__(kBlock)
-k_lrelu_bwd_s(const float4* x, const float4* dy, float4* dx, int64_t nvox, int cg, int64_t dyg, float slope) {
+k_lrelu_bwd_s(const float4* x, const float4* dy, float4* dx, int64_t nvox, int cg, int64_t dyg, float slope, const float4* add) {
   const int lanes = kBlock / cg, c = threadIdx.x % cg, vl = threadIdx.x / cg;
   if (vl >= lanes) return;
   for (int64_t v = (int64_t)blockIdx.x * lanes + vl; v < nvox; v += (int64_t)gridDim.x * lanes) {
@@ -73,6 +75,7 @@ k_lrelu_bwd_s(const float4* x, const float4* dy, float4* dx, int64_t nvox, int c
     float4 g = dy[v * dyg + c];
     g.x = a.x > 0.f ? g.x : g.x * slope; g.y = a.y > 0.f ? g.y : g.y * slope;
     g.z = a.z > 0.f ? g.z : g.z * slope; g.w = a.w > 0.f ? g.w : g.w * slope;
+    if (add) { const float4 b = add[v * cg + c]; g.x += b.x; g.y += b.y; g.z += b.z; g.w += b.w; }
     dx[v * cg + c] = g;
   }
 }
@@ -317,7 +320,7 @@ template <int VEC>
 __global__ void __launch_bounds__(kBlock)
 k_instnorm_lrelu_bwd(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ means,
                      const float* __restrict__ dy, float* __restrict__ dx, int64_t V, int C, float slope, int64_t dyg,
-                     int lanes) {
+                     int lanes, const float* __restrict__ add) {
   const int CG = C / VEC;
   const int cg = threadIdx.x % CG, vl = threadIdx.x / CG;
   const int n = blockIdx.y;
@@ -338,6 +341,12 @@ k_instnorm_lrelu_bwd(const float* __restrict__ x, const float* __restrict__ stat
       const float xh = (a[j] - mean[j]) * rstd[j];
       const float gn = xh > 0.f ? b[j] : b[j] * slope;
       r[j] = rstd[j] * (gn - m0[j] - xh * m1[j]);
+    }
+    if (add) {      // a second gradient of x (x also feeds a residual): summed here instead of by a pass of its own
+      float e[VEC];
+      Vec<VEC>::load(add, vox * CG + cg, e);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) r[j] += e[j];
     }
     Vec<VEC>::store(dx, vox * CG + cg, r);
   }
@@ -584,7 +593,7 @@ int cfun_lrelu_fwd(const float* x, float* y, int64_t n, float slope, cfun_stream
 int cfun_lrelu_bwd(const float* x, const float* dy, float* dx, int64_t n, float slope, cfun_stream_t stream) {
   if (n <= 0) return CFUN_OK;
   const int64_t n4 = (cfun_aligned16(x) && cfun_aligned16(dy) && cfun_aligned16(dx)) ? n / 4 : 0;
-  if (n4) hipLaunchKernelGGL(k_lrelu_bwd, dim3(ew_grid(n4)), dim3(kBlock), 0, cfun_st(stream), (const float4*)x, (const float4*)dy, (float4*)dx, n4, slope);
+  if (n4) hipLaunchKernelGGL(k_lrelu_bwd, dim3(ew_grid(n4)), dim3(kBlock), 0, cfun_st(stream), (const float4*)x, (const float4*)dy, (float4*)dx, n4, slope, (const float4*)nullptr);
   for (int64_t from = n4 * 4; from < n; from += 1024)
     hipLaunchKernelGGL(k_lrelu_bwd_tail, dim3(1), dim3(1024), 0, cfun_st(stream), x, dy, dx, from, n, slope);
   CFUN_LAUNCH_CHECK();
@@ -603,6 +612,22 @@ int cfun_lrelu_fwd_strided(const float* x, float* y, int64_t nvox, int32_t C, in
   return CFUN_OK;
 }
 
+int cfun_lrelu_bwd_add(const float* x, const float* dy, const float* add, float* dx, int64_t nvox, int32_t C,
+                       int64_t dy_stride, float slope, cfun_stream_t stream) {
+  if (nvox <= 0) return CFUN_OK;
+  if (C <= 0 || (C & 3) || (dy_stride & 3) || dy_stride < C) return CFUN_EINVAL;
+  if (!cfun_aligned16(x) || !cfun_aligned16(dy) || !cfun_aligned16(dx) || (add && !cfun_aligned16(add))) return CFUN_EALIGN;
+  if (C / 4 > kBlock) return CFUN_EINVAL;
+  if (dy_stride == C)
+    hipLaunchKernelGGL(k_lrelu_bwd, dim3(ew_grid(nvox * (C / 4))), dim3(kBlock), 0, cfun_st(stream), (const float4*)x,
+                       (const float4*)dy, (float4*)dx, nvox * (C / 4), slope, (const float4*)add);
+  else
+    hipLaunchKernelGGL(k_lrelu_bwd_s, dim3(apply_blocks(nvox, kBlock / (C / 4))), dim3(kBlock), 0, cfun_st(stream),
+                       (const float4*)x, (const float4*)dy, (float4*)dx, nvox, C / 4, dy_stride / 4, slope, (const float4*)add);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
 int cfun_lrelu_bwd_strided(const float* x, const float* dy, float* dx, int64_t nvox, int32_t C, int64_t dy_stride,
                            float slope, cfun_stream_t stream) {
   if (nvox <= 0) return CFUN_OK;
@@ -610,7 +635,7 @@ int cfun_lrelu_bwd_strided(const float* x, const float* dy, float* dx, int64_t n
   if (!cfun_aligned16(x) || !cfun_aligned16(dy) || !cfun_aligned16(dx)) return CFUN_EALIGN;
   if (C / 4 > kBlock) return CFUN_EINVAL;
   hipLaunchKernelGGL(k_lrelu_bwd_s, dim3(apply_blocks(nvox, kBlock / (C / 4))), dim3(kBlock), 0, cfun_st(stream),
-                     (const float4*)x, (const float4*)dy, (float4*)dx, nvox, C / 4, dy_stride / 4, slope);
+                     (const float4*)x, (const float4*)dy, (float4*)dx, nvox, C / 4, dy_stride / 4, slope, (const float4*)nullptr);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }
@@ -715,7 +740,14 @@ int cfun_instnorm_lrelu_bwd(const float* x, const float* stats, const float* dy,
 int cfun_instnorm_lrelu_bwd_strided(const float* x, const float* stats, const float* dy, float* dx, int32_t N, int64_t V,
                                     int32_t C, int64_t dy_stride, float slope, void* ws, size_t ws_bytes,
                                     cfun_stream_t stream) {
+  return cfun_instnorm_lrelu_bwd_add(x, stats, dy, nullptr, dx, N, V, C, dy_stride, slope, ws, ws_bytes, stream);
+}
+
+int cfun_instnorm_lrelu_bwd_add(const float* x, const float* stats, const float* dy, const float* add, float* dx, int32_t N,
+                                int64_t V, int32_t C, int64_t dy_stride, float slope, void* ws, size_t ws_bytes,
+                                cfun_stream_t stream) {
   if (N <= 0 || V <= 0) return CFUN_OK;
+  if (add && vec_of(C) == 4 && !cfun_aligned16(add)) return CFUN_EALIGN;
   if (C <= 0 || C / vec_of(C) > kBlock || dy_stride < C) return CFUN_EINVAL;
   const int vec = vec_of(C);
   if (dy_stride != C && (vec != 4 || (dy_stride & 3))) return CFUN_EINVAL;
@@ -735,8 +767,8 @@ int cfun_instnorm_lrelu_bwd_strided(const float* x, const float* stats, const fl
   hipLaunchKernelGGL(k_channel_finalize, dim3((N * C * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, cfun_st(stream),
                      (const double*)partial, means, N * C, C, r.blocks, 2, V, 0.f, 2);
   const dim3 grid(apply_blocks(V, r.lanes), (unsigned)N);
-  if (vec == 4) hipLaunchKernelGGL(k_instnorm_lrelu_bwd<4>, grid, dim3(kBlock), 0, cfun_st(stream), x, stats, (const float*)means, dy, dx, V, C, slope, dyg, r.lanes);
-  else hipLaunchKernelGGL(k_instnorm_lrelu_bwd<1>, grid, dim3(kBlock), 0, cfun_st(stream), x, stats, (const float*)means, dy, dx, V, C, slope, dyg, r.lanes);
+  if (vec == 4) hipLaunchKernelGGL(k_instnorm_lrelu_bwd<4>, grid, dim3(kBlock), 0, cfun_st(stream), x, stats, (const float*)means, dy, dx, V, C, slope, dyg, r.lanes, add);
+  else hipLaunchKernelGGL(k_instnorm_lrelu_bwd<1>, grid, dim3(kBlock), 0, cfun_st(stream), x, stats, (const float*)means, dy, dx, V, C, slope, dyg, r.lanes, add);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }
@@ -778,8 +810,8 @@ int cfun_instnorm_lrelu_bwd_apply(const float* x, const float* stats, const floa
   if (vec == 4 && (!cfun_aligned16(x) || !cfun_aligned16(dy) || !cfun_aligned16(dx))) return CFUN_EALIGN;
   const ReducePlan r = reduce_plan(N, V, C);
   const dim3 grid(apply_blocks(V, r.lanes), (unsigned)N);
-  if (vec == 4) hipLaunchKernelGGL(k_instnorm_lrelu_bwd<4>, grid, dim3(kBlock), 0, cfun_st(stream), x, stats, means, dy, dx, V, C, slope, dyg, r.lanes);
-  else hipLaunchKernelGGL(k_instnorm_lrelu_bwd<1>, grid, dim3(kBlock), 0, cfun_st(stream), x, stats, means, dy, dx, V, C, slope, dyg, r.lanes);
+  if (vec == 4) hipLaunchKernelGGL(k_instnorm_lrelu_bwd<4>, grid, dim3(kBlock), 0, cfun_st(stream), x, stats, means, dy, dx, V, C, slope, dyg, r.lanes, (const float*)nullptr);
+  else hipLaunchKernelGGL(k_instnorm_lrelu_bwd<1>, grid, dim3(kBlock), 0, cfun_st(stream), x, stats, means, dy, dx, V, C, slope, dyg, r.lanes, (const float*)nullptr);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }

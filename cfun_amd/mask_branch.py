@@ -200,10 +200,12 @@ class Modified3DUNet(nn.Module):
         sharded = (lambda: dist.depth_sharded_as(zs)) if zs is not None else dist.nullcontext
         folded = dist.slab_local if zs is not None else dist.nullcontext
 
-        def nl(t, out=None, rep=False, stats=None, lazy=False):      # rep: t is a replicated (folded) tensor -> plain local statistics
+        def nl(t, out=None, rep=False, stats=None, lazy=False, passthrough=False):      # rep: t is a replicated (folded) tensor -> plain local statistics
             # stats: the StatsSlot t's producer conv filled from its epilogue (empty on depth slabs: own pass then)
             # lazy: every consumer is a conv -> no apply pass, they stage t through the norm (ops.NormedInput)
-            return ops.instnorm_lrelu(t, out=out, shard=None if rep else zs, stats=stats, lazy=lazy and zs is None and LAZY)
+            # passthrough: also return t' (= t) for t's other consumer, the residual: gradients summed in the norm's backward
+            return ops.instnorm_lrelu(t, out=out, shard=None if rep else zs, stats=stats, lazy=lazy and zs is None and LAZY,
+                                      passthrough=passthrough)
 
         LAZY = os.environ.get("CFUN_FUSE_NORM", "1") != "0"      # (A/B switch: 0 = every norm / activation as its own pass)
         lz = zs is None and LAZY
@@ -230,7 +232,7 @@ class Modified3DUNet(nn.Module):
             # level 1: residual is the pre-activation stem output, context_1 is taken before the norm
             def head1(xp):
                 res = self.conv3d_c1_1(xp)
-                return ops.lrelu(res, lazy=lz), res
+                return ops.lrelu(res, lazy=lz, passthrough=True)       # (activation -> conv1, res' -> the residual add)
             s_out = slot(nb)
             out = self._dropout_pair(x, head1, self.conv3d_c1_2, self.lrelu_conv_c1[1], drop[0],
                                      lambda t, st: ops.lrelu(t, lazy=lz), out_stats=s_out)
@@ -238,8 +240,11 @@ class Modified3DUNet(nn.Module):
             # second half of that concat's buffer, the decoder later writes the first half -- no torch.cat, no copies
             b1 = self.base_n_filter
             cat1 = ops.ConcatBuffer(out, 2 * b1) if b1 % 4 == 0 else None
-            ctx = [ops.lrelu(out, out=None if cat1 is None else cat1.slot(b1, 2 * b1))]
-            h = nl(out, stats=s_out, lazy=True)      # -> conv3d_c2 only
+            # out feeds the level-1 concat (LeakyReLU) and the norm in front of conv3d_c2: the norm reads out' so that the two
+            # gradients meet inside the LeakyReLU's backward kernel
+            c0, out_ = ops.lrelu(out, out=None if cat1 is None else cat1.slot(b1, 2 * b1), passthrough=True)
+            ctx = [c0]
+            h = nl(out_, stats=s_out, lazy=True)      # -> conv3d_c2 only
         # levels 2..5: stride-2 conv, then the SAME norm_lrelu_conv weights twice around the dropout
         for lvl in (2, 3, 4, 5):
             down = getattr(self, "conv3d_c%d" % lvl)
@@ -254,7 +259,7 @@ class Modified3DUNet(nn.Module):
                 else:
                     sd = slot(nb)
                     res = down(hp, stats=sd)
-                return nl(res, rep=rep, stats=sd, lazy=True), res
+                return nl(res, rep=rep, stats=sd, lazy=True, passthrough=True)      # (normed -> conv1, res' -> the residual)
             head.stride = 2
             conv = getattr(self, "norm_lrelu_conv_c%d" % lvl)[2]
             with (folded() if rep else sharded()):

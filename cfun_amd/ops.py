@@ -809,8 +809,10 @@ def _combine_stats_over_ranks(stats, eps, shard):
 
 class _InstNormLReLU(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, eps, out=None, shard=None, pre=None, lazy=None):
+    def forward(ctx, x, eps, out=None, shard=None, pre=None, lazy=None, passthrough=False):
         # lazy: a list that receives the statistics -- no apply pass, the result aliases x (see NormedInput)
+        # passthrough: also return an alias of x for x's OTHER consumer (the residual add that follows, mask_branch.py:
+        # 131-176): its gradient arrives here as a second argument and is summed inside the backward kernel
         lib = _lib.load()
         x = _c(x)
         n, c = x.shape[0], x.shape[-1]
@@ -843,12 +845,16 @@ class _InstNormLReLU(torch.autograd.Function):
                                                       LRELU_SLOPE, st), "instnorm_lrelu_fwd_strided")
         ctx.shard = shard if zs else None
         ctx.save_for_backward(x, stats)
+        if passthrough:
+            return y, x.view(x.shape)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dx_other=None):
         lib = _lib.load()
         x, stats = ctx.saved_tensors
+        if dy is None:                      # only the passthrough branch was used
+            return dx_other, None, None, None, None, None, None
         n, c = x.shape[0], x.shape[-1]
         v = x.numel() // (n * c)
         rs = _row_stride(dy)
@@ -857,8 +863,10 @@ class _InstNormLReLU(torch.autograd.Function):
         dx = torch.empty_like(x)
         ws = workspace(lib.cfun_instnorm_workspace_bytes(n, v, c), x)
         if ctx.shard is None:
-            check(lib.cfun_instnorm_lrelu_bwd_strided(ptr(x), ptr(stats), ptr_raw(dy), ptr(dx), n, v, c, rs, LRELU_SLOPE,
-                                                      ptr(ws), ws.numel(), stream(x)), "instnorm_lrelu_bwd")
+            add = None if dx_other is None else _c(dx_other)
+            check(lib.cfun_instnorm_lrelu_bwd_add(ptr(x), ptr(stats), ptr_raw(dy), ptr(add), ptr(dx), n, v, c, rs, LRELU_SLOPE,
+                                                  ptr(ws), ws.numel(), stream(x)), "instnorm_lrelu_bwd")
+            dx_other = None
         else:       # z-sharded volume: the two means are over ALL slabs -- one all-reduce between the two kernel halves
             import torch.distributed as dist
             means = torch.empty((n, c, 2), dtype=torch.float32, device=x.device)
@@ -868,26 +876,32 @@ class _InstNormLReLU(torch.autograd.Function):
             means /= ctx.shard.world
             check(lib.cfun_instnorm_lrelu_bwd_apply(ptr(x), ptr(stats), ptr(means), ptr_raw(dy), ptr(dx), n, v, c, rs,
                                                     LRELU_SLOPE, stream(x)), "instnorm_lrelu_bwd_apply")
-        return dx, None, None, None, None, None
+        if dx_other is not None:
+            dx = dx + dx_other
+        return dx, None, None, None, None, None, None
 
 
-def instnorm_lrelu(x, eps=1e-5, out=None, shard=None, stats=None, lazy=False):
+def instnorm_lrelu(x, eps=1e-5, out=None, shard=None, stats=None, lazy=False, passthrough=False):
     """LeakyReLU(InstanceNorm3d(x)) (affine=False, biased variance), mask_branch.py:28-116.  ``out``: a
     ``ConcatBuffer.slot`` to write the result into (zero-copy concat).  ``shard``: x is this rank's equal depth slab of
     a volume z-sharded over ``shard``'s ranks -- the statistics (forward) and the two gradient means (backward) are
     combined with one small all-reduce each.  ``stats``: a ``StatsSlot`` the conv that produced x filled from its
     epilogue (this rank's slab for a sharded x) -- the statistics pass over x is then skipped.  ``lazy``: return a
-    ``NormedInput`` instead of running the apply pass -- the consumer convs stage x through the norm themselves."""
+    ``NormedInput`` instead of running the apply pass -- the consumer convs stage x through the norm themselves.
+    ``passthrough``: return (result, x') where x' aliases x and stands for it at x's other consumer (a residual add):
+    the two gradients of x are then summed inside the norm's backward kernel instead of by a pass of autograd's own."""
     if not lazy:
-        return _InstNormLReLU.apply(x, eps, out, shard, stats)
+        return _InstNormLReLU.apply(x, eps, out, shard, stats, None, passthrough)
     got = []
-    token = _InstNormLReLU.apply(x, eps, None, shard, stats, got)
-    return NormedInput(token, got[0], ACT_LRELU, LRELU_SLOPE)
+    r = _InstNormLReLU.apply(x, eps, None, shard, stats, got, passthrough)
+    if passthrough:
+        return NormedInput(r[0], got[0], ACT_LRELU, LRELU_SLOPE), r[1]
+    return NormedInput(r, got[0], ACT_LRELU, LRELU_SLOPE)
 
 
 class _LReLU(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, out=None, lazy=False):
+    def forward(ctx, x, out=None, lazy=False, passthrough=False):
         lib = _lib.load()
         x = _c(x)
         if lazy:                      # no pass: the result aliases x, the consumer conv applies the activation (NormedInput)
@@ -903,28 +917,45 @@ class _LReLU(torch.autograd.Function):
             check(lib.cfun_lrelu_fwd_strided(ptr(x), ptr_raw(y), x.numel() // c, c, c, out[0].c_total, LRELU_SLOPE,
                                              stream(x)), "lrelu_fwd_strided")
         ctx.save_for_backward(x)
+        if passthrough:               # (see _InstNormLReLU: x' for x's other consumer, gradients summed in the backward kernel)
+            return y, x.view(x.shape)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dx_other=None):
         lib = _lib.load()
         (x,) = ctx.saved_tensors
+        if dy is None:
+            return dx_other, None, None, None
         c = x.shape[-1]
         rs = _row_stride(dy)
         dx = torch.empty_like(x)
+        if dx_other is not None and c % 4 == 0 and x.data_ptr() % 16 == 0:
+            if rs is None:
+                dy, rs = _c(dy), c
+            add = _c(dx_other)
+            check(lib.cfun_lrelu_bwd_add(ptr(x), ptr_raw(dy), ptr(add), ptr(dx), x.numel() // c, c, rs, LRELU_SLOPE, stream(x)),
+                  "lrelu_bwd_add")
+            return dx, None, None, None
         if rs is None or rs == c or c % 4:          # dense (or odd) gradient: the flat kernel
             dy = _c(dy)
             check(lib.cfun_lrelu_bwd(ptr(x), ptr(dy), ptr(dx), x.numel(), LRELU_SLOPE, stream(x)), "lrelu_bwd")
         else:
             check(lib.cfun_lrelu_bwd_strided(ptr(x), ptr_raw(dy), ptr(dx), x.numel() // c, c, rs, LRELU_SLOPE,
                                              stream(x)), "lrelu_bwd_strided")
-        return dx, None, None
+        if dx_other is not None:
+            dx = dx + dx_other
+        return dx, None, None, None
 
 
-def lrelu(x, out=None, lazy=False):
-    if lazy:
-        return NormedInput(_LReLU.apply(x, None, True), None, ACT_LRELU, LRELU_SLOPE)
-    return _LReLU.apply(x, out)
+def lrelu(x, out=None, lazy=False, passthrough=False):
+    """LeakyReLU (mask_branch.py:18).  out / lazy / passthrough: see ``instnorm_lrelu``."""
+    r = _LReLU.apply(x, None if lazy else out, lazy, passthrough)
+    if not lazy:
+        return r
+    if passthrough:
+        return NormedInput(r[0], None, ACT_LRELU, LRELU_SLOPE), r[1]
+    return NormedInput(r, None, ACT_LRELU, LRELU_SLOPE)
 
 
 class _Add(torch.autograd.Function):

@@ -189,6 +189,11 @@ int cfun_lrelu_fwd_strided(const float* x, float* y, int64_t nvox, int32_t C, in
                            float slope, cfun_stream_t stream);
 int cfun_lrelu_bwd_strided(const float* x, const float* dy, float* dx, int64_t nvox, int32_t C, int64_t dy_stride,
                            float slope, cfun_stream_t stream);
+/* dx = lrelu'(x) * dy + add: x also feeds a second branch (a residual add, mask_branch.py:131-176; the level-1 concat,
+ * mask_branch.py:203) whose gradient `add` (dense, or NULL) is summed in the same pass instead of by autograd's own.
+ * dy may be channel-strided (dy_stride floats per voxel row; = C when dense).  C % 4 == 0. */
+int cfun_lrelu_bwd_add(const float* x, const float* dy, const float* add, float* dx, int64_t nvox, int32_t C,
+                       int64_t dy_stride, float slope, cfun_stream_t stream);
 int cfun_add(const float* a, const float* b, float* out, int64_t n, cfun_stream_t stream);
 /* lo[n,z,y,x,c] = sum of the 8 children of hi (backward of nearest x2 upsampling). lo dims D,H,W. */
 int cfun_upsample2_bwd(const float* hi, float* lo, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C,
@@ -208,6 +213,10 @@ int cfun_instnorm_lrelu_fwd_strided(const float* x, const float* stats, float* y
 int cfun_instnorm_lrelu_bwd_strided(const float* x, const float* stats, const float* dy, float* dx, int32_t N, int64_t V,
                                     int32_t C, int64_t dy_stride, float slope, void* ws, size_t ws_bytes,
                                     cfun_stream_t stream);
+/* ... + add (dense [N,V,C] or NULL): the second gradient of x when x also feeds a residual (see cfun_lrelu_bwd_add). */
+int cfun_instnorm_lrelu_bwd_add(const float* x, const float* stats, const float* dy, const float* add, float* dx, int32_t N,
+                                int64_t V, int32_t C, int64_t dy_stride, float slope, void* ws, size_t ws_bytes,
+                                cfun_stream_t stream);
 /* cfun_instnorm_lrelu_bwd in two halves, for a volume depth-sharded over several GPUs: the
  * means of gn = dy * lrelu'(xhat) and gn * xhat over the LOCAL voxels -> means [N,C,2]; the caller combines them across
  * the ranks (local voxel count weights, one all-reduce of 2*C floats per sample) and applies
