@@ -169,7 +169,7 @@ __device__ __forceinline__ void plane_sums(const float* __restrict__ probs, cons
       const float wd = B[j] * A[i], ws = A[j] * A[i];
       const float* pp = probs + vi * CT;
       const unsigned lab = labels[vi];
-      const uint32_t v = lab < (unsigned)CT ? (i == 1 ? 2u : 1u) << ((lab & 3u) * 8u) : 0u;   // (labels >= CT match no class)
+      const uint32_t v = (i == 1 ? 2u : 1u) << ((lab & 3u) * 8u);
       R[j][0] += (lab & 4u) ? 0u : v;
       R[j][1] += (lab & 4u) ? v : 0u;
 #pragma unroll
@@ -326,189 +326,6 @@ k_edge_bwd_gather(const float* __restrict__ dc, float* __restrict__ dprobs, int 
       }
 #pragma unroll
       for (int c = 0; c < CT - 1; ++c) { q0[0][c] = q0[1][c]; q0[1][c] = q0[2][c]; q1[0][c] = q1[1][c]; q1[1][c] = q1[2][c]; }
-    }
-  }
-}
-
-// ------------------------------------------------------------------ 8 classes: the class axis split over lane halves
-// Round 3.  The kernels above carry 7 foreground classes per thread: 182 registers, 2 waves per SIMD, and the march /
-// gather are bound by the latency of their 27 neighbour gathers per plane with too few waves to hide it.  For CT = 8 a
-// thread now owns FOUR classes of its column: lane = h * 32 + xl handles classes 4h .. 4h+3 (one packed target word, ONE
-// 16-byte load per neighbour; class 0 -- background, no edge term -- rides along in half 0 with weight 0).  The two
-// halves of a wave read the two 16-byte halves of the same 32 voxel records (1 KB contiguous per load instruction),
-// registers drop to a third, 4+ waves per SIMD are resident.  dc becomes [voxel][half][4 classes][dc0, dc1] (64 B, two
-// aligned 32-byte records per voxel); the softmax backward's dot product over all 8 classes is one __shfl_xor(.., 32).
-struct PlaneSums4 {
-  float dy[4], sm[4];
-};
-
-__device__ __forceinline__ void plane_sums4(const float* __restrict__ probs, const uint8_t* __restrict__ labels,
-                                            int64_t nbase, int z, int y, int x, int H, int W, unsigned h, PlaneSums4& P,
-                                            uint32_t& Tdyb, uint32_t& Tsm) {
-  const float A[3] = {1.f, 2.f, 1.f}, B[3] = {1.f, 0.f, -1.f};
-#pragma unroll
-  for (int c = 0; c < 4; ++c) { P.dy[c] = 0.f; P.sm[c] = 0.f; }
-  uint32_t R[3] = {0u, 0u, 0u};
-#pragma unroll
-  for (int j = 0; j < 3; ++j)
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int64_t vi = nbase + ((int64_t)z * H + (y + j)) * W + (x + i);
-      const float wd = B[j] * A[i], ws = A[j] * A[i];
-      const float4 pv = *reinterpret_cast<const float4*>(probs + vi * 8 + 4 * h);
-      const unsigned lab = labels[vi];
-      const uint32_t v = (i == 1 ? 2u : 1u) << ((lab & 3u) * 8u);
-      R[j] += ((lab >> 2) == h) ? v : 0u;      // (labels >= 8 match no class)
-      P.dy[0] += wd * pv.x; P.sm[0] += ws * pv.x;
-      P.dy[1] += wd * pv.y; P.sm[1] += ws * pv.y;
-      P.dy[2] += wd * pv.z; P.sm[2] += ws * pv.z;
-      P.dy[3] += wd * pv.w; P.sm[3] += ws * pv.w;
-    }
-  Tdyb = R[0] + 0x04040404u - R[2];
-  Tsm = R[0] + 2u * R[1] + R[2];
-}
-
-template <int MODE>       // as k_edge_march
-__global__ void __launch_bounds__(kBlock)
-k_edge_march_h(const float* __restrict__ probs, const uint8_t* __restrict__ labels, const float* __restrict__ gscale,
-               double* __restrict__ partial, float* __restrict__ dc, int n, int D, int H, int W) {
-  const int Do = D - 2, Ho = H - 2, Wo = W - 2;
-  const int nseg = (Do + kZSeg - 1) / kZSeg;
-  const int64_t total = (int64_t)n * nseg * Ho * Wo;
-  const float gs = MODE == 0 ? 0.f : (MODE == 1 ? gscale[0] : 1.f) * 2.f / ((float)Do * (float)Ho * (float)Wo * (float)n);
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const unsigned h = lane >> 5;
-  double acc = 0.0;
-  for (int64_t wcol = ((int64_t)blockIdx.x * (kBlock / 64) + wv) * 32; wcol < total; wcol += (int64_t)gridDim.x * (kBlock / 64) * 32) {
-    const int64_t i = wcol + (lane & 31);
-    if (i >= total) continue;
-    int64_t t = i;
-    const int x = (int)(t % Wo); t /= Wo;
-    const int y = (int)(t % Ho); t /= Ho;
-    const int seg = (int)(t % nseg);
-    const int64_t r = t / nseg;
-    const int64_t nbase = r * D * H * W;
-    const int z0 = seg * kZSeg;
-    const int z1 = z0 + kZSeg < Do ? z0 + kZSeg : Do;
-    PlaneSums4 P[3];
-    uint32_t Td[3], Ts[3];
-    plane_sums4(probs, labels, nbase, z0, y, x, H, W, h, P[0], Td[0], Ts[0]);
-    plane_sums4(probs, labels, nbase, z0 + 1, y, x, H, W, h, P[1], Td[1], Ts[1]);
-    float accf = 0.f;
-    for (int zo = z0; zo < z1; ++zo) {
-      plane_sums4(probs, labels, nbase, zo + 2, y, x, H, W, h, P[2], Td[2], Ts[2]);
-      const uint32_t t0b = Td[0] + 2u * Td[1] + Td[2];              // t0 + 16 per 8-bit field
-      const uint32_t t1b = Ts[0] + 0x10101010u - Ts[2];             // t1 + 16
-      float2 o4[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float live = (h == 0u && c == 0) ? 0.f : 1.f;         // class 0 has no edge term (model.py:958)
-        const float p0 = P[0].dy[c] + 2.f * P[1].dy[c] + P[2].dy[c], p1 = P[0].sm[c] - P[2].sm[c];
-        const float t0 = (float)((int)((t0b >> (c * 8)) & 0xffu) - 16);
-        const float t1 = (float)((int)((t1b >> (c * 8)) & 0xffu) - 16);
-        const float pm = cfun_fast_sqrt(p0 * p0 + p1 * p1 + p0 * p0);   // channel 0 twice (model.py:969-972)
-        const float tm = cfun_fast_sqrt(t0 * t0 + t1 * t1 + t0 * t0);
-        if (MODE != 1) {
-          const float d = pm - tm;
-          accf += live * (d * d);
-        }
-        if (MODE != 0) {
-          const float k = gs * (pm - tm) * cfun_fast_rcp(pm);       // 0 * inf -> NaN where torch's sqrt backward gives 0/0
-          o4[c] = (h == 0u && c == 0) ? make_float2(0.f, 0.f) : make_float2(k * 2.f * p0, k * p1);
-        }
-      }
-      if (MODE != 0) {
-        float4* o = reinterpret_cast<float4*>(dc + ((((r * Do + zo) * Ho + y) * Wo + x)) * 16 + 8 * h);
-        o[0] = make_float4(o4[0].x, o4[0].y, o4[1].x, o4[1].y);
-        o[1] = make_float4(o4[2].x, o4[2].y, o4[3].x, o4[3].y);
-      }
-      P[0] = P[1]; P[1] = P[2]; Td[0] = Td[1]; Td[1] = Td[2]; Ts[0] = Ts[1]; Ts[1] = Ts[2];
-    }
-    acc += (double)accf;
-  }
-  if (MODE != 1) {
-    const double s = block_sum(acc);
-    if (threadIdx.x == 0) partial[blockIdx.x] = s;
-  }
-}
-
-__device__ __forceinline__ void plane_adj4(const float* __restrict__ dc, int64_t r, int zo, int y, int x, int Do, int Ho,
-                                           int Wo, unsigned h, float (&q0)[4], float (&q1)[4]) {
-  const float A[3] = {1.f, 2.f, 1.f}, B[3] = {1.f, 0.f, -1.f};
-#pragma unroll
-  for (int c = 0; c < 4; ++c) { q0[c] = 0.f; q1[c] = 0.f; }
-  if (zo < 0 || zo >= Do) return;
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int oy = y - j;
-    if (oy < 0 || oy >= Ho) continue;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int ox = x - i;
-      if (ox < 0 || ox >= Wo) continue;
-      const float4* d = reinterpret_cast<const float4*>(dc + (((r * Do + zo) * Ho + oy) * Wo + ox) * 16 + 8 * h);
-      const float wd = B[j] * A[i], ws = A[j] * A[i];
-      const float4 a = d[0], b = d[1];
-      q0[0] += wd * a.x; q1[0] += ws * a.y; q0[1] += wd * a.z; q1[1] += ws * a.w;
-      q0[2] += wd * b.x; q1[2] += ws * b.y; q0[3] += wd * b.z; q1[3] += ws * b.w;
-    }
-  }
-}
-
-template <bool FUSE>      // as k_edge_bwd_gather
-__global__ void __launch_bounds__(kBlock)
-k_edge_bwd_gather_h(const float* __restrict__ dc, float* __restrict__ dprobs, int n, int D, int H, int W,
-                    const float* __restrict__ probs, const uint8_t* __restrict__ labels, const float* __restrict__ gce,
-                    const float* __restrict__ gedge) {
-  const int Do = D - 2, Ho = H - 2, Wo = W - 2;
-  const int nseg = (D + kZSeg - 1) / kZSeg;
-  const int64_t total = (int64_t)n * nseg * H * W;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const unsigned h = lane >> 5;
-  for (int64_t wcol = ((int64_t)blockIdx.x * (kBlock / 64) + wv) * 32; wcol < total; wcol += (int64_t)gridDim.x * (kBlock / 64) * 32) {
-    // (both halves of a column are live or idle together, so the __shfl_xor below always meets its partner)
-    const int64_t i = wcol + (lane & 31);
-    const bool on = i < total;
-    int64_t t = on ? i : 0;
-    const int x = (int)(t % W); t /= W;
-    const int y = (int)(t % H); t /= H;
-    const int seg = (int)(t % nseg);
-    const int64_t r = t / nseg;
-    const int z0 = seg * kZSeg;
-    const int z1 = z0 + kZSeg < D ? z0 + kZSeg : D;
-    float q0[3][4], q1[3][4];   // ring: [0] = zo = z-2, [1] = z-1, [2] = z
-    plane_adj4(dc, r, z0 - 2, y, x, Do, Ho, Wo, h, q0[0], q1[0]);
-    plane_adj4(dc, r, z0 - 1, y, x, Do, Ho, Wo, h, q0[1], q1[1]);
-    // every lane runs all kZSeg planes (a wave's 32 columns may lie in segments of different length, and the __shfl_xor
-    // must meet its partner in every iteration); planes past the segment are computed on clamped addresses, not stored
-    for (int k = 0; k < kZSeg; ++k) {
-      const int z = z0 + k;
-      const bool live = on && z < z1;
-      plane_adj4(dc, r, z, y, x, Do, Ho, Wo, h, q0[2], q1[2]);
-      const int64_t vox = ((r * D + (z < D ? z : D - 1)) * H + y) * W + x;
-      const float ge = gedge ? gedge[0] : 1.f;
-      float g[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) g[c] = ge * ((q0[2][c] + 2.f * q0[1][c] + q0[0][c]) + (q1[2][c] - q1[0][c]));
-      if (h == 0u) g[0] = 0.f;     // (its dc slot holds zeros anyway)
-      float4 out;
-      if (FUSE) {
-        const float gs = gce[0] / (float)((int64_t)n * D * H * W);
-        const unsigned lab = labels[vox];
-        const float4 pr = *reinterpret_cast<const float4*>(probs + vox * 8 + 4 * h);
-        float dot = pr.x * g[0] + pr.y * g[1] + pr.z * g[2] + pr.w * g[3];
-        dot += __shfl_xor(dot, 32, 64);
-        const unsigned l0 = 4u * h;
-        out = make_float4(pr.x * (g[0] - dot) + gs * (pr.x - (lab == l0 ? 1.f : 0.f)),
-                          pr.y * (g[1] - dot) + gs * (pr.y - (lab == l0 + 1u ? 1.f : 0.f)),
-                          pr.z * (g[2] - dot) + gs * (pr.z - (lab == l0 + 2u ? 1.f : 0.f)),
-                          pr.w * (g[3] - dot) + gs * (pr.w - (lab == l0 + 3u ? 1.f : 0.f)));
-      } else {
-        out = make_float4(g[0], g[1], g[2], g[3]);
-      }
-      if (live) *reinterpret_cast<float4*>(dprobs + vox * 8 + 4 * h) = out;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { q0[0][c] = q0[1][c]; q0[1][c] = q0[2][c]; q1[0][c] = q1[1][c]; q1[1][c] = q1[2][c]; }
     }
   }
 }
@@ -741,7 +558,7 @@ int cfun_edge_loss_fwd(const float* probs, const uint8_t* labels, float* loss, i
   const int64_t per = (int64_t)(D - 2) * (H - 2) * (W - 2);
   const int64_t cols = (int64_t)n * ((D - 2 + kZSeg - 1) / kZSeg) * (H - 2) * (W - 2);
   const unsigned blocks = vox_grid(cols);
-  if (C == 8) hipLaunchKernelGGL((k_edge_march_h<0>), dim3(blocks), dim3(kBlock), 0, cfun_st(stream), probs, labels, (const float*)nullptr, (double*)ws, (float*)nullptr, n, D, H, W);
+  if (C == 8) hipLaunchKernelGGL((k_edge_march<8, 0>), dim3(blocks), dim3(kBlock), 0, cfun_st(stream), probs, labels, (const float*)nullptr, (double*)ws, (float*)nullptr, n, D, H, W);
   else hipLaunchKernelGGL((k_edge_march<3, 0>), dim3(blocks), dim3(kBlock), 0, cfun_st(stream), probs, labels, (const float*)nullptr, (double*)ws, (float*)nullptr, n, D, H, W);
   hipLaunchKernelGGL(k_finalize_sum, dim3(1), dim3(64), 0, cfun_st(stream), (const double*)ws, (int)blocks,
                      1.0 / ((double)per * (double)n), loss);
@@ -751,8 +568,7 @@ int cfun_edge_loss_fwd(const float* probs, const uint8_t* labels, float* loss, i
 
 size_t cfun_edge_loss_bwd_workspace_bytes(int32_t n, int32_t D, int32_t H, int32_t W, int32_t C) {
   if (n <= 0 || D < 3 || H < 3 || W < 3 || C < 2) return 256;
-  const int per_vox = C == 8 ? 16 : 2 * (C - 1);      // 8 classes: [half][4 classes][2], see k_edge_march_h
-  return cfun_align_up((size_t)n * (D - 2) * (H - 2) * (W - 2) * per_vox * sizeof(float), 256);
+  return cfun_align_up((size_t)n * (D - 2) * (H - 2) * (W - 2) * 2 * (C - 1) * sizeof(float), 256);
 }
 
 int cfun_edge_loss_bwd(const float* probs, const uint8_t* labels, const float* gscale, float* dprobs, int32_t n,
@@ -765,8 +581,8 @@ int cfun_edge_loss_bwd(const float* probs, const uint8_t* labels, const float* g
   const int64_t cols_o = (int64_t)n * ((D - 2 + kZSeg - 1) / kZSeg) * (H - 2) * (W - 2);
   const int64_t cols_i = (int64_t)n * ((D + kZSeg - 1) / kZSeg) * H * W;
   if (C == 8) {
-    hipLaunchKernelGGL((k_edge_march_h<1>), dim3(vox_grid(cols_o)), dim3(kBlock), 0, cfun_st(stream), probs, labels, gscale, (double*)nullptr, (float*)ws, n, D, H, W);
-    hipLaunchKernelGGL((k_edge_bwd_gather_h<false>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dprobs, n, D, H, W, (const float*)nullptr, (const uint8_t*)nullptr, (const float*)nullptr, (const float*)nullptr);
+    hipLaunchKernelGGL((k_edge_march<8, 1>), dim3(vox_grid(cols_o)), dim3(kBlock), 0, cfun_st(stream), probs, labels, gscale, (double*)nullptr, (float*)ws, n, D, H, W);
+    hipLaunchKernelGGL((k_edge_bwd_gather<8, false>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dprobs, n, D, H, W, (const float*)nullptr, (const uint8_t*)nullptr, (const float*)nullptr, (const float*)nullptr);
   } else {
     hipLaunchKernelGGL((k_edge_march<3, 1>), dim3(vox_grid(cols_o)), dim3(kBlock), 0, cfun_st(stream), probs, labels, gscale, (double*)nullptr, (float*)ws, n, D, H, W);
     hipLaunchKernelGGL((k_edge_bwd_gather<3, false>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dprobs, n, D, H, W, (const float*)nullptr, (const uint8_t*)nullptr, (const float*)nullptr, (const float*)nullptr);
@@ -784,7 +600,7 @@ int cfun_edge_loss_fwd_save(const float* probs, const uint8_t* labels, float* lo
   const int64_t per = (int64_t)(D - 2) * (H - 2) * (W - 2);
   const int64_t cols = (int64_t)n * ((D - 2 + kZSeg - 1) / kZSeg) * (H - 2) * (W - 2);
   const unsigned blocks = vox_grid(cols);
-  if (C == 8) hipLaunchKernelGGL((k_edge_march_h<2>), dim3(blocks), dim3(kBlock), 0, cfun_st(stream), probs, labels, (const float*)nullptr, (double*)ws, dc, n, D, H, W);
+  if (C == 8) hipLaunchKernelGGL((k_edge_march<8, 2>), dim3(blocks), dim3(kBlock), 0, cfun_st(stream), probs, labels, (const float*)nullptr, (double*)ws, dc, n, D, H, W);
   else hipLaunchKernelGGL((k_edge_march<3, 2>), dim3(blocks), dim3(kBlock), 0, cfun_st(stream), probs, labels, (const float*)nullptr, (double*)ws, dc, n, D, H, W);
   hipLaunchKernelGGL(k_finalize_sum, dim3(1), dim3(64), 0, cfun_st(stream), (const double*)ws, (int)blocks,
                      1.0 / ((double)per * (double)n), loss);
@@ -801,7 +617,7 @@ int cfun_mask_losses_bwd_saved(const float* probs, const uint8_t* labels, const 
   if (total <= 0) return CFUN_OK;
   if (D < 3 || H < 3 || W < 3 || !dc || !g_edge) return CFUN_EINVAL;
   const int64_t cols_i = (int64_t)n * ((D + kZSeg - 1) / kZSeg) * H * W;
-  if (C == 8) hipLaunchKernelGGL((k_edge_bwd_gather_h<true>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), dc, dlogits, n, D, H, W, probs, labels, g_ce, g_edge);
+  if (C == 8) hipLaunchKernelGGL((k_edge_bwd_gather<8, true>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), dc, dlogits, n, D, H, W, probs, labels, g_ce, g_edge);
   else hipLaunchKernelGGL((k_edge_bwd_gather<3, true>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), dc, dlogits, n, D, H, W, probs, labels, g_ce, g_edge);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
@@ -818,8 +634,8 @@ int cfun_mask_losses_bwd(const float* probs, const uint8_t* labels, const float*
   const int64_t cols_o = (int64_t)n * ((D - 2 + kZSeg - 1) / kZSeg) * (H - 2) * (W - 2);
   const int64_t cols_i = (int64_t)n * ((D + kZSeg - 1) / kZSeg) * H * W;
   if (C == 8) {
-    hipLaunchKernelGGL((k_edge_march_h<1>), dim3(vox_grid(cols_o)), dim3(kBlock), 0, cfun_st(stream), probs, labels, g_edge, (double*)nullptr, (float*)ws, n, D, H, W);
-    hipLaunchKernelGGL((k_edge_bwd_gather_h<true>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dlogits, n, D, H, W, probs, labels, g_ce, (const float*)nullptr);
+    hipLaunchKernelGGL((k_edge_march<8, 1>), dim3(vox_grid(cols_o)), dim3(kBlock), 0, cfun_st(stream), probs, labels, g_edge, (double*)nullptr, (float*)ws, n, D, H, W);
+    hipLaunchKernelGGL((k_edge_bwd_gather<8, true>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dlogits, n, D, H, W, probs, labels, g_ce, (const float*)nullptr);
   } else {
     hipLaunchKernelGGL((k_edge_march<3, 1>), dim3(vox_grid(cols_o)), dim3(kBlock), 0, cfun_st(stream), probs, labels, g_edge, (double*)nullptr, (float*)ws, n, D, H, W);
     hipLaunchKernelGGL((k_edge_bwd_gather<3, true>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dlogits, n, D, H, W, probs, labels, g_ce, (const float*)nullptr);
