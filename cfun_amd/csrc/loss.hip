@@ -169,7 +169,7 @@ __device__ __forceinline__ void plane_sums(const float* __restrict__ probs, cons
       const float wd = B[j] * A[i], ws = A[j] * A[i];
       const float* pp = probs + vi * CT;
       const unsigned lab = labels[vi];
-      const uint32_t v = (i == 1 ? 2u : 1u) << ((lab & 3u) * 8u);
+      const uint32_t v = lab < (unsigned)CT ? (i == 1 ? 2u : 1u) << ((lab & 3u) * 8u) : 0u;   // (labels >= CT match no class)
       R[j][0] += (lab & 4u) ? 0u : v;
       R[j][1] += (lab & 4u) ? v : 0u;
 #pragma unroll
