@@ -1,0 +1,83 @@
+"""CPU tier: the dependency-free NIfTI-1 reader / writer (cfun_amd/nifti.py) -- round trips for the data types and
+layouts the reference's loaders meet (heart_main.py:211-352), gzip, big-endian files, scaled data, qform-only headers."""
+import struct
+
+import numpy as np
+import pytest
+
+from cfun_amd import nifti
+
+
+@pytest.mark.parametrize("dtype", ["uint8", "int16", "int32", "float32", "float64", "uint16"])
+@pytest.mark.parametrize("ext", [".nii", ".nii.gz"])
+def test_round_trip(tmp_path, dtype, ext):
+    rng = np.random.default_rng(0)
+    a = (rng.standard_normal((5, 7, 3)) * 50).astype(dtype)
+    aff = np.array([[0.0, -1.5, 0.0, 10.0], [2.0, 0.0, 0.0, -4.0], [0.0, 0.0, 3.0, 7.5], [0.0, 0.0, 0.0, 1.0]])
+    p = str(tmp_path / ("v" + ext))
+    nifti.save(nifti.Nifti1Image(a, aff), p)
+    img = nifti.load(p)
+    assert img.get_data().dtype == np.dtype(dtype) and img.shape == (5, 7, 3)
+    np.testing.assert_array_equal(img.get_data(), a)
+    np.testing.assert_allclose(img.affine, aff, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(img.header["pixdim"][1:4], [2.0, 1.5, 3.0], rtol=1e-6)
+
+
+def test_file_order_is_x_fastest(tmp_path):
+    """NIfTI stores x fastest: element (i, j, k) of the returned [X, Y, Z] array is voxel i + X*(j + Y*k) of the file."""
+    a = np.arange(2 * 3 * 4, dtype=np.int16).reshape((2, 3, 4), order="F")
+    p = str(tmp_path / "o.nii")
+    nifti.save(nifti.Nifti1Image(a, np.eye(4)), p)
+    raw = open(p, "rb").read()
+    np.testing.assert_array_equal(np.frombuffer(raw, "<i2", offset=352), np.arange(24))
+    np.testing.assert_array_equal(nifti.load(p).get_data(), a)
+
+
+def test_big_endian_scaled_qform(tmp_path):
+    """A big-endian file with scl_slope / scl_inter and only a qform (90 degree rotation about z, qfac -1)."""
+    a = np.arange(24, dtype=np.int16).reshape((2, 3, 4), order="F")
+    h = bytearray(348)
+    struct.pack_into(">i", h, 0, 348)
+    struct.pack_into(">8h", h, 40, 3, 2, 3, 4, 1, 1, 1, 1)
+    struct.pack_into(">2h", h, 70, 4, 16)
+    struct.pack_into(">8f", h, 76, -1.0, 2.0, 3.0, 4.0, 1.0, 1.0, 1.0, 1.0)
+    struct.pack_into(">3f", h, 108, 352.0, 0.5, 10.0)
+    struct.pack_into(">2h", h, 252, 1, 0)
+    s = float(np.sqrt(0.5))
+    struct.pack_into(">6f", h, 256, 0.0, 0.0, s, 1.0, 2.0, 3.0)     # quaternion (a = s, d = s): +90 degrees about z
+    h[344:348] = b"n+1\0"
+    p = str(tmp_path / "be.nii")
+    with open(p, "wb") as f:
+        f.write(bytes(h) + b"\0\0\0\0" + a.astype(">i2").tobytes(order="F"))
+    img = nifti.load(p)
+    np.testing.assert_allclose(img.get_data(), a * 0.5 + 10.0)
+    want = np.array([[0.0, -3.0, 0.0, 1.0], [2.0, 0.0, 0.0, 2.0], [0.0, 0.0, -4.0, 3.0], [0.0, 0.0, 0.0, 1.0]])
+    np.testing.assert_allclose(img.affine, want, atol=1e-6)
+
+
+def test_rejects_what_it_does_not_read(tmp_path):
+    p = str(tmp_path / "bad.nii")
+    open(p, "wb").write(b"\0" * 400)
+    with pytest.raises(ValueError):
+        nifti.load(p)
+    with pytest.raises(ValueError):
+        nifti.save(nifti.Nifti1Image(np.zeros((2, 2), np.complex64)), p)
+
+
+def test_reference_call_pattern(tmp_path):
+    """heart_main.py:300-302,349-352: load image + label, take the label's affine, save an int32 mask with it."""
+    rng = np.random.default_rng(1)
+    img = rng.standard_normal((8, 8, 4)).astype(np.float32)
+    lab = rng.integers(0, 8, (8, 8, 4)).astype(np.uint8)
+    aff = np.diag([0.8, 0.8, 1.2, 1.0])
+    nifti.save(nifti.Nifti1Image(img, aff), str(tmp_path / "i.nii.gz"))
+    nifti.save(nifti.Nifti1Image(lab, aff), str(tmp_path / "l.nii.gz"))
+    image = nifti.load(str(tmp_path / "i.nii.gz")).get_data().copy()
+    label = nifti.load(str(tmp_path / "l.nii.gz"))
+    mask = (label.get_data() > 3)
+    vol = nifti.Nifti1Image(mask.astype(np.int32), label.affine)
+    nifti.save(vol, str(tmp_path / "out.nii"))
+    back = nifti.load(str(tmp_path / "out.nii"))
+    assert image.shape == (8, 8, 4) and back.get_data().dtype == np.int32
+    np.testing.assert_array_equal(back.get_data(), mask.astype(np.int32))
+    np.testing.assert_allclose(back.affine, aff, atol=1e-6)
