@@ -64,6 +64,7 @@ _SIGNATURES = {
     "cfun_fc_workspace_bytes": (_Z, [_I, _I, _I]),
     "cfun_fc_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),
     "cfun_fc_bwd_weight": (C.c_int, [_P, _P, _P, _I, _I, _I, _P]),
+    "cfun_fc_bwd_weight_max_rows": (_I, [_I]),
     "cfun_fc_bwd_data": (C.c_int, [_P, _P, _P, _I, _I, _I, _P]),
     "cfun_lrelu_fwd": (C.c_int, [_P, _P, _L, _F, _P]),
     "cfun_lrelu_bwd": (C.c_int, [_P, _P, _P, _L, _F, _P]),

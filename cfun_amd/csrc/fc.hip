@@ -214,6 +214,18 @@ inline int fc_chunks(int K) { return (K + kKC - 1) / kKC; }
 
 }  // namespace
 
+// dynamic LDS a workgroup may use on this device (160 KB on MI355X); queried once
+static size_t fc_lds_limit() {
+  static size_t lim = 0;
+  if (!lim) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0)
+      v = 64 * 1024;
+    lim = (size_t)v;
+  }
+  return lim;
+}
+
 extern "C" size_t cfun_fc_workspace_bytes(int32_t R, int32_t K, int32_t O) {
   if (R <= 0 || K <= 0 || O <= 0) return 0;
   return (size_t)fc_chunks(K) * R * O * sizeof(float);
@@ -229,6 +241,7 @@ extern "C" int cfun_fc_fwd(const float* x, const float* w, const float* scale, c
   hipStream_t st = cfun_st(stream);
   const int nch = fc_chunks(K), nr = (R + 15) / 16;
   const size_t lds = (size_t)16 * nr * kXS * sizeof(float);
+  if (lds > fc_lds_limit()) return CFUN_EINVAL;
   auto kern = nr == 1 ? k_fc_fwd<1> : nr == 2 ? k_fc_fwd<2> : nr == 3 ? k_fc_fwd<3> : k_fc_fwd<4>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -242,9 +255,19 @@ extern "C" int cfun_fc_fwd(const float* x, const float* w, const float* scale, c
   return CFUN_OK;
 }
 
+// k_fc_bwd_weight keeps its x slice and all of g in LDS: R * (kXS + O rounded to 16) floats.  The largest R that fits
+// (>= 1 for every O the kernels accept); callers with more rows split them and add the partial gradients.
+extern "C" int32_t cfun_fc_bwd_weight_max_rows(int32_t O) {
+  if (O <= 0) return 0;
+  const size_t per_row = (size_t)(kXS + (O + 15) / 16 * 16) * sizeof(float);
+  const size_t r = fc_lds_limit() / per_row;
+  return (int32_t)(r > 64 ? 64 : r);
+}
+
 extern "C" int cfun_fc_bwd_weight(const float* x, const float* g, float* dw, int32_t R, int32_t K, int32_t O,
                                   cfun_stream_t stream) {
   if (R < 0 || K <= 0 || O <= 0 || (K & 3) || R > 64) return CFUN_EINVAL;
+  if (R > cfun_fc_bwd_weight_max_rows(O)) return CFUN_EINVAL;      // (not a raw hipError from hipFuncSetAttribute)
   if (!dw || !cfun_aligned16(dw)) return CFUN_EINVAL;
   hipStream_t st = cfun_st(stream);
   if (R == 0) return (int)hipMemsetAsync(dw, 0, (size_t)O * K * sizeof(float), st);
@@ -266,6 +289,7 @@ extern "C" int cfun_fc_bwd_data(const float* g, const float* w, float* dx, int32
   if (R == 0) return CFUN_OK;
   if (!g || !w || !dx || !cfun_aligned16(w) || !cfun_aligned16(dx)) return CFUN_EINVAL;
   const size_t lds = (size_t)O * kRT * sizeof(float);
+  if (lds > fc_lds_limit()) return CFUN_EINVAL;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fc_bwd_data),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -460,19 +460,41 @@ def local_anchor_index(level_counts, shard=None):
 _ZPLANS = {}
 
 
+def prepare_zshard_groups(group=None):
+    """Create, ONCE and for every possible number of positive RoIs, the sub-groups ``zshard_plan`` hands out: for each
+    divisor n of the group's size R (n < R) the n groups of R / n consecutive ranks.  ``dist.new_group`` is collective
+    over the DEFAULT process group -- every rank of the job must call this (same ``group`` argument), at set-up time;
+    creating groups lazily inside a step, keyed on the data-dependent RoI count, stalls all ranks mid-step and hangs
+    when ``group`` is a strict sub-group (hybrid data-parallel x depth-sharded layouts) because the outside ranks never
+    reach the call."""
+    world = dist.get_world_size(group)
+    base = dist.get_process_group_ranks(group) if group is not None else list(range(world))
+    plans = {}
+    for n_pos in range(1, world):
+        if world % n_pos:
+            continue
+        rs = world // n_pos
+        plans[n_pos] = (rs, [dist.new_group(ranks=base[i * rs:(i + 1) * rs]) for i in range(n_pos)])
+    _ZPLANS[(id(group), world)] = plans
+    return plans
+
+
 def zshard_plan(shard, n_pos):
     """Sub-groups for z-sharded mask heads: with more ranks than positive RoIs (8 GPUs, 4 RoIs) every RoI's U-Net is
     split over world / n_pos consecutive ranks.  Returns (ranks per RoI, [process group per RoI]) or None when the ranks
-    do not divide evenly (then RoIs are dealt round-robin, one whole U-Net per rank).  ``dist.new_group`` is collective:
-    every rank of ``shard`` must call this with the same arguments; the groups are cached."""
+    do not divide evenly (then RoIs are dealt round-robin, one whole U-Net per rank).  The groups come from
+    ``prepare_zshard_groups``; when the job has not called it, they are created on first use -- allowed only while
+    ``shard.group`` spans the whole job (then every rank is here and the collective ``new_group`` calls line up)."""
     if n_pos <= 0 or shard.world <= n_pos or shard.world % n_pos:
         return None
-    key = (id(shard.group), shard.world, n_pos)
+    key = (id(shard.group), shard.world)
     if key not in _ZPLANS:
-        rs = shard.world // n_pos
-        base = dist.get_process_group_ranks(shard.group) if shard.group is not None else list(range(shard.world))
-        _ZPLANS[key] = (rs, [dist.new_group(ranks=base[i * rs:(i + 1) * rs]) for i in range(n_pos)])
-    return _ZPLANS[key]
+        if shard.group is not None and shard.world != dist.get_world_size():
+            raise RuntimeError("zshard_plan: call cfun_amd.dist.prepare_zshard_groups(group) on EVERY rank of the job at "
+                               "set-up -- new_group is collective over the default group and cannot be created from "
+                               "inside a sub-group's step")
+        prepare_zshard_groups(shard.group)
+    return _ZPLANS[key].get(n_pos)
 
 
 def sharded_training_step(net, s, shard=None, zshard_unet=True, dropout_seed=0):

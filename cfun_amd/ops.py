@@ -711,7 +711,17 @@ class _FC(torch.autograd.Function):
             check(lib.cfun_fc_bwd_data(ptr(g), ptr(w), ptr(dx), r, k, o, st), "fc_bwd_data")
         if need_w:
             dw = torch.empty_like(w)
-            check(lib.cfun_fc_bwd_weight(ptr(x), ptr(g), ptr(dw), r, k, o, st), "fc_bwd_weight")
+            rmax = max(1, int(lib.cfun_fc_bwd_weight_max_rows(o)))      # rows whose g + x slice fit the kernel's LDS
+            if r <= rmax:
+                check(lib.cfun_fc_bwd_weight(ptr(x), ptr(g), ptr(dw), r, k, o, st), "fc_bwd_weight")
+            else:                       # (wide FC layers at large R: row chunks, partial gradients added)
+                part = torch.empty_like(w)
+                for i, r0 in enumerate(range(0, r, rmax)):
+                    xs, gs = _c(x[r0:r0 + rmax]), _c(g[r0:r0 + rmax])
+                    check(lib.cfun_fc_bwd_weight(ptr(xs), ptr(gs), ptr(dw if i == 0 else part), xs.shape[0], k, o, st),
+                          "fc_bwd_weight")
+                    if i:
+                        dw += part
         if need_shift:
             dshift = channel_sum(gp) if r else torch.zeros((o,), dtype=torch.float32, device=dy.device)
         return dx, dw, None, dshift, None

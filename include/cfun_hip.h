@@ -172,7 +172,11 @@ int cfun_channel_sum(const float* g, float* out, int64_t nvox, int32_t C, void* 
 size_t cfun_fc_workspace_bytes(int32_t R, int32_t K, int32_t O);
 int cfun_fc_fwd(const float* x, const float* w, const float* scale, const float* shift, float* y, int32_t R, int32_t K,
                 int32_t O, int32_t act, void* ws, size_t ws_bytes, cfun_stream_t stream);
-/* dw[O][K] = g[R][O]^T . x[R][K]   (g = dL/d(x.w^T), i.e. already multiplied by act' and scale: cfun_act_bwd) */
+/* dw[O][K] = g[R][O]^T . x[R][K]   (g = dL/d(x.w^T), i.e. already multiplied by act' and scale: cfun_act_bwd).
+ * The kernel keeps g and its x slice in LDS: R <= cfun_fc_bwd_weight_max_rows(O) (12+ RoIs at every O of the path; 64
+ * rows x O = 1024, the reference's default FC width at inference batch sizes, do not fit 160 KB) -- CFUN_EINVAL beyond
+ * that; callers split the rows and add the partial gradients (cfun_amd.ops._FC does). */
+int32_t cfun_fc_bwd_weight_max_rows(int32_t O);
 int cfun_fc_bwd_weight(const float* x, const float* g, float* dw, int32_t R, int32_t K, int32_t O, cfun_stream_t stream);
 /* dx[R][K] = g[R][O] . w[O][K] */
 int cfun_fc_bwd_data(const float* g, const float* w, float* dx, int32_t R, int32_t K, int32_t O, cfun_stream_t stream);

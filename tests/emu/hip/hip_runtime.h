@@ -33,6 +33,9 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "emulated hip error"; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+#define hipDeviceAttributeMaxSharedMemoryPerBlock 0
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 160 * 1024; return hipSuccess; }   // MI355X: 160 KB LDS per CU
 
 struct dim3 {
   unsigned x, y, z;
