@@ -86,6 +86,8 @@ _SIGNATURES = {
     "cfun_maxpool2_bwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cfun_roi_align3d_fwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "cfun_roi_align3d_bwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "cfun_roi_align3d_slab_fwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "cfun_roi_align3d_slab_bwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "cfun_nms3d_workspace_bytes": (_Z, [_I]),
     "cfun_nms3d": (C.c_int, [_P, _P, _I, _F, _I, _P, _P, _P, _Z, _P]),
     "cfun_softmax_fwd": (C.c_int, [_P, _P, _L, _I, _P]),

@@ -53,7 +53,9 @@ __device__ __forceinline__ Lerp make_lerp(int o, int in_size, int out_size) {
 
 __global__ void __launch_bounds__(256)
 k_roi_align_fwd(const float* __restrict__ fm, const int32_t* __restrict__ bounds, float* __restrict__ out,
-                int64_t total, int D, int H, int W, int C, int pd, int ph, int pw) {
+                int64_t total, int D, int H, int W, int C, int pd, int ph, int pw, int sz0, int sdl) {
+  // fm holds depth planes [sz0, sz0 + sdl) of the [D,H,W,C] map (a depth slab of a sharded volume; the whole map: 0, D);
+  // planes outside read as zeros, so the slabs' partial results add up to the RoIAlign of the whole map
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     int64_t t = i;
     const int c = (int)(t % C); t /= C;
@@ -65,21 +67,24 @@ k_roi_align_fwd(const float* __restrict__ fm, const int32_t* __restrict__ bounds
     const int nz = b[3] - b[0], ny = b[4] - b[1], nx = b[5] - b[2];
     if (nz <= 0 || ny <= 0 || nx <= 0) { out[i] = 0.f; continue; }  // failed crop -> zeros (model.py:284-287)
     const Lerp lz = make_lerp(oz, nz, pd), ly = make_lerp(oy, ny, ph), lx = make_lerp(ox, nx, pw);
-    const int64_t z0 = (int64_t)(b[0] + lz.i0) * H, z1 = (int64_t)(b[0] + lz.i1) * H;
+    const int za = b[0] + lz.i0 - sz0, zb = b[0] + lz.i1 - sz0;        // slab-local planes
+    const bool in_a = za >= 0 && za < sdl, in_b = zb >= 0 && zb < sdl;
+    const int64_t z0 = (int64_t)(in_a ? za : 0) * H, z1 = (int64_t)(in_b ? zb : 0) * H;
     const int64_t y0 = b[1] + ly.i0, y1 = b[1] + ly.i1;
     const int64_t x0 = b[2] + lx.i0, x1 = b[2] + lx.i1;
     const float v000 = fm[((z0 + y0) * W + x0) * C + c], v001 = fm[((z0 + y0) * W + x1) * C + c];
     const float v010 = fm[((z0 + y1) * W + x0) * C + c], v011 = fm[((z0 + y1) * W + x1) * C + c];
     const float v100 = fm[((z1 + y0) * W + x0) * C + c], v101 = fm[((z1 + y0) * W + x1) * C + c];
     const float v110 = fm[((z1 + y1) * W + x0) * C + c], v111 = fm[((z1 + y1) * W + x1) * C + c];
-    out[i] = lz.w0 * (ly.w0 * (lx.w0 * v000 + lx.w1 * v001) + ly.w1 * (lx.w0 * v010 + lx.w1 * v011)) +
-             lz.w1 * (ly.w0 * (lx.w0 * v100 + lx.w1 * v101) + ly.w1 * (lx.w0 * v110 + lx.w1 * v111));
+    const float pa = ly.w0 * (lx.w0 * v000 + lx.w1 * v001) + ly.w1 * (lx.w0 * v010 + lx.w1 * v011);
+    const float pb = ly.w0 * (lx.w0 * v100 + lx.w1 * v101) + ly.w1 * (lx.w0 * v110 + lx.w1 * v111);
+    out[i] = lz.w0 * (in_a ? pa : 0.f) + lz.w1 * (in_b ? pb : 0.f);
   }
 }
 
 __global__ void __launch_bounds__(256)
 k_roi_align_bwd(const float* __restrict__ dout, const int32_t* __restrict__ bounds, float* __restrict__ dfm,
-                int64_t total, int D, int H, int W, int C, int pd, int ph, int pw) {
+                int64_t total, int D, int H, int W, int C, int pd, int ph, int pw, int sz0, int sdl) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     int64_t t = i;
     const int c = (int)(t % C); t /= C;
@@ -97,7 +102,9 @@ k_roi_align_bwd(const float* __restrict__ dout, const int32_t* __restrict__ boun
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int a = k >> 2, bb = (k >> 1) & 1, cc = k & 1;
-      atomicAdd(&dfm[(((int64_t)zi[a] * H + yi[bb]) * W + xi[cc]) * C + c], g * wz[a] * wy[bb] * wx[cc]);
+      const int zl = zi[a] - sz0;
+      if (zl < 0 || zl >= sdl) continue;       // another slab's plane
+      atomicAdd(&dfm[(((int64_t)zl * H + yi[bb]) * W + xi[cc]) * C + c], g * wz[a] * wy[bb] * wx[cc]);
     }
   }
 }
@@ -378,24 +385,38 @@ extern "C" {
 
 int cfun_roi_align3d_fwd(const float* fm, const float* boxes, float* out, int32_t* bounds, int32_t R, int32_t D,
                          int32_t H, int32_t W, int32_t C, int32_t pd, int32_t ph, int32_t pw, cfun_stream_t stream) {
-  if (R <= 0) return CFUN_OK;
-  if (D <= 0 || H <= 0 || W <= 0 || C <= 0 || pd <= 0 || ph <= 0 || pw <= 0) return CFUN_EINVAL;
-  hipLaunchKernelGGL(k_roi_bounds, dim3((R + 63) / 64), dim3(64), 0, cfun_st(stream), boxes, bounds, R, D, H, W);
-  const int64_t total = (int64_t)R * pd * ph * pw * C;
-  int64_t blocks = (total + 255) / 256;
-  if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(k_roi_align_fwd, dim3((unsigned)blocks), dim3(256), 0, cfun_st(stream), fm, bounds, out, total, D, H, W, C, pd, ph, pw);
-  CFUN_LAUNCH_CHECK();
-  return CFUN_OK;
+  return cfun_roi_align3d_slab_fwd(fm, boxes, out, bounds, R, D, H, W, C, 0, D, pd, ph, pw, stream);
 }
 
 int cfun_roi_align3d_bwd(const float* dout, const int32_t* bounds, float* dfm, int32_t R, int32_t D, int32_t H,
                          int32_t W, int32_t C, int32_t pd, int32_t ph, int32_t pw, cfun_stream_t stream) {
+  return cfun_roi_align3d_slab_bwd(dout, bounds, dfm, R, D, H, W, C, 0, D, pd, ph, pw, stream);
+}
+
+int cfun_roi_align3d_slab_fwd(const float* fm, const float* boxes, float* out, int32_t* bounds, int32_t R, int32_t D,
+                              int32_t H, int32_t W, int32_t C, int32_t z0, int32_t dl, int32_t pd, int32_t ph, int32_t pw,
+                              cfun_stream_t stream) {
   if (R <= 0) return CFUN_OK;
+  if (D <= 0 || H <= 0 || W <= 0 || C <= 0 || pd <= 0 || ph <= 0 || pw <= 0) return CFUN_EINVAL;
+  if (z0 < 0 || dl <= 0 || z0 + dl > D) return CFUN_EINVAL;
+  hipLaunchKernelGGL(k_roi_bounds, dim3((R + 63) / 64), dim3(64), 0, cfun_st(stream), boxes, bounds, R, D, H, W);
   const int64_t total = (int64_t)R * pd * ph * pw * C;
   int64_t blocks = (total + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(k_roi_align_bwd, dim3((unsigned)blocks), dim3(256), 0, cfun_st(stream), dout, bounds, dfm, total, D, H, W, C, pd, ph, pw);
+  hipLaunchKernelGGL(k_roi_align_fwd, dim3((unsigned)blocks), dim3(256), 0, cfun_st(stream), fm, bounds, out, total, D, H, W, C, pd, ph, pw, z0, dl);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+int cfun_roi_align3d_slab_bwd(const float* dout, const int32_t* bounds, float* dfm, int32_t R, int32_t D, int32_t H,
+                              int32_t W, int32_t C, int32_t z0, int32_t dl, int32_t pd, int32_t ph, int32_t pw,
+                              cfun_stream_t stream) {
+  if (R <= 0) return CFUN_OK;
+  if (z0 < 0 || dl <= 0 || z0 + dl > D) return CFUN_EINVAL;
+  const int64_t total = (int64_t)R * pd * ph * pw * C;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(k_roi_align_bwd, dim3((unsigned)blocks), dim3(256), 0, cfun_st(stream), dout, bounds, dfm, total, D, H, W, C, pd, ph, pw, z0, dl);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }

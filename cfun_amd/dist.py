@@ -336,14 +336,47 @@ def gather_rpn_outputs(level_outputs, shard=None):
     return outs
 
 
+def gather_rpn_candidates(level_outputs, net, mode, shard=None):
+    """The proposal set of a depth-sharded volume from ONE small all-gather: every rank
+    takes the top PRE_NMS_LIMIT of its own anchors by foreground score and contributes (score, 6 raw box outputs, global
+    anchor index) -- K x 8 floats, 188 KB at K = 6000 -- instead of its whole logits / probs / bbox tensors (one
+    collective per tensor kind and level before).  The global top PRE_NMS_LIMIT is a subset of the union of the local
+    ones, so after the merge (score descending, ties by anchor index) every rank runs the identical, deterministic
+    decode / clip / NMS of ``model.proposal_layer``.  Returns rois [1, K', 6]."""
+    from . import model as M
+    shard = shard or _CTX
+    cfg = net.config
+    probs = torch.cat([lv[1] for lv in level_outputs], dim=1)[0].detach()          # [A/R, 2] local order: level 2, level 3
+    bbox = torch.cat([lv[2] for lv in level_outputs], dim=1)[0].detach()           # [A/R, 6]
+    counts = [lv[0].shape[1] * shard.world for lv in level_outputs]
+    gidx = local_anchor_index(counts, shard).to(probs.device)
+    n_local = probs.shape[0]
+    k = min(int(cfg.PRE_NMS_LIMIT), n_local)
+    sc, li = probs[:, 1].topk(k, sorted=True)
+    pack = torch.empty((k, 8), dtype=torch.float32, device=probs.device)
+    pack[:, 0] = sc
+    pack[:, 1:7] = bbox[li]
+    pack[:, 7] = gidx[li].to(torch.float32)         # (anchor counts are far below 2^24: exact in fp32)
+    parts = [torch.empty_like(pack) for _ in range(shard.world)]
+    dist.all_gather(parts, pack, group=shard.group)
+    allc = torch.cat(parts, dim=0)
+    idx = allc[:, 7].to(torch.long)
+    # score descending, ties by ascending anchor index: sort by index first, then a stable sort by score
+    o1 = torch.argsort(idx, stable=True)
+    o2 = torch.argsort(allc[o1, 0], descending=True, stable=True)
+    order = o1[o2][:min(int(cfg.PRE_NMS_LIMIT), sum(counts))]
+    count = cfg.POST_NMS_ROIS_TRAINING if mode == "training" else cfg.POST_NMS_ROIS_INFERENCE
+    return M.proposals_from_candidates(allc[order, 0], allc[order, 1:7], net.anchors[idx[order]], count, cfg.RPN_NMS_THRESHOLD, cfg)
+
+
 def sharded_backbone_rpn(net, image_slab):
     """Depth-sharded FPN -> RPN -> proposals of ``cfun_amd.step.CFUNHotPath`` on this rank's slab
     [1,1,D/R,H,W].  Returns (p2_slab, p3_slab, rpn_logits, rpn_probs, rpn_bbox, rpn_rois) with the RPN tensors and
     the proposals global and identical on every rank."""
     p2, p3 = net.fpn.forward_ndhwc(ops.to_ndhwc(image_slab))
     local = [net.rpn.forward_ndhwc(p) for p in (p2, p3)]
-    logits, probs, bbox = gather_rpn_outputs(local)
-    rois = net.proposals(probs, bbox, "inference" if not net.training else "training")
+    logits, probs, bbox = gather_rpn_outputs(local)         # (the full RPN tensors: this entry point returns them)
+    rois = gather_rpn_candidates(local, net, "inference" if not net.training else "training")
     return p2, p3, logits, probs, bbox, rois
 
 
@@ -370,6 +403,31 @@ class _AllGatherDepth(torch.autograd.Function):
         dist.all_reduce(g, group=shard.group)
         d = g.shape[1] // shard.world
         return g.narrow(1, shard.rank * d, d).contiguous(), None
+
+
+class _AllReduceSum(torch.autograd.Function):
+    """sum over the ranks, forward and backward (the ranks' additive shares of the RoI-aligned crops -> the crops; the
+    ranks' gradients of the crops, each non-zero only for the RoIs that rank classifies -> the full gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, shard):
+        ctx.shard = shard
+        y = x.contiguous().clone()
+        dist.all_reduce(y, group=shard.group)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().clone()
+        dist.all_reduce(g, group=ctx.shard.group)
+        return g, None
+
+
+def all_reduce_sum(x, shard=None):
+    shard = shard or _CTX
+    if shard is None or shard.world == 1:
+        return x
+    return _AllReduceSum.apply(x, shard)
 
 
 def gather_depth(x, shard=None):
@@ -502,11 +560,12 @@ def sharded_training_step(net, s, shard=None, zshard_unet=True, dropout_seed=0):
 
     * FPN / RPN depth-sharded (halo exchange inside the depth-coupled convs), proposals from one all-gather;
     * RPN losses on the rank's own anchors with the global normalisation (so local gradients are exact);
-    * head RoIs dealt round-robin: rank r classifies rois[r::R] (on the all-gathered p2 / p3) and runs the mask
-      U-Net on p_rois[r::R] (crops of the raw image, which every rank holds);
+    * head RoIs dealt round-robin: rank r classifies rois[r::R] -- on RoI-aligned crops every rank computes on its own
+      p2 / p3 slabs and ONE all-reduce sums (``ops.roi_align(slab=...)``) -- and runs the mask U-Net on p_rois[r::R]
+      (crops of the raw image, which every rank holds);
     * with more ranks than positive RoIs (``zshard_unet``; 8 GPUs, 4 RoIs): every RoI's U-Net z-sharded over
-      world / n_pos ranks (``zshard_plan``, ``Modified3DUNet.forward_ndhwc(zshard=...)``), its logits all-gathered inside
-      the sub-group and the mask losses evaluated redundantly there (each rank reports 1 / sub-group size of them);
+      world / n_pos ranks (``zshard_plan``, ``Modified3DUNet.forward_ndhwc(zshard=...)``), the mask losses evaluated on
+      the slabs (cross entropy voxel-local, the Sobel edge loss with one halo plane of probabilities from each neighbour);
     * every loss returned as THIS rank's additive share: sum over ranks = the single-GPU loss, and the sum over
       ranks of the parameter gradients = the single-GPU gradient (all-reduce them with op=SUM).
 
@@ -521,9 +580,8 @@ def sharded_training_step(net, s, shard=None, zshard_unet=True, dropout_seed=0):
     image = s["image"]
     p2s, p3s = net.fpn.forward_ndhwc(ops.to_ndhwc(slab(image, dim=2, shard=shard)))
     local = [net.rpn.forward_ndhwc(p) for p in (p2s, p3s)]
-    with torch.no_grad():
-        _, probs_g, bbox_g = gather_rpn_outputs([[t.detach() for t in lv] for lv in local], shard)
-    rpn_rois = net.proposals(probs_g, bbox_g, "training")           # identical on every rank (unused by the injected heads)
+    with torch.no_grad():      # one 188 KB all-gather of the ranks' top candidates; identical proposals on every rank
+        rpn_rois = gather_rpn_candidates(local, net, "training", shard)
 
     # ---- RPN losses on the local anchors (model.py:808-860), global normalisation
     counts = [lv[0].shape[1] * R for lv in local]
@@ -541,18 +599,21 @@ def sharded_training_step(net, s, shard=None, zshard_unet=True, dropout_seed=0):
     l_rpn_box = F.smooth_l1_loss(bbox_l[psel], s["rpn_bbox_t"][0, pos_rank[lidx[psel]]], reduction="sum") / max(npos * 6, 1) \
         if psel.numel() else bbox_l.sum() * 0.0
 
-    # ---- heads on this rank's share of the RoIs
-    p2, p3 = gather_depth(p2s, shard), gather_depth(p3s, shard)
+    # ---- heads on this rank's share of the RoIs.  The classifier's RoIAlign crosses slabs: every rank aligns ALL RoIs on
+    # its own p2 / p3 slabs (planes it does not hold count as zeros -- RoIAlign is linear in the map), ONE all-reduce adds
+    # the shares up (12 crops: 10.6 MB, instead of all-gathering p2 + p3: 66 MB forward, 2 x 66 MB backward at
+    # 512x512x256), and the backward all-reduces the crops' gradients the same way before each rank scatters into its slabs.
     rois = torch.cat([s["p_rois"], s["n_rois"]], dim=0)
     n_all, n_pos = rois.shape[0], s["p_rois"].shape[0]
     mine = torch.arange(r, n_all, R, device=rois.device)
-    # Every rank must run BOTH gathered maps' backward (an all-reduce each, _AllGatherDepth.backward): a rank whose
-    # RoIs all sit on one pyramid level -- or that holds no RoI at all when R > number of RoIs -- would otherwise skip
-    # a collective its peers issue.  `zero` touches p2 and p3 and is added to the total unconditionally.
-    zero = (p2.sum() + p3.sum()) * 0.0
+    slabs = tuple((r * t.shape[1], R * t.shape[1]) for t in (p2s, p3s))
+    crops = all_reduce_sum(M.pyramid_roi_align_ndhwc(rois.detach(), [p2s[0], p3s[0]], net.classifier.pool_size, slabs), shard)
+    # Every rank must run the crops' backward (an all-reduce): a rank that holds no RoI at all when R > number of RoIs
+    # would otherwise skip a collective its peers issue.  `zero` touches the crops and is added to the total unconditionally.
+    zero = crops.sum() * 0.0
     l_cls = l_box = zero
     if mine.numel():
-        cls_logits, _, cls_bbox = net.classifier.forward_ndhwc([p2[0], p3[0]], rois[mine])
+        cls_logits, _, cls_bbox = net.classifier.head_ndhwc(crops[mine])
         tcls = s["target_class_ids"][mine]
         l_cls = F.cross_entropy(cls_logits, (tcls > 0).long(), reduction="sum") / n_all
         pos = torch.nonzero(tcls > 0)[:, 0]
@@ -580,16 +641,26 @@ def sharded_training_step(net, s, shard=None, zshard_unet=True, dropout_seed=0):
                 mslab = unet.forward_ndhwc(slab(crop, dim=1, shard=zs).contiguous(), zshard=zs)
         finally:
             unet.dropout_masks = preset
-        mlog = gather_replicated(mslab, zs)
-        mprob = ops.softmax_channels(mlog)
+        # The mask losses on the rank's own slab (no 113 MB logits all-gather): the cross entropy is voxel-local; the Sobel
+        # edge loss (a valid 3x3x3 stencil on the probabilities) takes ONE halo plane from each neighbour -- this rank
+        # evaluates the output planes whose centre plane it owns -- and both come back weighted by the rank's share of
+        # the voxels / output planes, so that the plain sum over the ranks is the whole RoI's loss.
+        dl = mslab.shape[1]
+        Dm = dl * rs
+        z0 = zs.rank * dl
+        lab_full = s["mask_labels"][roi]                                   # [D,H,W] uint8, replicated
+        share = 1.0 / float(n_pos)
+        l_mask = ops.mask_cross_entropy(mslab, lab_full[z0:z0 + dl].unsqueeze(0).contiguous()) * (share * dl / Dm)
         pmine = torch.tensor([roi], device=rois.device)
-        labels = s["mask_labels"][pmine].contiguous()
-        share = 1.0 / float(n_pos * rs)
         if cfg.STAGE == "finetune":
-            ce, edge = ops.mask_losses(mlog, mprob, labels)
-            l_mask, l_edge = ce * share, edge * share
-        else:
-            l_mask = ops.mask_cross_entropy(mlog, labels) * share
+            mprob = ops.softmax_channels(mslab)
+            ph = halo_exchange(mprob, 1, 1, zs)                            # [1, dl+2, ...]; zeros beyond the volume
+            a, b = max(z0 - 1, 0), min(z0 + dl - 1, Dm - 2)                # output planes [a, b): inputs [a, b + 2)
+            if b > a:
+                psl = ph[:, a - (z0 - 1):b + 2 - (z0 - 1)].contiguous()
+                l_edge = ops.edge_loss(psl, lab_full[a:b + 2].unsqueeze(0).contiguous()) * (share * (b - a) / (Dm - 2))
+            else:
+                l_edge = ph.sum() * 0.0
     elif pmine.numel():
         with slab_local():      # the U-Net's 3x3x3 convs see whole RoI crops, not depth slabs
             mlog, mprob = net.mask.forward_ndhwc(ops.to_ndhwc(image)[0], s["p_rois"][pmine])

@@ -92,12 +92,19 @@ def proposal_layer(inputs, proposal_count, nms_threshold, anchors, config=None):
     descending, top PRE_NMS_LIMIT, decode, clip, HIP NMS, normalise.  Returns [1, K, 6]."""
     probs, bbox = inputs[0].squeeze(0), inputs[1].squeeze(0)
     scores = probs[:, 1]
-    std = torch.tensor(np.reshape(config.RPN_BBOX_STD_DEV, [1, 6]), dtype=torch.float32, device=bbox.device)
-    deltas = bbox * std
     limit = min(config.PRE_NMS_LIMIT, anchors.shape[0])
     scores, order = scores.sort(descending=True)
     order, scores = order[:limit], scores[:limit]
-    boxes = apply_box_deltas(anchors[order.detach()], deltas[order.detach()])
+    return proposals_from_candidates(scores, bbox[order.detach()], anchors[order.detach()], proposal_count, nms_threshold,
+                                     config)
+
+
+def proposals_from_candidates(scores, bbox, anchors, proposal_count, nms_threshold, config):
+    """The tail of proposal_layer on an already selected, score-sorted candidate set: scores [K], raw RPN box outputs
+    [K,6] and the candidates' anchors [K,6] (voxel units).  Shared with the depth-sharded path, where every rank
+    contributes its local top PRE_NMS_LIMIT (cfun_amd.dist.gather_rpn_candidates)."""
+    std = torch.tensor(np.reshape(config.RPN_BBOX_STD_DEV, [1, 6]), dtype=torch.float32, device=bbox.device)
+    boxes = apply_box_deltas(anchors, bbox * std)
     height, width, depth = [float(v) for v in config.IMAGE_SHAPE[:3]]
     boxes = clip_boxes(boxes, (0.0, 0.0, 0.0, depth, height, width))
     keep = utils.nms_device(boxes, scores, nms_threshold, proposal_count)
@@ -268,10 +275,13 @@ def roi_levels(boxes):
     return (4 + (1.0 / 3.0) * (torch.log(h * w * d) / ln2)).round().int().clamp(2, 3)
 
 
-def pyramid_roi_align_ndhwc(boxes, feature_maps, pool_size):
-    """boxes [R,6] normalised; feature_maps = two [D,H,W,C] maps (levels 2, 3) -> [R,pd,ph,pw,C]."""
+def pyramid_roi_align_ndhwc(boxes, feature_maps, pool_size, slabs=None):
+    """boxes [R,6] normalised; feature_maps = two [D,H,W,C] maps (levels 2, 3) -> [R,pd,ph,pw,C].  ``slabs`` = per level
+    (z0, D): the maps are this rank's depth slabs and the result its additive share of the crops (ops.roi_align)."""
+    if slabs is None:
+        slabs = (None, None)
     if feature_maps[0] is feature_maps[1]:      # mask head: both "levels" are the raw image (model.py:1413)
-        return ops.roi_align(feature_maps[0], boxes.detach(), pool_size)[0]
+        return ops.roi_align(feature_maps[0], boxes.detach(), pool_size, slabs[0])[0]
     lv = roi_levels(boxes)
     pooled, index = [], []
     for i, level in enumerate((2, 3)):
@@ -279,7 +289,7 @@ def pyramid_roi_align_ndhwc(boxes, feature_maps, pool_size):
         if ix.numel() == 0:
             continue
         index.append(ix)
-        pooled.append(ops.roi_align(feature_maps[i], boxes[ix].detach(), pool_size)[0])
+        pooled.append(ops.roi_align(feature_maps[i], boxes[ix].detach(), pool_size, slabs[i])[0])
     pooled = torch.cat(pooled, dim=0)
     _, back = torch.sort(torch.cat(index, dim=0))
     return pooled[back]
@@ -326,7 +336,11 @@ class Classifier(nn.Module):
         return ops.fc(x, conv.weight.reshape(conv.out_channels, -1), s, torch.addcmul(t, conv.bias, s), ACT_RELU)
 
     def forward_ndhwc(self, feature_maps, rois):
-        x = pyramid_roi_align_ndhwc(rois, feature_maps, self.pool_size)            # [R,pd,ph,pw,C]
+        return self.head_ndhwc(pyramid_roi_align_ndhwc(rois, feature_maps, self.pool_size))
+
+    def head_ndhwc(self, x):
+        """The head on RoI-aligned crops x [R,pd,ph,pw,C] (split from the pooling for the depth-sharded step, where the
+        crops are summed over the ranks' slabs first, cfun_amd.dist)."""
         x = x.permute(0, 4, 1, 2, 3).reshape(x.shape[0], -1)                        # OIDHW flatten order
         outs = []
         for i in range(0, max(x.shape[0], 1), 64):                                   # (64 RoIs per launch)

@@ -1022,19 +1022,21 @@ def maxpool2(x):
 
 class _RoIAlign(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, fm, boxes, pool):
+    def forward(ctx, fm, boxes, pool, slab=None):
+        # slab = (z0, D): fm holds depth planes [z0, z0 + fm.shape[0]) of a [D,H,W,C] map (see roi_align)
         lib = _lib.load()
         fm = _c(fm)
         boxes = _c(boxes.detach().float())
-        d, h, w, c = fm.shape
+        dl, h, w, c = fm.shape
+        z0, d = (0, dl) if slab is None else (int(slab[0]), int(slab[1]))
         r = boxes.shape[0]
         pd, ph, pw = [int(v) for v in pool]
         out = torch.empty((r, pd, ph, pw, c), dtype=torch.float32, device=fm.device)
         bounds = torch.empty((max(r, 1), 6), dtype=torch.int32, device=fm.device)
-        check(lib.cfun_roi_align3d_fwd(ptr(fm), ptr(boxes), ptr(out), ptr(bounds), r, d, h, w, c, pd, ph, pw,
-                                       stream(fm)), "roi_align3d_fwd")
+        check(lib.cfun_roi_align3d_slab_fwd(ptr(fm), ptr(boxes), ptr(out), ptr(bounds), r, d, h, w, c, z0, dl, pd, ph, pw,
+                                            stream(fm)), "roi_align3d_fwd")
         ctx.save_for_backward(bounds)
-        ctx.dims = (r, d, h, w, c, pd, ph, pw)
+        ctx.dims = (r, d, h, w, c, pd, ph, pw, z0, dl)
         ctx.mark_non_differentiable(bounds)
         return out, bounds
 
@@ -1042,17 +1044,19 @@ class _RoIAlign(torch.autograd.Function):
     def backward(ctx, dout, _dbounds):
         lib = _lib.load()
         (bounds,) = ctx.saved_tensors
-        r, d, h, w, c, pd, ph, pw = ctx.dims
+        r, d, h, w, c, pd, ph, pw, z0, dl = ctx.dims
         dout = _c(dout)
-        dfm = torch.zeros((d, h, w, c), dtype=torch.float32, device=dout.device)
-        check(lib.cfun_roi_align3d_bwd(ptr(dout), ptr(bounds), ptr(dfm), r, d, h, w, c, pd, ph, pw, stream(dout)),
-              "roi_align3d_bwd")
-        return dfm, None, None
+        dfm = torch.zeros((dl, h, w, c), dtype=torch.float32, device=dout.device)
+        check(lib.cfun_roi_align3d_slab_bwd(ptr(dout), ptr(bounds), ptr(dfm), r, d, h, w, c, z0, dl, pd, ph, pw,
+                                            stream(dout)), "roi_align3d_bwd")
+        return dfm, None, None, None
 
 
-def roi_align(fm, boxes, pool):
-    """fm [D,H,W,C], boxes [R,6] normalised -> ([R,pd,ph,pw,C], int32 crop bounds [R,6])."""
-    return _RoIAlign.apply(fm, boxes, tuple(pool))
+def roi_align(fm, boxes, pool, slab=None):
+    """fm [D,H,W,C], boxes [R,6] normalised -> ([R,pd,ph,pw,C], int32 crop bounds [R,6]).  ``slab`` = (z0, D): fm is the
+    depth slab [z0, z0 + fm.shape[0]) of a [D,H,W,C] map and the result is this slab's additive share of the crops
+    (planes outside count as zeros; RoIAlign is linear in the map)."""
+    return _RoIAlign.apply(fm, boxes, tuple(pool), slab)
 
 
 def mask_target_labels(labels, rois, mask_shape):

@@ -130,8 +130,8 @@ def main():
         IMAGE_MAX_DIM=32, IMAGE_MIN_DIM=32, MASK_POOL_SIZE=[32, 32, 32], POOL_SIZE=[4, 4, 4],
         UNET_MASK_BRANCH_CHANNEL=4, TOP_DOWN_PYRAMID_SIZE=16, RPN_CONV_CHANNELS=16, FPN_CLASSIFY_FC_LAYERS_SIZE=16,
         RPN_ANCHOR_SCALES=(16, 32), PRE_NMS_LIMIT=64, POST_NMS_ROIS_TRAINING=16))
-    cfg5 = cls("beginning")
-    cfg5.MASK_SHAPE = cfg5.MINI_MASK_SHAPE = (32, 32, 32)
+    cfg5 = cls("finetune")          # (the edge loss and the folded 5x5x5 conv ride along in every sharded step below)
+    cfg5.MASK_SHAPE = cfg5.MINI_MASK_SHAPE = (64, 64, 64)
     torch.manual_seed(4)
     net5 = step.CFUNHotPath(cfg5).to(dev)
     s5 = step.synthetic_inputs(cfg5, dev, 0)
