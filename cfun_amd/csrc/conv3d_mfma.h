@@ -245,6 +245,13 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
     return q * md.in_cqp + o4 * 4;
   };
   float4 xin[T::IN_LOADS], win[W_LOADS];
+  // tap skipping: only the 8 live taps {p, p+1}^3 of the tile's (tap_skip 1) / the chunk's (tap_skip 2) parity are staged
+  // -- slot j of the weight stage holds live tap j (8 * NT float4 items per chunk instead of 27 * NT)
+  const int w_items = (SPECIAL && TAPS == 27 && md.tap_skip) ? 8 * NT : W_ITEMS;
+  int q_staged = 0;
+  auto live_tap_of = [](int q, int j) {      // unflipped weight tap of live slot j = (a,b,c) for parity q = (pz,py,px)
+    return (((q >> 2) + (j >> 2)) * 3 + (((q >> 1) & 1) + ((j >> 1) & 1))) * 3 + ((q & 1) + (j & 1));
+  };
   // input prologue: the chunk's 4 channels carry (mean, rstd) of sample n -- wave-uniform, fetched with the chunk
   const bool in_fused = md.in_stats != nullptr || md.in_act != CFUN_ACT_NONE;
   float4 ns01 = make_float4(0.f, 1.f, 0.f, 1.f), ns23 = make_float4(0.f, 1.f, 0.f, 1.f);
@@ -258,14 +265,17 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
 #pragma unroll
     for (int i = 0; i < T::IN_LOADS; ++i)
       xin[i] = in_off[i] >= 0 ? *reinterpret_cast<const float4*>(x + in_off[i] + xo) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (SPECIAL && TAPS == 27 && md.tap_skip) q_staged = md.tap_skip == 1 ? cobase / (p.Co >> 3) : c / cpq;
 #pragma unroll
     for (int i = 0; i < W_LOADS; ++i) {
       const int it = tid + i * 256;
       win[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (it < W_ITEMS) {
+      if (it < w_items) {
         const int row = it / (NT / 4), col = (it % (NT / 4)) * 4;
-        const int tap = row >> 2, cc = row & 3;
-        const int tapw = md.flip ? TAPS - 1 - tap : tap;
+        int tapw = row >> 2;
+        const int cc = row & 3;
+        if (SPECIAL && TAPS == 27 && md.tap_skip) tapw = live_tap_of(q_staged, tapw);      // weight tap of live slot j
+        else if (md.flip) tapw = TAPS - 1 - tapw;
         if (cobase + col < p.CoP)
           win[i] = *reinterpret_cast<const float4*>(wp + ((int64_t)tapw * p.Ci + wrow + cc) * p.CoP + cobase + col);
       }
@@ -288,8 +298,13 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
 #pragma unroll
     for (int i = 0; i < W_LOADS; ++i) {
       const int it = tid + i * 256;
-      if (it < W_ITEMS) {
-        const int row = it / (NT / 4), col = (it % (NT / 4)) * 4;
+      if (it < w_items) {
+        int row = it / (NT / 4);
+        const int col = (it % (NT / 4)) * 4;
+        if (SPECIAL && TAPS == 27 && md.tap_skip) {      // live slot -> the row of its tap in the MFMA loop's (possibly mirrored) order
+          const int t = live_tap_of(q_staged, row >> 2);
+          row = (md.flip ? TAPS - 1 - t : t) * 4 + (row & 3);
+        }
         *reinterpret_cast<float4*>(Wl + row * NTP + col) = win[i];
       }
     }
