@@ -99,14 +99,22 @@ def stem_back_to_back(cfg, net, n_roi, dev, launches=64):
             1: "k_conv_mfma", 0: "k_conv_fwd_direct"}.get(kern, "kernel code %d" % kern)
     if kern == 3 and zpt not in ("2", "4"):
         name = "k_conv_stem<3,3,3,1,%d>" % conv.out_channels
+    # straight through the C ABI (packed weight, output and workspace allocated once): ~5 us of host time per call, so the
+    # launches queue up and the event pair measures the kernel's back-to-back rate, not Python's call overhead
+    lib = _lib.load()
     with torch.no_grad():
+        wp = ops.pack_weight(conv.weight)
+        y = torch.empty((n_roi,) + side + (conv.out_channels,), device=dev)
+        ws = _lib.workspace(lib.cfun_conv3d_fwd_workspace_bytes(C.byref(p)), x)
+        st = _lib.stream(x)
+        args = (_lib.ptr(x), _lib.ptr(wp), None, None, None, _lib.ptr(y), C.byref(p), _lib.ptr(ws), ws.numel(), st)
         for _ in range(4):
-            ops.conv3d_w(x, conv.weight, spec)
+            _lib.check(lib.cfun_conv3d_fwd(*args), "conv3d_fwd")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
         for _ in range(launches):
-            ops.conv3d_w(x, conv.weight, spec)
+            lib.cfun_conv3d_fwd(*args)
         e1.record()
         torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e-3 / launches, launches, name
@@ -205,14 +213,14 @@ def cpu_baseline(cfg, net, sample, threads, iters=1, small_iters=3):
 
     # warm-up: the same code path at the smallest configuration (BASELINE configs[0]'s 64x64x32 volume, 1 + 2 RoIs), then
     # `small_iters` timed iterations of it: the cfg0 figure SURVEY.md section 8(d) asks for beside cfg2's
-    wcfg = ccfg.heart_config(cfg.STAGE, 64, 64, 32) if not hasattr(cfg, "BACKBONE_LAYERS") else None
+    wcfg = ccfg.heart_config("beginning", 64, 64, 32) if not isinstance(cfg, ccfg.LiTSConfig) else None   # BASELINE configs[0]
     small = None
     if wcfg is not None:
         wnet = step.CFUNHotPath(wcfg)
         ws_ = step.synthetic_inputs(wcfg, torch.device("cpu"), 0)
         one(wcfg, wnet, ws_, 1)
         st = sorted(one(wcfg, wnet, ws_, 1)[0] for _ in range(max(1, small_iters)))
-        small = {"workload": "64x64x32 volume, stage '%s', 1 positive + 2 negative RoIs, same step" % cfg.STAGE,
+        small = {"workload": "BASELINE configs[0]: 64x64x32 volume, stage 'beginning', 1 positive + 2 negative RoIs, forward + backward",
                  "value": 1.0 / st[len(st) // 2], "unit": "volumes/s", "iters": len(st), "median_s": st[len(st) // 2]}
     times, losses = [], None
     for _ in range(max(1, iters)):
@@ -243,6 +251,9 @@ def main():
                     help="timed full iterations of the oracle's CPU step (median reported); each takes ~1 min at cfg2")
     ap.add_argument("--no-alt", action="store_true",
                     help="skip the extra, separately reported leg on the opt-in 3xBF16 conv kernels (CFUN_CONV_ALGO=b3)")
+    ap.add_argument("--no-hbm-loop", action="store_true",
+                    help="skip the 64 back-to-back launches of the HBM-bound stem conv behind `roofline_hbm` (profiling "
+                         "runs: the loop would show up in the per-step kernel statistics); the in-step timing is reported")
     ap.add_argument("--sharded", action="store_true",
                     help="N > 1: ONE volume per step over all ranks (depth-sharded FPN/RPN with halo exchange, head "
                          "RoIs dealt round-robin; strong scaling) instead of one volume per rank")
@@ -407,7 +418,7 @@ def main():
             result["alt_3xbf16"] = alt
         if durs_h:   # north_star's "HBM roofline on the 3x3x3 conv kernel": the C_in = 1 stem, algorithmic bytes / time
             t_step = sum(durs_h) / len(durs_h) * 1e-3       # one event pair per launch inside the step (~10 us of overhead)
-            t_h, nb2b, hname = stem_back_to_back(cfg, net, n_roi_launch, dev)
+            t_h, nb2b, hname = stem_back_to_back(cfg, net, n_roi_launch, dev, launches=1 if args.no_hbm_loop else 64)
             vox = n_roi_launch * side[0] * side[1] * side[2]
             nbytes = 4.0 * (vox + vox * b + 27 * b)
             result["roofline_hbm"] = {
