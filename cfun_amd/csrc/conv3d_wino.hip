@@ -450,7 +450,12 @@ int wino_nsub(int co, int twod) {
   return best;
 }
 
-// y in the Winograd domain as well?  CFUN_WINO_2D: 0 = never, 1 = every supported shape, unset = measured shapes
+// y in the Winograd domain as well?  CFUN_WINO_2D: 0 = never, 1 = every supported shape, unset = measured shapes:
+// round 3 (tools/bench_layers.py, profiles/round3_layers_wino_1d_vs_2d.log): at one wave per SIMD the 2-D kernel loses
+// 0.6 % on the chip-filling 40 -> 40 @ 4 x 96^3 launch but wins 2 - 11 % forward and data gradient on everything at
+// 48^3 and below (80 -> 80 @ 48^3: 1.02 -> 0.92 ms, @ 24^3: 0.192 -> 0.170 ms; the folded 5^3 conv's data gradient 1.31
+// -> 1.22 ms), where fewer MFMAs per tile matter more than the second resident wave -- so AUTO takes it up to 2^19
+// output voxels per launch, and for single-tile outputs of any size.
 int wino_2d(const CfunConv3dParams& p) {
   static int knob = -2;
   if (knob == -2) {
@@ -459,7 +464,9 @@ int wino_2d(const CfunConv3dParams& p) {
   }
   if (p.algo == CFUN_ALGO_WINO) return 0;       // tests: the 1-D kernel
   if (p.algo == CFUN_ALGO_WINO2 || knob == 1) return 1;
-  return 0;
+  if (knob == 0) return 0;
+  // (C_out <= 16 -- the folded 5^3 conv's data gradient -- runs one co tile: 64 accumulators, three waves per SIMD either way)
+  return p.Co <= 16 || (int64_t)p.N * p.Do * p.Ho * p.Wo <= ((int64_t)1 << 19);
 }
 
 struct Plan {
