@@ -426,8 +426,9 @@ def main():
                 "frac": nbytes / t_h / 1e9 / PEAK_HBM_GBS, "traffic": None,
                 "kernel": "%s (conv3d_c1_1: 3x3x3 1->%d @ %dx%d^3)" % (hname, b, n_roi_launch, side[0]),
                 "bytes_per_launch": nbytes, "avg_launch_ms": t_h * 1e3, "launches_timed": nb2b,
-                "timing": "%d back-to-back launches of the step's own call between ONE pair of HIP events on the launch "
-                          "stream (an event pair around a single ~80 us launch adds ~10 %%)" % nb2b,
+                "timing": "%d back-to-back launches of the step's own C-ABI call between ONE pair of HIP events on the "
+                          "launch stream (launch-to-launch rate; rocprofv3's kernel time for the same launch is ~15 %% "
+                          "shorter: profiles/)" % nb2b,
                 "avg_launch_ms_in_step": t_step * 1e3, "launches_timed_in_step": len(durs_h)}
         parity_fail = None
         if world == 1 and not args.no_cpu_baseline:
