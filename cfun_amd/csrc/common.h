@@ -54,6 +54,14 @@ __device__ __forceinline__ float cfun_fast_rcp(float v) {
 #endif
 }
 
+__device__ __forceinline__ float cfun_fast_rsq(float v) {      // v_rsq_f32 (1 ulp); rsq(0) = inf
+#ifdef CFUN_HIP_EMULATION
+  return 1.0f / sqrtf(v);
+#else
+  return __builtin_amdgcn_rsqf(v);
+#endif
+}
+
 // wave-level sum (all 64 lanes receive the total)
 __device__ __forceinline__ float cfun_wave_sum(float v) {
 #pragma unroll

@@ -136,6 +136,9 @@ k_ce_bwd(const float* __restrict__ logits, const uint8_t* __restrict__ labels, c
 // plane's 3x3 (y,x) neighbourhood into the two in-plane sums  dy = B(y)A(x)*f  and  sm = A(y)A(x)*f  (9 loads
 // instead of 27 per voxel) and combines a ring of three planes:  c0 = A(z)*dy,  c1 = B(z)*sm.
 constexpr int kZSeg = 16;   // output planes per thread
+// floats per voxel record of the coefficient field dc: (dc0, dc1) per foreground class.  (Padding the 56-byte records of 8
+// classes to 64 bytes -- every access 16-byte aligned -- was measured: the gather reads 14 % more and got 21 % slower.)
+constexpr int dc_stride(int ct) { return 2 * (ct - 1); }
 
 // The TARGET side of the stencil is integer arithmetic on one-hot labels: per input plane and class, R_j = sum_i A[i] *
 // [label(y+j, x+i) == c] (<= 4) for the three rows j; dy = R_0 - R_2 and sm = R_0 + 2 R_1 + R_2.  All classes are carried
@@ -215,7 +218,7 @@ k_edge_march(const float* __restrict__ probs, const uint8_t* __restrict__ labels
     float accf = 0.f;                                      // one column segment (<= 16 x 7 terms) in fp32, then fp64
     for (int zo = z0; zo < z1; ++zo) {
       plane_sums<CT>(probs, labels, nbase, zo + 2, y, x, H, W, P[2], T[2]);
-      float* o = MODE != 0 ? dc + ((((r * Do + zo) * Ho + y) * Wo + x)) * (2 * (CT - 1)) : nullptr;
+      float* o = MODE != 0 ? dc + ((((r * Do + zo) * Ho + y) * Wo + x)) * dc_stride(CT) : nullptr;
       uint32_t t0b[2], t1b[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -249,6 +252,148 @@ k_edge_march(const float* __restrict__ probs, const uint8_t* __restrict__ labels
   }
 }
 
+// ---- two y-outputs per thread (round 3).  The march is bound by the NUMBER of load instructions per voxel-plane (the class
+// split that raised occupancy instead made it slower), so a thread now owns the column PAIR (y, y+1):
+// the x-direction sums A(x)*f of the FOUR rows y .. y+3 (12 neighbour loads) serve both outputs -- out 0 combines rows
+// 0,1,2, out 1 rows 1,2,3 -- instead of 2 x 9 loads, and the in-plane arithmetic halves with them (one FMA per neighbour
+// and class for the row sum, then dy = r0 - r2, sm = r0 + 2 r1 + r2 per output).
+template <int CT>
+struct RowSums {
+  float a[4][CT - 1];     // A(x)-weighted sums of the probabilities of rows y .. y+3, classes 1 .. CT-1
+  uint32_t t[4][2];       // the same for the one-hot targets, packed 8-bit fields (classes 0-3 | 4-7)
+};
+
+template <int CT>
+__device__ __forceinline__ void row_sums(const float* __restrict__ probs, const uint8_t* __restrict__ labels, int64_t nbase,
+                                         int z, int y, int x, int H, int W, RowSums<CT>& S) {
+  const float A[3] = {1.f, 2.f, 1.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int yy = y + j < H ? y + j : H - 1;      // (row 3 past the volume: only when output 1 is not stored)
+#pragma unroll
+    for (int c = 0; c < CT - 1; ++c) S.a[j][c] = 0.f;
+    S.t[j][0] = 0u; S.t[j][1] = 0u;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int64_t vi = nbase + ((int64_t)z * H + yy) * W + (x + i);
+      const float* pp = probs + vi * CT;
+      const unsigned lab = labels[vi];
+      const uint32_t v = lab < (unsigned)CT ? (i == 1 ? 2u : 1u) << ((lab & 3u) * 8u) : 0u;
+      S.t[j][0] += (lab & 4u) ? 0u : v;
+      S.t[j][1] += (lab & 4u) ? v : 0u;
+#pragma unroll
+      for (int c = 1; c < CT; ++c) S.a[j][c - 1] += A[i] * pp[c];
+    }
+  }
+}
+
+template <int CT>
+__device__ __forceinline__ void pair_planes(const RowSums<CT>& S, PlaneSums<CT> (&P)[2], TargetPlane (&T)[2]) {
+#pragma unroll
+  for (int o = 0; o < 2; ++o) {
+#pragma unroll
+    for (int c = 0; c < CT - 1; ++c) {
+      P[o].dy[c] = S.a[o][c] - S.a[o + 2][c];
+      P[o].sm[c] = (S.a[o][c] + S.a[o + 2][c]) + 2.f * S.a[o + 1][c];
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      T[o].dyb[h] = S.t[o][h] + 0x04040404u - S.t[o + 2][h];
+      T[o].sm[h] = S.t[o][h] + 2u * S.t[o + 1][h] + S.t[o + 2][h];
+    }
+  }
+}
+
+template <int CT, int MODE>       // MODE as k_edge_march
+__global__ void __launch_bounds__(kBlock)
+k_edge_march2(const float* __restrict__ probs, const uint8_t* __restrict__ labels, const float* __restrict__ gscale,
+              double* __restrict__ partial, float* __restrict__ dc, int n, int D, int H, int W) {
+  static_assert(CT <= 8, "packed target sums: 8 classes");
+  const int Do = D - 2, Ho = H - 2, Wo = W - 2, Hp = (Ho + 1) / 2;
+  const int nseg = (Do + kZSeg - 1) / kZSeg;
+  // A block owns a 2-D patch of columns -- 16 x-columns x 16 y-pairs (32 rows) of one (sample, z segment) -- so that the
+  // rows its threads share stay in ITS L1 / its XCD's L2: with 256 consecutive (x, y) columns per block (round 2) a block
+  // covered 1.35 rows and read 3.35, and its row neighbours ran on other XCDs (blocks are dealt round-robin), i.e. every
+  // plane was fetched ~2.5 times (FETCH_SIZE: 2.6 GB for 0.93 GB of probabilities); the patch reads 34 x 18 for 32 x 16.
+  const int tX = (Wo + 15) / 16, tY = (Hp + 15) / 16;
+  const int64_t tiles = (int64_t)n * nseg * tY * tX;
+  const float gs = MODE == 0 ? 0.f : (MODE == 1 ? gscale[0] : 1.f) * 2.f / ((float)Do * (float)Ho * (float)Wo * (float)n);
+  double acc = 0.0;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    int64_t t = tile;
+    const int x = (int)(t % tX) * 16 + (threadIdx.x & 15); t /= tX;
+    const int y = 2 * ((int)(t % tY) * 16 + (threadIdx.x >> 4)); t /= tY;
+    const int seg = (int)(t % nseg);
+    const int64_t r = t / nseg;
+    if (x >= Wo || y >= Ho) continue;
+    const int64_t nbase = r * D * H * W;
+    const int z0 = seg * kZSeg;
+    const int z1 = z0 + kZSeg < Do ? z0 + kZSeg : Do;
+    const bool two = y + 1 < Ho;
+    PlaneSums<CT> P[3][2];          // [ring plane][output]
+    TargetPlane T[3][2];
+    {
+      RowSums<CT> S;
+      row_sums<CT>(probs, labels, nbase, z0, y, x, H, W, S);
+      pair_planes<CT>(S, P[0], T[0]);
+      row_sums<CT>(probs, labels, nbase, z0 + 1, y, x, H, W, S);
+      pair_planes<CT>(S, P[1], T[1]);
+    }
+    float accf = 0.f;
+    for (int zo = z0; zo < z1; ++zo) {
+      {
+        RowSums<CT> S;
+        row_sums<CT>(probs, labels, nbase, zo + 2, y, x, H, W, S);
+        pair_planes<CT>(S, P[2], T[2]);
+      }
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        const bool live = o == 0 || two;
+        float* op = MODE != 0 ? dc + ((((r * Do + zo) * Ho + (y + o)) * Wo + x)) * dc_stride(CT) : nullptr;
+        float ov[dc_stride(CT)];
+        uint32_t t0b[2], t1b[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          t0b[h] = T[0][o].dyb[h] + 2u * T[1][o].dyb[h] + T[2][o].dyb[h];       // t0 + 16 per 8-bit field
+          t1b[h] = T[0][o].sm[h] + 0x10101010u - T[2][o].sm[h];                 // t1 + 16
+        }
+#pragma unroll
+        for (int c = 0; c < CT - 1; ++c) {
+          const float p0 = P[0][o].dy[c] + 2.f * P[1][o].dy[c] + P[2][o].dy[c], p1 = P[0][o].sm[c] - P[2][o].sm[c];
+          const int cls = c + 1;
+          const float t0 = (float)((int)((t0b[cls >> 2] >> ((cls & 3) * 8)) & 0xffu) - 16);
+          const float t1 = (float)((int)((t1b[cls >> 2] >> ((cls & 3) * 8)) & 0xffu) - 16);
+          // |grad p| and 1 / |grad p| from ONE quarter-rate instruction (v_rsq_f32) instead of v_sqrt + v_rcp: the march is
+          // bound by VALU issue (profiles/round3_pmc_loss_kernels.txt), and the transcendentals are its costliest instructions
+          const float sp = p0 * p0 + p1 * p1 + p0 * p0;                    // channel 0 twice (model.py:969-972)
+          const float ip = cfun_fast_rsq(sp);                              // inf at 0
+          const float pm = sp > 0.f ? sp * ip : 0.f;
+          const float tm = cfun_fast_sqrt(t0 * t0 + t1 * t1 + t0 * t0);
+          if (MODE != 1) {
+            const float d = pm - tm;
+            accf += live ? d * d : 0.f;
+          }
+          if (MODE != 0) {
+            const float k = gs * (pm - tm) * ip;      // 0 * inf -> NaN exactly where torch's sqrt backward gives 0/0 (App. A-13)
+            ov[2 * c] = k * 2.f * p0; ov[2 * c + 1] = k * p1;
+          }
+        }
+        if (MODE != 0 && live) {
+#pragma unroll
+          for (int c = 0; c < CT - 1; ++c) reinterpret_cast<float2*>(op)[c] = make_float2(ov[2 * c], ov[2 * c + 1]);
+        }
+      }
+#pragma unroll
+      for (int o = 0; o < 2; ++o) { P[0][o] = P[1][o]; P[1][o] = P[2][o]; T[0][o] = T[1][o]; T[1][o] = T[2][o]; }
+    }
+    acc += (double)accf;
+  }
+  if (MODE != 1) {
+    const double s = block_sum(acc);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+  }
+}
+
 // transposed stencil, marching along z over the OUTPUT planes:  Q0[zo](y,x) = sum_{j,i} B[j]A[i] dc0[zo, y-j, x-i],
 // Q1[zo](y,x) = sum A[j]A[i] dc1[zo, y-j, x-i];  dprob[z] = sum_dz A[dz]*Q0[z-dz] + B[dz]*Q1[z-dz]
 template <int CT>
@@ -268,7 +413,7 @@ __device__ __forceinline__ void plane_adj(const float* __restrict__ dc, int64_t 
       if (ox < 0 || ox >= Wo) continue;
       // the voxel's 2*(CT-1) coefficients as (dc0, dc1) pairs: 8-byte loads (half the load instructions of the scalar
       // walk; the kernel is bound by its 9 neighbour gathers per plane, not by HBM)
-      const float2* d = reinterpret_cast<const float2*>(dc + (((r * Do + zo) * Ho + oy) * Wo + ox) * (2 * (CT - 1)));
+      const float2* d = reinterpret_cast<const float2*>(dc + (((r * Do + zo) * Ho + oy) * Wo + ox) * dc_stride(CT));
       const float wd = B[j] * A[i], ws = A[j] * A[i];
 #pragma unroll
       for (int c = 0; c < CT - 1; ++c) {
@@ -289,6 +434,9 @@ k_edge_bwd_gather(const float* __restrict__ dc, float* __restrict__ dprobs, int 
                   const float* __restrict__ gedge) {
   const int Do = D - 2, Ho = H - 2, Wo = W - 2;
   const int nseg = (D + kZSeg - 1) / kZSeg;
+  // (2-D patches of 16 x 16 columns per block, as in k_edge_march2, were measured here too: 1.28 -> 1.33 ms.  The counters
+  // -- profiles/round3_pmc_loss_kernels.txt -- show this kernel waiting on memory 79 % of its wave-cycles with FETCH_SIZE at
+  // the algorithmic bytes: latency at 3 waves per SIMD, not re-fetching, so the coalesced 1-D walk stays.)
   const int64_t total = (int64_t)n * nseg * H * W;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
     int64_t t = i;
@@ -556,10 +704,10 @@ int cfun_edge_loss_fwd(const float* probs, const uint8_t* labels, float* loss, i
   if (n <= 0 || D < 3 || H < 3 || W < 3) return (int)hipMemsetAsync(loss, 0, sizeof(float), cfun_st(stream));
   if (ws_bytes < kMaxBlocks * sizeof(double)) return CFUN_EWORKSPACE;
   const int64_t per = (int64_t)(D - 2) * (H - 2) * (W - 2);
-  const int64_t cols = (int64_t)n * ((D - 2 + kZSeg - 1) / kZSeg) * (H - 2) * (W - 2);
+  const int64_t cols = (int64_t)n * ((D - 2 + kZSeg - 1) / kZSeg) * ((H - 2 + 1) / 2) * (W - 2);      // y pairs (k_edge_march2)
   const unsigned blocks = vox_grid(cols);
-  if (C == 8) hipLaunchKernelGGL((k_edge_march<8, 0>), dim3(blocks), dim3(kBlock), 0, cfun_st(stream), probs, labels, (const float*)nullptr, (double*)ws, (float*)nullptr, n, D, H, W);
-  else hipLaunchKernelGGL((k_edge_march<3, 0>), dim3(blocks), dim3(kBlock), 0, cfun_st(stream), probs, labels, (const float*)nullptr, (double*)ws, (float*)nullptr, n, D, H, W);
+  if (C == 8) hipLaunchKernelGGL((k_edge_march2<8, 0>), dim3(blocks), dim3(kBlock), 0, cfun_st(stream), probs, labels, (const float*)nullptr, (double*)ws, (float*)nullptr, n, D, H, W);
+  else hipLaunchKernelGGL((k_edge_march2<3, 0>), dim3(blocks), dim3(kBlock), 0, cfun_st(stream), probs, labels, (const float*)nullptr, (double*)ws, (float*)nullptr, n, D, H, W);
   hipLaunchKernelGGL(k_finalize_sum, dim3(1), dim3(64), 0, cfun_st(stream), (const double*)ws, (int)blocks,
                      1.0 / ((double)per * (double)n), loss);
   CFUN_LAUNCH_CHECK();
@@ -568,7 +716,7 @@ int cfun_edge_loss_fwd(const float* probs, const uint8_t* labels, float* loss, i
 
 size_t cfun_edge_loss_bwd_workspace_bytes(int32_t n, int32_t D, int32_t H, int32_t W, int32_t C) {
   if (n <= 0 || D < 3 || H < 3 || W < 3 || C < 2) return 256;
-  return cfun_align_up((size_t)n * (D - 2) * (H - 2) * (W - 2) * 2 * (C - 1) * sizeof(float), 256);
+  return cfun_align_up((size_t)n * (D - 2) * (H - 2) * (W - 2) * dc_stride(C) * sizeof(float), 256);
 }
 
 int cfun_edge_loss_bwd(const float* probs, const uint8_t* labels, const float* gscale, float* dprobs, int32_t n,
@@ -578,13 +726,13 @@ int cfun_edge_loss_bwd(const float* probs, const uint8_t* labels, const float* g
   if (total <= 0) return CFUN_OK;
   if (D < 3 || H < 3 || W < 3) return (int)hipMemsetAsync(dprobs, 0, total * C * sizeof(float), cfun_st(stream));
   if (ws_bytes < cfun_edge_loss_bwd_workspace_bytes(n, D, H, W, C)) return CFUN_EWORKSPACE;
-  const int64_t cols_o = (int64_t)n * ((D - 2 + kZSeg - 1) / kZSeg) * (H - 2) * (W - 2);
+  const int64_t cols_o = (int64_t)n * ((D - 2 + kZSeg - 1) / kZSeg) * ((H - 2 + 1) / 2) * (W - 2);      // y pairs (k_edge_march2)
   const int64_t cols_i = (int64_t)n * ((D + kZSeg - 1) / kZSeg) * H * W;
   if (C == 8) {
-    hipLaunchKernelGGL((k_edge_march<8, 1>), dim3(vox_grid(cols_o)), dim3(kBlock), 0, cfun_st(stream), probs, labels, gscale, (double*)nullptr, (float*)ws, n, D, H, W);
+    hipLaunchKernelGGL((k_edge_march2<8, 1>), dim3(vox_grid(cols_o)), dim3(kBlock), 0, cfun_st(stream), probs, labels, gscale, (double*)nullptr, (float*)ws, n, D, H, W);
     hipLaunchKernelGGL((k_edge_bwd_gather<8, false>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dprobs, n, D, H, W, (const float*)nullptr, (const uint8_t*)nullptr, (const float*)nullptr, (const float*)nullptr);
   } else {
-    hipLaunchKernelGGL((k_edge_march<3, 1>), dim3(vox_grid(cols_o)), dim3(kBlock), 0, cfun_st(stream), probs, labels, gscale, (double*)nullptr, (float*)ws, n, D, H, W);
+    hipLaunchKernelGGL((k_edge_march2<3, 1>), dim3(vox_grid(cols_o)), dim3(kBlock), 0, cfun_st(stream), probs, labels, gscale, (double*)nullptr, (float*)ws, n, D, H, W);
     hipLaunchKernelGGL((k_edge_bwd_gather<3, false>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dprobs, n, D, H, W, (const float*)nullptr, (const uint8_t*)nullptr, (const float*)nullptr, (const float*)nullptr);
   }
   CFUN_LAUNCH_CHECK();
@@ -598,10 +746,10 @@ int cfun_edge_loss_fwd_save(const float* probs, const uint8_t* labels, float* lo
   if (n <= 0 || D < 3 || H < 3 || W < 3) return CFUN_EINVAL;
   if (ws_bytes < kMaxBlocks * sizeof(double)) return CFUN_EWORKSPACE;
   const int64_t per = (int64_t)(D - 2) * (H - 2) * (W - 2);
-  const int64_t cols = (int64_t)n * ((D - 2 + kZSeg - 1) / kZSeg) * (H - 2) * (W - 2);
+  const int64_t cols = (int64_t)n * ((D - 2 + kZSeg - 1) / kZSeg) * ((H - 2 + 1) / 2) * (W - 2);      // y pairs (k_edge_march2)
   const unsigned blocks = vox_grid(cols);
-  if (C == 8) hipLaunchKernelGGL((k_edge_march<8, 2>), dim3(blocks), dim3(kBlock), 0, cfun_st(stream), probs, labels, (const float*)nullptr, (double*)ws, dc, n, D, H, W);
-  else hipLaunchKernelGGL((k_edge_march<3, 2>), dim3(blocks), dim3(kBlock), 0, cfun_st(stream), probs, labels, (const float*)nullptr, (double*)ws, dc, n, D, H, W);
+  if (C == 8) hipLaunchKernelGGL((k_edge_march2<8, 2>), dim3(blocks), dim3(kBlock), 0, cfun_st(stream), probs, labels, (const float*)nullptr, (double*)ws, dc, n, D, H, W);
+  else hipLaunchKernelGGL((k_edge_march2<3, 2>), dim3(blocks), dim3(kBlock), 0, cfun_st(stream), probs, labels, (const float*)nullptr, (double*)ws, dc, n, D, H, W);
   hipLaunchKernelGGL(k_finalize_sum, dim3(1), dim3(64), 0, cfun_st(stream), (const double*)ws, (int)blocks,
                      1.0 / ((double)per * (double)n), loss);
   CFUN_LAUNCH_CHECK();
@@ -631,13 +779,13 @@ int cfun_mask_losses_bwd(const float* probs, const uint8_t* labels, const float*
   if (total <= 0) return CFUN_OK;
   if (D < 3 || H < 3 || W < 3) return CFUN_EINVAL;   // no edge term: use cfun_softmax_ce_bwd
   if (ws_bytes < cfun_edge_loss_bwd_workspace_bytes(n, D, H, W, C)) return CFUN_EWORKSPACE;
-  const int64_t cols_o = (int64_t)n * ((D - 2 + kZSeg - 1) / kZSeg) * (H - 2) * (W - 2);
+  const int64_t cols_o = (int64_t)n * ((D - 2 + kZSeg - 1) / kZSeg) * ((H - 2 + 1) / 2) * (W - 2);      // y pairs (k_edge_march2)
   const int64_t cols_i = (int64_t)n * ((D + kZSeg - 1) / kZSeg) * H * W;
   if (C == 8) {
-    hipLaunchKernelGGL((k_edge_march<8, 1>), dim3(vox_grid(cols_o)), dim3(kBlock), 0, cfun_st(stream), probs, labels, g_edge, (double*)nullptr, (float*)ws, n, D, H, W);
+    hipLaunchKernelGGL((k_edge_march2<8, 1>), dim3(vox_grid(cols_o)), dim3(kBlock), 0, cfun_st(stream), probs, labels, g_edge, (double*)nullptr, (float*)ws, n, D, H, W);
     hipLaunchKernelGGL((k_edge_bwd_gather<8, true>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dlogits, n, D, H, W, probs, labels, g_ce, (const float*)nullptr);
   } else {
-    hipLaunchKernelGGL((k_edge_march<3, 1>), dim3(vox_grid(cols_o)), dim3(kBlock), 0, cfun_st(stream), probs, labels, g_edge, (double*)nullptr, (float*)ws, n, D, H, W);
+    hipLaunchKernelGGL((k_edge_march2<3, 1>), dim3(vox_grid(cols_o)), dim3(kBlock), 0, cfun_st(stream), probs, labels, g_edge, (double*)nullptr, (float*)ws, n, D, H, W);
     hipLaunchKernelGGL((k_edge_bwd_gather<3, true>), dim3(vox_grid(cols_i)), dim3(kBlock), 0, cfun_st(stream), (const float*)ws, dlogits, n, D, H, W, probs, labels, g_ce, (const float*)nullptr);
   }
   CFUN_LAUNCH_CHECK();
