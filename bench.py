@@ -402,6 +402,10 @@ def main():
                          "convolution (SURVEY.md section 8d), whatever the kernel executes",
                          "mfma_flops_executed_per_launch": executed,
                          "mfma_pipe_frac": executed / t_k / 1e12 / PEAK_FP32_MFMA_TFLOPS if t_k > 0 else 0.0,
+                         "frac_note": "`frac` = algorithmic flops / time / peak, as the bench contract defines it; the kernel "
+                                      "executes fewer MACs (Winograd F(2,3) along x) on padded channel tiles, so the share "
+                                      "of the matrix pipe it keeps busy is `mfma_pipe_frac` (instruction count) / "
+                                      "`mfma_util_pmc` (SQ_VALU_MFMA_BUSY_CYCLES) -- read those as the utilisation figure",
                          "avg_launch_ms": t_k * 1e3, "launches_timed": len(durs)},
         }
         if args.workload == "cfg2" and not b3:
