@@ -460,8 +460,9 @@ int cfun_conv3d_fused_support(const CfunConv3dParams* p) {
   const int wg = wgrad_takes_prologue(p) ? CFUN_FUSE_IN_NORM_WGRAD : 0;
   if (p->algo == CFUN_ALGO_AUTO && cfun_conv_pointwise_supported(p))      // the streaming 1x1x1 -> 8 kernel: prologue only
     return cfun_conv_pointwise_in_supported(p) ? (CFUN_FUSE_IN_NORM | wg) : 0;
-  if (cfun_wino_supported(p)) return CFUN_FUSE_OUT_STATS;                 // k_conv_wino: epilogue statistics only
-  return CFUN_FUSE_OUT_STATS | CFUN_FUSE_IN_NORM | wg;
+  const int st = (p->Co >> 2) <= 256 ? CFUN_FUSE_OUT_STATS : 0;           // (the split-K statistic finish: one thread per channel quad)
+  if (cfun_wino_supported(p)) return st;                                  // k_conv_wino: epilogue statistics only
+  return st | CFUN_FUSE_IN_NORM | wg;
 }
 
 static size_t stat_part_bytes(const CfunConv3dParams* p) {
