@@ -155,103 +155,9 @@ struct PlaneSums {   // classes 1..CT-1 are stored at index c-1
   float dy[CT - 1], sm[CT - 1];
 };
 
-// in-plane sums of the probabilities (floats) and of the one-hot targets (packed) at input plane z, window (y..y+2, x..x+2)
-template <int CT>
-__device__ __forceinline__ void plane_sums(const float* __restrict__ probs, const uint8_t* __restrict__ labels,
-                                           int64_t nbase, int z, int y, int x, int H, int W, PlaneSums<CT>& P,
-                                           TargetPlane& T) {
-  const float A[3] = {1.f, 2.f, 1.f}, B[3] = {1.f, 0.f, -1.f};
-#pragma unroll
-  for (int c = 0; c < CT - 1; ++c) { P.dy[c] = 0.f; P.sm[c] = 0.f; }
-  uint32_t R[3][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}};
-#pragma unroll
-  for (int j = 0; j < 3; ++j)
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int64_t vi = nbase + ((int64_t)z * H + (y + j)) * W + (x + i);
-      const float wd = B[j] * A[i], ws = A[j] * A[i];
-      const float* pp = probs + vi * CT;
-      const unsigned lab = labels[vi];
-      const uint32_t v = lab < (unsigned)CT ? (i == 1 ? 2u : 1u) << ((lab & 3u) * 8u) : 0u;   // (labels >= CT match no class)
-      R[j][0] += (lab & 4u) ? 0u : v;
-      R[j][1] += (lab & 4u) ? v : 0u;
-#pragma unroll
-      for (int c = 1; c < CT; ++c) {
-        const float pv = pp[c];
-        P.dy[c - 1] += wd * pv;
-        P.sm[c - 1] += ws * pv;
-      }
-    }
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    T.dyb[h] = R[0][h] + 0x04040404u - R[2][h];
-    T.sm[h] = R[0][h] + 2u * R[1][h] + R[2][h];
-  }
-}
-
 // MODE 0: accumulate sum (|grad p| - |grad t|)^2 ; MODE 1: write dc[o][c-1][0..1] = dL/d(c0), dL/d(c1) scaled by gscale;
 // MODE 2: both in one pass -- the loss, and dc for an upstream gradient of 1 (the training forward saves it, so the
 // backward needs no second march over the probabilities)
-template <int CT, int MODE>
-__global__ void __launch_bounds__(kBlock)
-k_edge_march(const float* __restrict__ probs, const uint8_t* __restrict__ labels, const float* __restrict__ gscale,
-             double* __restrict__ partial, float* __restrict__ dc, int n, int D, int H, int W) {
-  static_assert(CT <= 8, "packed target sums: 8 classes");
-  const int Do = D - 2, Ho = H - 2, Wo = W - 2;
-  const int nseg = (Do + kZSeg - 1) / kZSeg;
-  const int64_t total = (int64_t)n * nseg * Ho * Wo;
-  const float gs = MODE == 0 ? 0.f : (MODE == 1 ? gscale[0] : 1.f) * 2.f / ((float)Do * (float)Ho * (float)Wo * (float)n);
-  double acc = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
-    int64_t t = i;
-    const int x = (int)(t % Wo); t /= Wo;
-    const int y = (int)(t % Ho); t /= Ho;
-    const int seg = (int)(t % nseg);
-    const int64_t r = t / nseg;
-    const int64_t nbase = r * D * H * W;
-    const int z0 = seg * kZSeg;
-    const int z1 = z0 + kZSeg < Do ? z0 + kZSeg : Do;     // outputs [z0, z1) need input planes [z0, z1 + 2)
-    PlaneSums<CT> P[3];
-    TargetPlane T[3];
-    plane_sums<CT>(probs, labels, nbase, z0, y, x, H, W, P[0], T[0]);
-    plane_sums<CT>(probs, labels, nbase, z0 + 1, y, x, H, W, P[1], T[1]);
-    float accf = 0.f;                                      // one column segment (<= 16 x 7 terms) in fp32, then fp64
-    for (int zo = z0; zo < z1; ++zo) {
-      plane_sums<CT>(probs, labels, nbase, zo + 2, y, x, H, W, P[2], T[2]);
-      float* o = MODE != 0 ? dc + ((((r * Do + zo) * Ho + y) * Wo + x)) * dc_stride(CT) : nullptr;
-      uint32_t t0b[2], t1b[2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        t0b[h] = T[0].dyb[h] + 2u * T[1].dyb[h] + T[2].dyb[h];       // t0 + 16 per 8-bit field
-        t1b[h] = T[0].sm[h] + 0x10101010u - T[2].sm[h];              // t1 + 16
-      }
-#pragma unroll
-      for (int c = 0; c < CT - 1; ++c) {
-        const float p0 = P[0].dy[c] + 2.f * P[1].dy[c] + P[2].dy[c], p1 = P[0].sm[c] - P[2].sm[c];
-        const int cls = c + 1;
-        const float t0 = (float)((int)((t0b[cls >> 2] >> ((cls & 3) * 8)) & 0xffu) - 16);
-        const float t1 = (float)((int)((t1b[cls >> 2] >> ((cls & 3) * 8)) & 0xffu) - 16);
-        const float pm = cfun_fast_sqrt(p0 * p0 + p1 * p1 + p0 * p0);   // channel 0 twice (model.py:969-972)
-        const float tm = cfun_fast_sqrt(t0 * t0 + t1 * t1 + t0 * t0);
-        if (MODE != 1) {
-          const float d = pm - tm;
-          accf += d * d;
-        }
-        if (MODE != 0) {
-          const float k = gs * (pm - tm) * cfun_fast_rcp(pm);   // 0 * inf -> NaN exactly where torch's sqrt backward gives 0/0 (App. A-13)
-          reinterpret_cast<float2*>(o)[c] = make_float2(k * 2.f * p0, k * p1);     // (dc0, dc1) of class c+1: one 8-byte store
-        }
-      }
-      P[0] = P[1]; P[1] = P[2]; T[0] = T[1]; T[1] = T[2];
-    }
-    acc += (double)accf;
-  }
-  if (MODE != 1) {
-    const double s = block_sum(acc);
-    if (threadIdx.x == 0) partial[blockIdx.x] = s;
-  }
-}
-
 // ---- two y-outputs per thread (round 3).  The march is bound by the NUMBER of load instructions per voxel-plane (the class
 // split that raised occupancy instead made it slower), so a thread now owns the column PAIR (y, y+1):
 // the x-direction sums A(x)*f of the FOUR rows y .. y+3 (12 neighbour loads) serve both outputs -- out 0 combines rows
@@ -304,7 +210,7 @@ __device__ __forceinline__ void pair_planes(const RowSums<CT>& S, PlaneSums<CT> 
   }
 }
 
-template <int CT, int MODE>       // MODE as k_edge_march
+template <int CT, int MODE>
 __global__ void __launch_bounds__(kBlock)
 k_edge_march2(const float* __restrict__ probs, const uint8_t* __restrict__ labels, const float* __restrict__ gscale,
               double* __restrict__ partial, float* __restrict__ dc, int n, int D, int H, int W) {
