@@ -383,28 +383,6 @@ def sharded_backbone_rpn(net, image_slab):
 # ---------------------------------------------------------------------------------------------------------------
 # One volume over R ranks: the whole training step (BASELINE.json configs[3])
 # ---------------------------------------------------------------------------------------------------------------
-class _AllGatherDepth(torch.autograd.Function):
-    """Slab [1, d, H, W, C] -> the full [1, d*R, H, W, C] map on every rank (RoIAlign of the classifier head reads
-    boxes that cross slabs; p2 + p3 are 9.4 MB at cfg2).  Backward: every rank holds a gradient for the full map;
-    the owner of a slab needs their sum -> one all-reduce, then the local slice."""
-
-    @staticmethod
-    def forward(ctx, x, shard):
-        ctx.shard = shard
-        x = x.contiguous()
-        parts = [torch.empty_like(x) for _ in range(shard.world)]
-        dist.all_gather(parts, x, group=shard.group)
-        return torch.cat(parts, dim=1)
-
-    @staticmethod
-    def backward(ctx, g):
-        shard = ctx.shard
-        g = g.contiguous()
-        dist.all_reduce(g, group=shard.group)
-        d = g.shape[1] // shard.world
-        return g.narrow(1, shard.rank * d, d).contiguous(), None
-
-
 class _AllReduceSum(torch.autograd.Function):
     """sum over the ranks, forward and backward (the ranks' additive shares of the RoI-aligned crops -> the crops; the
     ranks' gradients of the crops, each non-zero only for the RoIs that rank classifies -> the full gradient)."""
@@ -428,13 +406,6 @@ def all_reduce_sum(x, shard=None):
     if shard is None or shard.world == 1:
         return x
     return _AllReduceSum.apply(x, shard)
-
-
-def gather_depth(x, shard=None):
-    shard = shard or _CTX
-    if shard is None or shard.world == 1:
-        return x
-    return _AllGatherDepth.apply(x, shard)
 
 
 # ---------------------------------------------------------------------------------------------------------------
