@@ -292,6 +292,96 @@ def check_elementwise(device, seed=2):
     assert_close(ops.channel_sum(g2.to(device)), g2.sum(0), "channel_sum")
 
 
+def check_norm_passthrough(device, seed=31):
+    """The norm / activation nodes' second output (an alias of x for x's other consumer, gradients summed inside the
+    backward kernel) and their lazy form (a NormedInput materialized once) against plain torch."""
+    gen = _gen(seed)
+    for shape in ((2, 3, 4, 5, 8), (1, 2, 3, 3, 20), (1, 2, 2, 2, 3)):
+        x = randn(gen, *shape) * 1.5 + randn(gen, 1, 1, 1, 1, shape[-1])
+        g1, g2 = randn(gen, *shape), randn(gen, *shape)
+        for norm in (True, False):
+            def ref_fn(t):
+                if norm:
+                    return F.leaky_relu(F.instance_norm(t.permute(0, 4, 1, 2, 3), eps=1e-5), 0.01).permute(0, 2, 3, 4, 1)
+                return F.leaky_relu(t, 0.01)
+            xr = x.clone().requires_grad_(True)
+            ((ref_fn(xr) * g1).sum() + (xr * g2).sum()).backward()
+            for lazy in (False, True):
+                xd = x.clone().to(device).requires_grad_(True)
+                xs = ops.add(xd, torch.zeros_like(xd))          # a non-leaf producer, like a conv's output
+                fn = ops.instnorm_lrelu if norm else ops.lrelu
+                y, x2 = fn(xs, lazy=lazy, passthrough=True)
+                if lazy:
+                    assert isinstance(y, ops.NormedInput)
+                    assert y.materialize() is y.materialize()     # one apply pass however many consumers ask
+                    y = y.materialize()
+                ((y * g1.to(device)).sum() + (x2 * g2.to(device)).sum()).backward()
+                what = "%s lazy=%s %s" % ("norm" if norm else "lrelu", lazy, shape)
+                assert_close(y, ref_fn(x), what + " y")
+                assert_close(xd.grad, xr.grad, what + " dx", 1e-4)
+            # only the passthrough branch used: the gradient passes through untouched
+            xd = x.clone().to(device).requires_grad_(True)
+            _, x2 = (ops.instnorm_lrelu if norm else ops.lrelu)(ops.add(xd, torch.zeros_like(xd)), passthrough=True)
+            (x2 * g2.to(device)).sum().backward()
+            assert torch.equal(xd.grad.cpu(), g2)
+
+
+def check_roi_align_slabs(device, seed=33):
+    """RoIAlign on depth slabs: the slabs' additive shares sum to the crop of the whole map, their gradients are the
+    whole map's gradient cut into the same slabs (dist.sharded_training_step relies on both)."""
+    gen = _gen(seed)
+    d, h, w, c = 9, 7, 6, 8
+    fm = randn(gen, d, h, w, c)
+    boxes = torch.tensor([[0.0, 0.0, 0.0, 1.0, 1.0, 1.0], [0.1, 0.2, 0.3, 0.6, 0.9, 0.8], [0.4, 0.0, 0.5, 0.45, 0.3, 0.55],
+                          [-0.2, -0.1, 0.0, 0.5, 1.2, 0.7], [0.0, 0.0, 0.0, 0.0, 0.0, 0.0]])
+    pool = (4, 3, 5)
+    gy = randn(gen, boxes.shape[0], *pool, c)
+    fd = fm.clone().to(device).requires_grad_(True)
+    full, b_full = ops.roi_align(fd, boxes.to(device), pool)
+    (full * gy.to(device)).sum().backward()
+    for cuts in ((0, 3, 4, 9), (0, 1, 9), (0, 9)):
+        total, grads = None, []
+        for z0, z1 in zip(cuts[:-1], cuts[1:]):
+            sd = fm[z0:z1].clone().to(device).requires_grad_(True)
+            part, b = ops.roi_align(sd, boxes.to(device), pool, slab=(z0, d))
+            assert torch.equal(b.cpu(), b_full.cpu())           # the crop bounds are those of the whole map
+            (part * gy.to(device)).sum().backward()
+            grads.append(sd.grad)
+            total = part if total is None else total + part
+        assert float((total - full).detach().abs().max()) < 2e-6 * max(1.0, float(full.detach().abs().max())), cuts
+        assert float((torch.cat(grads, 0) - fd.grad).abs().max()) < 1e-5 * max(1.0, float(fd.grad.abs().max())), cuts
+
+
+def check_fc(device, seed=35):
+    """The weight-streaming FC kernels (classifier head) against torch, including the weight gradient in row chunks
+    when the rows' g + x slices exceed the kernel's LDS (wide layers)."""
+    from cfun_amd import _lib
+    gen = _gen(seed)
+    lib = _lib.load()
+    for r, k, o, act in ((5, 64, 12, ACT_RELU), (33, 200, 24, ACT_NONE), (64, 128, 1024, ACT_NONE), (1, 8, 3, ACT_RELU)):
+        x, w = randn(gen, r, k), randn(gen, o, k) * (k ** -0.5)
+        shift, gy = randn(gen, o), randn(gen, r, o)
+        xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), shift.clone().requires_grad_(True)
+        yr = F.linear(xr, wr, br)
+        yr = F.relu(yr) if act == ACT_RELU else yr
+        yr.backward(gy)
+        xd, wd, bd = [t.clone().to(device).requires_grad_(True) for t in (x, w, shift)]
+        y = ops.fc(xd, wd, None, bd, act)
+        y.backward(gy.to(device))
+        what = "fc r%d k%d o%d" % (r, k, o)
+        assert_close(y, yr, what + " y")
+        assert_close(xd.grad, xr.grad, what + " dx")
+        assert_close(wd.grad, wr.grad, what + " dw")
+        assert_close(bd.grad, br.grad, what + " dshift")
+    assert 1 <= int(lib.cfun_fc_bwd_weight_max_rows(1024)) <= 64
+    assert int(lib.cfun_fc_bwd_weight_max_rows(16)) == 64
+    # more rows than the kernel's LDS holds is an argument error at the C ABI, not a launch failure
+    rmax = int(lib.cfun_fc_bwd_weight_max_rows(4096))
+    if rmax < 64:
+        t = torch.zeros(64 * 4096, device=device)
+        assert lib.cfun_fc_bwd_weight(ops.ptr(t), ops.ptr(t), ops.ptr(t), rmax + 1, 16, 4096, ops.stream(t)) == -1   # CFUN_EINVAL
+
+
 def check_maxpool(device, seed=3):
     gen = _gen(seed)
     x = F.relu(randn(gen, 2, 4, 6, 8, 16))   # ReLU output: many exact ties at 0 like the real stem

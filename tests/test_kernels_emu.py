@@ -36,6 +36,18 @@ def test_elementwise(emu):
     kc.check_elementwise(emu)
 
 
+def test_norm_passthrough(emu):
+    kc.check_norm_passthrough(emu)
+
+
+def test_roi_align_slabs(emu):
+    kc.check_roi_align_slabs(emu)
+
+
+def test_fc(emu):
+    kc.check_fc(emu)
+
+
 def test_maxpool(emu):
     kc.check_maxpool(emu)
 

@@ -47,6 +47,18 @@ def test_elementwise(gpu):
     kc.check_elementwise(gpu)
 
 
+def test_norm_passthrough(gpu):
+    kc.check_norm_passthrough(gpu)
+
+
+def test_roi_align_slabs(gpu):
+    kc.check_roi_align_slabs(gpu)
+
+
+def test_fc(gpu):
+    kc.check_fc(gpu)
+
+
 def test_maxpool(gpu):
     kc.check_maxpool(gpu)
 
