@@ -81,12 +81,15 @@ k_wino2_weights(const float* __restrict__ wp, float4* __restrict__ u, int Ci, in
 // 4/9 of the MFMAs.  Staging is unchanged (rows stay x-transformed in LDS); the y transform of the input is applied when
 // the fragment is read (two rows, one add per point), MFMA columns are the 2 x 8 tiles of the wave's 4 x 16 plane and the
 // accumulators are [4 py][4 px][NSUB].
-template <int NSUB, bool S2D, bool TWOD, bool STATS = false>
-__global__ void __launch_bounds__(256)
+// SB (TWOD only): one LDS buffer and two barriers per chunk like the 1-D loop, and registers capped for two waves per
+// SIMD at NSUB = 2 (128 + 128): the second resident workgroup hides the staging instead of the second buffer.
+// co0: first output channel of this launch's tiles (a launch may cover a channel range: see cfun_wino_fwd)
+template <int NSUB, bool S2D, bool TWOD, bool STATS = false, bool SB = false>
+__global__ void __launch_bounds__(256, (TWOD && SB) ? (NSUB == 1 ? 3 : 2) : 1)
 k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const float* __restrict__ scale,
             const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y, CfunConv3dParams p,
             int ntz, int nty, int ntx, int ncot, float* __restrict__ partial, int chunks_per_split, int s2d_cq,
-            cfun_mfma::ConvMode md) {
+            cfun_mfma::ConvMode md, int co0) {
   constexpr int NT = 16 * NSUB;
   constexpr int UROWS = TWOD ? 12 : 9;        // (dz,py) or (dz,dy) groups of 4 channel rows
   constexpr int W_ITEMS = UROWS * 4 * NT;     // float4 (= 4 x-points of one output channel) items per chunk
@@ -103,7 +106,7 @@ k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const flo
   int tz, ty, tx;
   cfun_mfma::tile_raster(lid - (unsigned)n * per_n, ntz, nty, ntx, tz, ty, tx);
   const int z0 = tz * TD, y0 = ty * TH, x0 = tx * TW;
-  const int cobase = cot * NT;
+  const int cobase = co0 + cot * NT;
 
   // ---- staging descriptors.  X item = (halo row r = (z, y), column pair jj of 9): the two voxels x = 2jj, 2jj+1 for TWO
   // consecutive channel chunks (each 16-byte piece; both come out of the same 64-byte sector, so issued back to back
@@ -171,9 +174,7 @@ k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const flo
     }
   };
   constexpr int LBUF = 4 * VPLANE4 + UROWS * 4 * NT;      // float4 per LDS buffer (TWOD runs two of them)
-  auto commit = [&](int buf, int half) {           // half: which chunk of the prefetched pair
-    float4* Vl = smem + buf * LBUF;
-    float4* Ul = Vl + 4 * VPLANE4;
+  auto commit_x = [&](float4* Vl, int half) {      // half: which chunk of the prefetched pair
 #pragma unroll
     for (int i = 0; i < X_PASSES; ++i) {
       float d[4][4];                                // [voxel 0..3 of the x-pair][channel]
@@ -196,11 +197,17 @@ k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const flo
           v[cc * VPLANE4] = make_float4(d[0][cc] - d[2][cc], d[1][cc] + d[2][cc], d[2][cc] - d[1][cc], d[1][cc] - d[3][cc]);
       }
     }
+  };
+  auto commit_w = [&](float4* Ul) {
 #pragma unroll
     for (int i = 0; i < W_LOADS; ++i) {
       const int it = tid + i * 256;
       if (it < W_ITEMS) Ul[it] = win[i];
     }
+  };
+  auto commit = [&](int buf, int half) {
+    commit_x(smem + buf * LBUF, half);
+    commit_w(smem + buf * LBUF + 4 * VPLANE4);
   };
 
   constexpr int NMG = TWOD ? 4 : 2;           // row groups (1-D) / y points (2-D)
@@ -221,20 +228,9 @@ k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const flo
   const int c_begin = blockIdx.y * chunks_per_split;
   const int c_end = (c_begin + chunks_per_split < nchunks) ? c_begin + chunks_per_split : nchunks;
   if constexpr (TWOD) {
-  // TWOD runs one wave per SIMD (192 accumulator registers at NSUB = 3), so nothing else hides the staging: LDS is double
-  // buffered (2 x 55 KB) -- the next chunk is committed to the other buffer after this chunk's MFMAs were issued, one
-  // barrier per chunk
-  if (c_begin < c_end) {
-    prefetch_x(c_begin, c_begin + 1 < c_end ? c_begin + 1 : c_begin);
-    prefetch_w(c_begin);
-    commit(0, 0);
-    __syncthreads();
-  }
-  for (int c = c_begin; c < c_end; ++c) {
-    if (c + 1 < c_end) prefetch_w(c + 1);
-    if constexpr (TWOD) {
-      const float4* Vw = Vw0 + ((c - c_begin) & 1) * LBUF;
-      const float4* Uw = Uw0 + ((c - c_begin) & 1) * LBUF;
+    auto twod_phase = [&](int voff, int uoff) {      // float4 offsets of the V / U buffers to read
+      const float4* Vw = Vw0 + voff;
+      const float4* Uw = Uw0 + uoff;
       // 12 steps (dz,py): the 4 x-transformed rows of the next dz and the next step's weight fragment are in flight
       // under the current step's 4*NSUB MFMAs
       float4 rows[2][4], a2[2][NSUB];
@@ -287,14 +283,54 @@ k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const flo
 #endif
       };
       static_for(std::make_integer_sequence<int, 12>{}, step);
-      if (c + 1 < c_end) {
-        const int half = (c + 1 - c_begin) & 1;
-        commit(((c - c_begin) & 1) ^ 1, half);
-        if (half && c + 2 < c_end) prefetch_x(c + 2, c + 3 < c_end ? c + 3 : c + 2);     // both halves consumed: next pair
+    };
+    if constexpr (SB) {
+      // a chunk's MFMA phase is short here (48 * NSUB MFMAs): BOTH chunks of the register pair are transformed into LDS at
+      // once (two V buffers, one U buffer), so the next pair's loads are in flight under two MFMA phases instead of one.
+      // LDS = [V0][V1][U]; the second chunk's U is committed between the phases (two more barriers, 6 stores)
+      float4* const V1 = smem + 4 * VPLANE4;
+      float4* const Ub = smem + 8 * VPLANE4;
+      if (c_begin < c_end) { prefetch_x(c_begin, c_begin + 1 < c_end ? c_begin + 1 : c_begin); prefetch_w(c_begin); }
+      for (int c = c_begin; c < c_end; c += 2) {
+        __syncthreads();
+        commit_x(smem, 0);
+        if (c + 1 < c_end) commit_x(V1, 1);
+        commit_w(Ub);
+        __syncthreads();
+        if (c + 2 < c_end) prefetch_x(c + 2, c + 3 < c_end ? c + 3 : c + 2);
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+          if (c + h >= c_end) break;
+          if (h) {
+            __syncthreads();
+            commit_w(Ub);
+            __syncthreads();
+          }
+          if (c + h + 1 < c_end) prefetch_w(c + h + 1);
+          twod_phase(h * 4 * VPLANE4, 4 * VPLANE4);
+        }
       }
-      __syncthreads();
+    } else {
+      // without SB, TWOD runs one wave per SIMD (192 accumulator registers at NSUB = 3), so nothing else hides the staging:
+      // LDS is double buffered (2 x 55 KB) -- the next chunk is committed to the other buffer after this chunk's MFMAs
+      // were issued, one barrier per chunk
+      if (c_begin < c_end) {
+        prefetch_x(c_begin, c_begin + 1 < c_end ? c_begin + 1 : c_begin);
+        prefetch_w(c_begin);
+        commit(0, 0);
+        __syncthreads();
+      }
+      for (int c = c_begin; c < c_end; ++c) {
+        if (c + 1 < c_end) prefetch_w(c + 1);
+        twod_phase(((c - c_begin) & 1) * LBUF, ((c - c_begin) & 1) * LBUF);
+        if (c + 1 < c_end) {
+          const int half = (c + 1 - c_begin) & 1;
+          commit(((c - c_begin) & 1) ^ 1, half);
+          if (half && c + 2 < c_end) prefetch_x(c + 2, c + 3 < c_end ? c + 3 : c + 2);     // both halves consumed: next pair
+        }
+        __syncthreads();
+      }
     }
-  }
   } else {
     auto mfma_phase = [&]() {
       const float4* Vw = Vw0;
@@ -456,6 +492,17 @@ int wino_nsub(int co, int twod) {
 // 48^3 and below (80 -> 80 @ 48^3: 1.02 -> 0.92 ms, @ 24^3: 0.192 -> 0.170 ms; the folded 5^3 conv's data gradient 1.31
 // -> 1.22 ms), where fewer MFMAs per tile matter more than the second resident wave -- so AUTO takes it up to 2^19
 // output voxels per launch, and for single-tile outputs of any size.
+static int env_knob(const char* name) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : -1;
+}
+
+// C_out = 32 k + (1..16): k tiles of 32 channels and one of 16 (see make_plan); CFUN_WINO_COSPLIT=0 turns it off
+static bool cosplit_shape(const CfunConv3dParams& p) {
+  static const int knob = env_knob("CFUN_WINO_COSPLIT");
+  return knob != 0 && p.Co > 32 && (p.Co % 32) >= 1 && (p.Co % 32) <= 16 && !p.d2s;
+}
+
 int wino_2d(const CfunConv3dParams& p) {
   static int knob = -2;
   if (knob == -2) {
@@ -466,24 +513,39 @@ int wino_2d(const CfunConv3dParams& p) {
   if (p.algo == CFUN_ALGO_WINO2 || knob == 1) return 1;
   if (knob == 0) return 0;
   // (C_out <= 16 -- the folded 5^3 conv's data gradient -- runs one co tile: 64 accumulators, three waves per SIMD either way)
-  return p.Co <= 16 || (int64_t)p.N * p.Do * p.Ho * p.Wo <= ((int64_t)1 << 19);
+  // (C_out = 32 k + 1..16, k >= 1: 2-D with the channel split of make_plan -- two waves per SIMD at any size)
+  return p.Co <= 16 || cosplit_shape(p) || (int64_t)p.N * p.Do * p.Ho * p.Wo <= ((int64_t)1 << 19);
 }
 
 struct Plan {
-  int nsub, twod, ntz, nty, ntx, ncot, ksplit, cps;
+  int nsub, twod, sb, tail_nsub, ntz, nty, ntx, ncot, ksplit, cps;
   int64_t nblk;
   size_t u_bytes, part_bytes;
 };
 
 Plan make_plan(const CfunConv3dParams& p, size_t ws_for_partials) {
+  static const int sb_knob = env_knob("CFUN_WINO_SB");      // 0: the double-buffered one-wave-per-SIMD loop for every NSUB
   Plan w;
   w.twod = wino_2d(p);
-  w.nsub = wino_nsub(p.Co, w.twod);
-  const int nt = 16 * w.nsub;
-  w.ntz = cdiv(p.Do, TD); w.nty = cdiv(p.Ho, TH); w.ntx = cdiv(p.Wo, TW); w.ncot = cdiv(p.Co, nt);
-  w.nblk = (int64_t)p.N * w.ntz * w.nty * w.ntx * w.ncot;
+  w.ntz = cdiv(p.Do, TD); w.nty = cdiv(p.Ho, TH); w.ntx = cdiv(p.Wo, TW);
+  const int64_t tiles = (int64_t)p.N * w.ntz * w.nty * w.ntx;
+  auto fill = [&](int nsub, int ncot) {
+    w.nsub = nsub; w.ncot = ncot; w.nblk = tiles * ncot;
+    w.ksplit = cfun_mfma::splitk_factor(w.nblk, p.Ci >> 2, p, ws_for_partials);
+  };
+  const int nsub = wino_nsub(p.Co, w.twod);
+  fill(nsub, cdiv(p.Co, 16 * nsub));
+  // channel split: C_out = 32 k + (1..16) as k tiles of 32 at two waves per SIMD and, in a second launch, one tile of 16 --
+  // instead of 48-wide tiles at one wave per SIMD (192 accumulators); the same count of 16-column MFMAs.  For launches
+  // that fill the chip (no split-K).
+  w.tail_nsub = 0;
+  if (w.twod && nsub == 3 && w.ksplit == 1 && sb_knob != 0 && cosplit_shape(p)) {
+    fill(2, p.Co / 32);
+    if (w.ksplit == 1) w.tail_nsub = 1;
+    else fill(nsub, cdiv(p.Co, 16 * nsub));
+  }
+  w.sb = w.twod && w.nsub <= 2 && sb_knob != 0;
   w.u_bytes = cfun_align_up((size_t)(w.twod ? 48 : 36) * p.Ci * p.CoP * sizeof(float), 256);
-  w.ksplit = cfun_mfma::splitk_factor(w.nblk, p.Ci >> 2, p, ws_for_partials);
   w.cps = cdiv(p.Ci >> 2, w.ksplit);
   w.part_bytes = w.ksplit > 1 ? (size_t)w.ksplit * p.N * p.Do * p.Ho * p.Wo * p.Co * sizeof(float) : 0;
   return w;
@@ -491,13 +553,20 @@ Plan make_plan(const CfunConv3dParams& p, size_t ws_for_partials) {
 
 template <int NSUB>
 int launch(const float* x, const float4* u, const float* scale, const float* shift, const float* res, float* y,
-           const CfunConv3dParams& p, const Plan& w, float* partial, int s2d_cq, const cfun_mfma::ConvMode& md, hipStream_t st) {
-  const size_t lds = (size_t)(w.twod ? 2 : 1) * (4 * VPLANE4 + (w.twod ? 48 : 36) * 16 * NSUB) * sizeof(float4);
+           const CfunConv3dParams& p, const Plan& w, float* partial, int s2d_cq, const cfun_mfma::ConvMode& md, hipStream_t st,
+           int co0 = 0, int ncot = -1) {
+  if (ncot < 0) ncot = w.ncot;
+  const bool sb = w.twod && w.sb && NSUB <= 2;
+  const size_t lds = sb ? (size_t)(8 * VPLANE4 + 48 * 16 * NSUB) * sizeof(float4)      // [V0][V1][U]
+                        : (size_t)(w.twod ? 2 : 1) * (4 * VPLANE4 + (w.twod ? 48 : 36) * 16 * NSUB) * sizeof(float4);
   auto kern = s2d_cq ? k_conv_wino<NSUB, true, false> : k_conv_wino<NSUB, false, false>;
   if constexpr (NSUB <= 3) {     // 16 accumulator sets per wave: 64 * NSUB registers
     if (w.twod) kern = s2d_cq ? k_conv_wino<NSUB, true, true> : k_conv_wino<NSUB, false, true>;
   } else if (w.twod) {
     return CFUN_EINVAL;
+  }
+  if constexpr (NSUB <= 2) {
+    if (sb) kern = s2d_cq ? k_conv_wino<NSUB, true, true, false, true> : k_conv_wino<NSUB, false, true, false, true>;
   }
   if (md.out_part) {             // epilogue statistics (forward only: never with the s2d gather)
     if (s2d_cq) return CFUN_EINVAL;
@@ -505,13 +574,17 @@ int launch(const float* x, const float4* u, const float* scale, const float* shi
     if constexpr (NSUB <= 3) {
       if (w.twod) kern = k_conv_wino<NSUB, false, true, true>;
     }
+    if constexpr (NSUB <= 2) {
+      if (sb) kern = k_conv_wino<NSUB, false, true, true, true>;
+    }
   }
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)w.nblk, (unsigned)w.ksplit), dim3(256), lds, st, x, u, scale, shift, res, y, p,
-                     w.ntz, w.nty, w.ntx, w.ncot, partial, w.cps, s2d_cq, md);
+  const int64_t nblk = (int64_t)p.N * w.ntz * w.nty * w.ntx * ncot;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)w.ksplit), dim3(256), lds, st, x, u, scale, shift, res, y, p,
+                     w.ntz, w.nty, w.ntx, ncot, partial, w.cps, s2d_cq, md, co0);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }
@@ -607,6 +680,8 @@ int cfun_wino_fwd(const float* x, const float* wp, int flip, int s2d_cq, const f
     default: rc = launch<5>(x, u, scale, shift, res, y, *p, w, partial, s2d_cq, md, st); break;
   }
   if (rc) return rc;
+  if (w.tail_nsub)      // the last 1..16 channels (make_plan): their own 16-wide tiles, same spatial tiling and statistics slots
+    return launch<1>(x, u, scale, shift, res, y, *p, w, partial, s2d_cq, md, st, w.ncot * 16 * w.nsub, 1);
   if (w.ksplit > 1) return cfun_splitk_finish(partial, w.ksplit, scale, shift, res, y, p, finish_part, st);
   return CFUN_OK;
 }

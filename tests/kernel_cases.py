@@ -106,6 +106,7 @@ CONV_CASES = {
     "wino2_333_d2s_slab": (1, (6, 4, 5), 8, 64, (3, 3, 3), dict(algo=ALGO_WINO2, d2s=True, res=True, pad=(0, 1, 1))),
     "wino_333_80_80_nsub1_tiles": (1, (5, 4, 10), 80, 80, (3, 3, 3), dict(algo=ALGO_WINO, act=ACT_LRELU)),      # 5 co tiles of 16, 5 ci subtiles
     "wino_333_12_20_small_ci": (1, (4, 6, 9), 12, 20, (3, 3, 3), dict(algo=ALGO_WINO)),                        # C_in = 12: one half-empty ci subtile
+    "wino2_333_12_24_odd_chunks": (2, (5, 4, 9), 12, 24, (3, 3, 3), dict(algo=ALGO_WINO2, act=ACT_LRELU, shift=True)),   # 3 channel chunks: a half-filled register pair
     "wino2_333_40_40": (1, (4, 5, 19), 40, 40, (3, 3, 3), dict(algo=ALGO_WINO2, res=True)),
     "wino_333_slab_pd0": (2, (7, 5, 9), 16, 32, (3, 3, 3), dict(algo=ALGO_WINO, pad=(0, 1, 1), shift=True)),   # a depth slab with its halo
     "wino_333_d2s_res": (2, (3, 4, 5), 8, 64, (3, 3, 3), dict(algo=ALGO_WINO, d2s=True, res=True, act=ACT_LRELU)),

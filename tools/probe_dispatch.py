@@ -32,6 +32,7 @@ for b, (hw, xcc, t0, t1) in enumerate(o):
     cu, sh, se = (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7
     per_cu[(xcc & 15, se, sh, cu)] += 1
 print(f"{nblocks} blocks, lds {lds} B: {len(per_cu)} distinct CUs used")
+print("wave slot (HW_ID WAVE_ID) of wave 0, histogram:", dict(sorted(collections.Counter(r[0] & 15 for r in o).items())), " simd:", dict(sorted(collections.Counter((r[0] >> 4) & 3 for r in o).items())))
 hist = collections.Counter(per_cu.values())
 print("blocks per CU histogram:", dict(sorted(hist.items())))
 for x in range(8):
