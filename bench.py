@@ -61,25 +61,35 @@ PMC_MFMA_JSON = "profiles/round3_pmc_mfma_wino_l4_0.json"
 
 
 def dominant_kernel_info(cfg, n_roi):
-    """Which kernel the library runs for conv_norm_lrelu_l4.0 (cfun_conv3d_fwd_kernel) and the MFMA flops it actually
-    issues per launch: the Winograd kernel runs 9 (dz,dy) x 4 points instead of 27 taps per pair of x outputs (x 2/3),
-    on output-channel tiles padded to 16 * NSUB (40 -> 48)."""
+    """Which kernels the library runs for conv_norm_lrelu_l4.0 (cfun_conv3d_fwd_kernel / cfun_conv3d_wino_plan) and the
+    MFMA flops they actually issue per call: the Winograd kernels run 9 (dz,dy) x 4 points (1-D, x 2/3) or 3 (dz) x 16
+    points per 2x2 outputs (2-D, x 4/9) instead of 27 taps, on output-channel columns padded to whole 16-wide subtiles
+    (40 -> 48).  Returns (kernel code, executed flops, label)."""
     import ctypes as C
     from cfun_amd import _lib, ops
     b, side = cfg.UNET_MASK_BRANCH_CHANNEL, tuple(cfg.MASK_POOL_SIZE)
     spec = ops.ConvSpec(k=(3, 3, 3), co=2 * b, pad=(1, 1, 1))
     p = ops._params(spec, (n_roi,) + side + (2 * b,), False, False, False)
-    kern = int(_lib.load().cfun_conv3d_fwd_kernel(C.byref(p)))
-    nsub, best_pad = 1, 1 << 30      # conv3d_wino.hip wino_nsub(): fewest padded channels, widest on ties, at most 3
-    for n_ in (1, 2, 3):
-        pad = -(-2 * b // (16 * n_)) * 16 * n_
-        if pad <= best_pad:
-            nsub, best_pad = n_, pad
-    co_pad = best_pad if kern == 2 else -(-2 * b // 16) * 16
+    lib = _lib.load()
+    kern = int(lib.cfun_conv3d_fwd_kernel(C.byref(p)))
     tiles = n_roi * -(-side[0] // 4) * -(-side[1] // 4) * -(-side[2] // 16)
-    macs_per_tile_ch = 256 * 27 * (2.0 / 3.0 if kern == 2 else 1.0)
-    executed = 2.0 * tiles * macs_per_tile_ch * (2 * b) * co_pad
-    return kern, executed, nsub
+    if kern != 2:
+        co_pad = -(-2 * b // 16) * 16
+        return kern, 2.0 * tiles * 256 * 27 * (2 * b) * co_pad, "k_conv_mfma<3,3,3,1,3>"
+    plan = (C.c_int32 * 4)()
+    _lib.check(lib.cfun_conv3d_wino_plan(C.byref(p), plan), "conv3d_wino_plan")
+    twod, nsub, tail, cols = [int(v) for v in plan]
+    executed = 2.0 * tiles * 256 * 27 * ((4.0 / 9.0) if twod else (2.0 / 3.0)) * (2 * b) * cols
+    if twod:
+        label = ("k_conv_wino<%d, .., 2-D%s> (x and y in the Winograd F(2x2,3x3) domain: 4/9 of the direct MACs on the MFMA "
+                 "pipe; the call = k_wino2_weights + %s)"
+                 % (nsub, ", two waves per SIMD" if nsub <= 2 else "",
+                    "a %d-column launch and a 16-column launch for the last %d channels" % (cols - 16, 2 * b - (cols - 16))
+                    if tail else "one launch"))
+    else:
+        label = ("k_conv_wino<%d> (x axis in the Winograd F(2,3) domain: 2/3 of the direct MACs on the MFMA pipe, incl. its "
+                 "k_wino_weights transform launch)" % nsub)
+    return kern, executed, label
 
 
 def stem_back_to_back(cfg, net, n_roi, dev, launches=64):
@@ -367,9 +377,7 @@ def main():
         flops = 2.0 * (2 * b) * (2 * b) * 27 * side[0] * side[1] * side[2] * n_roi_launch   # per launch
         durs = timer.durations_ms("mfma")
         durs_h = timer.durations_ms("hbm")
-        kern, executed, nsub_w = dominant_kernel_info(cfg, n_roi_launch)
-        kname = {2: "k_conv_wino<%d> (x axis" % nsub_w + " in the Winograd F(2,3) domain: 2/3 of the direct MACs on the MFMA pipe, "
-                    "incl. its k_wino_weights transform launch)", 1: "k_conv_mfma<3,3,3,1,3>"}.get(kern, "kernel code %d" % kern)
+        kern, executed, kname = dominant_kernel_info(cfg, n_roi_launch)
         t_k = sum(durs) / max(len(durs), 1) * 1e-3
         achieved = flops / t_k / 1e12 if t_k > 0 else 0.0
         result = {
@@ -403,7 +411,7 @@ def main():
                          "mfma_flops_executed_per_launch": executed,
                          "mfma_pipe_frac": executed / t_k / 1e12 / PEAK_FP32_MFMA_TFLOPS if t_k > 0 else 0.0,
                          "frac_note": "`frac` = algorithmic flops / time / peak, as the bench contract defines it; the kernel "
-                                      "executes fewer MACs (Winograd F(2,3) along x) on padded channel tiles, so the share "
+                                      "executes fewer MACs (Winograd domain) on padded channel tiles, so the share "
                                       "of the matrix pipe it keeps busy is `mfma_pipe_frac` (instruction count) / "
                                       "`mfma_util_pmc` (SQ_VALU_MFMA_BUSY_CYCLES) -- read those as the utilisation figure",
                          "avg_launch_ms": t_k * 1e3, "launches_timed": len(durs)},

@@ -48,6 +48,7 @@ _SIGNATURES = {
     "cfun_error_string": (C.c_char_p, [C.c_int]),
     "cfun_conv3d_fwd_workspace_bytes": (_Z, [_PP]),
     "cfun_conv3d_fwd_kernel": (_I, [_PP]),
+    "cfun_conv3d_wino_plan": (C.c_int, [_PP, C.POINTER(C.c_int32)]),
     "cfun_conv3d_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _PP, _P, _Z, _P]),
     "cfun_conv3d_fused_support": (C.c_int, [_PP]),
     "cfun_conv3d_fwd_fused_workspace_bytes": (_Z, [_PP, _PF]),

@@ -636,6 +636,14 @@ int cfun_wino_s2d_dgrad_supported(const CfunConv3dParams* p, const CfunConv3dPar
   return (int64_t)q->N * q->Do * q->Ho * q->Wo > 0;
 }
 
+extern "C" int cfun_conv3d_wino_plan(const CfunConv3dParams* p, int32_t out[4]) {
+  if (!p || !out || !cfun_wino_supported(p)) return CFUN_EINVAL;
+  const Plan w = make_plan(*p, (size_t)-1);
+  out[0] = w.twod; out[1] = w.nsub; out[2] = w.tail_nsub;
+  out[3] = w.ncot * 16 * w.nsub + 16 * w.tail_nsub;
+  return CFUN_OK;
+}
+
 size_t cfun_wino_workspace_bytes(const CfunConv3dParams* p) {
   const Plan w = make_plan(*p, (size_t)-1);
   return w.u_bytes + cfun_align_up(w.part_bytes, 256);

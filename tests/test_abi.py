@@ -114,3 +114,16 @@ def test_conv_kernel_selection(emu):
     assert kern((4, 96, 96, 96, 1), co=20, **k3) == STEM
     assert kern((4, 96, 96, 96, 40), co=8, k=(1, 1, 1), pad=(0, 0, 0)) == POINTWISE
     assert kern((1, 8, 8, 8, 3), co=5, **k3) == DIRECT                         # channel counts the MFMA tiles cannot take
+
+    def plan(shape, **spec):
+        p = ops._params(ops.ConvSpec(**spec), shape, False, False, False)
+        out = (C.c_int32 * 4)()
+        rc = int(lib.cfun_conv3d_wino_plan(C.byref(p), out))
+        return rc, [int(v) for v in out]
+
+    # the Winograd plan: {2-D, subtiles of the main launch, subtiles of the launch for the last channels, columns computed}
+    assert plan((4, 96, 96, 96, 40), co=40, **k3) == (0, [1, 2, 1, 48])        # 32 + 8 channels, two waves per SIMD each
+    assert plan((4, 48, 48, 48, 80), co=80, **k3) == (0, [1, 1, 0, 80])        # five 16-wide tiles
+    assert plan((4, 24, 24, 24, 160), co=160, **k3) == (0, [1, 2, 0, 160])
+    assert plan((4, 96, 96, 96, 64), co=64, **k3) == (0, [0, 2, 0, 64])        # > 2^19 voxels, no channel split: x axis only
+    assert plan((4, 96, 96, 96, 20), co=20, **k3)[0] != 0                      # not a Winograd launch

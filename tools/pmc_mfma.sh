@@ -14,21 +14,26 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --ker
     python "$REPO/tools/bench_layers.py" --filter l4.0 --iters 1 > "$REPO/gpurun_out/pmc_mfma.log" 2>&1
 cp "$(find /tmp/pmc_mfma -name '*counter_collection.csv' | head -1)" "$REPO/gpurun_out/pmc_mfma.csv"
 REPO="$REPO" python - "$REPO/gpurun_out/pmc_mfma.csv" <<'PY'
-import csv, json, os, sys
+import csv, json, os, re, sys
 sys.path.insert(0, os.path.join(os.environ["REPO"], "tools"))
-from pmc_traffic import git_blob_sha1, SRC
-K = os.environ.get("CFUN_PMC_KERNEL", "k_conv_wino<3, false, false, false>")
+from pmc_traffic import git_blob_sha1, SRC, KERNEL, kernel_label
 acc = {}
 for row in csv.DictReader(open(sys.argv[1])):
-    if K in row["Kernel_Name"]:
-        acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
-avg = {k: sum(v) / len(v) for k, v in acc.items()}
+    if re.search(KERNEL, row["Kernel_Name"]):
+        acc.setdefault(kernel_label(row["Kernel_Name"]), {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+per = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
+avg = {}
+for d in per.values():            # one conv call = these kernels one after the other: counters add
+    for c, v in d.items():
+        avg[c] = avg.get(c, 0.0) + v
 cus = 256
 rec = {"what": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES (one pass, --kernel-trace only) "
                "around tools/bench_layers.py --filter l4.0 --iters 1 on MI355X (tools/pmc_mfma.sh)",
-       "kernel": "%s (3x3x3 40->40 @ 4x96^3, forward / data gradient)" % K,
+       "kernel": "%s (3x3x3 40->40 @ 4x96^3, forward / data gradient; counters summed over the call's kernels)" % " + ".join(sorted(per)),
        "kernel_src": "cfun_amd/csrc/" + os.path.basename(SRC), "kernel_src_blob": git_blob_sha1(SRC),
-       "dispatches": len(next(iter(acc.values()))) if acc else 0, "counters_avg": avg}
+       "dispatches": min(len(next(iter(d.values()))) for d in acc.values()) if acc else 0, "counters_avg": avg,
+       "per_kernel": {k: dict(d, mfma_util=d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] / 8.0 * cus * 4))
+                      for k, d in per.items() if d.get("GRBM_GUI_ACTIVE")}}
 if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and "GRBM_GUI_ACTIVE" in avg and avg["GRBM_GUI_ACTIVE"] > 0:
     busy = avg["GRBM_GUI_ACTIVE"] / 8.0            # the counter is reported summed over the 8 XCDs
     rec["busy_cycles_per_xcd"] = busy

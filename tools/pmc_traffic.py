@@ -6,6 +6,7 @@ import csv
 import hashlib
 import json
 import os
+import re
 import sys
 
 SRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cfun_amd", "csrc", os.environ.get("CFUN_PMC_SRC", "conv3d_wino.hip"))
@@ -16,29 +17,46 @@ def git_blob_sha1(path):
     data = open(path, "rb").read()
     return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 
-KERNEL = os.environ.get("CFUN_PMC_KERNEL", "k_conv_wino<3, false, false, false>")
+# the kernels of ONE conv call (regex over rocprofv3's kernel names): the 2-D Winograd launch covering 32 channels
+# (NSUB = 2) and the one covering the last 8 (NSUB = 1), both with STATS = false -- forward / data gradient of l4.0
+KERNEL = os.environ.get("CFUN_PMC_KERNEL", r"k_conv_wino<[12], false, true, false, true>")
+
+
+def kernel_label(name):
+    m = re.search(r"(k_\w+<[^>]*>)", name)
+    return m.group(1) if m else name[:60]
+
+
+def per_kernel_avg(path, counters):
+    """{kernel label: {counter: (average per dispatch, dispatches)}} of the kernels matching KERNEL"""
+    acc = {}
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if re.search(KERNEL, row["Kernel_Name"]) and row["Counter_Name"] in counters:
+                acc.setdefault(kernel_label(row["Kernel_Name"]), {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    if not acc:
+        raise SystemExit("no %s rows for %s in %s" % (counters, KERNEL, path))
+    return {k: {c: (sum(v) / len(v), len(v)) for c, v in d.items()} for k, d in acc.items()}
 
 
 def avg_counter(path, counter):
-    vals = []
-    with open(path) as f:
-        for row in csv.DictReader(f):
-            if KERNEL in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                vals.append(float(row["Counter_Value"]))
-    if not vals:
-        raise SystemExit("no %s rows for %s in %s" % (counter, KERNEL, path))
-    return sum(vals) / len(vals), len(vals)
+    """per-call figure: the sum over the call's kernels of each kernel's per-dispatch average"""
+    per = per_kernel_avg(path, (counter,))
+    return sum(d[counter][0] for d in per.values()), min(d[counter][1] for d in per.values()), per
 
 
 def main():
-    fetch, n = avg_counter(sys.argv[1], "FETCH_SIZE")
-    write, _ = avg_counter(sys.argv[2], "WRITE_SIZE")
+    fetch, n, per_f = avg_counter(sys.argv[1], "FETCH_SIZE")
+    write, _, per_w = avg_counter(sys.argv[2], "WRITE_SIZE")
     algorithmic = 4 * (2 * 4 * 96 ** 3 * 40 + 27 * 40 * 40)
     rec = {
         "what": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) around "
                 "tools/bench_layers.py --filter l4.0 --iters 1 on MI355X (tools/pmc_traffic.sh)",
-        "kernel": "%s (conv_norm_lrelu_l4.0 forward / data gradient: 3x3x3 40->40 @ 4x96^3)" % KERNEL,
+        "kernel": "%s (conv_norm_lrelu_l4.0 forward / data gradient: 3x3x3 40->40 @ 4x96^3; per CALL = the sum over "
+                  "these kernels of their per-dispatch averages)" % " + ".join(sorted(per_f)),
         "dispatches": n,
+        "per_kernel_avg_KB": {k: {"FETCH_SIZE": round(per_f[k]["FETCH_SIZE"][0], 1),
+                                  "WRITE_SIZE": round(per_w.get(k, {}).get("WRITE_SIZE", (0.0, 0))[0], 1)} for k in sorted(per_f)},
         "FETCH_SIZE_avg_KB": round(fetch, 1),
         "WRITE_SIZE_avg_KB": round(write, 1),
         "correction": "MI355X_MICROARCH.md section HBM: FETCH_SIZE counts half of a wide (16 B/lane) coalesced read "
