@@ -78,14 +78,11 @@ def dominant_kernel_info(cfg, n_roi):
         return kern, 2.0 * tiles * 256 * 27 * (2 * b) * co_pad, "k_conv_mfma<3,3,3,1,3>"
     plan = (C.c_int32 * 4)()
     _lib.check(lib.cfun_conv3d_wino_plan(C.byref(p), plan), "conv3d_wino_plan")
-    twod, nsub, tail, cols = [int(v) for v in plan]
+    twod, nsub, sb, cols = [int(v) for v in plan]
     executed = 2.0 * tiles * 256 * 27 * ((4.0 / 9.0) if twod else (2.0 / 3.0)) * (2 * b) * cols
     if twod:
-        label = ("k_conv_wino<%d, .., 2-D%s> (x and y in the Winograd F(2x2,3x3) domain: 4/9 of the direct MACs on the MFMA "
-                 "pipe; the call = k_wino2_weights + %s)"
-                 % (nsub, ", two waves per SIMD" if nsub <= 2 else "",
-                    "a %d-column launch and a 16-column launch for the last %d channels" % (cols - 16, 2 * b - (cols - 16))
-                    if tail else "one launch"))
+        label = ("k_conv_wino<%d, 2-D%s> (x and y in the Winograd F(2x2,3x3) domain: 4/9 of the direct MACs on the MFMA pipe, "
+                 "incl. its k_wino2_weights transform launch)" % (nsub, ", two waves per SIMD" if sb else ""))
     else:
         label = ("k_conv_wino<%d> (x axis in the Winograd F(2,3) domain: 2/3 of the direct MACs on the MFMA pipe, incl. its "
                  "k_wino_weights transform launch)" % nsub)

@@ -83,13 +83,12 @@ k_wino2_weights(const float* __restrict__ wp, float4* __restrict__ u, int Ci, in
 // accumulators are [4 py][4 px][NSUB].
 // SB (TWOD only): one LDS buffer and two barriers per chunk like the 1-D loop, and registers capped for two waves per
 // SIMD at NSUB = 2 (128 + 128): the second resident workgroup hides the staging instead of the second buffer.
-// co0: first output channel of this launch's tiles (a launch may cover a channel range: see cfun_wino_fwd)
 template <int NSUB, bool S2D, bool TWOD, bool STATS = false, bool SB = false>
 __global__ void __launch_bounds__(256, (TWOD && SB) ? (NSUB == 1 ? 3 : 2) : 1)
 k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const float* __restrict__ scale,
             const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y, CfunConv3dParams p,
             int ntz, int nty, int ntx, int ncot, float* __restrict__ partial, int chunks_per_split, int s2d_cq,
-            cfun_mfma::ConvMode md, int co0) {
+            cfun_mfma::ConvMode md) {
   constexpr int NT = 16 * NSUB;
   constexpr int UROWS = TWOD ? 12 : 9;        // (dz,py) or (dz,dy) groups of 4 channel rows
   constexpr int W_ITEMS = UROWS * 4 * NT;     // float4 (= 4 x-points of one output channel) items per chunk
@@ -106,7 +105,7 @@ k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const flo
   int tz, ty, tx;
   cfun_mfma::tile_raster(lid - (unsigned)n * per_n, ntz, nty, ntx, tz, ty, tx);
   const int z0 = tz * TD, y0 = ty * TH, x0 = tx * TW;
-  const int cobase = co0 + cot * NT;
+  const int cobase = cot * NT;
 
   // ---- staging descriptors.  X item = (halo row r = (z, y), column pair jj of 9): the two voxels x = 2jj, 2jj+1 for TWO
   // consecutive channel chunks (each 16-byte piece; both come out of the same 64-byte sector, so issued back to back
@@ -497,12 +496,6 @@ static int env_knob(const char* name) {
   return e ? atoi(e) : -1;
 }
 
-// C_out = 32 k + (1..16): k tiles of 32 channels and one of 16 (see make_plan); CFUN_WINO_COSPLIT=0 turns it off
-static bool cosplit_shape(const CfunConv3dParams& p) {
-  static const int knob = env_knob("CFUN_WINO_COSPLIT");
-  return knob != 0 && p.Co > 32 && (p.Co % 32) >= 1 && (p.Co % 32) <= 16 && !p.d2s;
-}
-
 int wino_2d(const CfunConv3dParams& p) {
   static int knob = -2;
   if (knob == -2) {
@@ -513,12 +506,11 @@ int wino_2d(const CfunConv3dParams& p) {
   if (p.algo == CFUN_ALGO_WINO2 || knob == 1) return 1;
   if (knob == 0) return 0;
   // (C_out <= 16 -- the folded 5^3 conv's data gradient -- runs one co tile: 64 accumulators, three waves per SIMD either way)
-  // (C_out = 32 k + 1..16, k >= 1: 2-D with the channel split of make_plan -- two waves per SIMD at any size)
-  return p.Co <= 16 || cosplit_shape(p) || (int64_t)p.N * p.Do * p.Ho * p.Wo <= ((int64_t)1 << 19);
+  return p.Co <= 16 || (int64_t)p.N * p.Do * p.Ho * p.Wo <= ((int64_t)1 << 19);
 }
 
 struct Plan {
-  int nsub, twod, sb, tail_nsub, ntz, nty, ntx, ncot, ksplit, cps;
+  int nsub, twod, sb, ntz, nty, ntx, ncot, ksplit, cps;
   int64_t nblk;
   size_t u_bytes, part_bytes;
 };
@@ -527,25 +519,18 @@ Plan make_plan(const CfunConv3dParams& p, size_t ws_for_partials) {
   static const int sb_knob = env_knob("CFUN_WINO_SB");      // 0: the double-buffered one-wave-per-SIMD loop for every NSUB
   Plan w;
   w.twod = wino_2d(p);
-  w.ntz = cdiv(p.Do, TD); w.nty = cdiv(p.Ho, TH); w.ntx = cdiv(p.Wo, TW);
-  const int64_t tiles = (int64_t)p.N * w.ntz * w.nty * w.ntx;
-  auto fill = [&](int nsub, int ncot) {
-    w.nsub = nsub; w.ncot = ncot; w.nblk = tiles * ncot;
-    w.ksplit = cfun_mfma::splitk_factor(w.nblk, p.Ci >> 2, p, ws_for_partials);
-  };
-  const int nsub = wino_nsub(p.Co, w.twod);
-  fill(nsub, cdiv(p.Co, 16 * nsub));
-  // channel split: C_out = 32 k + (1..16) as k tiles of 32 at two waves per SIMD and, in a second launch, one tile of 16 --
-  // instead of 48-wide tiles at one wave per SIMD (192 accumulators); the same count of 16-column MFMAs.  For launches
-  // that fill the chip (no split-K).
-  w.tail_nsub = 0;
-  if (w.twod && nsub == 3 && w.ksplit == 1 && sb_knob != 0 && cosplit_shape(p)) {
-    fill(2, p.Co / 32);
-    if (w.ksplit == 1) w.tail_nsub = 1;
-    else fill(nsub, cdiv(p.Co, 16 * nsub));
-  }
+  w.nsub = wino_nsub(p.Co, w.twod);
+  // 2-D tiles of 16 / 32 channels run two (three) waves per SIMD on the single-U-buffer loop (k_conv_wino's SB).
+  // (Measured and dropped, round 3: C_out = 40 as a 32-wide launch at two waves per SIMD plus a 16-wide one for the last
+  // 8 channels instead of 48-wide tiles at one -- 5 % faster than the 1-D kernel on 4 x 96^3 (2.14 vs 2.27 ms), but the
+  // second launch stages the whole input again for 8 channels: 3.2 GB through the L2's fabric side per call instead of
+  // 1.5 GB; both in ONE launch, the 16-wide workgroup next to the 32-wide one of the same voxels, measured 2.5 ms.)
   w.sb = w.twod && w.nsub <= 2 && sb_knob != 0;
+  const int nt = 16 * w.nsub;
+  w.ntz = cdiv(p.Do, TD); w.nty = cdiv(p.Ho, TH); w.ntx = cdiv(p.Wo, TW); w.ncot = cdiv(p.Co, nt);
+  w.nblk = (int64_t)p.N * w.ntz * w.nty * w.ntx * w.ncot;
   w.u_bytes = cfun_align_up((size_t)(w.twod ? 48 : 36) * p.Ci * p.CoP * sizeof(float), 256);
+  w.ksplit = cfun_mfma::splitk_factor(w.nblk, p.Ci >> 2, p, ws_for_partials);
   w.cps = cdiv(p.Ci >> 2, w.ksplit);
   w.part_bytes = w.ksplit > 1 ? (size_t)w.ksplit * p.N * p.Do * p.Ho * p.Wo * p.Co * sizeof(float) : 0;
   return w;
@@ -553,9 +538,7 @@ Plan make_plan(const CfunConv3dParams& p, size_t ws_for_partials) {
 
 template <int NSUB>
 int launch(const float* x, const float4* u, const float* scale, const float* shift, const float* res, float* y,
-           const CfunConv3dParams& p, const Plan& w, float* partial, int s2d_cq, const cfun_mfma::ConvMode& md, hipStream_t st,
-           int co0 = 0, int ncot = -1) {
-  if (ncot < 0) ncot = w.ncot;
+           const CfunConv3dParams& p, const Plan& w, float* partial, int s2d_cq, const cfun_mfma::ConvMode& md, hipStream_t st) {
   const bool sb = w.twod && w.sb && NSUB <= 2;
   const size_t lds = sb ? (size_t)(8 * VPLANE4 + 48 * 16 * NSUB) * sizeof(float4)      // [V0][V1][U]
                         : (size_t)(w.twod ? 2 : 1) * (4 * VPLANE4 + (w.twod ? 48 : 36) * 16 * NSUB) * sizeof(float4);
@@ -582,9 +565,8 @@ int launch(const float* x, const float4* u, const float* scale, const float* shi
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  const int64_t nblk = (int64_t)p.N * w.ntz * w.nty * w.ntx * ncot;
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)w.ksplit), dim3(256), lds, st, x, u, scale, shift, res, y, p,
-                     w.ntz, w.nty, w.ntx, ncot, partial, w.cps, s2d_cq, md, co0);
+  hipLaunchKernelGGL(kern, dim3((unsigned)w.nblk, (unsigned)w.ksplit), dim3(256), lds, st, x, u, scale, shift, res, y, p,
+                     w.ntz, w.nty, w.ntx, w.ncot, partial, w.cps, s2d_cq, md);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }
@@ -639,8 +621,8 @@ int cfun_wino_s2d_dgrad_supported(const CfunConv3dParams* p, const CfunConv3dPar
 extern "C" int cfun_conv3d_wino_plan(const CfunConv3dParams* p, int32_t out[4]) {
   if (!p || !out || !cfun_wino_supported(p)) return CFUN_EINVAL;
   const Plan w = make_plan(*p, (size_t)-1);
-  out[0] = w.twod; out[1] = w.nsub; out[2] = w.tail_nsub;
-  out[3] = w.ncot * 16 * w.nsub + 16 * w.tail_nsub;
+  out[0] = w.twod; out[1] = w.nsub; out[2] = w.sb;
+  out[3] = w.ncot * 16 * w.nsub;
   return CFUN_OK;
 }
 
@@ -688,8 +670,6 @@ int cfun_wino_fwd(const float* x, const float* wp, int flip, int s2d_cq, const f
     default: rc = launch<5>(x, u, scale, shift, res, y, *p, w, partial, s2d_cq, md, st); break;
   }
   if (rc) return rc;
-  if (w.tail_nsub)      // the last 1..16 channels (make_plan): their own 16-wide tiles, same spatial tiling and statistics slots
-    return launch<1>(x, u, scale, shift, res, y, *p, w, partial, s2d_cq, md, st, w.ncot * 16 * w.nsub, 1);
   if (w.ksplit > 1) return cfun_splitk_finish(partial, w.ksplit, scale, shift, res, y, p, finish_part, st);
   return CFUN_OK;
 }

@@ -375,7 +375,17 @@ WgPlanW make_wg_plan(const CfunConv3dParams& p) {
   w.ntiles = p.N * w.ntz * w.nty * w.ntx;
   w.ncisub = cdiv(p.Ci, 16);
   w.ncot = cdiv(p.CoP, 16 * w.nsub);
-  int want = 512 / (w.ncisub * w.ncot);       // ~2 workgroups per CU in total (as cfun_mfma::wgrad_plan)
+  // workgroups per launch: ~2 per CU (as cfun_mfma::wgrad_plan) while a (ci, co) tile pair gets many voxel chunks; with
+  // many tile pairs (wide layers on small volumes: 160 -> 160 @ 24^3, 320 -> 320 @ 12^3) a chunk count of 3 - 10 quantises
+  // badly, and 3 - 4 per CU measured 7 - 15 % faster (tools/bench_layers.py, round 3).  CFUN_WINO_WGRAD_WGS overrides.
+  static int knob = -1;
+  if (knob < 0) {
+    const char* e = getenv("CFUN_WINO_WGRAD_WGS");
+    knob = e && atoi(e) > 0 ? atoi(e) : 0;
+  }
+  const int pairs = w.ncisub * w.ncot;
+  const int total = knob ? knob : pairs >= 100 ? 1024 : pairs >= 48 ? 768 : 512;
+  int want = total / pairs;
   if (want > w.ntiles) want = w.ntiles;
   if (want < 1) want = 1;
   w.tiles_per_chunk = cdiv(w.ntiles, want);

@@ -107,9 +107,9 @@ size_t cfun_conv3d_fwd_workspace_bytes(const CfunConv3dParams* p);
 #define CFUN_KERNEL_POINTWISE 4   /* k_conv_pointwise: 1x1x1 -> 8 channels, streaming */
 int cfun_conv3d_fwd_kernel(const CfunConv3dParams* p);
 /* For CFUN_KERNEL_WINO launches: out = {2-D (y in the Winograd domain too: 4/9 of the MFMAs) ? 1 : 0, 16-channel subtiles
- * per tile of the main launch, 16-channel subtiles of the second launch that takes the last C_out % 32 channels (0: one
- * launch), output-channel columns computed in all (a multiple of 16 >= C_out)}.  Returns 0, or CFUN_EINVAL if p does not
- * run on the Winograd kernels.  (Labels and the executed-MFMA count of bench.py; not needed to call the conv.) */
+ * per output-channel tile, two-waves-per-SIMD loop (2-D tiles of 16 / 32 channels) ? 1 : 0, output-channel columns computed
+ * (a multiple of 16 >= C_out)}.  Returns 0, or CFUN_EINVAL if p does not run on the Winograd kernels.  (Labels and the
+ * executed-MFMA count of bench.py; not needed to call the conv.) */
 int cfun_conv3d_wino_plan(const CfunConv3dParams* p, int32_t out[4]);
 int cfun_conv3d_fwd(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
                     float* y, const CfunConv3dParams* p, void* ws, size_t ws_bytes, cfun_stream_t stream);

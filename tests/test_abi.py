@@ -121,9 +121,10 @@ def test_conv_kernel_selection(emu):
         rc = int(lib.cfun_conv3d_wino_plan(C.byref(p), out))
         return rc, [int(v) for v in out]
 
-    # the Winograd plan: {2-D, subtiles of the main launch, subtiles of the launch for the last channels, columns computed}
-    assert plan((4, 96, 96, 96, 40), co=40, **k3) == (0, [1, 2, 1, 48])        # 32 + 8 channels, two waves per SIMD each
-    assert plan((4, 48, 48, 48, 80), co=80, **k3) == (0, [1, 1, 0, 80])        # five 16-wide tiles
-    assert plan((4, 24, 24, 24, 160), co=160, **k3) == (0, [1, 2, 0, 160])
-    assert plan((4, 96, 96, 96, 64), co=64, **k3) == (0, [0, 2, 0, 64])        # > 2^19 voxels, no channel split: x axis only
+    # the Winograd plan: {2-D, subtiles per channel tile, two-waves-per-SIMD 2-D loop, columns computed}
+    assert plan((4, 96, 96, 96, 40), co=40, **k3) == (0, [0, 3, 0, 48])        # > 2^19 voxels: x axis only, 48-wide tiles
+    assert plan((4, 48, 48, 48, 40), co=40, **k3) == (0, [1, 3, 0, 48])        # 2-D, 192 accumulators: one wave per SIMD
+    assert plan((4, 48, 48, 48, 80), co=80, **k3) == (0, [1, 1, 1, 80])        # five 16-wide tiles
+    assert plan((4, 24, 24, 24, 160), co=160, **k3) == (0, [1, 2, 1, 160])
+    assert plan((4, 96, 96, 96, 64), co=64, **k3) == (0, [0, 2, 0, 64])
     assert plan((4, 96, 96, 96, 20), co=20, **k3)[0] != 0                      # not a Winograd launch

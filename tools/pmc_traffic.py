@@ -17,9 +17,9 @@ def git_blob_sha1(path):
     data = open(path, "rb").read()
     return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 
-# the kernels of ONE conv call (regex over rocprofv3's kernel names): the 2-D Winograd launch covering 32 channels
-# (NSUB = 2) and the one covering the last 8 (NSUB = 1), both with STATS = false -- forward / data gradient of l4.0
-KERNEL = os.environ.get("CFUN_PMC_KERNEL", r"k_conv_wino<[12], false, true, false, true>")
+# the kernel(s) of ONE conv call (regex over rocprofv3's kernel names; several kernels' per-dispatch averages are summed):
+# the forward / data gradient of l4.0 runs k_conv_wino<NSUB = 3, S2D = false, TWOD = false, STATS = false, SB = false>
+KERNEL = os.environ.get("CFUN_PMC_KERNEL", r"k_conv_wino<3, false, false, false, false>")
 
 
 def kernel_label(name):
