@@ -14,6 +14,12 @@ update launch per arena, instead of ~8 tiny launches per parameter tensor.
 On this path every BatchNorm parameter is frozen (model.py:1297-1304), so the 'bn' group of the reference is empty
 and the weight decay is uniform over the arena; a trainable parameter with 'bn' in its name is rejected rather
 than silently decayed.
+
+torch.optim.SGD skips a parameter whose ``.grad`` is None -- no weight decay, no momentum update: the layers a stage
+does not run (the 'finetune'-only up-convs during 'beginning', a skipped head) stay exactly as they are.  Here every
+``p.grad`` is a view of an arena and never None, so the optimizer records which parameters a backward pass reached
+(post-accumulate hooks) and puts the untouched ones -- and their momentum -- back after the fused launch.  (With
+data-parallel ranks a parameter untouched here may have a gradient elsewhere: the all-reduced arena is applied as is.)
 """
 import torch
 
@@ -33,15 +39,20 @@ class FlatSGD:
         self.lr, self.momentum, self.weight_decay, self.clip_norm = float(lr), float(momentum), float(weight_decay), clip_norm
         self.reducer = cdist.GradientReducer([p for _, p in named], bucket_bytes=bucket_bytes, group=group)
         self.param_arenas, self.momentum_arenas = [], []
-        for bucket in self.reducer.buckets:          # parameters move into arenas laid out like the gradient buckets
+        self._slots = []                             # (parameter, arena index, offset) for the untouched-parameter restore
+        for a, bucket in enumerate(self.reducer.buckets):          # parameters move into arenas laid out like the gradient buckets
             flat = torch.zeros_like(bucket["flat"])
             with torch.no_grad():
                 for p, off in zip(bucket["params"], bucket["offsets"]):
                     view = flat[off:off + p.numel()].view_as(p)
                     view.copy_(p.data)
                     p.data = view
+                    self._slots.append((p, a, off))
             self.param_arenas.append(flat)
             self.momentum_arenas.append(torch.zeros_like(flat))
+        self._touched = [False] * len(self._slots)
+        self._hooks = [p.register_post_accumulate_grad_hook(lambda _p, i=i: self._touched.__setitem__(i, True))
+                       for i, (p, _, _) in enumerate(self._slots)]
         dev = self.param_arenas[0].device if self.param_arenas else torch.device("cpu")
         lib = _lib.load()
         self._npart = int(lib.cfun_sumsq_partials_count())
@@ -51,6 +62,25 @@ class FlatSGD:
 
     def zero_grad(self):
         self.reducer.zero_grad()
+        self._touched = [False] * len(self._slots)
+
+    @torch.no_grad()
+    def clip_(self):
+        """torch.nn.utils.clip_grad_norm_(parameters, clip_norm) on the gradient arenas, in place -- what the reference does
+        after EVERY backward (model.py:1641), also the ones that only accumulate (BATCH_SIZE > 1); ``step`` has the clip
+        of the backward it follows fused in.  The norm stays on the device (``grad_norm``)."""
+        clip = float(self.clip_norm) if self.clip_norm else 0.0
+        if clip <= 0.0:
+            return
+        lib = _lib.load()
+        for i, bucket in enumerate(self.reducer.buckets):
+            g = bucket["flat"]
+            check(lib.cfun_sumsq_partials(ptr(g), g.numel(), ptr(self._partials[i * self._npart:]), stream(g)), "sumsq_partials")
+        check(lib.cfun_norm_finalize(ptr(self._partials), self._partials.numel(), ptr(self.grad_norm), stream(self.grad_norm)),
+              "norm_finalize")
+        coef = (clip / (self.grad_norm + 1e-6)).clamp(max=1.0)
+        for bucket in self.reducer.buckets:
+            bucket["flat"].mul_(coef)
 
     @torch.no_grad()
     def step(self):
@@ -65,9 +95,18 @@ class FlatSGD:
                       "sumsq_partials")
             check(lib.cfun_norm_finalize(ptr(self._partials), self._partials.numel(), ptr(self.grad_norm),
                                          stream(self.grad_norm)), "norm_finalize")
+        keep = []            # parameters no backward pass reached since zero_grad(): torch.optim.SGD leaves them alone
+        if not self.reducer.active:
+            for (p, a, off), hit in zip(self._slots, self._touched):
+                if not hit:
+                    m = self.momentum_arenas[a][off:off + p.numel()]
+                    keep.append((p, m, p.data.clone(), m.clone()))
         for bucket, p, m in zip(self.reducer.buckets, self.param_arenas, self.momentum_arenas):
             g = bucket["flat"]
             check(lib.cfun_sgd_momentum_step(ptr(p), ptr(g), ptr(m), p.numel(), self.lr, self.momentum,
                                              self.weight_decay, clip, ptr(self.grad_norm) if clip > 0.0 else None,
                                              1 if self.steps == 0 else 0, stream(p)), "sgd_momentum_step")
+        for p, m, p0, m0 in keep:
+            p.data.copy_(p0)
+            m.copy_(m0)
         self.steps += 1

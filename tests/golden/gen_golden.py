@@ -485,6 +485,75 @@ def case_predict():
     save("predict_cfg0", **arrs)
 
 
+def case_train_epoch():
+    """The reference's OWN MaskRCNN.train_epoch (model.py:1574-1676) for 3 optimizer steps at cfg0 (64x64x32, 'beginning')
+    on the fixed sample of predict_cfg0.npz, with the optimizer train_model builds (model.py:1538-1545: SGD, weight decay on
+    the trainables without 'bn' in their name, momentum) -- the data generator and load_image_gt (augmentation, anchor
+    targets: host-side, out of the path) are replaced by that sample.  Recorded: the randperm draws and Dropout3d masks of
+    every step, the six losses of every step, the epoch's return value, and what the three steps did to the parameters."""
+    import torch.optim as optim
+    stage = "beginning"
+    cfg = make_cfg(stage, 64, 32)
+    cfg.BATCH_SIZE = 1              # = IMAGES_PER_GPU x GPU_COUNT on one GPU (GPU_COUNT = 0 here keeps the tensors on the host)
+    net = ref_model.MaskRCNN(cfg, "/tmp/cfun_logs", test_flag=False)
+    load_formula(net)
+    g = dict(np.load(os.path.join(HERE, "predict_cfg0.npz"), allow_pickle=False))      # inputs only
+    img = g["image"]
+    lab = g["gt_masks_labels"].astype(np.int64)
+    gt_masks = np.stack([(lab == k) for k in range(8)]).astype(np.float32)
+    sample = (img[None], g["rpn_match"][0], g["rpn_bbox_t"][0], g["gt_class_ids"][0], g["gt_boxes"][0], gt_masks)
+    orig_load, orig_losses, orig_randperm = ref_model.load_image_gt, ref_model.compute_losses, torch.randperm
+    perms, step_losses = [], []
+
+    def fake_load_image_gt(image, mask, angle, dataset, config, anchors):
+        return sample
+
+    def rec_losses(*a):
+        out = orig_losses(*a)
+        step_losses.append([float(l.detach()) for l in out])
+        return out
+
+    def rec_randperm(n, *a, **k):
+        p_ = orig_randperm(n, generator=torch.Generator().manual_seed(100 + len(perms)))
+        perms.append(p_.numpy())
+        return p_
+
+    # model.py:1534-1545, verbatim in effect
+    net.set_trainable(".*")
+    trainables_wo_bn = [param for name, param in net.named_parameters() if param.requires_grad and 'bn' not in name]
+    trainables_only_bn = [param for name, param in net.named_parameters() if param.requires_grad and 'bn' in name]
+    assert not trainables_only_bn          # BatchNorm is frozen on this path (TRAIN_BN = False)
+    optimizer = optim.SGD([{'params': trainables_wo_bn, 'weight_decay': cfg.WEIGHT_DECAY}, {'params': trainables_only_bn}],
+                          lr=cfg.LEARNING_RATE, momentum=cfg.LEARNING_MOMENTUM)
+    before = {k: v.detach().clone() for k, v in net.named_parameters() if v.requires_grad}
+    steps = 3
+    datagen = [(torch.from_numpy(img)[None], torch.zeros(1, 1), torch.from_numpy(lab)[None]) for _ in range(steps + 1)]
+    ref_model.load_image_gt, ref_model.compute_losses, torch.randperm = fake_load_image_gt, rec_losses, rec_randperm
+    torch.manual_seed(3)
+    try:
+        with DropRecorder() as rec:
+            ret = net.train_epoch(datagen, optimizer, steps, 0, None)
+    finally:
+        ref_model.load_image_gt, ref_model.compute_losses, torch.randperm = orig_load, orig_losses, orig_randperm
+    assert len(step_losses) == steps and len(perms) == 2 * steps and len(rec.masks) == 5 * steps, (len(perms), len(rec.masks))
+    after = dict(net.named_parameters())
+    names = sorted(before)
+    delta_norm = np.array([float((after[k].detach() - before[k]).double().norm()) for k in names])
+    arrs = dict(step_losses=np.array(step_losses), epoch_return=np.array([float(v) for v in ret]), steps=np.array(steps),
+                lr=np.array(cfg.LEARNING_RATE), momentum=np.array(cfg.LEARNING_MOMENTUM), weight_decay=np.array(cfg.WEIGHT_DECAY),
+                param_names=np.array(names), delta_norm=delta_norm)
+    for i, p_ in enumerate(perms):
+        arrs["randperm%d" % i] = p_
+    for i, m in enumerate(rec.masks):
+        arrs["drop%d" % i] = m.numpy()
+    for k in ("fpn.C1.0.weight", "fpn.P2_conv2.bias", "rpn.conv_class.weight", "classifier.linear_class.weight",
+              "classifier.conv2.weight", "mask.modified_u_net.conv3d_c1_1.weight",
+              "mask.modified_u_net.norm_lrelu_conv_c3.2.weight", "mask.modified_u_net.conv3d_l4.weight"):
+        arrs["delta:" + k] = (after[k].detach() - before[k]).numpy()
+    print("train_epoch: step losses", step_losses, "return", [float(v) for v in ret])
+    save("train_epoch_cfg0", **arrs)
+
+
 def case_refine():
     """model.refine_detections (model.py:584-672): crafted so that several classes pass the 0.7 filter, some boxes
     of one class overlap (per-class NMS at 0.3 suppresses them) and more survive than DETECTION_MAX_INSTANCES."""
@@ -799,11 +868,12 @@ def case_unmold_lits():
 
 CASES = dict(fpn_rpn_lits=case_fpn_rpn_lits, unet_lits=case_unet_lits, dtl_lits=case_dtl_lits, predict_lits=case_predict_lits,
              losses_lits=case_losses_lits, unmold_lits=case_unmold_lits, unmold=case_unmold, refine=case_refine, nms=case_nms, anchors=case_anchors, roi_align=case_roi_align, fpn_rpn=case_fpn_rpn, unet=case_unet,
-             losses=case_losses, proposal=case_proposal, classifier=case_classifier, predict=case_predict)
+             losses=case_losses, proposal=case_proposal, classifier=case_classifier, predict=case_predict,
+             train_epoch=case_train_epoch)
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or [k for k in CASES if k not in ("predict", "predict_lits")]
+    which = sys.argv[1:] or [k for k in CASES if k not in ("predict", "predict_lits", "train_epoch")]
     for k in which:
         print("== case", k)
         CASES[k]()

@@ -667,6 +667,105 @@ def check_predict_cfg0_golden(device):
     return [float(l.detach()) for l in losses]
 
 
+def check_train_epoch_accumulate(device, seed=2):
+    """train.train_epoch with BATCH_SIZE = 2 (two backward passes per optimizer step, clipped after each) against the
+    reference's loop written out with torch.nn.utils.clip_grad_norm_ + torch.optim.SGD on a copy of the same net -- same
+    kernels on both sides, so the parameters must agree to the optimizer's rounding."""
+    import copy
+    from cfun_amd import step, train
+    cfg = tiny_config("beginning")
+    cfg.BATCH_SIZE = 2
+    torch.manual_seed(seed)
+    net = step.CFUNHotPath(cfg).to(device)
+    b = cfg.UNET_MASK_BRANCH_CHANNEL
+    gen = torch.Generator().manual_seed(1)
+    masks = [torch.empty(cfg.TRAIN_ROIS_PER_IMAGE, c).bernoulli_(0.4, generator=gen) / 0.4 for c in (b, 2 * b, 4 * b, 8 * b, 16 * b)]
+    net.mask.modified_u_net.dropout_masks = masks
+    s = step.synthetic_inputs(cfg, device, seed)
+    d, h, w = cfg.image_dhw
+    nfg = cfg.NUM_CLASSES - 1
+    dev = torch.device(device)
+    sample = dict(image=s["image"], gt_class_ids=torch.arange(1, nfg + 1, device=dev),
+                  gt_boxes=torch.tensor([[0, h // 4, w // 4, d, 3 * h // 4, 3 * w // 4]] * nfg, dtype=torch.float32, device=dev),
+                  gt_labels=torch.from_numpy(s["labels_volume"]).to(dev), rpn_match=s["rpn_match"], rpn_bbox_t=s["rpn_bbox_t"])
+    ref_net = copy.deepcopy(net)
+    ref_net.mask.modified_u_net.dropout_masks = masks
+    # the reference's loop (model.py:1587-1645), two samples = one optimizer step
+    params = [p for p in ref_net.parameters() if p.requires_grad]
+    opt_ref = torch.optim.SGD([{"params": params, "weight_decay": cfg.WEIGHT_DECAY}], lr=cfg.LEARNING_RATE,
+                              momentum=cfg.LEARNING_MOMENTUM)
+    opt_ref.zero_grad()
+    ref_vals = []
+    torch.manual_seed(11)          # detection_target_layer's randperm draws: the same sequence on both sides
+    for i in range(2):
+        _, losses, total = step.training_step_full(ref_net, sample["image"], sample["gt_class_ids"], sample["gt_boxes"],
+                                                   sample["gt_labels"], sample["rpn_match"], sample["rpn_bbox_t"])
+        torch.nn.utils.clip_grad_norm_(params, 5.0)
+        ref_vals.append([float(total.detach())] + [float(l.detach()) for l in losses])
+    opt_ref.step()
+    opt = train.make_optimizer(net, cfg, bucket_bytes=1 << 16)
+    torch.manual_seed(11)
+    ret = train.train_epoch(net, [sample, sample, sample], opt, 2, cfg)
+    assert opt.steps == 1
+    np.testing.assert_allclose(np.array(ret), np.mean(np.array(ref_vals), axis=0), rtol=1e-6, atol=1e-7)
+    for (n, a), (_, r) in zip(net.named_parameters(), ref_net.named_parameters()):
+        if a.requires_grad:
+            np.testing.assert_allclose(a.detach().cpu().numpy(), r.detach().cpu().numpy(), rtol=5e-6, atol=1e-7, err_msg=n)
+
+
+def check_train_epoch_golden(device):
+    """cfun_amd.train.train_epoch + make_optimizer against the REFERENCE's own MaskRCNN.train_epoch (model.py:1574-1676) with the
+    optimizer of train_model (model.py:1538-1545): 3 optimizer steps at BASELINE configs[0] on the sample of
+    predict_cfg0.npz, replaying the reference's randperm draws and Dropout3d masks of every step
+    (tests/golden/train_epoch_cfg0.npz).  Checked: the epoch's return value (mean weighted total + six mean losses) and
+    what the three clip + SGD(momentum, weight decay) steps did to EVERY trainable tensor."""
+    from cfun_amd import config, step, train
+    g0, g = load_golden("predict_cfg0"), load_golden("train_epoch_cfg0")
+    cfg = config.heart_config("beginning", 64, 64, 32)
+    cfg.BATCH_SIZE = 1
+    assert (cfg.LEARNING_RATE, cfg.LEARNING_MOMENTUM, cfg.WEIGHT_DECAY) == (float(g["lr"]), float(g["momentum"]), float(g["weight_decay"]))
+    net = step.CFUNHotPath(cfg)
+    net.load_state_dict(golden_state_dict(g0), strict=True)
+    net = net.to(device)
+    dev = torch.device(device)
+    steps = int(g["steps"])
+    before = {k: v.detach().clone() for k, v in net.named_parameters() if v.requires_grad}
+    sample = dict(image=torch.from_numpy(g0["image"])[None, None].to(dev),
+                  gt_class_ids=torch.from_numpy(g0["gt_class_ids"][0].astype(np.int64)).to(dev),
+                  gt_boxes=torch.from_numpy(g0["gt_boxes"][0]).to(dev), gt_labels=torch.from_numpy(g0["gt_masks_labels"]).to(dev),
+                  rpn_match=torch.from_numpy(g0["rpn_match"]).to(dev), rpn_bbox_t=torch.from_numpy(g0["rpn_bbox_t"]).to(dev))
+
+    def samples():          # the generator runs right before each step: that step's recorded Dropout3d masks go in
+        for i in range(steps + 1):
+            net.mask.modified_u_net.dropout_masks = [torch.from_numpy(g["drop%d" % (5 * min(i, steps - 1) + j)]) for j in range(5)]
+            yield sample
+
+    perms = [(torch.from_numpy(g["randperm%d" % (2 * i)]), torch.from_numpy(g["randperm%d" % (2 * i + 1)])) for i in range(steps)]
+    opt = train.make_optimizer(net, cfg)
+    ret = train.train_epoch(net, samples(), opt, steps, cfg, perms=perms)
+    assert opt.steps == steps
+    np.testing.assert_allclose(np.array(ret), g["epoch_return"], rtol=2e-4, atol=1e-6)
+    after = dict(net.named_parameters())
+    names = [str(n) for n in g["param_names"]]
+    assert names == sorted(before)
+    # tolerances: the single-step gradients of this sample agree with the reference's to UNET_GRAD_L2_TOL (fp32 on both
+    # sides, check_predict_cfg0_golden); three clipped momentum steps on top stay well inside half of that
+    worst, worst_norm, bad = 0.0, 0.0, []
+    for n, ref_norm in zip(names, g["delta_norm"]):
+        d = (after[n].detach() - before[n]).double()
+        if ("delta:" + n) in g:          # eight tensors across the heads: the update itself
+            e = rel_l2(d.cpu().numpy(), g["delta:" + n])
+            worst = max(worst, e)
+            if e >= 0.5 * UNET_GRAD_L2_TOL:
+                bad.append("%s: update rel L2 %.3e" % (n, e))
+        en = abs(float(d.norm()) - float(ref_norm)) / max(float(ref_norm), 1e-12)
+        worst_norm = max(worst_norm, en)
+        if en >= 0.5 * UNET_GRAD_L2_TOL:
+            bad.append("%s: |update| %.6e vs %.6e" % (n, float(d.norm()), float(ref_norm)))
+    assert not bad, "\n".join(bad)
+    return dict(epoch_return=ret, worst_update_rel_l2=worst, worst_update_norm_dev=worst_norm)
+
+
 def check_detection_target_layer(device, seed=3, lits=False):
     """cfun_amd.model.detection_target_layer vs the oracle restatement (itself pinned to the reference by
     test_predict_cfg0_full_dataflow) on random proposals, distinct GT boxes, injected permutations.  ``lits``: the
@@ -726,9 +825,11 @@ def check_flat_sgd(device, seed=5):
         grads = [torch.randn(*s, generator=gen) * gscale for s in shapes]
         opt_ref.zero_grad()
         opt.zero_grad()
-        for r, m, g in zip(ref, mine, grads):
+        for r, g in zip(ref, grads):
             r.grad = g.clone()
-            m.grad.copy_(g)                                       # p.grad is a view of the gradient arena
+        # through autograd, as a training step does: p.grad is a view of the gradient arena, and the optimizer only
+        # updates parameters a backward pass reached (torch.optim.SGD skips .grad None)
+        torch.autograd.backward([(m * g.to(device)).sum() for m, g in zip(mine, grads)])
         total = torch.nn.utils.clip_grad_norm_(ref, 5.0)
         opt_ref.step()
         opt.step()
@@ -736,6 +837,42 @@ def check_flat_sgd(device, seed=5):
         for r, m in zip(ref, mine):
             np.testing.assert_allclose(m.detach().cpu().numpy(), r.detach().numpy(), rtol=2e-6, atol=1e-7)
     assert torch.equal(frozen.cpu(), named[-1][1].cpu())
+    # gradient accumulation the reference's way (model.py:1640-1645 with BATCH_SIZE = 2): clip_grad_norm_ after EVERY
+    # backward, also the one that only accumulates -- FlatSGD.clip_() in place, then the step's fused clip
+    g1 = [torch.randn(*s, generator=gen) * 20.0 for s in shapes]
+    g2 = [torch.randn(*s, generator=gen) * 0.5 for s in shapes]
+    opt_ref.zero_grad()
+    opt.zero_grad()
+    for r, a in zip(ref, g1):
+        r.grad = a.clone()
+    torch.autograd.backward([(m * a.to(device)).sum() for m, a in zip(mine, g1)])
+    t1 = torch.nn.utils.clip_grad_norm_(ref, 5.0)
+    opt.clip_()
+    assert abs(float(opt.grad_norm[0]) - float(t1)) <= 1e-5 * float(t1)
+    for r, m, b in zip(ref, mine, g2):
+        np.testing.assert_allclose(m.grad.cpu().numpy(), r.grad.numpy(), rtol=2e-6, atol=1e-7)
+        r.grad += b
+    torch.autograd.backward([(m * b.to(device)).sum() for m, b in zip(mine, g2)])
+    torch.nn.utils.clip_grad_norm_(ref, 5.0)
+    opt_ref.step()
+    opt.step()
+    for r, m in zip(ref, mine):
+        np.testing.assert_allclose(m.detach().cpu().numpy(), r.detach().numpy(), rtol=2e-6, atol=1e-7)
+    # a parameter no backward pass reached keeps its value AND its momentum (torch: .grad is None -> skipped), while
+    # the others take a normal step
+    opt_ref.zero_grad()          # (set_to_none: the skipped parameter's .grad is None on the torch side too)
+    opt.zero_grad()
+    g3 = [torch.randn(*s, generator=gen) for s in shapes]
+    for r, a in list(zip(ref, g3))[1:]:
+        r.grad = a.clone()
+    torch.autograd.backward([(m * a.to(device)).sum() for m, a in list(zip(mine, g3))[1:]])
+    kept = mine[0].detach().clone()
+    torch.nn.utils.clip_grad_norm_(ref, 5.0)
+    opt_ref.step()
+    opt.step()
+    assert torch.equal(mine[0].detach(), kept)
+    for r, m in zip(ref, mine):
+        np.testing.assert_allclose(m.detach().cpu().numpy(), r.detach().numpy(), rtol=2e-6, atol=1e-7)
     try:
         optim.FlatSGD([("fpn.C1.bn.weight", mine[1])], lr=0.1)
         raise AssertionError("a trainable 'bn' parameter must be rejected")

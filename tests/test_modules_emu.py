@@ -101,6 +101,10 @@ def test_flat_sgd_vs_torch(emu):
     mc.check_flat_sgd(emu)
 
 
+def test_train_epoch_accumulate(emu):
+    mc.check_train_epoch_accumulate(emu)
+
+
 def test_unmold_golden(emu):
     mc.check_unmold_golden(emu)
 

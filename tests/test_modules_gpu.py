@@ -266,6 +266,16 @@ def test_flat_sgd_vs_torch(gpu):
     mc.check_flat_sgd(gpu)
 
 
+def test_train_epoch_accumulate(gpu):
+    mc.check_train_epoch_accumulate(gpu)
+
+
+def test_train_epoch_reference_golden(gpu):
+    """train.train_epoch + train.make_optimizer vs the reference's own train_epoch / train_model optimizer, 3 steps at cfg0."""
+    r = mc.check_train_epoch_golden(gpu)
+    print("train_epoch golden:", r)
+
+
 def test_train_loop_flat_sgd(gpu):
     """A short train_epoch-style loop (model.py:1600-1650) on the tiny config: hot path forward/backward, global
     clip to 5.0 and SGD(momentum, weight decay) on the flat arenas; the loss goes down on the fixed sample."""
