@@ -225,6 +225,32 @@ def test_predict_cfg0_full_dataflow():
         assert e < 2e-2, "%s: rel L2 %.3e" % (k, e)   # LeakyReLU mask flips, see tests/module_cases.UNET_GRAD_L2_TOL
 
 
+def test_train_epoch_golden_is_consistent():
+    """tests/golden/train_epoch_cfg0.npz (the reference's own train_epoch, 3 optimizer steps; the product is held to it
+    in the GPU tier, module_cases.check_train_epoch_golden): its first step IS the step of predict_cfg0.npz -- same
+    sample, same seeds -- which the oracle reproduces above; the epoch's return value is the mean of the recorded steps
+    (model.py:1659-1666: weighted total first, then the six unweighted losses); the recorded draws have the sizes the
+    replay needs.  Running the oracle through all three steps would take minutes here."""
+    g0, g = load_golden("predict_cfg0"), load_golden("train_epoch_cfg0")
+    steps = int(g["steps"])
+    sl = g["step_losses"]
+    assert sl.shape == (steps, 6)
+    np.testing.assert_allclose(sl[0], g0["losses"], rtol=1e-6, atol=0)
+    np.testing.assert_array_equal(g["randperm0"], g0["randperm0"])
+    np.testing.assert_array_equal(g["randperm1"], g0["randperm1"])
+    for i in range(5):
+        np.testing.assert_array_equal(g["drop%d" % i], g0["drop%d" % i])
+    np.testing.assert_allclose(g["epoch_return"][1:], sl.mean(axis=0), rtol=1e-6, atol=1e-9)
+    totals = (sl * np.array(orc.LOSS_WEIGHTS, dtype=np.float64)[None]).sum(axis=1)
+    np.testing.assert_allclose(g["epoch_return"][0], totals.mean(), rtol=1e-5)
+    assert totals[-1] < totals[0]                         # three clipped SGD steps on one sample: the loss goes down
+    assert all(("randperm%d" % i) in g for i in range(2 * steps)) and all(("drop%d" % i) in g for i in range(5 * steps))
+    assert len(g["param_names"]) == len(g["delta_norm"]) and float(g["delta_norm"].max()) > 0
+    # the layers the 'beginning' stage never runs were left alone (torch.optim.SGD skips .grad None): no weight decay either
+    untouched = [str(n) for n, d in zip(g["param_names"], g["delta_norm"]) if d == 0.0]
+    assert any("out_upscale" in n for n in untouched)
+
+
 def test_unmold_golden():
     """utils.unmold_mask / MaskRCNN.unmold_detections (inference tail) vs the
     reference's own outputs."""
