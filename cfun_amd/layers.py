@@ -54,7 +54,7 @@ class Conv3dParams(nn.Module):
         pad = None
         if bn is not None:
             scale, t = folded_bn(bn, bn.eps if bn_eps is None else bn_eps)
-            shift = t if self.bias is None else torch.addcmul(t, self.bias, scale)   # (b - mean) * s + beta
+            shift = t if self.bias is None else ops.fold_bias(self.bias, scale, t)   # (b - mean) * s + beta
         elif scale is not None:
             per_n = True
         shard = dist.current()

@@ -80,10 +80,23 @@ def apply_box_deltas(boxes, deltas):
     return torch.cat([lo, lo + size], dim=1)
 
 
+_CONSTANTS = {}
+
+
+def _const(values, dtype, device):
+    """A small constant tensor on ``device``, built once per (values, dtype, device): torch.tensor(list, device=gpu) is a
+    host-to-device copy on every call."""
+    key = (tuple(float(v) for v in values), dtype, str(device))
+    t = _CONSTANTS.get(key)
+    if t is None:
+        t = _CONSTANTS[key] = torch.tensor(list(key[0]), dtype=dtype, device=device)
+    return t
+
+
 def clip_boxes(boxes, window):
     """model.py:185-196; window = (z1,y1,x1,z2,y2,x2)."""
-    lo = torch.tensor([window[0], window[1], window[2]] * 2, dtype=boxes.dtype, device=boxes.device)
-    hi = torch.tensor([window[3], window[4], window[5]] * 2, dtype=boxes.dtype, device=boxes.device)
+    lo = _const([window[0], window[1], window[2]] * 2, boxes.dtype, boxes.device)
+    hi = _const([window[3], window[4], window[5]] * 2, boxes.dtype, boxes.device)
     return torch.max(torch.min(boxes, hi), lo)
 
 
@@ -103,12 +116,12 @@ def proposals_from_candidates(scores, bbox, anchors, proposal_count, nms_thresho
     """The tail of proposal_layer on an already selected, score-sorted candidate set: scores [K], raw RPN box outputs
     [K,6] and the candidates' anchors [K,6] (voxel units).  Shared with the depth-sharded path, where every rank
     contributes its local top PRE_NMS_LIMIT (cfun_amd.dist.gather_rpn_candidates)."""
-    std = torch.tensor(np.reshape(config.RPN_BBOX_STD_DEV, [1, 6]), dtype=torch.float32, device=bbox.device)
+    std = _const(np.reshape(config.RPN_BBOX_STD_DEV, [6]), torch.float32, bbox.device).reshape(1, 6)
     boxes = apply_box_deltas(anchors, bbox * std)
     height, width, depth = [float(v) for v in config.IMAGE_SHAPE[:3]]
     boxes = clip_boxes(boxes, (0.0, 0.0, 0.0, depth, height, width))
     keep = utils.nms_device(boxes, scores, nms_threshold, proposal_count)
-    norm = torch.tensor([depth, height, width, depth, height, width], dtype=torch.float32, device=boxes.device)
+    norm = _const([depth, height, width, depth, height, width], torch.float32, boxes.device)
     return (boxes[keep] / norm).unsqueeze(0)
 
 
@@ -271,7 +284,7 @@ def roi_levels(boxes):
     d = boxes[:, 3] - boxes[:, 0]
     h = boxes[:, 4] - boxes[:, 1]
     w = boxes[:, 5] - boxes[:, 2]
-    ln2 = torch.log(torch.tensor([2.0], dtype=torch.float32, device=boxes.device))
+    ln2 = _const([float(np.log(np.float32(2.0)))], torch.float32, boxes.device)      # fp32 log(2), as torch.log gives it
     return (4 + (1.0 / 3.0) * (torch.log(h * w * d) / ln2)).round().int().clamp(2, 3)
 
 
@@ -333,7 +346,7 @@ class Classifier(nn.Module):
     def _conv_bn_relu(x, conv, bn):
         """relu(bn(conv(x))) for a conv that reduces its whole input: one GEMM, bias and the frozen BN in the epilogue."""
         s, t = folded_bn(bn, bn.eps)
-        return ops.fc(x, conv.weight.reshape(conv.out_channels, -1), s, torch.addcmul(t, conv.bias, s), ACT_RELU)
+        return ops.fc(x, conv.weight.reshape(conv.out_channels, -1), s, ops.fold_bias(conv.bias, s, t), ACT_RELU)
 
     def forward_ndhwc(self, feature_maps, rois):
         return self.head_ndhwc(pyramid_roi_align_ndhwc(rois, feature_maps, self.pool_size))

@@ -57,24 +57,90 @@ def pack_weight(w):
     return _PackWeight.apply(w)
 
 
+_FOLD_MATRICES = {}
+
+
+def _fold_matrix(k, dtype, device):
+    """f[parity p][low-res offset a + 1][hi-res tap t] = 1 where tap t of output parity p reads low-res offset a -- a
+    constant per kernel size, built on the host once (element writes on a device tensor are one launch each)."""
+    key = (k, dtype, str(device))
+    f = _FOLD_MATRICES.get(key)
+    if f is None:
+        f = torch.zeros(2, 3, k, dtype=dtype)
+        for p in range(2):
+            for t in range(k):
+                f[p, (p + t - k // 2) // 2 + 1, t] = 1.0
+        f = _FOLD_MATRICES[key] = f.to(device)
+    return f
+
+
+class _FoldBias(torch.autograd.Function):
+    """t + b * s for a trainable conv bias b under a frozen BatchNorm's constant fold (s, t): the epilogue shift of
+    bn(conv + b) = conv * s + (b * s + t).  One launch each way (db = g * s) instead of addcmul's generic backward."""
+
+    @staticmethod
+    def forward(ctx, bias, s, t):
+        ctx.save_for_backward(s)
+        return torch.addcmul(t, bias, s)
+
+    @staticmethod
+    def backward(ctx, g):
+        (s,) = ctx.saved_tensors
+        return g * s, None, None
+
+
+def fold_bias(bias, s, t):
+    return _FoldBias.apply(bias, s, t)
+
+
+def _fold_tensor(k, dtype, device):
+    """F [8 parities (p,q,r)][k^3 hi-res taps (t,u,v)][27 low-res taps (a,b,c)] = f[p,a,t] f[q,b,u] f[r,c,v]: 0 / 1, constant
+    per kernel size (cached)."""
+    key = ("F", k, dtype, str(device))
+    big = _FOLD_MATRICES.get(key)
+    if big is None:
+        f = _fold_matrix(k, dtype, "cpu")
+        big = torch.einsum("pat,qbu,rcv->pqrtuvabc", f, f, f).reshape(8, k * k * k, 27).contiguous()
+        big = _FOLD_MATRICES[key] = big.to(device)
+    return big
+
+
+class _FoldUp2(torch.autograd.Function):
+    """fold_up2_weight as ONE batched matmul each way: wf[pqr][o][i][abc] = sum_tuv w[o][i][tuv] F[pqr][tuv][abc] (the
+    eight parities are the batch, w is broadcast); an einsum over the three axes costs ~10 launches per weight and
+    direction, four folded weights per step."""
+
+    @staticmethod
+    def forward(ctx, w, cqp):
+        o, i, k = w.shape[0], w.shape[1], w.shape[-1]
+        big = _fold_tensor(k, w.dtype, w.device)
+        a = w.detach().reshape(o, i * k ** 3)
+        if cqp != o:      # pad every parity group to cqp output channels (tile-aligned tap skipping): zero rows
+            a = torch.nn.functional.pad(a, (0, 0, 0, cqp - o))
+        wf = torch.matmul(a.reshape(1, cqp * i, k ** 3), big)              # [8, cqp*i, 27]
+        ctx.save_for_backward(big)
+        ctx.dims = (o, i, k, cqp)
+        return wf.reshape(8 * cqp, i, 3, 3, 3)
+
+    @staticmethod
+    def backward(ctx, g):
+        (big,) = ctx.saved_tensors
+        o, i, k, cqp = ctx.dims
+        g = g.reshape(8, cqp * i, 27)
+        dw = torch.matmul(g, big.transpose(1, 2)).sum(dim=0)               # [cqp*i, k^3]
+        return dw.reshape(cqp, i, k, k, k)[:o], None
+
+
 def fold_up2_weight(w, cqp=None):
     """Fold "nearest x2 upsample -> conv k^3 (pad k//2)" into a 3x3x3 conv (pad 1) on the LOW-resolution input
     that produces the 8 output parities as channels: [O,I,k,k,k] -> [8*O, I, 3,3,3], channel ((pz*2+py)*2+px)*O + o.
     Hi-res tap t of output parity p reads low-res offset floor((p + t - k//2) / 2) in {-1,0,1}; taps that hit the
     same low-res voxel are summed (differentiable, so the gradient reaches the original 5x5x5 weight).  The
     hi-res zero padding of k//2 <= 2 maps exactly onto a low-res zero padding of 1."""
-    o, i, k = w.shape[0], w.shape[1], w.shape[-1]
+    k = w.shape[-1]
     if k not in (3, 5):
         raise ValueError("fold_up2_weight: kernel size %d" % k)
-    f = torch.zeros(2, 3, k, dtype=w.dtype, device=w.device)
-    for p in range(2):
-        for t in range(k):
-            f[p, (p + t - k // 2) // 2 + 1, t] = 1.0
-    wf = torch.einsum("pat,qbu,rcv,oituv->pqroiabc", f, f, f, w)
-    if cqp is not None and cqp != o:   # pad every parity group to cqp output channels (tile-aligned tap skipping)
-        wf = torch.nn.functional.pad(wf, (0, 0, 0, 0, 0, 0, 0, 0, 0, cqp - o))
-        o = cqp
-    return wf.reshape(8 * o, i, 3, 3, 3)
+    return _FoldUp2.apply(w, w.shape[0] if cqp is None else cqp)
 
 
 class _GatherSlices(torch.autograd.Function):

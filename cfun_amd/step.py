@@ -84,6 +84,8 @@ class CFUNHotPath(nn.Module):
         return out
 
     # ------------------------------------------------------------------------------------------
+    _loss_weights = {}
+
     def backbone_rpn(self, image):
         """image [1,1,D,H,W] -> p2, p3 (NDHWC), rpn_class_logits [1,A,2], rpn_probs, rpn_bbox [1,A,6]."""
         p2, p3 = self.fpn.forward_ndhwc(ops.to_ndhwc(image))
@@ -259,7 +261,12 @@ class CFUNHotPath(nn.Module):
         w = self.config.LOSS_WEIGHTS
         keys = ("rpn_class_loss", "rpn_bbox_loss", "mrcnn_class_loss", "mrcnn_bbox_loss", "mrcnn_mask_loss",
                 "mrcnn_mask_edge_loss")
-        return sum(float(w[k]) * l for k, l in zip(keys, losses))
+        vals = tuple(float(w[k]) for k in keys)
+        key = (vals, str(losses[0].device))
+        wv = self._loss_weights.get(key)
+        if wv is None:          # (a constant per weights and device: built once, not one host-to-device copy per step)
+            wv = self._loss_weights[key] = torch.tensor(vals, dtype=torch.float32, device=losses[0].device)
+        return (torch.stack(list(losses)) * wv).sum()      # 3 launches (and 3 in the backward) instead of 12 (+ 6)
 
 
 # ---------------------------------------------------------------------------------------------- synthetic step
