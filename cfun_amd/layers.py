@@ -53,8 +53,9 @@ class Conv3dParams(nn.Module):
         per_n = False
         pad = None
         if bn is not None:
-            scale, t = folded_bn(bn, bn.eps if bn_eps is None else bn_eps)
-            shift = t if self.bias is None else ops.fold_bias(self.bias, scale, t)   # (b - mean) * s + beta
+            eps = bn.eps if bn_eps is None else bn_eps
+            scale, t = folded_bn(bn, eps)
+            shift = t if self.bias is None else _step_shift(self, bn, eps, scale, t)   # (b - mean) * s + beta
         elif scale is not None:
             per_n = True
         shard = dist.current()
@@ -104,6 +105,55 @@ def sharded_conv(x, w, spec, kd, stride, pd, scale, shift, res, shard):
             return y
     lo, hi = dist.conv_depth_halo(kd, stride, pd)
     return ops.conv3d_w(dist.halo_exchange(x, lo, hi, shard), w, spec, scale=scale, shift=shift, res=res)
+
+
+# ---- the bias folds of a step, batched.  Which (conv, bn) pairs a network runs is only known at the call sites, so the first
+# step between begin_step / end_step records them; later steps fold all of them in ONE multi-tensor launch up front
+# (ops.fold_bias_many) and the convs pick their shift up here.  Entries live only inside that window and carry the
+# identity of (s, t), so a call outside a step, another pairing or a re-folded BatchNorm falls back to the per-conv fold.
+_STEP = {"shifts": None, "record": None}
+
+
+BATCH_BIAS_FOLD = os.environ.get("CFUN_BATCH_BIAS_FOLD", "1") != "0"
+
+
+def begin_step(net):
+    if not BATCH_BIAS_FOLD:
+        return
+    pairs = getattr(net, "_cfun_fold_pairs", None)
+    if pairs is None:
+        _STEP["shifts"], _STEP["record"] = None, []
+        return
+    _STEP["record"] = None
+    live = [(c, bn, eps) + folded_bn(bn, eps) for c, bn, eps in pairs if c.bias is not None and c.bias.requires_grad]
+    if not live:
+        _STEP["shifts"] = None
+        return
+    outs = ops.fold_bias_many([c.bias for c, _, _, _, _ in live], [s for _, _, _, s, _ in live], [t for _, _, _, _, t in live])
+    _STEP["shifts"] = {id(c): (sh, id(bn), eps, s, t) for (c, bn, eps, s, t), sh in zip(live, outs)}
+
+
+def end_step(net):
+    rec = _STEP["record"]
+    if rec is not None and getattr(net, "_cfun_fold_pairs", None) is None:
+        seen, pairs = set(), []
+        for c, bn, eps in rec:
+            if id(c) not in seen:
+                seen.add(id(c))
+                pairs.append((c, bn, eps))
+        net._cfun_fold_pairs = pairs
+    _STEP["shifts"], _STEP["record"] = None, None
+
+
+def _step_shift(conv, bn, eps, s, t):
+    shifts = _STEP["shifts"]
+    if shifts is not None:
+        e = shifts.get(id(conv))
+        if e is not None and e[1] == id(bn) and e[2] == eps and e[3] is s and e[4] is t:
+            return e[0]
+    if _STEP["record"] is not None:
+        _STEP["record"].append((conv, bn, eps))
+    return ops.fold_bias(conv.bias, s, t)
 
 
 def folded_bn(bn, eps):

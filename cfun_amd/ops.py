@@ -93,6 +93,32 @@ def fold_bias(bias, s, t):
     return _FoldBias.apply(bias, s, t)
 
 
+class _FoldBiasMany(torch.autograd.Function):
+    """[t_i + b_i * s_i for i]: the bias folds of ALL conv + frozen-BatchNorm pairs of a step as one multi-tensor launch
+    each way (torch._foreach_*), instead of one tiny launch per pair and direction."""
+
+    @staticmethod
+    def forward(ctx, n, *args):
+        biases, ss, ts = args[:n], args[n:2 * n], args[2 * n:]
+        ctx.ss = ss
+        return tuple(torch._foreach_addcmul([t for t in ts], [b.detach() for b in biases], list(ss)))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ss = ctx.ss
+        idx = [i for i, g in enumerate(grads) if g is not None]
+        out = [None] * len(grads)
+        if idx:
+            prods = torch._foreach_mul([grads[i] for i in idx], [ss[i] for i in idx])
+            for i, p in zip(idx, prods):
+                out[i] = p
+        return (None,) + tuple(out) + (None,) * (2 * len(grads))
+
+
+def fold_bias_many(biases, ss, ts):
+    return _FoldBiasMany.apply(len(biases), *biases, *ss, *ts)
+
+
 def _fold_tensor(k, dtype, device):
     """F [8 parities (p,q,r)][k^3 hi-res taps (t,u,v)][27 low-res taps (a,b,c)] = f[p,a,t] f[q,b,u] f[r,c,v]: 0 / 1, constant
     per kernel size (cached)."""

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import backbone, model, ops, utils
+from . import backbone, layers, model, ops, utils
 
 # CFUN_OVERLAP_MASK_HEAD=1 runs the mask head on its own HIP stream beside FPN / RPN / classifier (see _mask_head).
 # Off by default: measured on one MI355X at cfg2 it is 1.2 ms per step SLOWER (56.8 vs 55.6 ms) -- the U-Net's convs
@@ -127,13 +127,17 @@ class CFUNHotPath(nn.Module):
         self.train()
         mask_logits = mask_probs = cls_logits = cls_probs = cls_bbox = None
         join = lambda: None
-        if not self.detector_phase_only:
-            mask_logits, mask_probs, join = self._mask_head(image, p_rois)  # enqueued first, on its own stream
-        p2, p3, rpn_logits, rpn_probs, rpn_bbox = self.backbone_rpn(image)
-        rpn_rois = self.proposals(rpn_probs, rpn_bbox, "training")
-        if not self.mask_phase_only:
-            rois = torch.cat([p_rois, n_rois], dim=0)
-            cls_logits, cls_probs, cls_bbox = self.classifier.forward_ndhwc([p2[0], p3[0]], rois)
+        layers.begin_step(self)         # the step's conv-bias folds under frozen BatchNorm: one multi-tensor launch
+        try:
+            if not self.detector_phase_only:
+                mask_logits, mask_probs, join = self._mask_head(image, p_rois)  # enqueued first, on its own stream
+            p2, p3, rpn_logits, rpn_probs, rpn_bbox = self.backbone_rpn(image)
+            rpn_rois = self.proposals(rpn_probs, rpn_bbox, "training")
+            if not self.mask_phase_only:
+                rois = torch.cat([p_rois, n_rois], dim=0)
+                cls_logits, cls_probs, cls_bbox = self.classifier.forward_ndhwc([p2[0], p3[0]], rois)
+        finally:
+            layers.end_step(self)
         join()
         return dict(rpn_class_logits=rpn_logits, rpn_probs=rpn_probs, rpn_bbox=rpn_bbox, rpn_rois=rpn_rois,
                     mrcnn_class_logits=cls_logits, mrcnn_class=cls_probs, mrcnn_bbox=cls_bbox,
