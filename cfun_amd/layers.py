@@ -52,13 +52,20 @@ class Conv3dParams(nn.Module):
         shift = self.bias
         per_n = False
         pad = None
+        shard = dist.current()
+        sharded = shard is not None and shard.world > 1
+        pre = False                 # shift = t + b * scale with the "conv hands back db" contract (ops.fold_bias, pre)
         if bn is not None:
             eps = bn.eps if bn_eps is None else bn_eps
             scale, t = folded_bn(bn, eps)
-            shift = t if self.bias is None else _step_shift(self, bn, eps, scale, t)   # (b - mean) * s + beta
+            if self.bias is None:
+                shift = t
+            elif sharded:           # (the split / halo launches go through the plain contract)
+                shift = ops.fold_bias(self.bias, scale, t)                      # (b - mean) * s + beta
+            else:
+                shift, pre = _step_shift(self, bn, eps, scale, t), True
         elif scale is not None:
             per_n = True
-        shard = dist.current()
         if shard is not None and shard.world > 1 and isinstance(x, ops.NormedInput):
             x = x.materialize()          # depth slabs: the split / padded launches take a real tensor
         if shard is not None and shard.world > 1 and self.kernel_size[0] > 1:
@@ -68,7 +75,7 @@ class Conv3dParams(nn.Module):
             return sharded_conv(x, self.weight, self.spec(act, False, res_up2, per_n, (0, self.padding[1], self.padding[2])),
                                 self.kernel_size[0], self.stride, self.padding[0], scale, shift, res, shard)
         return ops.conv3d_w(x, self.weight, self.spec(act, up2, res_up2, per_n, pad), scale=scale, shift=shift, res=res,
-                            stats=stats)
+                            stats=stats, shift_scaled=pre)
 
     def extra_repr(self):
         return "%d, %d, kernel_size=%s, stride=%d, padding=%s, bias=%s" % (
@@ -129,7 +136,8 @@ def begin_step(net):
     if not live:
         _STEP["shifts"] = None
         return
-    outs = ops.fold_bias_many([c.bias for c, _, _, _, _ in live], [s for _, _, _, s, _ in live], [t for _, _, _, _, t in live])
+    outs = ops.fold_bias_many([c.bias for c, _, _, _, _ in live], [s for _, _, _, s, _ in live], [t for _, _, _, _, t in live],
+                              pre=True)
     _STEP["shifts"] = {id(c): (sh, id(bn), eps, s, t) for (c, bn, eps, s, t), sh in zip(live, outs)}
 
 
@@ -153,7 +161,7 @@ def _step_shift(conv, bn, eps, s, t):
             return e[0]
     if _STEP["record"] is not None:
         _STEP["record"].append((conv, bn, eps))
-    return ops.fold_bias(conv.bias, s, t)
+    return ops.fold_bias(conv.bias, s, t, pre=True)
 
 
 def folded_bn(bn, eps):

@@ -76,21 +76,26 @@ def _fold_matrix(k, dtype, device):
 
 class _FoldBias(torch.autograd.Function):
     """t + b * s for a trainable conv bias b under a frozen BatchNorm's constant fold (s, t): the epilogue shift of
-    bn(conv + b) = conv * s + (b * s + t).  One launch each way (db = g * s) instead of addcmul's generic backward."""
+    bn(conv + b) = conv * s + (b * s + t).  One launch each way (db = g * s) instead of addcmul's generic backward.
+    ``pre``: the consumer is a conv called with ``shift_scaled=True`` and scale = s -- it hands back db itself (the sum of
+    ITS scaled gradient, see _Conv3d.backward), so the backward here is the identity."""
 
     @staticmethod
-    def forward(ctx, bias, s, t):
+    def forward(ctx, bias, s, t, pre):
+        ctx.pre = pre
         ctx.save_for_backward(s)
         return torch.addcmul(t, bias, s)
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.pre:
+            return g, None, None, None
         (s,) = ctx.saved_tensors
-        return g * s, None, None
+        return g * s, None, None, None
 
 
-def fold_bias(bias, s, t):
-    return _FoldBias.apply(bias, s, t)
+def fold_bias(bias, s, t, pre=False):
+    return _FoldBias.apply(bias, s, t, pre)
 
 
 class _FoldBiasMany(torch.autograd.Function):
@@ -98,25 +103,26 @@ class _FoldBiasMany(torch.autograd.Function):
     each way (torch._foreach_*), instead of one tiny launch per pair and direction."""
 
     @staticmethod
-    def forward(ctx, n, *args):
+    def forward(ctx, n, pre, *args):
         biases, ss, ts = args[:n], args[n:2 * n], args[2 * n:]
-        ctx.ss = ss
+        ctx.ss, ctx.pre = ss, pre
         return tuple(torch._foreach_addcmul([t for t in ts], [b.detach() for b in biases], list(ss)))
 
     @staticmethod
     def backward(ctx, *grads):
         ss = ctx.ss
-        idx = [i for i, g in enumerate(grads) if g is not None]
-        out = [None] * len(grads)
-        if idx:
-            prods = torch._foreach_mul([grads[i] for i in idx], [ss[i] for i in idx])
-            for i, p in zip(idx, prods):
-                out[i] = p
-        return (None,) + tuple(out) + (None,) * (2 * len(grads))
+        out = list(grads)            # pre: the consumer convs deliver db themselves (see _FoldBias)
+        if not ctx.pre:
+            idx = [i for i, g in enumerate(grads) if g is not None]
+            if idx:
+                prods = torch._foreach_mul([grads[i] for i in idx], [ss[i] for i in idx])
+                for i, p in zip(idx, prods):
+                    out[i] = p
+        return (None, None) + tuple(out) + (None,) * (2 * len(grads))
 
 
-def fold_bias_many(biases, ss, ts):
-    return _FoldBiasMany.apply(len(biases), *biases, *ss, *ts)
+def fold_bias_many(biases, ss, ts, pre=False):
+    return _FoldBiasMany.apply(len(biases), pre, *biases, *ss, *ts)
 
 
 def _fold_tensor(k, dtype, device):
@@ -321,7 +327,8 @@ class StatsSlot:
 
 class _Conv3d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, wp, scale, shift, res, spec, out=None, dx_slot=None, w_src=None, stats=None, pro=None):
+    def forward(ctx, x, wp, scale, shift, res, spec, out=None, dx_slot=None, w_src=None, stats=None, pro=None,
+                shift_scaled=False):
         # pro = (stats [N,Ci,2] or None, act, slope): the conv reads act((x - mean) * rstd) in place of x (NormedInput)
         lib = _lib.load()
         x = _c(x)
@@ -400,6 +407,7 @@ class _Conv3d(torch.autograd.Function):
         ctx.wshape = None if w_src is None else tuple(w_src.shape)
         ctx.b3 = b3
         ctx.pro = None if pro is None else (int(pro[1]), float(pro[2]))
+        ctx.shift_scaled = bool(shift_scaled)
         ctx.save_for_backward(x, wp, scale, y if spec.act != ACT_NONE else None, wpT,
                               w_src.detach() if b3 and ctx.needs_input_grad[0] else None,
                               None if pro is None or pro[0] is None else _c(pro[0]))
@@ -422,17 +430,27 @@ class _Conv3d(torch.autograd.Function):
         st = stream(dy)
         nvox = p.N * p.Do * p.Ho * p.Wo
         # gp = dL/d(pre-activation); g = gp * scale = dL/d(conv sum)
+        # shift_scaled (the shift is t + b * scale of a folded BatchNorm, ops.fold_bias(..., pre=True)): db = scale * sum(gp)
+        # = sum(g), so the pre-activation gradient is never needed by itself (unless a residual wants it) and g comes
+        # out of ONE pass: g = dy * act'(y) * scale
+        one_pass = ctx.shift_scaled and scale is not None and not spec.d2s and not need_res
         gp = dy
-        if spec.act != ACT_NONE:
-            gp = torch.empty_like(dy)
-            check(lib.cfun_act_bwd(ptr(y), ptr(dy), None, ptr(gp), dy.numel() // dy.shape[-1], dy.shape[-1],
-                                   p.Do * p.Ho * p.Wo * (8 if spec.d2s else 1), spec.act, LRELU_SLOPE, 0, st), "act_bwd")
-        gp_out = gp     # for d2s convs the kernels take the gradient in y's hi-res layout and gather the parities
-        g = gp
-        if scale is not None:
+        if one_pass:
             g = torch.empty_like(dy)
-            check(lib.cfun_act_bwd(None, ptr(gp), ptr(scale), ptr(g), nvox, p.Co, p.Do * p.Ho * p.Wo, ACT_NONE,
-                                   LRELU_SLOPE, p.scale_mode, st), "act_bwd(scale)")
+            check(lib.cfun_act_bwd(ptr(y) if spec.act != ACT_NONE else None, ptr(dy), ptr(scale), ptr(g), nvox, p.Co,
+                                   p.Do * p.Ho * p.Wo, spec.act, LRELU_SLOPE, p.scale_mode, st), "act_bwd(act, scale)")
+            gp = gp_out = g
+        else:
+            if spec.act != ACT_NONE:
+                gp = torch.empty_like(dy)
+                check(lib.cfun_act_bwd(ptr(y), ptr(dy), None, ptr(gp), dy.numel() // dy.shape[-1], dy.shape[-1],
+                                       p.Do * p.Ho * p.Wo * (8 if spec.d2s else 1), spec.act, LRELU_SLOPE, 0, st), "act_bwd")
+            gp_out = gp     # for d2s convs the kernels take the gradient in y's hi-res layout and gather the parities
+            g = gp
+            if scale is not None:
+                g = torch.empty_like(dy)
+                check(lib.cfun_act_bwd(None, ptr(gp), ptr(scale), ptr(g), nvox, p.Co, p.Do * p.Ho * p.Wo, ACT_NONE,
+                                       LRELU_SLOPE, p.scale_mode, st), "act_bwd(scale)")
         dx = dwp = dshift = dres = dw = None
         if need_x:
             # dx of a per-sample conv goes straight into its sample of the batch's gradient (zero-copy batch split)
@@ -487,8 +505,8 @@ class _Conv3d(torch.autograd.Function):
                 ws = workspace(nb, x)
                 check(lib.cfun_conv3d_bwd_weight_oidhw(ptr(x), ptr(g), ptr(dw), C.byref(p), ptr(ws), ws.numel(), st),
                       "conv3d_bwd_weight_oidhw")
-        if need_shift:
-            dshift = channel_sum(gp.view(-1, p.Co))
+        if need_shift:      # (shift_scaled: db = sum(g) whichever way g was formed)
+            dshift = channel_sum((g if ctx.shift_scaled and scale is not None else gp).view(-1, p.Co))
         if need_res:
             if spec.d2s:
                 dres = torch.empty(ctx.res_shape, dtype=torch.float32, device=dy.device)
@@ -500,7 +518,7 @@ class _Conv3d(torch.autograd.Function):
                       "upsample2_bwd")
             else:
                 dres = gp
-        return dx, dwp, None, dshift, dres, None, None, None, dw, None, None
+        return dx, dwp, None, dshift, dres, None, None, None, dw, None, None, None
 
 
 class NormedInput:
@@ -588,7 +606,7 @@ def conv3d(x, wp, spec, scale=None, shift=None, res=None, out=None, dx_slot=None
     return _Conv3d.apply(x, wp, scale, shift, res, spec, out, dx_slot, None, stats, pro)
 
 
-def conv3d_w(x, w, spec, scale=None, shift=None, res=None, out=None, dx_slot=None, stats=None):
+def conv3d_w(x, w, spec, scale=None, shift=None, res=None, out=None, dx_slot=None, stats=None, shift_scaled=False):
     """``conv3d`` on an OIDHW weight [Co,Ci,kd,kh,kw] (a parameter, a gathered slice of one, a folded up-conv
     weight): packed inside the op, and the weight gradient is produced directly in OIDHW -- the reduction of the
     wgrad kernel's per-chunk partial sums and the un-packing are one kernel (cfun_conv3d_bwd_weight_oidhw) instead
@@ -599,7 +617,7 @@ def conv3d_w(x, w, spec, scale=None, shift=None, res=None, out=None, dx_slot=Non
             x, pro = x.token, x.pro()
         else:
             x = x.materialize()
-    return _Conv3d.apply(x, None, scale, shift, res, spec, out, dx_slot, w, stats, pro)
+    return _Conv3d.apply(x, None, scale, shift, res, spec, out, dx_slot, w, stats, pro, shift_scaled)
 
 
 # ---- EXPERIMENTAL: 3x3x3 conv with fp32 emulated on the bf16 matrix cores (conv3d_b3.hip; not used by the modules) ----

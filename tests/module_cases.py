@@ -667,6 +667,64 @@ def check_predict_cfg0_golden(device):
     return [float(l.detach()) for l in losses]
 
 
+def check_conv_bn_bias_fold(device, seed=4):
+    """conv (with bias) -> frozen BatchNorm3d -> ReLU [-> + residual] through layers.Conv3dParams: the bias reaches the
+    epilogue as shift = t + b * s and its gradient comes back as the sum of the conv's SCALED gradient (one
+    act'(y) * scale pass when no residual needs the unscaled one) -- against torch's conv3d / batch_norm / relu, for x,
+    weight, bias and the residual; once alone and once inside a begin_step / end_step window (batched fold)."""
+    import torch.nn.functional as F
+    from cfun_amd import layers, ops
+    gen = torch.Generator().manual_seed(seed)
+    for with_res in (False, True):
+        for windowed in (False, True):
+            conv = layers.Conv3dParams(8, 12, 3, padding=1, bias=True)
+            bn = nn.BatchNorm3d(12)
+            with torch.no_grad():
+                bn.weight.copy_(torch.rand(12, generator=gen) + 0.5); bn.bias.copy_(torch.randn(12, generator=gen))
+                bn.running_mean.copy_(torch.randn(12, generator=gen)); bn.running_var.copy_(torch.rand(12, generator=gen) + 0.5)
+            bn.eval()
+            for p_ in bn.parameters():
+                p_.requires_grad = False
+            conv, bn = conv.to(device), bn.to(device)
+            x = torch.randn(2, 4, 5, 6, 8, generator=gen)
+            r = torch.randn(2, 4, 5, 6, 12, generator=gen) if with_res else None
+            gy = torch.randn(2, 4, 5, 6, 12, generator=gen)
+            xd = x.clone().to(device).requires_grad_(True)
+            rd = None if r is None else r.clone().to(device).requires_grad_(True)
+            holder = nn.Module()
+            if windowed:
+                for _ in range(2):      # first window records the pair, the second one folds it in the batched launch
+                    conv.zero_grad(set_to_none=True)
+                    xd.grad = None
+                    if rd is not None:
+                        rd.grad = None
+                    layers.begin_step(holder)
+                    try:
+                        y = conv(xd, act=ops.ACT_RELU, bn=bn, res=rd)
+                    finally:
+                        layers.end_step(holder)
+                    y.backward(gy.to(device))
+                assert len(holder._cfun_fold_pairs) == 1
+            else:
+                y = conv(xd, act=ops.ACT_RELU, bn=bn, res=rd)
+                y.backward(gy.to(device))
+            xr = x.clone().permute(0, 4, 1, 2, 3).requires_grad_(True)
+            wr = conv.weight.detach().cpu().clone().requires_grad_(True)
+            br = conv.bias.detach().cpu().clone().requires_grad_(True)
+            rr = None if r is None else r.clone().permute(0, 4, 1, 2, 3).requires_grad_(True)
+            z = F.batch_norm(F.conv3d(xr, wr, br, padding=1), bn.running_mean.cpu(), bn.running_var.cpu(), bn.weight.cpu(),
+                             bn.bias.cpu(), False, 0.0, bn.eps)
+            yr = F.relu(z + rr if rr is not None else z)
+            yr.backward(gy.permute(0, 4, 1, 2, 3))
+            what = "res=%s windowed=%s " % (with_res, windowed)
+            assert rel_l2(y.detach().cpu().numpy(), yr.detach().permute(0, 2, 3, 4, 1).numpy()) < 1e-5, what + "y"
+            assert rel_l2(conv.bias.grad.cpu().numpy(), br.grad.numpy()) < 1e-5, what + "bias grad"
+            assert rel_l2(conv.weight.grad.cpu().numpy(), wr.grad.numpy()) < 1e-5, what + "weight grad"
+            assert rel_l2(xd.grad.cpu().numpy(), xr.grad.permute(0, 2, 3, 4, 1).numpy()) < 1e-5, what + "x grad"
+            if rd is not None:
+                assert rel_l2(rd.grad.cpu().numpy(), rr.grad.permute(0, 2, 3, 4, 1).numpy()) < 1e-6, what + "residual grad"
+
+
 def check_train_epoch_accumulate(device, seed=2):
     """train.train_epoch with BATCH_SIZE = 2 (two backward passes per optimizer step, clipped after each) against the
     reference's loop written out with torch.nn.utils.clip_grad_norm_ + torch.optim.SGD on a copy of the same net -- same

@@ -101,6 +101,10 @@ def test_flat_sgd_vs_torch(emu):
     mc.check_flat_sgd(emu)
 
 
+def test_conv_bn_bias_fold(emu):
+    mc.check_conv_bn_bias_fold(emu)
+
+
 def test_train_epoch_accumulate(emu):
     mc.check_train_epoch_accumulate(emu)
 

@@ -266,6 +266,10 @@ def test_flat_sgd_vs_torch(gpu):
     mc.check_flat_sgd(gpu)
 
 
+def test_conv_bn_bias_fold(gpu):
+    mc.check_conv_bn_bias_fold(gpu)
+
+
 def test_train_epoch_accumulate(gpu):
     mc.check_train_epoch_accumulate(gpu)
 
