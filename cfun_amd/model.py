@@ -60,8 +60,8 @@ class RPN(nn.Module):
         spec = ops.ConvSpec(k=(1, 1, 1), co=w.shape[0], algo=default_algo())
         out = ops.conv3d_w(h, w, spec, shift=b)
         a2 = 2 * self.anchors_per_location
-        logits = out[..., :a2].reshape(n, -1, 2)
-        bbox = out[..., a2:].reshape(n, -1, 6)
+        logits, bbox = ops.split_channels(out, a2)
+        logits, bbox = logits.reshape(n, -1, 2), bbox.reshape(n, -1, 6)
         probs = ops.softmax_channels(logits)
         return [logits, probs, bbox]
 

@@ -175,6 +175,29 @@ def fold_up2_weight(w, cqp=None):
     return _FoldUp2.apply(w, w.shape[0] if cqp is None else cqp)
 
 
+class _SplitChannels(torch.autograd.Function):
+    """y [..., C] -> (y[..., :c0], y[..., c0:]) as dense tensors; the gradient is ONE concatenation instead of two
+    zero-filled tensors, two copies and their sum (the fused RPN head: class and box outputs of one conv)."""
+
+    @staticmethod
+    def forward(ctx, y, c0):
+        ctx.lead, ctx.widths = tuple(y.shape[:-1]), (c0, y.shape[-1] - c0)
+        return y[..., :c0].contiguous(), y[..., c0:].contiguous()
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None and gb is None:
+            return None, None
+        like = gb if ga is None else ga
+        ga = like.new_zeros(ctx.lead + (ctx.widths[0],)) if ga is None else ga
+        gb = like.new_zeros(ctx.lead + (ctx.widths[1],)) if gb is None else gb
+        return torch.cat([ga, gb], dim=-1), None
+
+
+def split_channels(y, c0):
+    return _SplitChannels.apply(y, c0)
+
+
 class _GatherSlices(torch.autograd.Function):
     """w -> tuple(w.index_select(dim, idx) for idx in idxs) with ONE gradient: zeros + one index_add_ per slice.
     n separate index_select nodes each build a full-size zero-filled gradient and autograd then adds the n of them
