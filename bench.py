@@ -56,8 +56,8 @@ def dominant_kernel_match(cfg):
     return match
 
 
-PMC_TRAFFIC_JSON = "profiles/round3_pmc_wino_l4_0.json"
-PMC_MFMA_JSON = "profiles/round3_pmc_mfma_wino_l4_0.json"
+PMC_TRAFFIC_JSON = "profiles/round4_pmc_wino_l4_0.json"
+PMC_MFMA_JSON = "profiles/round4_pmc_mfma_wino_l4_0.json"
 
 
 def dominant_kernel_info(cfg, n_roi):

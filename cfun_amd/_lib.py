@@ -24,7 +24,8 @@ class ConvParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("N", "Di", "Hi", "Wi", "Ci", "Do", "Ho", "Wo", "Co", "CoP", "CiP",
                                          "kd", "kh", "kw", "stride", "pd", "ph", "pw", "up2", "act")] + \
                [("slope", C.c_float)] + \
-               [(n, C.c_int32) for n in ("scale_mode", "has_shift", "res_mode", "res_up2", "d2s", "d2s_cq", "tap_skip", "algo")]
+               [(n, C.c_int32) for n in ("scale_mode", "has_shift", "res_mode", "res_up2", "d2s", "d2s_cq", "tap_skip", "algo",
+                                         "w_prepared")]
 
 
 class ConvFusion(C.Structure):
@@ -34,6 +35,16 @@ class ConvFusion(C.Structure):
 
 
 FUSE_OUT_STATS, FUSE_IN_NORM, FUSE_IN_NORM_WGRAD = 1, 2, 4
+
+
+class WeightJob(C.Structure):
+    """CfunWeightJob (include/cfun_hip.h): one conv's weight operands in the batched cfun_weight_prepare launch."""
+    _fields_ = [("w", C.c_void_p), ("fwd", C.c_void_p), ("dgrad", C.c_void_p), ("co_idx", C.c_void_p), ("ci_idx", C.c_void_p),
+                ("Co", C.c_int32), ("Ci", C.c_int32), ("T", C.c_int32), ("src_ci", C.c_int32), ("fwd_kind", C.c_int32),
+                ("dgrad_kind", C.c_int32), ("block_begin", C.c_uint32), ("reserved", C.c_int32)]
+
+
+WOP_NONE = 0
 
 _P = C.c_void_p
 _I = C.c_int32
@@ -118,6 +129,9 @@ _SIGNATURES = {
     "cfun_weight_pack": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "cfun_weight_pack_transpose": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "cfun_weight_pack_both": (C.c_int, [_P, _P, _P, _I, _I, _I, _P]),
+    "cfun_weight_prepare_kinds": (C.c_int, [_PP, C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]),
+    "cfun_weight_prepare_plan": (C.c_int, [C.POINTER(WeightJob), _I, C.POINTER(C.c_int64)]),
+    "cfun_weight_prepare": (C.c_int, [_P, _I, _L, _P]),
     "cfun_conv3d_b3_supported": (C.c_int, [_PP]),
     "cfun_conv3d_b3_preferred": (C.c_int, [_PP]),
     "cfun_weight_pack_b3_bytes": (_Z, [_I, _I]),

@@ -24,7 +24,8 @@ int cfun_wino_supported(const CfunConv3dParams*);
 size_t cfun_wino_workspace_bytes(const CfunConv3dParams*);
 int cfun_wino_s2d_dgrad_supported(const CfunConv3dParams*, const CfunConv3dParams*);
 int cfun_wino_fwd(const float*, const float*, int, int, const float*, const float*, const float*, float*,
-                  const CfunConv3dParams*, void*, size_t, const cfun_mfma::ConvMode*, hipStream_t);
+                  const CfunConv3dParams*, void*, size_t, const cfun_mfma::ConvMode*, int, hipStream_t);
+int cfun_wino_is_2d(const CfunConv3dParams*);
 int cfun_wino_stat_slots(const CfunConv3dParams*, size_t);
 // elementwise.hip: (mean, rstd) per (n, channel) from per-slot fp64 sums [N][slots][2][C]
 int cfun_stats_finalize(const double* part, float* stats, int N, int slots, int C, int64_t V, float eps, int slot_minor, hipStream_t st);
@@ -137,7 +138,7 @@ bool make_dgrad_params(const CfunConv3dParams* p, CfunConv3dParams* q) {
   q->pd = p->kd - 1 - p->pd; q->ph = p->kh - 1 - p->ph; q->pw = p->kw - 1 - p->pw;
   if (q->pd < 0 || q->ph < 0 || q->pw < 0) return false;
   q->up2 = 0; q->act = CFUN_ACT_NONE; q->scale_mode = 0; q->has_shift = 0; q->res_mode = 0; q->res_up2 = 0;
-  q->d2s = 0; q->d2s_cq = 0; q->tap_skip = 0;
+  q->d2s = 0; q->d2s_cq = 0; q->tap_skip = 0; q->w_prepared = 0;
   return true;
 }
 
@@ -181,7 +182,7 @@ CfunConv3dParams folded_s2_params(const CfunConv3dParams* p) {
   q.CoP = (8 * p->Ci + 15) / 16 * 16; q.CiP = p->CoP;
   q.kd = q.kh = q.kw = 2; q.stride = 1; q.pd = q.ph = q.pw = 0;
   q.up2 = 0; q.act = CFUN_ACT_NONE; q.scale_mode = 0; q.has_shift = 0; q.res_mode = 0; q.res_up2 = 0; q.d2s = 1;
-  q.d2s_cq = 0; q.tap_skip = 0;
+  q.d2s_cq = 0; q.tap_skip = 0; q.w_prepared = 0;
   return q;
 }
 
@@ -432,11 +433,13 @@ static int conv_fwd_impl(const float* x, const float* wp, const float* scale, co
     fwd_mode(p, s, &md, &nsub);
     if (fused) { md.in_stats = fz->in_stats; md.in_act = fz->in_act; md.in_slope = fz->in_slope; md.out_part = fz->out_part; }
     if (ws && !cfun_aligned16(ws)) return CFUN_EALIGN;
+    const bool prepared = (p->w_prepared & 1) != 0;
     if (ws && cfun_wino_supported(p) && ws_bytes >= cfun_wino_workspace_bytes(p)) {   // x axis in the Winograd F(2,3) domain
       if (md.in_stats || md.in_act) return CFUN_EINVAL;       // (no input prologue in k_conv_wino: cfun_conv3d_fused_support)
       if (stat_slots) *stat_slots = cfun_wino_stat_slots(p, ws_bytes);      // (negative: by the split-K finish)
-      return cfun_wino_fwd(x, wp, 0, 0, scale, shift, res, y, p, ws, ws_bytes, &md, cfun_st(stream));
+      return cfun_wino_fwd(x, wp, 0, 0, scale, shift, res, y, p, ws, ws_bytes, &md, prepared, cfun_st(stream));
     }
+    if (prepared && cfun_wino_supported(p)) return CFUN_EWORKSPACE;      // wp is the Winograd operand: no plain kernel can read it
     if (stat_slots) *stat_slots = cfun_mfma::fwd_stat_slots(nsub, *p, md, ws ? ws_bytes : 0);
     return s->fwd(nsub, x, wp, scale, shift, res, y, *p, md, ws, ws ? ws_bytes : 0, cfun_st(stream));
   }
@@ -505,6 +508,39 @@ int cfun_conv3d_fwd_fused(const float* x, const float* wp, const float* scale, c
                              (int64_t)p->Do * p->Ho * p->Wo * (p->d2s ? 8 : 1), f->out_eps, slots > 0, cfun_st(stream));
 }
 
+// Which operand the forward / data gradient of p read when p->w_prepared is set: mirrors the dispatch of conv_fwd_impl and
+// cfun_conv3d_bwd_data (given their full workspaces).
+int cfun_weight_prepare_kinds(const CfunConv3dParams* p, int32_t kinds[2], size_t bytes[2]) {
+  if (!kinds || !bytes) return CFUN_EINVAL;
+  kinds[0] = kinds[1] = CFUN_WOP_NONE;
+  bytes[0] = bytes[1] = 0;
+  if (!valid_params(p)) return CFUN_EINVAL;
+  const int T = p->kd * p->kh * p->kw;
+  if (T > 27) return CFUN_OK;
+  kinds[0] = CFUN_WOP_PACK;
+  bytes[0] = (size_t)T * p->Ci * p->CoP * sizeof(float);
+  const bool pointwise = p->algo == CFUN_ALGO_AUTO && cfun_conv_pointwise_supported(p);
+  if (!pointwise && p->algo != CFUN_ALGO_DIRECT && mfma_shape(p) && cfun_wino_supported(p)) {
+    const int twod = cfun_wino_is_2d(p);
+    kinds[0] = twod ? CFUN_WOP_WINO2 : CFUN_WOP_WINO1;
+    bytes[0] = (size_t)(twod ? 48 : 36) * p->Ci * p->CoP * sizeof(float);
+  }
+  kinds[1] = CFUN_WOP_PACKT;
+  bytes[1] = (size_t)T * p->Co * p->CiP * sizeof(float);
+  CfunConv3dParams q;
+  const Shape* s;
+  if (use_folded_s2_dgrad(p)) {
+    kinds[1] = CFUN_WOP_S2FOLD;
+    bytes[1] = (size_t)8 * p->Co * ((8 * p->Ci + 15) / 16 * 16) * sizeof(float);
+  } else if (use_mfma_dgrad(p, &q, &s) && !p->up2 &&
+             (p->d2s ? cfun_wino_s2d_dgrad_supported(p, &q) : cfun_wino_supported(&q))) {
+    const int twod = cfun_wino_is_2d(&q);
+    kinds[1] = twod ? CFUN_WOP_WINO2_T : CFUN_WOP_WINO1_T;
+    bytes[1] = (size_t)(twod ? 48 : 36) * p->Co * p->CiP * sizeof(float);
+  }
+  return CFUN_OK;
+}
+
 size_t cfun_conv3d_bwd_data_workspace_bytes(const CfunConv3dParams* p) {
   if (!valid_params(p)) return 0;
   CfunConv3dParams q;
@@ -528,16 +564,21 @@ int cfun_conv3d_bwd_data(const float* g, const float* wpT, float* dx, const Cfun
   if (!valid_params(p)) return CFUN_EINVAL;
   CfunConv3dParams q;
   const Shape* s;
+  const bool prepared = (p->w_prepared & 2) != 0;       // wpT = the data-gradient operand of cfun_weight_prepare
   if (use_folded_s2_dgrad(p)) {
     if (!cfun_aligned16(g) || !cfun_aligned16(wpT) || !cfun_aligned16(dx) || !cfun_aligned16(ws)) return CFUN_EALIGN;
     if (ws_bytes < cfun_conv3d_bwd_data_workspace_bytes(p)) return CFUN_EWORKSPACE;
     q = folded_s2_params(p);
-    const int64_t nw = (int64_t)8 * p->Co * q.CoP;
-    hipLaunchKernelGGL(k_fold_s2_dgrad_weights, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, cfun_st(stream), wpT,
-                       (float*)ws, p->Ci, p->Co, p->CiP, q.CoP);
-    CFUN_LAUNCH_CHECK();
+    const float* wd = wpT;
+    if (!prepared) {
+      const int64_t nw = (int64_t)8 * p->Co * q.CoP;
+      hipLaunchKernelGGL(k_fold_s2_dgrad_weights, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, cfun_st(stream), wpT,
+                         (float*)ws, p->Ci, p->Co, p->CiP, q.CoP);
+      CFUN_LAUNCH_CHECK();
+      wd = (const float*)ws;
+    }
     const Shape* s2 = find_shape(2, 2, 2, 1);
-    return s2->fwd(pick_nsub(q.Co, s2->max_nsub), g, (const float*)ws, nullptr, nullptr, nullptr, dx, q, kPlain, nullptr, 0, cfun_st(stream));
+    return s2->fwd(pick_nsub(q.Co, s2->max_nsub), g, wd, nullptr, nullptr, nullptr, dx, q, kPlain, nullptr, 0, cfun_st(stream));
   }
   if (use_mfma_dgrad(p, &q, &s)) {
     if (!cfun_aligned16(g) || !cfun_aligned16(wpT) || !cfun_aligned16(dx)) return CFUN_EALIGN;
@@ -550,9 +591,11 @@ int cfun_conv3d_bwd_data(const float* g, const float* wpT, float* dx, const Cfun
       md.in_cq = p->d2s_cq > 0 ? p->d2s_cq : md.in_cqp;
       md.tap_skip = p->tap_skip ? 2 : 0;
     }
-    if (!p->up2 && cfun_aligned16(ws) && ws_bytes >= cfun_wino_workspace_bytes(&q) &&
-        (p->d2s ? cfun_wino_s2d_dgrad_supported(p, &q) : cfun_wino_supported(&q)))
-      return cfun_wino_fwd(g, wpT, 1, p->d2s ? (p->Co >> 3) : 0, nullptr, nullptr, nullptr, dx, &q, ws, ws_bytes, nullptr, cfun_st(stream));
+    const bool wino = !p->up2 && (p->d2s ? cfun_wino_s2d_dgrad_supported(p, &q) : cfun_wino_supported(&q));
+    if (wino && cfun_aligned16(ws) && ws_bytes >= cfun_wino_workspace_bytes(&q))
+      return cfun_wino_fwd(g, wpT, 1, p->d2s ? (p->Co >> 3) : 0, nullptr, nullptr, nullptr, dx, &q, ws, ws_bytes, nullptr,
+                           prepared, cfun_st(stream));
+    if (wino && prepared) return CFUN_EWORKSPACE;       // wpT is the Winograd operand
     if (!p->up2) return s->fwd(nsub, g, wpT, nullptr, nullptr, nullptr, dx, q, md, ws, cfun_aligned16(ws) ? ws_bytes : 0, cfun_st(stream));
     if (ws_bytes < cfun_conv3d_bwd_data_workspace_bytes(p) || !cfun_aligned16(ws)) return CFUN_EWORKSPACE;
     const int rc = s->fwd(nsub, g, wpT, nullptr, nullptr, nullptr, (float*)ws, q, md, nullptr, 0, cfun_st(stream));

@@ -641,21 +641,29 @@ int cfun_wino_stat_slots(const CfunConv3dParams* p, size_t ws_bytes) {
   return w.ksplit > 1 ? -cfun_splitk_stat_slots(p) : w.ntz * w.nty * w.ntx * (p->d2s ? 8 : 1);
 }
 
+// y in the Winograd domain as well for conv p (which transform cfun_wino_fwd applies / expects prepared)
+int cfun_wino_is_2d(const CfunConv3dParams* p) { return wino_2d(*p); }
+
+// prepared: wp already is the transformed U this launch reads (cfun_weight_prepare: CFUN_WOP_WINO1/2 or their _T forms)
 int cfun_wino_fwd(const float* x, const float* wp, int flip, int s2d_cq, const float* scale, const float* shift,
                   const float* res, float* y, const CfunConv3dParams* p, void* ws, size_t ws_bytes,
-                  const cfun_mfma::ConvMode* fz, hipStream_t st) {
+                  const cfun_mfma::ConvMode* fz, int prepared, hipStream_t st) {
   Plan w = make_plan(*p, 0);
   if (!ws || ws_bytes < w.u_bytes) return CFUN_EWORKSPACE;
   w = make_plan(*p, ws_bytes - w.u_bytes);
   if (w.nblk > 0x7fffffffLL) return CFUN_EINVAL;
-  float4* u = (float4*)ws;
+  const float4* u = prepared ? (const float4*)wp : (const float4*)ws;
   float* partial = (float*)((char*)ws + w.u_bytes);
   const int64_t nu = (int64_t)9 * p->Ci * p->CoP;
-  if (w.twod)
-    hipLaunchKernelGGL(k_wino2_weights, dim3((unsigned)((nu / 3 + 255) / 256)), dim3(256), 0, st, wp, u, p->Ci, p->CoP, flip);
-  else
-    hipLaunchKernelGGL(k_wino_weights, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, st, wp, u, p->Ci, p->CoP, flip);
-  CFUN_LAUNCH_CHECK();
+  if (prepared) {
+    if (!cfun_aligned16(wp)) return CFUN_EALIGN;
+  } else {
+    if (w.twod)
+      hipLaunchKernelGGL(k_wino2_weights, dim3((unsigned)((nu / 3 + 255) / 256)), dim3(256), 0, st, wp, (float4*)ws, p->Ci, p->CoP, flip);
+    else
+      hipLaunchKernelGGL(k_wino_weights, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, st, wp, (float4*)ws, p->Ci, p->CoP, flip);
+    CFUN_LAUNCH_CHECK();
+  }
   cfun_mfma::ConvMode md = {0, 0, 0, 0, 0, nullptr, 0, 0.f, nullptr, 0};
   if (fz) { md.in_stats = fz->in_stats; md.in_act = fz->in_act; md.in_slope = fz->in_slope; md.out_part = fz->out_part; }
   md.out_slots = w.ntz * w.nty * w.ntx * (p->d2s ? 8 : 1);

@@ -125,6 +125,10 @@ BATCH_BIAS_FOLD = os.environ.get("CFUN_BATCH_BIAS_FOLD", "1") != "0"
 
 
 def begin_step(net):
+    # the weight operands of the step's convs outside the U-Net (FPN, RPN, classifier): one batched preparation launch
+    scope = ops.WeightScope(net)
+    scope.__enter__()
+    _STEP["wscope"] = scope
     if not BATCH_BIAS_FOLD:
         return
     pairs = getattr(net, "_cfun_fold_pairs", None)
@@ -141,7 +145,10 @@ def begin_step(net):
     _STEP["shifts"] = {id(c): (sh, id(bn), eps, s, t) for (c, bn, eps, s, t), sh in zip(live, outs)}
 
 
-def end_step(net):
+def end_step(net, ok=True):
+    scope = _STEP.pop("wscope", None)
+    if scope is not None:
+        scope.__exit__(None if ok else RuntimeError, None, None)
     rec = _STEP["record"]
     if rec is not None and getattr(net, "_cfun_fold_pairs", None) is None:
         seen, pairs = set(), []

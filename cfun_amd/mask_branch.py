@@ -98,15 +98,16 @@ class Modified3DUNet(nn.Module):
 
     def _upload_dropout(self, drops, device):
         """All five masks and all kept-channel lists go to the device in TWO transfers at the start of the forward
-        pass: a pageable host-to-device copy in the middle of the pass waits for the stream and leaves the GPU idle
-        until the host has caught up (10 such stalls cost ~1 ms per step; pinning the staging buffers per step costs
-        more than it saves)."""
+        pass, asynchronously through persistent pinned staging buffers (ops.upload): a pageable host-to-device copy waits
+        for the stream and leaves the GPU idle until the host has caught up (10 such stalls in the middle of the pass cost
+        ~1 ms per step in round 1; pinning fresh staging buffers per step cost more than it saved -- the ring is allocated
+        once)."""
         if drops[0] is None:
             return [None] * 5
         lists = [self._kept_channels(m) for m in drops]
-        flat_idx = torch.tensor([j for lv in lists for l in lv for j in l], dtype=torch.long).to(device)
+        flat_idx = ops.upload(torch.tensor([j for lv in lists for l in lv for j in l], dtype=torch.long), device)
         pad = [(-m.numel()) % 4 for m in drops]                       # every mask starts 16-byte aligned
-        flat_m = torch.cat([torch.nn.functional.pad(m.reshape(-1), (0, p)) for m, p in zip(drops, pad)]).to(device)
+        flat_m = ops.upload(torch.cat([torch.nn.functional.pad(m.reshape(-1), (0, p)) for m, p in zip(drops, pad)]), device)
         out, oi, om = [], 0, 0
         for m, lv, p in zip(drops, lists, pad):
             idxs = []
@@ -117,7 +118,7 @@ class Modified3DUNet(nn.Module):
             om += m.numel() + p
         return out
 
-    def _dropout_pair(self, src, head, conv1, conv2, drop_cpu, pre2, out_stats=None):
+    def _dropout_pair(self, src, head, conv1, conv2, drop_cpu, pre2, out_stats=None, level=None):
         """One level's ``(a, res) = head(src); out = conv2(pre2(Dropout3d(conv1(a)))) + res``: conv1 / conv2 are the
         level's 3x3x3 Conv3dParams (conv1: Ci -> C, conv2: C -> Co), drop_cpu = (device mask [N,C] (keep / (1-p)),
         per-sample kept-channel index tensors) from ``_upload_dropout`` or None, ``head`` the ops that produce the
@@ -146,9 +147,12 @@ class Modified3DUNet(nn.Module):
         res_parts = ops.split_batch(res_all)
         ybuf, gbuf = ops.BatchBuffer(n), ops.BatchBuffer(n)     # outputs / conv1 input gradients, written in place
         outs = []
-        w1s, w2s = ops.gather_slices(conv1.weight, 0, idxs), ops.gather_slices(conv2.weight, 1, idxs)
         zs = dist.current()
         zs = zs if zs is not None and zs.world > 1 else None      # z-sharded RoI: slabs, halos inside the convs
+        # (level: the key of this level's index lists in the pass's ops.WeightScope -- the slices' conv operands are then
+        # gathered by the batched weight preparation and the slices themselves never materialised)
+        gk = None if (zs is not None or level is None) else level
+        w1s, w2s = ops.gather_slices(conv1.weight, 0, idxs, key=gk), ops.gather_slices(conv2.weight, 1, idxs, key=gk)
         for i in range(n):
             a, res = a_parts[i], res_parts[i]
             idx = idxs[i]
@@ -197,6 +201,13 @@ class Modified3DUNet(nn.Module):
         zs = zshard if zshard is not None and zshard.world > 1 else None
         if zs is not None and x.shape[0] != 1:
             raise ValueError("a z-sharded U-Net handles one RoI per sub-group")
+        drop = self._upload_dropout(self._drop_masks(x.shape[0], x.device), x.device)
+        # every conv weight of the pass in the layout its kernels read, by ONE launch (ops.WeightScope: recorded on the
+        # first pass; the per-RoI Dropout3d slices are gathered by that launch from this pass's index lists)
+        with ops.WeightScope(self, dyn={lv: d[1] for lv, d in enumerate(drop) if d is not None}):
+            return self._forward_body(x, zs, drop)
+
+    def _forward_body(self, x, zs, drop):
         sharded = (lambda: dist.depth_sharded_as(zs)) if zs is not None else dist.nullcontext
         folded = dist.slab_local if zs is not None else dist.nullcontext
 
@@ -214,8 +225,6 @@ class Modified3DUNet(nn.Module):
             return ops.StatsSlot(t_or_n if isinstance(t_or_n, int) else t_or_n.shape[0])
 
         nb = x.shape[0]
-
-        drop = self._upload_dropout(self._drop_masks(x.shape[0], x.device), x.device)
 
         def nluc(h, holder, out=None, src="same", stats=None, lazy_out=False):
             """norm -> lrelu -> nearest x2 -> 3x3x3 conv -> norm -> lrelu (mask_branch.py:108-116).  src: where h lives --
@@ -235,7 +244,7 @@ class Modified3DUNet(nn.Module):
                 return ops.lrelu(res, lazy=lz, passthrough=True)       # (activation -> conv1, res' -> the residual add)
             s_out = slot(nb)
             out = self._dropout_pair(x, head1, self.conv3d_c1_2, self.lrelu_conv_c1[1], drop[0],
-                                     lambda t, st: ops.lrelu(t, lazy=lz), out_stats=s_out)
+                                     lambda t, st: ops.lrelu(t, lazy=lz), out_stats=s_out, level=0)
             # context_1 is only ever read by the level-1 concat (mask_branch.py:203): it is written straight into the
             # second half of that concat's buffer, the decoder later writes the first half -- no torch.cat, no copies
             b1 = self.base_n_filter
@@ -265,7 +274,8 @@ class Modified3DUNet(nn.Module):
             with (folded() if rep else sharded()):
                 s_out = slot(nb)
                 out = self._dropout_pair(h, head, conv, conv, drop[lvl - 1],
-                                         lambda t, st, rep=rep: nl(t, rep=rep, stats=st, lazy=True), out_stats=s_out)
+                                         lambda t, st, rep=rep: nl(t, rep=rep, stats=st, lazy=True), out_stats=s_out,
+                                         level=lvl - 1)
                 if lvl < 5:
                     h = nl(out, rep=rep, stats=s_out)
                     ctx.append(h)

@@ -172,7 +172,15 @@ def fold_up2_weight(w, cqp=None):
     k = w.shape[-1]
     if k not in (3, 5):
         raise ValueError("fold_up2_weight: kernel size %d" % k)
-    return _FoldUp2.apply(w, w.shape[0] if cqp is None else cqp)
+    cqp = w.shape[0] if cqp is None else cqp
+    scope = WeightScope.current()
+    if scope is not None:          # folded at the start of the pass, its operands are part of the batched preparation
+        wf = scope.folds.get((id(w), cqp))
+        if wf is not None:
+            return wf
+    wf = _FoldUp2.apply(w, cqp)
+    wf._cfun_src = ("f", w, cqp)
+    return wf
 
 
 class _SplitChannels(torch.autograd.Function):
@@ -201,13 +209,23 @@ def split_channels(y, c0):
 class _GatherSlices(torch.autograd.Function):
     """w -> tuple(w.index_select(dim, idx) for idx in idxs) with ONE gradient: zeros + one index_add_ per slice.
     n separate index_select nodes each build a full-size zero-filled gradient and autograd then adds the n of them
-    (per-RoI Dropout3d weight slices: 3n - 1 launches per weight instead of n + 1)."""
+    (per-RoI Dropout3d weight slices: 3n - 1 launches per weight instead of n + 1).
+    ``lazy``: the slices are returned as UNWRITTEN tensors of the right shape -- their only consumers are convs whose
+    operands the batched weight preparation (WeightScope) has already gathered straight from ``w``; a consumer that
+    needs the values calls ``materialize_weight`` first."""
 
     @staticmethod
-    def forward(ctx, w, dim, *idxs):
+    def forward(ctx, w, dim, lazy, *idxs):
         ctx.dim, ctx.wshape = dim, tuple(w.shape)
         ctx.save_for_backward(*idxs)
-        return tuple(w.index_select(dim, idx) for idx in idxs)
+        if not lazy:
+            return tuple(w.index_select(dim, idx) for idx in idxs)
+        shp = list(w.shape)
+        outs = []
+        for idx in idxs:
+            shp[dim] = idx.numel()
+            outs.append(torch.empty(shp, dtype=w.dtype, device=w.device))
+        return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):
@@ -219,12 +237,211 @@ class _GatherSlices(torch.autograd.Function):
             if dw is None:
                 dw = torch.zeros(ctx.wshape, dtype=g.dtype, device=g.device)
             dw.index_add_(ctx.dim, idx, g)
-        return (dw, None) + (None,) * len(idxs)
+        return (dw, None, None) + (None,) * len(idxs)
 
 
-def gather_slices(w, dim, idxs):
-    """[w.index_select(dim, idx) for idx in idxs], differentiable w.r.t. w with a single accumulated gradient."""
-    return _GatherSlices.apply(w, dim, *idxs)
+def gather_slices(w, dim, idxs, key=None):
+    """[w.index_select(dim, idx) for idx in idxs], differentiable w.r.t. w with a single accumulated gradient.  ``key``
+    names the index lists inside the active ``WeightScope`` (its ``dyn`` table): where the scope has prepared the operands
+    of every slice the slices themselves are never gathered (see _GatherSlices)."""
+    scope = WeightScope.current()
+    lazy = bool(scope is not None and key is not None and scope.has_gather(w, dim, key, len(idxs)))
+    outs = _GatherSlices.apply(w, dim, lazy, *idxs)
+    if key is not None:
+        for i, (t, idx) in enumerate(zip(outs, idxs)):
+            t._cfun_src = ("g", w, dim, key, i)
+            t._cfun_lazy = (w, dim, idx) if lazy else None
+    return outs
+
+
+def materialize_weight(w):
+    """The values of a lazily gathered weight slice (gather_slices inside a WeightScope), written on first demand."""
+    lz = getattr(w, "_cfun_lazy", None)
+    if lz is not None:
+        base, dim, idx = lz
+        with torch.no_grad():
+            w.detach().copy_(base.detach().index_select(dim, idx))
+        w._cfun_lazy = None
+    return w
+
+
+class WeightScope:
+    """The weight operands of every conv a module runs in one pass, prepared by ONE launch (cfun_weight_prepare) instead of
+    2 - 3 small launches per conv (pack, Winograd transform, stride-2 fold) and one index_select per gathered slice.
+
+    Which convs run, with which parameters, is only known at the call sites: the first pass inside ``with
+    WeightScope(owner)`` records (weight source, conv parameters, needs a data gradient) per ``conv3d_w`` call and stores
+    the list on ``owner``; later passes replay it up front -- fold the up-conv weights, build the job table (one
+    host-to-device copy), launch -- and the convs pick their operands up by (source, operand kinds).  A conv the table
+    does not cover (first pass, another shape, a changed graph) packs its own weight as before and is recorded for the
+    next pass, so the scope never changes results, only the number of launches.  Sources: an ``nn.Parameter``; slice i of
+    ``gather_slices(param, dim, idxs, key=k)`` with this pass's index lists given as ``dyn[k]``; ``fold_up2_weight(param,
+    cqp)``."""
+
+    _stack = []
+
+    def __init__(self, owner, dyn=None, enabled=True):
+        self.owner, self.dyn = owner, dyn or {}
+        self.enabled = bool(enabled) and os.environ.get("CFUN_WEIGHT_SCOPE", "1") != "0"
+        self.table, self.folds, self.seen, self.seen_keys = {}, {}, [], {}
+        self.hits = self.misses = 0
+
+    @classmethod
+    def current(cls):
+        return cls._stack[-1] if cls._stack else None
+
+    def __enter__(self):
+        if self.enabled:
+            WeightScope._stack.append(self)
+            plan = getattr(self.owner, "_cfun_wplan", None)
+            if plan:
+                try:
+                    self._prepare(plan)
+                except Exception:
+                    WeightScope._stack.pop()
+                    raise
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            WeightScope._stack.pop()
+            if exc[0] is None:
+                self.owner._cfun_wplan = self.seen
+        return False
+
+    # -- keys ---------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _desc(w):
+        src = getattr(w, "_cfun_src", None)
+        if src is not None:
+            return src
+        if isinstance(w, torch.nn.Parameter):
+            return ("p", w)
+        return None
+
+    @staticmethod
+    def _desc_key(desc):
+        return (desc[0], id(desc[1])) + tuple(desc[2:])
+
+    @staticmethod
+    def _kinds(p):
+        kinds, nbytes = (C.c_int32 * 2)(), (C.c_size_t * 2)()
+        check(_lib.load().cfun_weight_prepare_kinds(C.byref(p), kinds, nbytes), "weight_prepare_kinds")
+        return int(kinds[0]), int(kinds[1]), int(nbytes[0]), int(nbytes[1])
+
+    def has_gather(self, w, dim, key, n):
+        have = [k for k in self.table if k[0] == "g" and k[1] == id(w) and k[2] == dim and k[3] == key]
+        return len({k[4] for k in have}) == n and n > 0
+
+    # -- the batched preparation ---------------------------------------------------------------------------------------
+    def _prepare(self, plan):
+        lib = _lib.load()
+        jobs, outs, keep = [], [], []
+        total = 0
+        for desc, pbytes, need_dgrad in plan:
+            p = ConvParams.from_buffer_copy(pbytes)
+            base = desc[1]
+            co_idx = ci_idx = None
+            if desc[0] == "p":
+                src = base
+            elif desc[0] == "f":
+                wf = self.folds.get((id(base), desc[2]))
+                if wf is None:
+                    wf = self.folds[(id(base), desc[2])] = fold_up2_weight_eager(base, desc[2])
+                src = wf
+            else:
+                _, _, dim, key, i = desc
+                idxs = self.dyn.get(key)
+                if idxs is None or i >= len(idxs):
+                    continue
+                n = int(idxs[i].numel())
+                if dim == 0:
+                    p.Co, p.CoP, co_idx = n, _round16(n), idxs[i]
+                    if p.d2s or p.d2s_cq:
+                        continue
+                else:
+                    p.Ci, p.CiP, ci_idx = n, _round16(n), idxs[i]
+                src = base
+            if not src.is_contiguous() or src.dtype != torch.float32:
+                continue
+            try:
+                fk, dk, fb, db = self._kinds(p)
+            except RuntimeError:
+                continue
+            if fk == _lib.WOP_NONE:
+                continue
+            if not need_dgrad:
+                dk, db = _lib.WOP_NONE, 0
+            key = self._desc_key(desc) + (fk, dk)
+            if key in self.table:
+                continue
+            offs = []
+            for nb in (fb, db):
+                offs.append(total)
+                total += (nb + 255) // 256 * 256
+            t = p.kd * p.kh * p.kw
+            jobs.append((src, co_idx, ci_idx, int(p.Co), int(p.Ci), t, int(src.shape[1]), fk, dk))
+            outs.append((key, offs, fb, db))
+            self.table[key] = None
+        if not jobs:
+            return
+        dev = jobs[0][0].device
+        arena = torch.empty(max(total, 256), dtype=torch.uint8, device=dev)
+        base_ptr = arena.data_ptr()
+        arr = (_lib.WeightJob * len(jobs))()
+        for j, ((src, co_idx, ci_idx, co, ci, t, src_ci, fk, dk), (key, offs, fb, db)) in enumerate(zip(jobs, outs)):
+            a = arr[j]
+            a.w = ptr(src.detach())
+            a.fwd = base_ptr + offs[0]
+            a.dgrad = (base_ptr + offs[1]) if dk != _lib.WOP_NONE else None
+            a.co_idx = None if co_idx is None else ptr(co_idx)
+            a.ci_idx = None if ci_idx is None else ptr(ci_idx)
+            a.Co, a.Ci, a.T, a.src_ci, a.fwd_kind, a.dgrad_kind = co, ci, t, src_ci, fk, dk
+            self.table[key] = (arena[offs[0]:offs[0] + fb].view(torch.float32),
+                               arena[offs[1]:offs[1] + db].view(torch.float32) if dk != _lib.WOP_NONE else None)
+        nblocks = C.c_int64(0)
+        check(lib.cfun_weight_prepare_plan(arr, len(jobs), C.byref(nblocks)), "weight_prepare_plan")
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        tab = upload(host, dev)
+        check(lib.cfun_weight_prepare(ptr(tab), len(jobs), nblocks.value, stream(arena)), "weight_prepare")
+        self._keep = (tab, [j[0] for j in jobs])      # (held until the launch has been enqueued; the arena lives in the views)
+
+    # -- the conv call site ---------------------------------------------------------------------------------------------
+    def lookup(self, w, p, need_dgrad):
+        """(forward operand, data-gradient operand or None, w_prepared bits) for conv p on weight w, or None."""
+        desc = self._desc(w)
+        if desc is None:
+            return None
+        try:
+            fk, dk, _, _ = self._kinds(p)
+        except RuntimeError:
+            return None
+        if fk == _lib.WOP_NONE:
+            return None
+        dkey = self._desc_key(desc)
+        rec = self.seen_keys.get(dkey + (fk,))
+        if rec is None:
+            p0 = ConvParams.from_buffer_copy(bytes(p))
+            p0.w_prepared = 0
+            self.seen_keys[dkey + (fk,)] = len(self.seen)
+            self.seen.append((desc, bytes(p0), bool(need_dgrad)))
+        elif need_dgrad and not self.seen[rec][2]:
+            self.seen[rec] = self.seen[rec][:2] + (True,)
+        ops_ = self.table.get(dkey + (fk, dk if need_dgrad else _lib.WOP_NONE))
+        if ops_ is None and not need_dgrad:      # prepared with the data-gradient operand although this pass needs none
+            ops_ = self.table.get(dkey + (fk, dk))
+        if ops_ is None:
+            self.misses += 1
+            return None
+        self.hits += 1
+        fwd, dg = ops_
+        return fwd, (dg if need_dgrad else None), (1 | (2 if (need_dgrad and dg is not None) else 0))
+
+
+def fold_up2_weight_eager(w, cqp):
+    wf = _FoldUp2.apply(w, cqp)
+    wf._cfun_src = ("f", w, cqp)
+    return wf
 
 
 def _transpose_pack(wp, co):
@@ -363,15 +580,21 @@ class _Conv3d(torch.autograd.Function):
         # opt-in 3xBF16 kernels (CFUN_CONV_ALGO=b3): forward here, data gradient in backward; wgrad stays exact fp32
         b3 = bool(spec.algo == ALGO_B3 and w_src is not None and _b3_wanted(lib, p))
         if b3:
-            wp, wb3 = None, pack_weight_b3(w_src)
+            wp, wb3 = None, pack_weight_b3(materialize_weight(w_src))
         elif w_src is not None:      # OIDHW weight: packed here, its gradient comes back in OIDHW (one fused pass)
-            if ctx.needs_input_grad[0]:      # the data gradient's layout in the same launch, kept for backward
-                wp, wpT = _pack(w_src, both=True)
+            scope = WeightScope.current()
+            got = scope.lookup(w_src, p, ctx.needs_input_grad[0]) if scope is not None else None
+            if got is not None:          # operands from the pass's batched preparation (the Winograd U etc., not plain packs)
+                wp, wpT, p.w_prepared = got
             else:
-                wp = _pack(w_src)
+                materialize_weight(w_src)
+                if ctx.needs_input_grad[0]:      # the data gradient's layout in the same launch, kept for backward
+                    wp, wpT = _pack(w_src, both=True)
+                else:
+                    wp = _pack(w_src)
         if not b3:
             wp = _c(wp)
-            if wp.shape != (p.kd * p.kh * p.kw, p.Ci, p.CoP):
+            if not (p.w_prepared & 1) and wp.shape != (p.kd * p.kh * p.kw, p.Ci, p.CoP):
                 raise RuntimeError("packed weight %s does not match conv %s" % (tuple(wp.shape), spec))
         if spec.d2s:
             cq = spec.d2s_cq or p.Co // 8
@@ -431,7 +654,7 @@ class _Conv3d(torch.autograd.Function):
         ctx.b3 = b3
         ctx.pro = None if pro is None else (int(pro[1]), float(pro[2]))
         ctx.shift_scaled = bool(shift_scaled)
-        ctx.save_for_backward(x, wp, scale, y if spec.act != ACT_NONE else None, wpT,
+        ctx.save_for_backward(x, wp if not (p.w_prepared & 1) else None, scale, y if spec.act != ACT_NONE else None, wpT,
                               w_src.detach() if b3 and ctx.needs_input_grad[0] else None,
                               None if pro is None or pro[0] is None else _c(pro[0]))
         return y
@@ -498,6 +721,8 @@ class _Conv3d(torch.autograd.Function):
                                              st), "conv3d_b3_fwd(dgrad)")
             else:
                 if wpT is None:
+                    if wp is None and w_b3 is None:
+                        raise RuntimeError("conv3d backward: no weight operand was kept for the data gradient")
                     wpT = _transpose_pack(wp if wp is not None else _pack(w_b3), p.Co)
                 nb = lib.cfun_conv3d_bwd_data_workspace_bytes(C.byref(p))
                 ws = workspace(nb, x)
@@ -1507,6 +1732,88 @@ def halo_unpack(buf, x, z0):
     buf = _c(buf)                  # held across the launch (a temporary could be recycled before the kernel reads it)
     check(lib.cfun_halo_unpack(ptr(buf), ptr(x), n, d, h, w, c, z0, planes, stream(x)), "halo_unpack")
     return x
+
+
+# ---- host -> device uploads that never block the host -----------------------------------------------------------------
+class _UploadRing:
+    """Small per-step host tensors (Dropout3d masks and kept-channel lists, weight-preparation tables) go to the device
+    through a ring of PERSISTENT pinned staging buffers with an asynchronous copy.  A pageable ``tensor.to(device)`` is a
+    blocking copy in stream order: the host stops until the GPU has drained everything queued before it -- the previous
+    step's backward -- and the GPU then idles until the host has caught up (tools/gap_report.py: ~2.7 ms of gaps per step
+    before).  A slot is reused only after the copy that read it has completed (its event; by then long done)."""
+
+    SLOTS = 8
+
+    def __init__(self, device):
+        self.device, self.slots, self.i = device, [[None, None] for _ in range(self.SLOTS)], 0
+
+    def upload(self, host):
+        host = host.contiguous()
+        nbytes = host.numel() * host.element_size()
+        out = torch.empty(host.shape, dtype=host.dtype, device=self.device)
+        if nbytes == 0:
+            return out
+        slot = self.slots[self.i]
+        self.i = (self.i + 1) % self.SLOTS
+        if slot[1] is not None:
+            slot[1].synchronize()
+        if slot[0] is None or slot[0].numel() < nbytes:
+            slot[0] = torch.empty(max(2 * nbytes, 1 << 16), dtype=torch.uint8).pin_memory()
+        stage = slot[0][:nbytes].view(host.dtype).view(host.shape)
+        stage.copy_(host)
+        out.copy_(stage, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        slot[1] = ev
+        return out
+
+
+class AsyncScalar:
+    """A small device tensor on its way to the host: the copy into a persistent pinned buffer is enqueued now, ``get()``
+    waits only for THAT copy (an event), not for whatever was enqueued after it."""
+
+    _ring, _i = [], 0
+
+    def __init__(self, t):
+        cls = AsyncScalar
+        if t.is_cuda:
+            if len(cls._ring) < 16:
+                cls._ring.append([torch.empty(64, dtype=torch.int64).pin_memory(), None])
+            slot = cls._ring[cls._i % len(cls._ring)]
+            cls._i += 1
+            if slot[1] is not None:
+                slot[1].synchronize()
+            n = t.numel() * t.element_size()
+            if n > slot[0].numel() * 8:
+                raise RuntimeError("AsyncScalar: tensor of %d bytes" % n)
+            self.host = slot[0].view(torch.uint8)[:n].view(t.dtype).view(t.shape)
+            self.host.copy_(t, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record(torch.cuda.current_stream(t.device))
+            slot[1] = self.event
+        else:
+            self.host, self.event = t.detach().clone(), None
+
+    def get(self):
+        if self.event is not None:
+            self.event.synchronize()
+            self.host, self.event = self.host.clone(), None      # (the ring slot may be reused)
+        return self.host
+
+
+_UPLOADERS = {}
+
+
+def upload(host, device):
+    """``host`` (a CPU tensor) on ``device`` without blocking the host (see _UploadRing); plain copy on a CPU device."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        return host.to(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    ring = _UPLOADERS.get(idx)
+    if ring is None:
+        ring = _UPLOADERS[idx] = _UploadRing(torch.device("cuda", idx))
+    return ring.upload(host)
 
 
 # ---- layout helpers (module boundary only; NCDHW <-> NDHWC) -------------------------------------------

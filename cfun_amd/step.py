@@ -14,10 +14,13 @@ import torch.nn as nn
 
 from . import backbone, layers, model, ops, utils
 
-# CFUN_OVERLAP_MASK_HEAD=1 runs the mask head on its own HIP stream beside FPN / RPN / classifier (see _mask_head).
-# Off by default: measured on one MI355X at cfg2 it is 1.2 ms per step SLOWER (56.8 vs 55.6 ms) -- the U-Net's convs
-# already fill the chip, and the small kernels they now share it with cost them more than the overlap hides.
-OVERLAP_MASK_HEAD = os.environ.get("CFUN_OVERLAP_MASK_HEAD", "0") == "1"
+# The mask head runs on its own HIP stream beside FPN / RPN / classifier (see _mask_head); CFUN_OVERLAP_MASK_HEAD=0 puts
+# everything on one stream.  Round 1 measured the overlap 1.2 ms per step SLOWER (56.8 vs 55.6 ms) and left it off -- but
+# that step still had a dozen host synchronisations inside (pageable uploads, nonzero() in the losses and the RoI level
+# split, the NMS count), each of which stalled BOTH streams.  With the step free of host waits (round 4) the few hundred
+# small, latency-bound launches of the detector hide beside the U-Net's chip-filling convs: 44.9 -> 42.9 ms per step at
+# cfg2 (profiles/round4_*), same bits (test_mask_head_side_stream).
+OVERLAP_MASK_HEAD = os.environ.get("CFUN_OVERLAP_MASK_HEAD", "1") == "1"
 
 
 class CFUNHotPath(nn.Module):
@@ -93,11 +96,11 @@ class CFUNHotPath(nn.Module):
         logits, probs, bbox = [torch.cat([o[i] for o in outs], dim=1) for i in range(3)]
         return p2, p3, logits, probs, bbox
 
-    def proposals(self, rpn_probs, rpn_bbox, mode="training"):
+    def proposals(self, rpn_probs, rpn_bbox, mode="training", lazy=False):
         cfg = self.config
         count = cfg.POST_NMS_ROIS_TRAINING if mode == "training" else cfg.POST_NMS_ROIS_INFERENCE
         return model.proposal_layer([rpn_probs, rpn_bbox], proposal_count=count, nms_threshold=cfg.RPN_NMS_THRESHOLD,
-                                    anchors=self.anchors, config=cfg)
+                                    anchors=self.anchors, config=cfg, lazy=lazy)
 
     def _mask_head(self, image, p_rois):
         """The mask head (RoIAlign of the raw image + U-Net + softmax) on its own HIP stream: it reads only the image
@@ -121,9 +124,10 @@ class CFUNHotPath(nn.Module):
                 t.record_stream(main)
         return logits, probs, join
 
-    def predict_training(self, image, p_rois, n_rois):
+    def predict_training(self, image, p_rois, n_rois, lazy_rois=False):
         """BatchNorm stays in eval mode while the rest trains (model.py:1397-1406): folded BN needs no switch.
-        p_rois [n_pos,6] / n_rois [n_neg,6] normalised.  Returns a dict of the path's outputs."""
+        p_rois [n_pos,6] / n_rois [n_neg,6] normalised.  Returns a dict of the path's outputs.  ``lazy_rois``:
+        ``rpn_rois`` comes back as a ``model.LazyProposals`` (the NMS keep count is not read yet: no host wait here)."""
         self.train()
         mask_logits = mask_probs = cls_logits = cls_probs = cls_bbox = None
         join = lambda: None
@@ -132,7 +136,7 @@ class CFUNHotPath(nn.Module):
             if not self.detector_phase_only:
                 mask_logits, mask_probs, join = self._mask_head(image, p_rois)  # enqueued first, on its own stream
             p2, p3, rpn_logits, rpn_probs, rpn_bbox = self.backbone_rpn(image)
-            rpn_rois = self.proposals(rpn_probs, rpn_bbox, "training")
+            rpn_rois = self.proposals(rpn_probs, rpn_bbox, "training", lazy=lazy_rois)
             if not self.mask_phase_only:
                 rois = torch.cat([p_rois, n_rois], dim=0)
                 cls_logits, cls_probs, cls_bbox = self.classifier.forward_ndhwc([p2[0], p3[0]], rois)
@@ -349,10 +353,13 @@ def training_step_full(net, image, gt_class_ids, gt_boxes, gt_labels, rpn_match,
 
 
 def training_step(net, s):
-    """One forward + 6 losses + backward of the hot path on the sample ``s`` (no optimizer step)."""
-    out = net.predict_training(s["image"], s["p_rois"], s["n_rois"])
+    """One forward + 6 losses + backward of the hot path on the sample ``s`` (no optimizer step).  The head RoI sets are
+    inputs here, so nothing consumes the proposals inside the step: their NMS keep count is read only after the backward
+    pass has been enqueued (model.LazyProposals) and the host never waits for the GPU mid-step."""
+    out = net.predict_training(s["image"], s["p_rois"], s["n_rois"], lazy_rois=True)
     losses = net.compute_losses(out, s["rpn_match"], s["rpn_bbox_t"], s["target_class_ids"], s["target_deltas"],
                                 s["mask_labels"])
     total = net.total_loss(losses)
     total.backward()
+    out["rpn_rois"] = out["rpn_rois"].resolve()
     return out, losses, total

@@ -94,6 +94,10 @@ typedef struct CfunConv3dParams {
                                    (ops.fold_up2_weight): only the 2x2x2 taps {p,p+1}^3 of each output parity are
                                    non-zero and the kernels skip the rest (8/27 of the FLOPs). */
   int32_t algo;                 /* CFUN_ALGO_* */
+  int32_t w_prepared;           /* bit 0: the `wp` given to cfun_conv3d_fwd* is the forward operand of cfun_weight_prepare
+                                   (for Winograd shapes the transformed U, not the plain pack); bit 1: the `wpT` given to
+                                   cfun_conv3d_bwd_data is its data-gradient operand.  0: plain packs (the kernels transform
+                                   them per call). */
 } CfunConv3dParams;
 
 /* ws: cfun_conv3d_fwd_workspace_bytes(p) bytes (split-K partials for volumes too small to fill the chip);
@@ -389,6 +393,41 @@ int cfun_conv3d_b3_wgrad_preferred(const CfunConv3dParams* p);
 size_t cfun_conv3d_b3_wgrad_workspace_bytes(const CfunConv3dParams* p);
 int cfun_conv3d_b3_wgrad_oidhw(const float* x, const float* g, float* dw, const CfunConv3dParams* p, void* ws,
                                size_t ws_bytes, cfun_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Weight operands of MANY convolutions in ONE launch, straight from their OIDHW tensors.
+ * cfun_weight_prepare_kinds(p): which operand the forward (kinds[0]) and the data gradient (kinds[1]) of conv p read
+ * when p->w_prepared says so, and its size in bytes -- the plain packs, or what the kernels would otherwise derive from
+ * them per call: the Winograd-transformed weights of k_conv_wino (1-D / 2-D; the data gradient's with mirrored taps), the
+ * parity-folded 2x2x2 weights of a stride-2 conv's data gradient.  CFUN_WOP_NONE: not preparable (more than 27 taps) --
+ * use cfun_weight_pack*.  The host fills a table of jobs, cfun_weight_prepare_plan assigns the workgroups
+ * (block_begin), the caller copies the table to the device and cfun_weight_prepare runs all jobs as one grid.  A job may
+ * gather output channels (co_idx) / input channels (ci_idx) of its source: the per-RoI Dropout3d weight slices of
+ * mask_branch.py:130-175 without index_select launches.  Values are bit-identical to pack + per-call transform.
+ * ---------------------------------------------------------------------------------------------- */
+#define CFUN_WOP_NONE 0
+#define CFUN_WOP_PACK 1           /* [tap][Ci][CoP] */
+#define CFUN_WOP_PACKT 2          /* [tap][Co][CiP] */
+#define CFUN_WOP_WINO1 3          /* [9 (dz,dy)][Ci][CoP] x 4 x-points */
+#define CFUN_WOP_WINO2 4          /* [12 (dz,py)][Ci][CoP] x 4 x-points */
+#define CFUN_WOP_WINO1_T 5        /* the data gradient's: [9][Co][CiP] x 4, taps mirrored */
+#define CFUN_WOP_WINO2_T 6        /* [12][Co][CiP] x 4, taps mirrored */
+#define CFUN_WOP_S2FOLD 7         /* [8][Co][round16(8*Ci)]: stride-2 3x3x3 data gradient as a 2x2x2 conv + depth-to-space */
+typedef struct CfunWeightJob {
+  const float* w;                 /* source [*, src_ci, T] (OIDHW viewed 3-D), device */
+  float* fwd;                     /* forward operand (fwd_kind), 16-byte aligned, or NULL */
+  float* dgrad;                   /* data-gradient operand (dgrad_kind) or NULL */
+  const int64_t* co_idx;          /* NULL, or Co source rows (gathered output channels), device */
+  const int64_t* ci_idx;          /* NULL, or Ci source columns (gathered input channels), device */
+  int32_t Co, Ci, T;              /* the conv's channels (after gathering) and taps (<= 27) */
+  int32_t src_ci;                 /* input channels of the source tensor (its row length is src_ci * T) */
+  int32_t fwd_kind, dgrad_kind;   /* CFUN_WOP_* */
+  uint32_t block_begin;           /* filled by cfun_weight_prepare_plan */
+  int32_t reserved;
+} CfunWeightJob;
+int cfun_weight_prepare_kinds(const CfunConv3dParams* p, int32_t kinds[2], size_t bytes[2]);
+int cfun_weight_prepare_plan(CfunWeightJob* jobs_host, int32_t njobs, int64_t* nblocks);
+int cfun_weight_prepare(const CfunWeightJob* jobs_dev, int32_t njobs, int64_t nblocks, cfun_stream_t stream);
 
 /* cfun_weight_pack and cfun_weight_pack_transpose of the same OIDHW weight in ONE launch (a training step needs both
  * layouts of every conv weight: wp for the forward / weight-gradient kernels, wpT for the data gradient). */

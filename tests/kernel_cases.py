@@ -640,3 +640,58 @@ def check_mask_losses_lits(device, g):
     with torch.no_grad():
         el2 = ops.edge_loss_raw(ops.softmax_channels(ld.detach()), labd)
     assert float(el2) == float(el)
+
+
+# ---- batched weight preparation (ops.WeightScope / cfun_weight_prepare): every operand kind against the per-conv path
+WEIGHT_SCOPE_CASES = [
+    # ci, co, k, stride, algo, (D,H,W), gather (None | 0 | 1: output / input channels gathered from a wider weight)
+    (8, 40, (3, 3, 3), 1, ALGO_MFMA, (4, 5, 7), None),       # PACK / PACKT
+    (16, 32, (3, 3, 3), 1, ALGO_WINO, (4, 5, 9), None),      # WINO1 / WINO1_T
+    (16, 48, (3, 3, 3), 1, ALGO_WINO2, (5, 4, 9), None),     # WINO2 / WINO2_T
+    (8, 16, (3, 3, 3), 2, ALGO_AUTO, (8, 8, 8), None),       # PACK / S2FOLD
+    (20, 36, (3, 3, 3), 2, ALGO_AUTO, (4, 6, 8), None),      # S2FOLD with padding columns (8*20 = 160 -> 160, 36 rows: ragged tiles)
+    (24, 8, (1, 1, 1), 1, ALGO_AUTO, (4, 4, 8), None),       # pointwise
+    (16, 16, (1, 3, 3), 1, ALGO_AUTO, (3, 6, 7), None),
+    (16, 20, (3, 1, 1), 1, ALGO_AUTO, (5, 4, 6), None),
+    (3, 5, (3, 3, 3), 1, ALGO_AUTO, (4, 4, 5), None),        # C % 4 != 0: the direct kernels read the same packs
+    (20, 12, (3, 3, 3), 1, ALGO_AUTO, (4, 4, 8), 0),         # Dropout3d slices: 12 of 20 output channels gathered
+    (12, 20, (3, 3, 3), 1, ALGO_AUTO, (4, 4, 8), 1),         # ... 12 of 20 input channels
+    (32, 40, (3, 3, 3), 1, ALGO_WINO2, (4, 4, 8), 1),        # gathered input channels into a Winograd operand
+]
+
+
+def check_weight_scope(device, seed=41):
+    """Each case runs forward + backward three times inside ops.WeightScope: pass 1 records and packs per conv, passes 2
+    and 3 take their operands from the ONE cfun_weight_prepare launch of the scope.  y, dx, dw must agree bit for bit and
+    the later passes must not miss (a miss = the table's operand kinds differ from what the conv's dispatch wants)."""
+    gen = _gen(seed)
+    for ci, co, k, stride, algo, dhw, gather in WEIGHT_SCOPE_CASES:
+        wide = 20 if gather is not None and max(ci, co) <= 20 else max(ci, co) + 8
+        wshape = (wide if gather == 0 else co, wide if gather == 1 else ci) + tuple(k)
+        w = torch.nn.Parameter((randn(gen, *wshape) / float(ci * k[0] * k[1] * k[2]) ** 0.5).to(device))
+        x = randn(gen, 2, *dhw, ci).to(device)
+        pad = tuple(kk // 2 for kk in k)
+        spec = ops.ConvSpec(k=tuple(k), co=co, stride=stride, pad=pad, algo=algo)
+        idx = None
+        if gather is not None:
+            n = co if gather == 0 else ci
+            idx = torch.sort(torch.randperm(wide, generator=gen)[:n]).values.to(device)
+        owner = torch.nn.Module()
+        ref = None
+        for it in range(3):
+            xi = x.clone().requires_grad_(True)
+            w.grad = None
+            with ops.WeightScope(owner, dyn={"lv": [idx]}) as scope:
+                wi = w if idx is None else ops.gather_slices(w, gather, [idx], key="lv")[0]
+                y = ops.conv3d_w(xi, wi, spec)
+                y.backward(torch.ones_like(y) * 0.5 + y.detach() * 0.25)
+                if it:
+                    assert scope.hits == 1 and scope.misses == 0, (ci, co, k, stride, algo, gather, scope.hits, scope.misses)
+            cur = (y.detach().clone(), xi.grad.clone(), w.grad.clone())
+            if ref is None:
+                ref = cur
+                yr = ref_conv(x.cpu(), (w.detach() if idx is None else w.detach().index_select(gather, idx)).cpu(), spec, None, None, None)
+                assert_close(y, yr, "y (%s)" % (spec,), 2e-5)
+            else:
+                for a, c, nm in zip(ref, cur, ("y", "dx", "dw")):
+                    assert torch.equal(a, c), "%s differs on the prepared pass %d of case %s" % (nm, it, (ci, co, k, stride, algo, gather))

@@ -1091,3 +1091,57 @@ def check_input_pipeline(device, seed=11):
     np.testing.assert_allclose(metas, rmeta, rtol=0, atol=1e-12)
     np.testing.assert_allclose(windows, rwin, rtol=0, atol=1e-12)
     assert float(molded.max()) <= 1.0 and float(molded.min()) >= 0.0 and float(molded.std()) > 0.05
+
+
+def check_weight_scope_bit_identical(device, cfg, steps=3, seed=0):
+    """ops.WeightScope: the first training step records which convs run and packs every weight per conv; later steps prepare
+    all operands with ONE launch per scope (cfun_weight_prepare: packs, Winograd transforms, stride-2 folds, the per-RoI
+    Dropout3d slices gathered straight from the full weight).  Same Dropout3d masks -> losses and every parameter gradient
+    of the later steps must equal the first step's BIT FOR BIT, and the later steps must have found their operands in the
+    scopes (hits, no index_select of a slice)."""
+    from cfun_amd import ops, step
+    torch.manual_seed(seed)
+    net = step.CFUNHotPath(cfg).to(device)
+    s = step.synthetic_inputs(cfg, torch.device(device), seed)
+    b = cfg.UNET_MASK_BRANCH_CHANNEL
+    gen = torch.Generator().manual_seed(1)
+    keep = 1.0 - getattr(cfg, "UNET_DROPOUT", 0.6)
+    unet = net.mask.modified_u_net
+    if keep < 1.0:
+        unet.dropout_masks = [torch.empty(s["p_rois"].shape[0], ch).bernoulli_(keep, generator=gen) / keep
+                              for ch in (b, 2 * b, 4 * b, 8 * b, 16 * b)]
+    stats = []
+    orig_exit = ops.WeightScope.__exit__
+
+    def spy(self, *exc):
+        stats[-1].append((type(self.owner).__name__, self.hits, self.misses))
+        return orig_exit(self, *exc)
+
+    ops.WeightScope.__exit__ = spy
+    names = ["loss%d" % i for i in range(6)] + [k for k, p in net.named_parameters() if p.requires_grad]
+    try:
+        ref = None
+        for it in range(steps):
+            stats.append([])
+            net.zero_grad(set_to_none=True)
+            _, losses, _ = step.training_step(net, s)
+            cur = [l.detach().clone() for l in losses] + [p.grad.detach().clone() if p.grad is not None else None
+                                                          for p in net.parameters() if p.requires_grad]
+            if ref is None:
+                ref = cur
+            else:
+                for nm, a, c in zip(names, ref, cur):
+                    if a is None or c is None:
+                        assert a is None and c is None, nm
+                    elif nm.startswith("fpn."):
+                        # downstream of the RoIAlign backward, whose fp32 atomicAdd order varies run to run on a GPU
+                        assert rel_l2(c.cpu(), a.cpu()) < 1e-5, "%s: %g" % (nm, rel_l2(c.cpu(), a.cpu()))
+                    else:
+                        assert torch.equal(a, c), "%s differs between the recorded and the prepared step %d" % (nm, it)
+    finally:
+        ops.WeightScope.__exit__ = orig_exit
+    first, later = stats[0], stats[1:]
+    assert all(h == 0 for _, h, _ in first), first
+    for st in later:
+        assert sum(h for _, h, _ in st) > 0 and all(m == 0 for _, _, m in st), st
+    return stats

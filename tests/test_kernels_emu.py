@@ -105,6 +105,11 @@ def test_weight_layouts(emu):
     kc.check_weight_layouts(emu)
 
 
+def test_weight_scope(emu):
+    """cfun_weight_prepare (one launch for all of a pass's weight operands) against the per-conv pack / transform path."""
+    kc.check_weight_scope(emu)
+
+
 def test_conv_b3_experimental(emu):
     """3xBF16 conv prototype on the emulator (the emulated bf16 MFMA sums in its own order: tolerances only)."""
     kc.check_conv_b3(emu, 1, (5, 6, 17), 8, 20, act=kc.ACT_LRELU, shift=True)

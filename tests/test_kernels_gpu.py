@@ -159,6 +159,10 @@ def test_weight_layouts(gpu):
     kc.check_weight_layouts(gpu)
 
 
+def test_weight_scope(gpu):
+    kc.check_weight_scope(gpu)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,dhw,ci,co", [(1, (5, 6, 17), 8, 20), (2, (8, 12, 32), 40, 40), (1, (12, 12, 16), 80, 80),
                                          (1, (6, 6, 16), 160, 160), (2, (9, 7, 21), 24, 32), (2, (8, 8, 16), 20, 20),

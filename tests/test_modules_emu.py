@@ -70,6 +70,12 @@ def test_training_step_winograd_channels_vs_oracle(emu):
     assert all(l == l for l in r["losses"])
 
 
+def test_weight_scope_step_bit_identical(emu_direct):
+    """The batched weight preparation (ops.WeightScope) changes launches, not bits: step 2 (operands from one launch per
+    scope, Dropout3d slices gathered by it) equals step 1 (recorded, packed per conv) in every loss and gradient."""
+    mc.check_weight_scope_bit_identical(emu_direct, mc.tiny_config("beginning"), steps=2)
+
+
 def test_training_step_lits_shapes(emu_direct):
     """LiTS fork shapes: P3D35, (5,7,7) stem, 3 classes (C % 4 != 0 heads on the direct kernels), no dropout."""
     mc.check_training_step_vs_oracle(emu_direct, mc.tiny_lits_config(), n_pos=1, fp64_bound=False)

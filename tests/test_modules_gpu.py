@@ -65,6 +65,16 @@ def test_training_step_finetune_b20_vs_oracle(gpu):
     assert r["losses"][5] > 0.0        # the edge loss is live
 
 
+@pytest.mark.parametrize("which", ["tiny_wino_finetune", "b20_finetune"])
+def test_weight_scope_step_bit_identical(gpu, which):
+    """ops.WeightScope on the real kernels: the steps whose weight operands come from one cfun_weight_prepare launch per
+    scope (packs, Winograd transforms, stride-2 folds, gathered Dropout3d slices) equal the recorded first step bit for
+    bit -- at the benchmarked channel counts too (b = 20: 1-D and 2-D Winograd operands, the parity-folded up-convs)."""
+    from cfun_amd import config
+    cfg = mc.tiny_wino_config("finetune") if which == "tiny_wino_finetune" else config.heart_config("finetune", 64, 64, 32)
+    mc.check_weight_scope_bit_identical(gpu, cfg, steps=3)
+
+
 def test_cfg2_full_size_step_properties(gpu, monkeypatch):
     """BASELINE.json configs[2] at FULL size (256x256x128, 'finetune', b = 20, 4 + 8 injected RoIs, 96^3 -> 192^3) --
     the step bench.py times: the heads are not skipped, all six losses and the gradients of all 95 trainable tensors are
