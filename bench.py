@@ -183,6 +183,22 @@ def parity_dropout_masks(cfg, n_pos):
     return [torch.empty(n_pos, ch).bernoulli_(0.4, generator=gen) / 0.4 for ch in (b, 2 * b, 4 * b, 8 * b, 16 * b)]
 
 
+# parameter gradients compared between the extra GPU step and the oracle's CPU step at full size (`grad_parity`): the
+# first, the dominant and the last conv of the U-Net, its deepest level, and one tensor of each detector part; rel. L2
+# bounds: both legs are fp32 with different summation orders -- the U-Net tensors sit behind 25 InstanceNorms (fp32 noise
+# floor 2e-4 ... 7e-3 against fp64 at these shapes, tests/module_cases.py GRAD_FP64_FACTOR table), the others do not
+GRAD_PARITY_KEYS = {
+    "mask.modified_u_net.conv3d_c1_1.weight": 1e-2,
+    "mask.modified_u_net.conv_norm_lrelu_l4.0.weight": 1e-2,
+    "mask.modified_u_net.norm_lrelu_conv_c5.2.weight": 2e-2,
+    "mask.modified_u_net.out_upscale_conv.1.weight": 1e-2,
+    "fpn.C1.0.weight": 1e-3,
+    "fpn.P2_conv2.weight": 1e-3,
+    "rpn.conv_shared.weight": 1e-3,
+    "classifier.conv1.weight": 1e-3,
+}
+
+
 def cpu_baseline(cfg, net, sample, threads, iters=1, small_iters=3):
     """The reference's CPU path timed beside the GPU run: the oracle (oracle/cfun_oracle.py -- the plain fp32 torch-CPU
     restatement of the reference, pinned to it by tests/golden) runs THE SAME training step -- this run's weights, image,
@@ -216,7 +232,9 @@ def cpu_baseline(cfg, net, sample, threads, iters=1, small_iters=3):
                                 stage_split=getattr(cfg_i, "STAGE_SPLIT", False),
                                 loss_weights=[float(cfg_i.LOSS_WEIGHTS[k]) for k in keys])
         ref["total"].backward()
-        return time.perf_counter() - t0, [float(l) for l in ref["losses"]]
+        dt = time.perf_counter() - t0
+        grads = {k: sd[k].grad.detach().clone() for k in GRAD_PARITY_KEYS if k in sd and sd[k].grad is not None}
+        return dt, [float(l) for l in ref["losses"]], grads
 
     # warm-up: the same code path at the smallest configuration (BASELINE configs[0]'s 64x64x32 volume, 1 + 2 RoIs), then
     # `small_iters` timed iterations of it: the cfg0 figure SURVEY.md section 8(d) asks for beside cfg2's
@@ -229,9 +247,9 @@ def cpu_baseline(cfg, net, sample, threads, iters=1, small_iters=3):
         st = sorted(one(wcfg, wnet, ws_, 1)[0] for _ in range(max(1, small_iters)))
         small = {"workload": "BASELINE configs[0]: 64x64x32 volume, stage 'beginning', 1 positive + 2 negative RoIs, forward + backward",
                  "value": 1.0 / st[len(st) // 2], "unit": "volumes/s", "iters": len(st), "median_s": st[len(st) // 2]}
-    times, losses = [], None
+    times, losses, grads = [], None, None
     for _ in range(max(1, iters)):
-        t, losses = one(cfg, net, sample, 4)
+        t, losses, grads = one(cfg, net, sample, 4)
         times.append(t)
     med = sorted(times)[len(times) // 2]
     d, h, w = cfg.image_dhw
@@ -244,7 +262,7 @@ def cpu_baseline(cfg, net, sample, threads, iters=1, small_iters=3):
                        "timed full iteration(s) after a warm-up at 64x64x32: %s s (median %.1f s); nothing extrapolated"
                        % (torch.__version__, torch.get_num_threads(), phys, logical, h, w, d, cfg.STAGE, len(times),
                           ", ".join("%.1f" % t for t in times), med),
-                losses=losses, small_config=small)
+                losses=losses, small_config=small, _grads=grads)
 
 
 def main():
@@ -451,9 +469,12 @@ def main():
             finally:
                 unet.dropout_masks = prev_masks
             torch.cuda.synchronize()
+            named = dict(net.named_parameters())
+            gg = {k: named[k].grad.detach().cpu().clone() for k in GRAD_PARITY_KEYS if k in named and named[k].grad is not None}
             torch.cuda.empty_cache()
             phys, _ = physical_cores()
             cb = cpu_baseline(cfg, net, sample, threads=max(1, min(phys, 64)), iters=args.cpu_baseline_iters)
+            cg = cb.pop("_grads") or {}
             result["cpu_baseline"] = cb
             rel = [abs(g - c) / max(abs(c), 1e-12) for g, c in zip(gl, cb["losses"])]
             tol = 1e-4
@@ -463,6 +484,18 @@ def main():
                                      "ok": bool(max(rel) <= tol)}
             if max(rel) > tol:
                 parity_fail = "loss parity FAILED at full size: rel diff %s > %g" % (rel, tol)
+            # ... and the parameter gradients of the same two steps (the oracle leg calls backward() anyway)
+            gp = {}
+            for k, bound in GRAD_PARITY_KEYS.items():
+                if k in gg and k in cg:
+                    a, c = gg[k].double(), cg[k].double()
+                    gp[k] = {"rel_l2": float((a - c).norm() / c.norm().clamp(min=1e-300)), "bound": bound,
+                             "norm_cpu": float(c.norm())}
+            ok = bool(gp) and all(v["rel_l2"] <= v["bound"] for v in gp.values())
+            result["grad_parity"] = {"what": "rel. L2 difference of parameter gradients, the same extra GPU step vs the "
+                                             "oracle's CPU backward at the benchmarked size", "tensors": gp, "ok": ok}
+            if not ok and parity_fail is None:
+                parity_fail = "gradient parity FAILED at full size: %s" % {k: v["rel_l2"] for k, v in gp.items()}
         print(json.dumps(result), flush=True)
         if parity_fail:
             sys.stderr.write(parity_fail + "\n")

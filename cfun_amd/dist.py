@@ -682,6 +682,7 @@ class GradientReducer:
             ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
             group = dist.new_group(ranks=ranks)       # collective: every rank of `group` constructs the reducer
         self.group = group
+        self.hold = False           # True: backward passes only accumulate (no collective is launched from the hooks)
         self._next = 0              # buckets are launched strictly in index order (see _on_grad)
         self.params = [p for p in params if p.requires_grad]
         self.buckets = []       # dicts: flat, params, pending, ready, work
@@ -732,11 +733,28 @@ class GradientReducer:
     def zero_grad(self):
         """Zero the buckets and (re)attach ``p.grad`` to its bucket view; call instead of ``net.zero_grad()``."""
         self._next = 0
+        self.hold = False
         for bucket in self.buckets:
             bucket["flat"].zero_()
             bucket["pending"], bucket["work"], bucket["launched"] = len(bucket["params"]), None, False
             for p, v in zip(bucket["params"], bucket["views"]):
                 p.grad = v
+
+    def arm(self, sync=True):
+        """Before a backward pass that ACCUMULATES into buckets an earlier pass already filled (gradient accumulation over
+        BATCH_SIZE samples, model.py:1640-1645): ``sync=False`` -- this pass launches no collective (the hooks stay
+        quiet); ``sync=True`` -- the last pass of the batch: the hooks count this pass's gradients afresh and launch each
+        bucket, holding the accumulated sums, once it is complete.  ``zero_grad`` arms for a single synchronising pass."""
+        if self.in_flight():
+            raise RuntimeError("GradientReducer.arm: a reduction is in flight (finish() the previous batch first)")
+        self.hold = not sync
+        self._next = 0
+        for bucket in self.buckets:
+            bucket["pending"], bucket["work"], bucket["launched"] = len(bucket["params"]), None, False
+
+    def in_flight(self):
+        """Has any bucket's all-reduce been launched since the last zero_grad() / arm() (and not been finished)?"""
+        return bool(self.active and any(b["launched"] for b in self.buckets))
 
     def _launch(self, bucket):
         bucket["launched"] = True
@@ -757,6 +775,12 @@ class GradientReducer:
         bucket = self.buckets[b]
         if p.grad is None or p.grad.data_ptr() != bucket["views"][slot].data_ptr():
             raise RuntimeError("GradientReducer: call zero_grad() of the reducer before backward()")
+        if self.hold:
+            return
+        if bucket["launched"]:
+            raise RuntimeError("GradientReducer: a gradient arrived for a bucket whose all-reduce is already in flight -- "
+                               "a second backward() without arm() / zero_grad() (gradient accumulation: arm(sync=False) "
+                               "for the passes that only accumulate, arm(sync=True) for the last)")
         bucket["pending"] -= 1
         # Fixed launch order, as DDP does: bucket i goes out only once buckets 0..i-1 have.  A rank on which some
         # bucket never completes through the hooks (its heads were skipped: no positive proposal / no mask RoI on
@@ -770,6 +794,7 @@ class GradientReducer:
         """Complete every bucket's reduction and scale to the mean; the compute stream waits for the comm stream."""
         if not self.active:
             return
+        self.hold = False
         for bucket in self.buckets[self._next:]:          # the rest, still in index order
             self._launch(bucket)
         self._next = len(self.buckets)
@@ -780,6 +805,8 @@ class GradientReducer:
         if self.average:
             for bucket in self.buckets:
                 bucket["flat"].div_(self.world)
+        for bucket in self.buckets:                       # reduced: nothing is in flight any more
+            bucket["launched"] = False
 
     def remove(self):
         for h in self._hooks:

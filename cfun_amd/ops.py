@@ -106,6 +106,7 @@ class _FoldBiasMany(torch.autograd.Function):
     def forward(ctx, n, pre, *args):
         biases, ss, ts = args[:n], args[n:2 * n], args[2 * n:]
         ctx.ss, ctx.pre = ss, pre
+        ctx.set_materialize_grads(False)      # a fold no conv consumed this step: its bias gets NO gradient, not zeros
         return tuple(torch._foreach_addcmul([t for t in ts], [b.detach() for b in biases], list(ss)))
 
     @staticmethod
@@ -189,6 +190,7 @@ class _SplitChannels(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, c0):
+        ctx.set_materialize_grads(False)
         ctx.lead, ctx.widths = tuple(y.shape[:-1]), (c0, y.shape[-1] - c0)
         return y[..., :c0].contiguous(), y[..., c0:].contiguous()
 
@@ -1181,6 +1183,7 @@ class _InstNormLReLU(torch.autograd.Function):
         # lazy: a list that receives the statistics -- no apply pass, the result aliases x (see NormedInput)
         # passthrough: also return an alias of x for x's OTHER consumer (the residual add that follows, mask_branch.py:
         # 131-176): its gradient arrives here as a second argument and is summed inside the backward kernel
+        ctx.set_materialize_grads(False)      # (an unused output's gradient arrives as None, not as a zero tensor)
         lib = _lib.load()
         x = _c(x)
         n, c = x.shape[0], x.shape[-1]
@@ -1270,6 +1273,7 @@ def instnorm_lrelu(x, eps=1e-5, out=None, shard=None, stats=None, lazy=False, pa
 class _LReLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, out=None, lazy=False, passthrough=False):
+        ctx.set_materialize_grads(False)
         lib = _lib.load()
         x = _c(x)
         if lazy:                      # no pass: the result aliases x, the consumer conv applies the activation (NormedInput)
@@ -1821,12 +1825,12 @@ def upload(host, device):
 _SIDE_STREAMS = {}
 
 
-def side_stream(device, name):
-    """The process-wide side HIP stream ``name`` of ``device`` (created on first use)."""
+def side_stream(device, name, priority=0):
+    """The process-wide side HIP stream ``name`` of ``device`` (created on first use; ``priority`` < 0: high)."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     key = (idx, name)
     if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=idx)
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=idx, priority=priority)
     return _SIDE_STREAMS[key]
 
 

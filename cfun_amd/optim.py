@@ -18,8 +18,9 @@ than silently decayed.
 torch.optim.SGD skips a parameter whose ``.grad`` is None -- no weight decay, no momentum update: the layers a stage
 does not run (the 'finetune'-only up-convs during 'beginning', a skipped head) stay exactly as they are.  Here every
 ``p.grad`` is a view of an arena and never None, so the optimizer records which parameters a backward pass reached
-(post-accumulate hooks) and puts the untouched ones -- and their momentum -- back after the fused launch.  (With
-data-parallel ranks a parameter untouched here may have a gradient elsewhere: the all-reduced arena is applied as is.)
+(post-accumulate hooks) and puts the untouched ones -- and their momentum -- back after the fused launch.  With
+data-parallel ranks a parameter untouched here may have a gradient elsewhere: the flags are combined (MAX) over the
+ranks, a parameter is left alone only where no rank reached it.
 """
 import torch
 
@@ -64,6 +65,14 @@ class FlatSGD:
         self.reducer.zero_grad()
         self._touched = [False] * len(self._slots)
 
+    def begin_backward(self, last=True):
+        """Gradient accumulation over several backward passes per step (BATCH_SIZE > 1, model.py:1640-1645) with
+        data-parallel ranks: the passes that only accumulate launch no all-reduce (``last=False``); the last one
+        (``last=True``) reduces each bucket -- the accumulated sums -- as soon as ITS gradients have arrived.  Without
+        ranks to reduce over this is a no-op."""
+        if self.reducer.active:
+            self.reducer.arm(sync=last)
+
     @torch.no_grad()
     def clip_(self):
         """torch.nn.utils.clip_grad_norm_(parameters, clip_norm) on the gradient arenas, in place -- what the reference does
@@ -72,6 +81,10 @@ class FlatSGD:
         clip = float(self.clip_norm) if self.clip_norm else 0.0
         if clip <= 0.0:
             return
+        if self.reducer.in_flight():      # (the arenas are being all-reduced on the communication stream)
+            raise RuntimeError("FlatSGD.clip_: a gradient all-reduce is in flight -- with data-parallel ranks the passes that "
+                               "only accumulate must not synchronise: begin_backward(last=False) before them "
+                               "(cfun_amd.train.train_epoch does); the clip then acts on the rank's own accumulated gradient")
         lib = _lib.load()
         for i, bucket in enumerate(self.reducer.buckets):
             g = bucket["flat"]
@@ -96,11 +109,16 @@ class FlatSGD:
             check(lib.cfun_norm_finalize(ptr(self._partials), self._partials.numel(), ptr(self.grad_norm),
                                          stream(self.grad_norm)), "norm_finalize")
         keep = []            # parameters no backward pass reached since zero_grad(): torch.optim.SGD leaves them alone
-        if not self.reducer.active:
-            for (p, a, off), hit in zip(self._slots, self._touched):
-                if not hit:
-                    m = self.momentum_arenas[a][off:off + p.numel()]
-                    keep.append((p, m, p.data.clone(), m.clone()))
+        touched = self._touched
+        if self.reducer.active and self._slots:      # ... on ANY rank: a parameter is left alone only if no rank reached it
+            import torch.distributed as tdist
+            flags = torch.tensor([1 if t else 0 for t in touched], dtype=torch.int32, device=self.param_arenas[0].device)
+            tdist.all_reduce(flags, op=tdist.ReduceOp.MAX, group=self.reducer.group)
+            touched = [bool(v) for v in flags.tolist()]
+        for (p, a, off), hit in zip(self._slots, touched):
+            if not hit:
+                m = self.momentum_arenas[a][off:off + p.numel()]
+                keep.append((p, m, p.data.clone(), m.clone()))
         for bucket, p, m in zip(self.reducer.buckets, self.param_arenas, self.momentum_arenas):
             g = bucket["flat"]
             check(lib.cfun_sgd_momentum_step(ptr(p), ptr(g), ptr(m), p.numel(), self.lr, self.momentum,

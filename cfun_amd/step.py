@@ -113,7 +113,7 @@ class CFUNHotPath(nn.Module):
             logits, probs = self.mask.forward_ndhwc(img, p_rois)
             return logits, probs, (lambda: None)
         main = torch.cuda.current_stream(image.device)
-        side = ops.side_stream(image.device, "mask_head")
+        side = ops.side_stream(image.device, "mask_head", priority=int(os.environ.get("CFUN_MASK_STREAM_PRIORITY", "0")))
         side.wait_stream(main)                  # image / RoIs / this step's weights are ready
         with torch.cuda.stream(side):
             logits, probs = self.mask.forward_ndhwc(img, p_rois)

@@ -36,6 +36,9 @@ def train_epoch(net, samples, optimizer, steps, config, perms=None):
     for i, s in enumerate(samples):
         batch_count += 1
         pm = next(perms) if perms is not None else None
+        # data-parallel ranks: only the last backward of the batch all-reduces (the accumulated sums); the clip after an
+        # accumulating pass acts on the rank's own gradient, the step's fused clip on the mean over the ranks
+        optimizer.begin_backward(last=(batch_count % batch_size == 0))
         _, losses, total = step.training_step_full(net, s["image"], s["gt_class_ids"], s["gt_boxes"], s["gt_labels"],
                                                    s["rpn_match"], s["rpn_bbox_t"], perms=pm)
         if batch_count % batch_size == 0:

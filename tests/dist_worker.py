@@ -33,217 +33,270 @@ def main():
     import module_cases as mc
 
     res = {}
-    # 1) halo exchange forward + backward against plain padding of the full tensor
-    g = torch.Generator().manual_seed(0)
-    full = torch.randn(1, 8, 3, 4, 4, generator=g).to(dev)
-    gy_full = torch.randn(1, 8 + 2 * world, 3, 4, 4, generator=g).to(dev)     # per-rank padded slabs, concatenated
-    with cdist.depth_sharded() as sh:
-        x = cdist.slab(full, dim=1).clone().requires_grad_(True)
-        y = cdist.halo_exchange(x, 1, 1)
-        dl = full.shape[1] // world
-        gy = gy_full[:, rank * (dl + 2):(rank + 1) * (dl + 2)]
-        (y * gy).sum().backward()
-    res["halo_y"] = y.detach().cpu().numpy()
-    res["halo_gx"] = x.grad.cpu().numpy()
+    from cfun_amd import config as ccfg
+    only = extra.endswith("_only")      # skip the basic sections 1 - 7 (a second GPU-tier run at another volume size)
+    if not only:
+        # 1) halo exchange forward + backward against plain padding of the full tensor
+        g = torch.Generator().manual_seed(0)
+        full = torch.randn(1, 8, 3, 4, 4, generator=g).to(dev)
+        gy_full = torch.randn(1, 8 + 2 * world, 3, 4, 4, generator=g).to(dev)     # per-rank padded slabs, concatenated
+        with cdist.depth_sharded() as sh:
+            x = cdist.slab(full, dim=1).clone().requires_grad_(True)
+            y = cdist.halo_exchange(x, 1, 1)
+            dl = full.shape[1] // world
+            gy = gy_full[:, rank * (dl + 2):(rank + 1) * (dl + 2)]
+            (y * gy).sum().backward()
+        res["halo_y"] = y.detach().cpu().numpy()
+        res["halo_gx"] = x.grad.cpu().numpy()
 
-    # 2) depth-sharded FPN -> RPN -> proposals == single-rank result
-    cfg = mc.tiny_config("beginning")
-    cfg.IMAGE_SHAPE = np.array([32, 32, 32, 1])           # D = 32: 16 planes per rank, 1 p3 plane per rank
-    torch.manual_seed(0)
-    net = step.CFUNHotPath(cfg).to(dev).eval()
-    image = torch.randn(1, 1, 32, 32, 32, generator=g).to(dev)
-    with torch.no_grad():
+        # 2) depth-sharded FPN -> RPN -> proposals == single-rank result
+        cfg = mc.tiny_config("beginning")
+        cfg.IMAGE_SHAPE = np.array([32, 32, 32, 1])           # D = 32: 16 planes per rank, 1 p3 plane per rank
+        torch.manual_seed(0)
+        net = step.CFUNHotPath(cfg).to(dev).eval()
+        image = torch.randn(1, 1, 32, 32, 32, generator=g).to(dev)
+        with torch.no_grad():
+            with cdist.depth_sharded():
+                p2, p3, logits, probs, bbox, rois = cdist.sharded_backbone_rpn(net, cdist.slab(image, dim=2))
+            if rank == 0:
+                rp2, rp3, rlogits, rprobs, rbbox = net.backbone_rpn(image)
+                rrois = net.proposals(rprobs, rbbox, "inference")
+                res.update(ref_p2=rp2.cpu().numpy(), ref_p3=rp3.cpu().numpy(), ref_logits=rlogits.cpu().numpy(), ref_bbox=rbbox.cpu().numpy(),
+                           ref_rois=rrois.cpu().numpy())
+        res.update(p2=p2.cpu().numpy(), p3=p3.cpu().numpy(), logits=logits.cpu().numpy(), bbox=bbox.cpu().numpy(), rois=rois.cpu().numpy())
+
+        # 3) a depth-coupled conv trains through the halo exchange: gradients equal the unsharded ones
+        from cfun_amd.layers import Conv3dParams
+        torch.manual_seed(1)
+        conv = Conv3dParams(4, 8, 3, padding=1).to(dev)
+        xs = torch.randn(1, 8, 4, 4, 4, generator=g).to(dev)
+        gys = torch.randn(1, 8, 4, 4, 8, generator=g).to(dev)
         with cdist.depth_sharded():
-            p2, p3, logits, probs, bbox, rois = cdist.sharded_backbone_rpn(net, cdist.slab(image, dim=2))
+            xl = cdist.slab(xs, dim=1).clone().requires_grad_(True)
+            yl = conv(xl)
+            (yl * cdist.slab(gys, dim=1)).sum().backward()
+            wg = conv.weight.grad.clone()
+            dist.all_reduce(wg)                                  # data-parallel style sum of the slabs' contributions
+        res["conv_y"] = yl.detach().cpu().numpy()
+        res["conv_gx"] = xl.grad.cpu().numpy()
+        res["conv_gw"] = wg.cpu().numpy()
         if rank == 0:
-            rp2, rp3, rlogits, rprobs, rbbox = net.backbone_rpn(image)
-            rrois = net.proposals(rprobs, rbbox, "inference")
-            res.update(ref_p2=rp2.cpu().numpy(), ref_p3=rp3.cpu().numpy(), ref_logits=rlogits.cpu().numpy(), ref_bbox=rbbox.cpu().numpy(),
-                       ref_rois=rrois.cpu().numpy())
-    res.update(p2=p2.cpu().numpy(), p3=p3.cpu().numpy(), logits=logits.cpu().numpy(), bbox=bbox.cpu().numpy(), rois=rois.cpu().numpy())
-
-    # 3) a depth-coupled conv trains through the halo exchange: gradients equal the unsharded ones
-    from cfun_amd.layers import Conv3dParams
-    torch.manual_seed(1)
-    conv = Conv3dParams(4, 8, 3, padding=1).to(dev)
-    xs = torch.randn(1, 8, 4, 4, 4, generator=g).to(dev)
-    gys = torch.randn(1, 8, 4, 4, 8, generator=g).to(dev)
-    with cdist.depth_sharded():
-        xl = cdist.slab(xs, dim=1).clone().requires_grad_(True)
-        yl = conv(xl)
-        (yl * cdist.slab(gys, dim=1)).sum().backward()
-        wg = conv.weight.grad.clone()
-        dist.all_reduce(wg)                                  # data-parallel style sum of the slabs' contributions
-    res["conv_y"] = yl.detach().cpu().numpy()
-    res["conv_gx"] = xl.grad.cpu().numpy()
-    res["conv_gw"] = wg.cpu().numpy()
-    if rank == 0:
-        conv.weight.grad = None
-        xr = xs.clone().requires_grad_(True)
-        yr = conv(xr)
-        (yr * gys).sum().backward()
-        res.update(ref_conv_y=yr.detach().cpu().numpy(), ref_conv_gx=xr.grad.cpu().numpy(), ref_conv_gw=conv.weight.grad.cpu().numpy())
-    # 3b) the same with channel counts for which AUTO picks the Winograd kernels (16 -> 32): the slabs run them with depth
-    #     padding 0 on their halo planes (interior / edge launches of halo_conv), the data gradient with depth padding 2
-    torch.manual_seed(2)
-    convw = Conv3dParams(16, 32, 3, padding=1).to(dev)
-    xw = torch.randn(1, 8, 4, 6, 16, generator=g).to(dev)
-    gyw = torch.randn(1, 8, 4, 6, 32, generator=g).to(dev)
-    with cdist.depth_sharded():
-        xlw = cdist.slab(xw, dim=1).clone().requires_grad_(True)
-        ylw = convw(xlw)
-        (ylw * cdist.slab(gyw, dim=1)).sum().backward()
-        wgw = convw.weight.grad.clone()
-        dist.all_reduce(wgw)
-    res["wconv_y"], res["wconv_gx"], res["wconv_gw"] = ylw.detach().cpu().numpy(), xlw.grad.cpu().numpy(), wgw.cpu().numpy()
-    if rank == 0:
-        convw.weight.grad = None
-        xrw = xw.clone().requires_grad_(True)
-        yrw = convw(xrw)
-        (yrw * gyw).sum().backward()
-        res.update(ref_wconv_y=yrw.detach().cpu().numpy(), ref_wconv_gx=xrw.grad.cpu().numpy(), ref_wconv_gw=convw.weight.grad.cpu().numpy())
-    # 4) data-parallel replicas: bucketed gradient averaging overlapped with backward (hooks), incl. a parameter that
-    #    gets no gradient and a weight used twice (one accumulate, one hook call)
-    torch.manual_seed(2)
-    c1, c2, unused = [m.to(dev) for m in (Conv3dParams(4, 8, 3, padding=1), Conv3dParams(8, 8, 1), Conv3dParams(8, 4, 1))]
-    plist = list(c1.parameters()) + list(c2.parameters()) + list(unused.parameters())
-    red = cdist.GradientReducer(plist, bucket_bytes=300)           # several buckets
-    assert len(red.buckets) > 2
-    xr = torch.randn(1, 4, 4, 4, 4, generator=torch.Generator().manual_seed(10 + rank)).to(dev)
-    for it in range(2):                                             # buckets are reusable across steps
-        red.zero_grad()
+            conv.weight.grad = None
+            xr = xs.clone().requires_grad_(True)
+            yr = conv(xr)
+            (yr * gys).sum().backward()
+            res.update(ref_conv_y=yr.detach().cpu().numpy(), ref_conv_gx=xr.grad.cpu().numpy(), ref_conv_gw=conv.weight.grad.cpu().numpy())
+        # 3b) the same with channel counts for which AUTO picks the Winograd kernels (16 -> 32): the slabs run them with depth
+        #     padding 0 on their halo planes (interior / edge launches of halo_conv), the data gradient with depth padding 2
+        torch.manual_seed(2)
+        convw = Conv3dParams(16, 32, 3, padding=1).to(dev)
+        xw = torch.randn(1, 8, 4, 6, 16, generator=g).to(dev)
+        gyw = torch.randn(1, 8, 4, 6, 32, generator=g).to(dev)
+        with cdist.depth_sharded():
+            xlw = cdist.slab(xw, dim=1).clone().requires_grad_(True)
+            ylw = convw(xlw)
+            (ylw * cdist.slab(gyw, dim=1)).sum().backward()
+            wgw = convw.weight.grad.clone()
+            dist.all_reduce(wgw)
+        res["wconv_y"], res["wconv_gx"], res["wconv_gw"] = ylw.detach().cpu().numpy(), xlw.grad.cpu().numpy(), wgw.cpu().numpy()
+        if rank == 0:
+            convw.weight.grad = None
+            xrw = xw.clone().requires_grad_(True)
+            yrw = convw(xrw)
+            (yrw * gyw).sum().backward()
+            res.update(ref_wconv_y=yrw.detach().cpu().numpy(), ref_wconv_gx=xrw.grad.cpu().numpy(), ref_wconv_gw=convw.weight.grad.cpu().numpy())
+        # 4) data-parallel replicas: bucketed gradient averaging overlapped with backward (hooks), incl. a parameter that
+        #    gets no gradient and a weight used twice (one accumulate, one hook call)
+        torch.manual_seed(2)
+        c1, c2, unused = [m.to(dev) for m in (Conv3dParams(4, 8, 3, padding=1), Conv3dParams(8, 8, 1), Conv3dParams(8, 4, 1))]
+        plist = list(c1.parameters()) + list(c2.parameters()) + list(unused.parameters())
+        red = cdist.GradientReducer(plist, bucket_bytes=300)           # several buckets
+        assert len(red.buckets) > 2
+        xr = torch.randn(1, 4, 4, 4, 4, generator=torch.Generator().manual_seed(10 + rank)).to(dev)
+        for it in range(2):                                             # buckets are reusable across steps
+            red.zero_grad()
+            y = c2(c2(c1(xr)))
+            (y * y).sum().backward()
+            red.finish()
+        res["dp_grads"] = np.concatenate([p.grad.reshape(-1).cpu().numpy() for p in plist])
+        for p in plist:
+            p.grad = None
+        red.remove()
         y = c2(c2(c1(xr)))
         (y * y).sum().backward()
-        red.finish()
-    res["dp_grads"] = np.concatenate([p.grad.reshape(-1).cpu().numpy() for p in plist])
-    for p in plist:
-        p.grad = None
-    red.remove()
-    y = c2(c2(c1(xr)))
-    (y * y).sum().backward()
-    res["dp_local"] = np.concatenate([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).cpu().numpy()
-                                      for p in plist])
-    # 5) ONE volume over 2 ranks: depth-sharded FPN/RPN + round-robin head RoIs; the ranks' loss shares add up to
-    #    the single-process losses and the summed gradients equal the single-process gradients
-    from cfun_amd import config as ccfg
-    cls = type("TinyHeart32", (ccfg.HeartConfig,), dict(
-        IMAGE_MAX_DIM=32, IMAGE_MIN_DIM=32, MASK_POOL_SIZE=[32, 32, 32], POOL_SIZE=[4, 4, 4],
-        UNET_MASK_BRANCH_CHANNEL=4, TOP_DOWN_PYRAMID_SIZE=16, RPN_CONV_CHANNELS=16, FPN_CLASSIFY_FC_LAYERS_SIZE=16,
-        RPN_ANCHOR_SCALES=(16, 32), PRE_NMS_LIMIT=64, POST_NMS_ROIS_TRAINING=16))
-    cfg5 = cls("finetune")          # (the edge loss and the folded 5x5x5 conv ride along in every sharded step below)
-    cfg5.MASK_SHAPE = cfg5.MINI_MASK_SHAPE = (64, 64, 64)
-    torch.manual_seed(4)
-    net5 = step.CFUNHotPath(cfg5).to(dev)
-    s5 = step.synthetic_inputs(cfg5, dev, 0)
-    s5["p_rois"], s5["mask_labels"] = s5["p_rois"][:2], s5["mask_labels"][:2]      # 2 positives + 4 negatives
-    s5["n_rois"] = s5["n_rois"][:4]
-    keep = [0, 1, 4, 5, 6, 7]
-    s5["target_class_ids"], s5["target_deltas"] = s5["target_class_ids"][keep], s5["target_deltas"][keep]
-    b5 = cfg5.UNET_MASK_BRANCH_CHANNEL
-    g5 = torch.Generator().manual_seed(9)
-    masks5 = [torch.empty(2, c).bernoulli_(0.4, generator=g5) / 0.4 for c in (b5, 2 * b5, 4 * b5, 8 * b5, 16 * b5)]
-    net5.mask.modified_u_net.dropout_masks = [mk[rank::world] for mk in masks5]
-    net5.zero_grad(set_to_none=True)
-    with cdist.depth_sharded():
-        losses5, total5, rois5 = cdist.sharded_training_step(net5, s5)
-    lv = torch.stack([l.detach().float() for l in losses5])
-    dist.all_reduce(lv)
-    names5 = [k for k, p in net5.named_parameters() if p.requires_grad]
-    flat5 = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
-                       for k, p in net5.named_parameters() if p.requires_grad])
-    dist.all_reduce(flat5)
-    res["sh_losses"], res["sh_grads"], res["sh_rois"] = lv.cpu().numpy(), flat5.cpu().numpy(), rois5.detach().cpu().numpy()
-    if rank == 0:
-        net5.mask.modified_u_net.dropout_masks = masks5
+        res["dp_local"] = np.concatenate([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).cpu().numpy()
+                                          for p in plist])
+        # 4b) gradient ACCUMULATION with data-parallel ranks through FlatSGD: two backward passes per step,
+        #     clip after the first (rank-local), all-reduce only in the second, fused clip + SGD on the mean -- against the
+        #     same arithmetic done by hand with torch on rank 0 (both ranks' inputs are reproducible from their seeds)
+        import copy
+        from cfun_amd import optim as coptim
+        torch.manual_seed(3)
+        a1, a2 = [m.to(dev) for m in (Conv3dParams(4, 8, 3, padding=1), Conv3dParams(8, 4, 1))]
+        r1, r2 = copy.deepcopy(a1), copy.deepcopy(a2)
+        never = Conv3dParams(4, 4, 1).to(dev)          # reached by no rank: must keep value and momentum under DP too
+        never0 = never.weight.detach().clone()
+
+        def xin(r, j):
+            return torch.randn(1, 4, 4, 4, 4, generator=torch.Generator().manual_seed(100 + 10 * r + j)).to(dev)
+
+        def loss_of(m1, m2, x):
+            y = m2(m1(x))
+            return (y * y).sum()
+        named = [("a1." + k, p) for k, p in a1.named_parameters()] + [("a2." + k, p) for k, p in a2.named_parameters()] + \
+                [("never." + k, p) for k, p in never.named_parameters()]
+        opt = coptim.FlatSGD(named, lr=0.05, momentum=0.9, weight_decay=1e-3, clip_norm=0.5, bucket_bytes=300)
+        for it in range(2):                             # two optimizer steps: momentum state, re-armed reducer
+            opt.zero_grad()
+            opt.begin_backward(last=False)
+            loss_of(a1, a2, xin(rank, 2 * it)).backward()
+            opt.clip_()
+            opt.begin_backward(last=True)
+            loss_of(a1, a2, xin(rank, 2 * it + 1)).backward()
+            opt.step()
+        res["acc_params"] = np.concatenate([p.detach().reshape(-1).cpu().numpy() for _, p in named])
+        res["acc_never_moved"] = np.array([float((never.weight.detach() - never0).abs().max())])
+        if rank == 0:
+            rp = list(r1.parameters()) + list(r2.parameters())
+            sgd = torch.optim.SGD(rp, lr=0.05, momentum=0.9, weight_decay=1e-3)
+            for it in range(2):
+                mean = [torch.zeros_like(p) for p in rp]
+                for r in range(world):
+                    for p in rp:
+                        p.grad = None
+                    loss_of(r1, r2, xin(r, 2 * it)).backward()
+                    torch.nn.utils.clip_grad_norm_(rp, 0.5)
+                    loss_of(r1, r2, xin(r, 2 * it + 1)).backward()
+                    for m, p in zip(mean, rp):
+                        m += p.grad / world
+                for m, p in zip(mean, rp):
+                    p.grad = m
+                torch.nn.utils.clip_grad_norm_(rp, 0.5)
+                sgd.step()
+            res["acc_ref_params"] = np.concatenate([p.detach().reshape(-1).cpu().numpy() for p in rp])
+        # 5) ONE volume over 2 ranks: depth-sharded FPN/RPN + round-robin head RoIs; the ranks' loss shares add up to
+        #    the single-process losses and the summed gradients equal the single-process gradients
+        from cfun_amd import config as ccfg
+        cls = type("TinyHeart32", (ccfg.HeartConfig,), dict(
+            IMAGE_MAX_DIM=32, IMAGE_MIN_DIM=32, MASK_POOL_SIZE=[32, 32, 32], POOL_SIZE=[4, 4, 4],
+            UNET_MASK_BRANCH_CHANNEL=4, TOP_DOWN_PYRAMID_SIZE=16, RPN_CONV_CHANNELS=16, FPN_CLASSIFY_FC_LAYERS_SIZE=16,
+            RPN_ANCHOR_SCALES=(16, 32), PRE_NMS_LIMIT=64, POST_NMS_ROIS_TRAINING=16))
+        cfg5 = cls("finetune")          # (the edge loss and the folded 5x5x5 conv ride along in every sharded step below)
+        cfg5.MASK_SHAPE = cfg5.MINI_MASK_SHAPE = (64, 64, 64)
+        torch.manual_seed(4)
+        net5 = step.CFUNHotPath(cfg5).to(dev)
+        s5 = step.synthetic_inputs(cfg5, dev, 0)
+        s5["p_rois"], s5["mask_labels"] = s5["p_rois"][:2], s5["mask_labels"][:2]      # 2 positives + 4 negatives
+        s5["n_rois"] = s5["n_rois"][:4]
+        keep = [0, 1, 4, 5, 6, 7]
+        s5["target_class_ids"], s5["target_deltas"] = s5["target_class_ids"][keep], s5["target_deltas"][keep]
+        b5 = cfg5.UNET_MASK_BRANCH_CHANNEL
+        g5 = torch.Generator().manual_seed(9)
+        masks5 = [torch.empty(2, c).bernoulli_(0.4, generator=g5) / 0.4 for c in (b5, 2 * b5, 4 * b5, 8 * b5, 16 * b5)]
+        net5.mask.modified_u_net.dropout_masks = [mk[rank::world] for mk in masks5]
         net5.zero_grad(set_to_none=True)
-        out_r, losses_r, total_r = step.training_step(net5, s5)
-        res["ref_losses"] = np.array([float(l.detach()) for l in losses_r], np.float32)
-        res["ref_grads"] = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
-                                      for k, p in net5.named_parameters() if p.requires_grad]).cpu().numpy()
-        res["ref_rois5"] = out_r["rpn_rois"].detach().cpu().numpy()
-        sizes = [int(p.numel()) for k, p in net5.named_parameters() if p.requires_grad]
-        res["grad_sizes"] = np.array(sizes)
-        res["grad_names"] = np.array(names5)
-    # 6) more ranks than RoIs of a kind, through the GradientReducer: 1 positive + 1 negative RoI on 2 ranks -> rank 1
-    #    holds no mask RoI (its U-Net parameters get no gradient: that bucket never completes through the hooks) and
-    #    each rank's single classifier RoI sits on ONE pyramid level (the other gathered map is reached only through
-    #    the unconditional anchor term).  Must neither hang nor mis-pair collectives; summed gradients = single process.
-    s6 = dict(s5)
-    s6["p_rois"], s6["mask_labels"], s6["n_rois"] = s5["p_rois"][:1], s5["mask_labels"][:1], s5["n_rois"][:1]
-    s6["target_class_ids"], s6["target_deltas"] = s5["target_class_ids"][[0, 2]], s5["target_deltas"][[0, 2]]
-    net5.mask.modified_u_net.dropout_masks = [mk[:1] for mk in masks5]
-    for p in net5.parameters():
-        p.grad = None
-    red6 = cdist.GradientReducer(net5.parameters(), bucket_bytes=4096, average=False)
-    assert len(red6.buckets) > 4
-    red6.zero_grad()
-    with cdist.depth_sharded():
-        losses6, _, _ = cdist.sharded_training_step(net5, s6, zshard_unet=False)
-    red6.finish()
-    red6.remove()
-    lv6 = torch.stack([l.detach().float() for l in losses6])
-    dist.all_reduce(lv6)
-    res["sh6_losses"] = lv6.cpu().numpy()
-    res["sh6_grads"] = torch.cat([p.grad.reshape(-1) for k, p in net5.named_parameters() if p.requires_grad]).cpu().numpy()
-    if rank == 0:
+        with cdist.depth_sharded():
+            losses5, total5, rois5 = cdist.sharded_training_step(net5, s5)
+        lv = torch.stack([l.detach().float() for l in losses5])
+        dist.all_reduce(lv)
+        names5 = [k for k, p in net5.named_parameters() if p.requires_grad]
+        flat5 = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                           for k, p in net5.named_parameters() if p.requires_grad])
+        dist.all_reduce(flat5)
+        res["sh_losses"], res["sh_grads"], res["sh_rois"] = lv.cpu().numpy(), flat5.cpu().numpy(), rois5.detach().cpu().numpy()
+        if rank == 0:
+            net5.mask.modified_u_net.dropout_masks = masks5
+            net5.zero_grad(set_to_none=True)
+            out_r, losses_r, total_r = step.training_step(net5, s5)
+            res["ref_losses"] = np.array([float(l.detach()) for l in losses_r], np.float32)
+            res["ref_grads"] = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                                          for k, p in net5.named_parameters() if p.requires_grad]).cpu().numpy()
+            res["ref_rois5"] = out_r["rpn_rois"].detach().cpu().numpy()
+            sizes = [int(p.numel()) for k, p in net5.named_parameters() if p.requires_grad]
+            res["grad_sizes"] = np.array(sizes)
+            res["grad_names"] = np.array(names5)
+        # 6) more ranks than RoIs of a kind, through the GradientReducer: 1 positive + 1 negative RoI on 2 ranks -> rank 1
+        #    holds no mask RoI (its U-Net parameters get no gradient: that bucket never completes through the hooks) and
+        #    each rank's single classifier RoI sits on ONE pyramid level (the other gathered map is reached only through
+        #    the unconditional anchor term).  Must neither hang nor mis-pair collectives; summed gradients = single process.
+        s6 = dict(s5)
+        s6["p_rois"], s6["mask_labels"], s6["n_rois"] = s5["p_rois"][:1], s5["mask_labels"][:1], s5["n_rois"][:1]
+        s6["target_class_ids"], s6["target_deltas"] = s5["target_class_ids"][[0, 2]], s5["target_deltas"][[0, 2]]
+        net5.mask.modified_u_net.dropout_masks = [mk[:1] for mk in masks5]
         for p in net5.parameters():
             p.grad = None
-        _, losses_r6, _ = step.training_step(net5, s6)
-        res["ref6_losses"] = np.array([float(l.detach()) for l in losses_r6], np.float32)
-        res["ref6_grads"] = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
-                                       for k, p in net5.named_parameters() if p.requires_grad]).cpu().numpy()
-    # 6b) the same 1 + 1 RoI step with the positive RoI's U-Net z-sharded over BOTH ranks (more ranks than positive RoIs):
-    #     loss shares and summed gradients again equal the single-process step
-    for p in net5.parameters():
-        p.grad = None
-    with cdist.depth_sharded():
-        losses6b, _, _ = cdist.sharded_training_step(net5, s6, zshard_unet=True)
-    lv6b = torch.stack([l.detach().float() for l in losses6b])
-    dist.all_reduce(lv6b)
-    flat6b = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
-                        for k, p in net5.named_parameters() if p.requires_grad])
-    dist.all_reduce(flat6b)
-    res["sh6b_losses"], res["sh6b_grads"] = lv6b.cpu().numpy(), flat6b.cpu().numpy()
-
-    # 7) ONE RoI's U-Net z-sharded over the 2 ranks (levels at full and half resolution on depth slabs with halos and
-    #    all-reduced InstanceNorm statistics, the lower levels folded onto both ranks): logits slabs and the summed
-    #    parameter gradients equal the single-process U-Net, in both stages, with Dropout3d active
-    from cfun_amd.mask_branch import Modified3DUNet
-    for stage7 in ("beginning", "finetune"):
-        torch.manual_seed(7)
-        unet = Modified3DUNet(1, 8, stage7, 4).to(dev)
-        unet.train()
-        g7 = torch.Generator().manual_seed(17)
-        unet.dropout_masks = [torch.empty(1, c).bernoulli_(0.4, generator=g7) / 0.4 for c in (4, 8, 16, 32, 64)]
-        x7 = torch.randn(1, 32, 32, 32, 1, generator=g7).to(dev)
-        side = 64 if stage7 == "finetune" else 32
-        gy7 = torch.randn(1, side, side, side, 8, generator=g7).to(dev)
-        zs = cdist.ShardContext()
-        for p_ in unet.parameters():
-            p_.grad = None
-        y7 = unet.forward_ndhwc(cdist.slab(x7, dim=1, shard=zs).contiguous(), zshard=zs)
-        (y7 * cdist.slab(gy7, dim=1, shard=zs)).sum().backward()
-        flat7 = torch.cat([(p_.grad if p_.grad is not None else torch.zeros_like(p_)).reshape(-1) for p_ in unet.parameters()])
-        dist.all_reduce(flat7)
-        res["zu_y_" + stage7], res["zu_g_" + stage7] = y7.detach().cpu().numpy(), flat7.cpu().numpy()
+        red6 = cdist.GradientReducer(net5.parameters(), bucket_bytes=4096, average=False)
+        assert len(red6.buckets) > 4
+        red6.zero_grad()
+        with cdist.depth_sharded():
+            losses6, _, _ = cdist.sharded_training_step(net5, s6, zshard_unet=False)
+        red6.finish()
+        red6.remove()
+        lv6 = torch.stack([l.detach().float() for l in losses6])
+        dist.all_reduce(lv6)
+        res["sh6_losses"] = lv6.cpu().numpy()
+        res["sh6_grads"] = torch.cat([p.grad.reshape(-1) for k, p in net5.named_parameters() if p.requires_grad]).cpu().numpy()
         if rank == 0:
+            for p in net5.parameters():
+                p.grad = None
+            _, losses_r6, _ = step.training_step(net5, s6)
+            res["ref6_losses"] = np.array([float(l.detach()) for l in losses_r6], np.float32)
+            res["ref6_grads"] = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                                           for k, p in net5.named_parameters() if p.requires_grad]).cpu().numpy()
+        # 6b) the same 1 + 1 RoI step with the positive RoI's U-Net z-sharded over BOTH ranks (more ranks than positive RoIs):
+        #     loss shares and summed gradients again equal the single-process step
+        for p in net5.parameters():
+            p.grad = None
+        with cdist.depth_sharded():
+            losses6b, _, _ = cdist.sharded_training_step(net5, s6, zshard_unet=True)
+        lv6b = torch.stack([l.detach().float() for l in losses6b])
+        dist.all_reduce(lv6b)
+        flat6b = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                            for k, p in net5.named_parameters() if p.requires_grad])
+        dist.all_reduce(flat6b)
+        res["sh6b_losses"], res["sh6b_grads"] = lv6b.cpu().numpy(), flat6b.cpu().numpy()
+
+        # 7) ONE RoI's U-Net z-sharded over the 2 ranks (levels at full and half resolution on depth slabs with halos and
+        #    all-reduced InstanceNorm statistics, the lower levels folded onto both ranks): logits slabs and the summed
+        #    parameter gradients equal the single-process U-Net, in both stages, with Dropout3d active
+        from cfun_amd.mask_branch import Modified3DUNet
+        for stage7 in ("beginning", "finetune"):
+            torch.manual_seed(7)
+            unet = Modified3DUNet(1, 8, stage7, 4).to(dev)
+            unet.train()
+            g7 = torch.Generator().manual_seed(17)
+            unet.dropout_masks = [torch.empty(1, c).bernoulli_(0.4, generator=g7) / 0.4 for c in (4, 8, 16, 32, 64)]
+            x7 = torch.randn(1, 32, 32, 32, 1, generator=g7).to(dev)
+            side = 64 if stage7 == "finetune" else 32
+            gy7 = torch.randn(1, side, side, side, 8, generator=g7).to(dev)
+            zs = cdist.ShardContext()
             for p_ in unet.parameters():
                 p_.grad = None
-            yr7 = unet.forward_ndhwc(x7)
-            (yr7 * gy7).sum().backward()
-            res["zu_ref_y_" + stage7] = yr7.detach().cpu().numpy()
-            res["zu_ref_g_" + stage7] = torch.cat([(p_.grad if p_.grad is not None else torch.zeros_like(p_)).reshape(-1)
-                                                   for p_ in unet.parameters()]).cpu().numpy()
-            res["zu_sizes"] = np.array([int(p_.numel()) for p_ in unet.parameters()])
-            res["zu_names"] = np.array([k for k, _ in unet.named_parameters()])
+            y7 = unet.forward_ndhwc(cdist.slab(x7, dim=1, shard=zs).contiguous(), zshard=zs)
+            (y7 * cdist.slab(gy7, dim=1, shard=zs)).sum().backward()
+            flat7 = torch.cat([(p_.grad if p_.grad is not None else torch.zeros_like(p_)).reshape(-1) for p_ in unet.parameters()])
+            dist.all_reduce(flat7)
+            res["zu_y_" + stage7], res["zu_g_" + stage7] = y7.detach().cpu().numpy(), flat7.cpu().numpy()
+            if rank == 0:
+                for p_ in unet.parameters():
+                    p_.grad = None
+                yr7 = unet.forward_ndhwc(x7)
+                (yr7 * gy7).sum().backward()
+                res["zu_ref_y_" + stage7] = yr7.detach().cpu().numpy()
+                res["zu_ref_g_" + stage7] = torch.cat([(p_.grad if p_.grad is not None else torch.zeros_like(p_)).reshape(-1)
+                                                       for p_ in unet.parameters()]).cpu().numpy()
+                res["zu_sizes"] = np.array([int(p_.numel()) for p_ in unet.parameters()])
+                res["zu_names"] = np.array([k for k, _ in unet.named_parameters()])
     # 8) (GPU tier, "cfg0") BASELINE configs[0]'s volume (64x64x32) with the REAL channel counts, stage 'finetune' (edge
     #    loss), 4 + 8 RoIs, 96^3 -> 192^3 masks -- the shapes of the benchmarked step -- as ONE volume over 2 ranks:
     #    (a) depth-sharded FPN/RPN (halo_conv: interior planes overlapped with the side-stream exchange; Winograd /
     #    MFMA kernels on slabs) + round-robin heads, gradients summed by the ordered GradientReducer; (b) 1 positive RoI
     #    whose U-Net is z-sharded over both ranks (b = 20, slabs of 48 / 24 planes, all-reduced InstanceNorm statistics).
     #    Both against the single-process step of rank 0.
-    if "cfg0" in extra:
-        cfg8 = ccfg.heart_config("finetune", 64, 64, 32)
+    #    "cfg1vol": the same at BASELINE configs[1]'s volume (128x128x64: 4 / 2 p3 planes per rank, interior planes present
+    #    on every level) -- VERDICT round 3: the sharded step had only run at 64x64x32.
+    if "cfg0" in extra or "cfg1vol" in extra:
+        cfg8 = ccfg.heart_config("finetune", 128, 128, 64) if "cfg1vol" in extra else ccfg.heart_config("finetune", 64, 64, 32)
         torch.manual_seed(8)
         net8 = step.CFUNHotPath(cfg8).to(dev)
         s8 = step.synthetic_inputs(cfg8, dev, 0)

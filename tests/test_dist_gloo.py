@@ -84,6 +84,12 @@ def check_world2(r, conv_tol=1.0):
     mean = 0.5 * (r[0]["dp_local"] + r[1]["dp_local"])
     for k in range(2):
         np.testing.assert_allclose(r[k]["dp_grads"], mean, rtol=1e-5, atol=1e-6)
+    # gradient accumulation (two backward passes per optimizer step) with data-parallel ranks through FlatSGD: identical
+    # parameters on both ranks, equal to the hand-written torch arithmetic; a parameter no rank reached did not move
+    np.testing.assert_array_equal(r[0]["acc_params"], r[1]["acc_params"])
+    n_ref = r[0]["acc_ref_params"].size
+    np.testing.assert_allclose(r[0]["acc_params"][:n_ref], r[0]["acc_ref_params"], rtol=2e-5, atol=2e-6)
+    assert float(r[0]["acc_never_moved"][0]) == 0.0 and float(r[1]["acc_never_moved"][0]) == 0.0
     assert np.abs(r[0]["dp_local"] - r[1]["dp_local"]).max() > 1e-3      # the ranks really saw different data
 
     # one volume over 2 ranks (sharded_training_step): loss shares and gradient sums equal the single-process step

@@ -54,3 +54,24 @@ def test_two_ranks_on_real_kernels(gpu, tmp_path):
     np.testing.assert_allclose(r[0]["c0z_losses"], ref["c0z_ref_losses"], rtol=5e-4, atol=1e-6)
     w = _grads_close(ref["c0_names"], ref["c0_sizes"], r[0]["c0z_grads"], ref["c0z_ref_grads"], 2e-3, 2e-2)
     print("cfg0 z-sharded U-Net step, worst gradient rel-L2 vs single process:", w)
+
+
+def test_two_ranks_cfg1_volume_sharded_step(gpu, tmp_path):
+    """The sharded 'finetune' step (depth-sharded FPN / RPN with overlapped halos, one all-gather for the proposals,
+    slab-wise RoIAlign + mask losses, round-robin heads, ordered GradientReducer) at BASELINE configs[1]'s volume
+    (128x128x64, real channel counts, 4 + 8 RoIs, 96^3 -> 192^3) over two ranks against the single-process step, and one
+    RoI's U-Net z-sharded over both ranks -- until round 4 this step had only run at 64x64x32."""
+    env = {k: v for k, v in os.environ.items() if k not in ("CFUN_LIB_PATH", "CFUN_CONV_ALGO")}
+    env["PYTHONPATH"] = ROOT
+    r = run_world2(tmp_path, env, worker_args=("cuda:0", "cfg1vol_only"), timeout=1500)
+    ref = r[0]
+    np.testing.assert_allclose(r[0]["c0_losses"], ref["c0_ref_losses"], rtol=2e-4, atol=1e-6)
+    np.testing.assert_array_equal(r[0]["c0_losses"], r[1]["c0_losses"])
+    np.testing.assert_array_equal(r[0]["c0_grads"], r[1]["c0_grads"])
+    assert r[0]["c0_rois"].shape == ref["c0_ref_rois"].shape
+    np.testing.assert_allclose(r[0]["c0_rois"], ref["c0_ref_rois"], rtol=0, atol=1e-5)
+    w = _grads_close(ref["c0_names"], ref["c0_sizes"], r[0]["c0_grads"], ref["c0_ref_grads"], 2e-3, 1e-2)
+    print("128x128x64 sharded step, worst gradient rel-L2 vs single process:", w)
+    np.testing.assert_allclose(r[0]["c0z_losses"], ref["c0z_ref_losses"], rtol=5e-4, atol=1e-6)
+    w = _grads_close(ref["c0_names"], ref["c0_sizes"], r[0]["c0z_grads"], ref["c0z_ref_grads"], 2e-3, 2e-2)
+    print("128x128x64 z-sharded U-Net step, worst gradient rel-L2 vs single process:", w)

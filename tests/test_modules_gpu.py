@@ -336,6 +336,51 @@ def test_cfg3_volume_forward_properties(gpu):
     assert float(rois.min()) >= 0.0 and float(rois.max()) <= 1.0
 
 
+def test_cfg3_full_step_properties(gpu):
+    """BASELINE.json configs[3]'s volume (512x512x256, 147 456 anchors) through the FULL 'finetune' step on one GPU --
+    FPN / RPN / proposals on 8x the voxels of cfg2, classifier on 12 RoIs, the U-Net on 4 positive RoIs (96^3 -> 192^3),
+    six losses incl. the edge loss, backward (cfg3 had only been run forward).  Size-independent
+    properties: the heads are not skipped, every one of the 95 trainable tensors receives a finite non-zero gradient,
+    the proposals lie in the unit cube, and with fixed Dropout3d masks the losses and every gradient that does not pass
+    through RoIAlign's atomic scatter repeat bit for bit."""
+    from cfun_amd import config, step
+    cfg = config.heart_config("finetune", 512, 512, 256)
+    torch.manual_seed(0)
+    net = step.CFUNHotPath(cfg).to(gpu)
+    s = step.synthetic_inputs(cfg, gpu, 0)
+    assert s["p_rois"].shape[0] == 4 and s["n_rois"].shape[0] == 8 and tuple(s["image"].shape) == (1, 1, 256, 512, 512)
+    b = cfg.UNET_MASK_BRANCH_CHANNEL
+    gen = torch.Generator().manual_seed(1)
+    net.mask.modified_u_net.dropout_masks = [torch.empty(4, c).bernoulli_(0.4, generator=gen) / 0.4
+                                             for c in (b, 2 * b, 4 * b, 8 * b, 16 * b)]
+
+    def run():
+        net.zero_grad(set_to_none=True)
+        out, losses, _ = step.training_step(net, s)
+        torch.cuda.synchronize()
+        return out, [float(l.detach()) for l in losses], {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    out, l1, g1 = run()
+    assert out["rpn_class_logits"].shape[1] == 147456 == net.anchors.shape[0]
+    assert tuple(out["mrcnn_mask_logits"].shape) == (4, 192, 192, 192, 8) and tuple(out["mrcnn_class_logits"].shape) == (12, 2)
+    rois = out["rpn_rois"]
+    assert 1 <= rois.shape[1] <= cfg.POST_NMS_ROIS_TRAINING and float(rois.min()) >= 0.0 and float(rois.max()) <= 1.0
+    assert all(np.isfinite(v) and v > 0 for v in l1), l1
+    trainable = [k for k, p in net.named_parameters() if p.requires_grad]
+    assert len(trainable) == 95 and sorted(g1) == sorted(trainable)
+    for k, v in g1.items():
+        assert bool(torch.isfinite(v).all()) and float(v.abs().max()) > 0, k
+    del out
+    _, l2, g2 = run()
+    assert l1 == l2
+    for k in g1:
+        if k.startswith("mask.") or k.startswith("rpn."):
+            assert torch.equal(g1[k], g2[k]), k
+        else:
+            assert float((g1[k] - g2[k]).abs().max()) <= 1e-5 * float(g1[k].abs().max()), k
+    del g1, g2
+    torch.cuda.empty_cache()
+
+
 def test_lits_full_size_step_properties(gpu):
     """BASELINE.json configs[4] at the fork's real sizes (320x320x256 volume, P3D35, (5,7,7) stem, b = 32, 3 classes,
     32x80x80 crops), both training phases of the fork: 'beginning' trains the detector only (no mask head), 'together'
