@@ -451,17 +451,28 @@ k_conv_wino(const float* __restrict__ x, const float4* __restrict__ u, const flo
       if constexpr (stats_on) park(nn, sa, sb);
     }
   } else {
+    // voxel by voxel, all channel subtiles of a voxel back to back: the 1-D kernel runs the chip-filling launches (96^3),
+    // where an L2 line that has received only one subtile's 64 bytes does not survive until the next subtile's stores a
+    // few hundred instructions later -- WRITE_SIZE was 1.43 x the output bytes with the subtile loop outermost
+    // (profiles/round4_pmc_write_probe.txt; 1.02 - 1.04 x on the 48^3 launches either way)
+    float sa[NSUB][4], sb[NSUB][4];
 #pragma unroll
-    for (int nn = 0; nn < NSUB; ++nn) {
-      float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int nn = 0; nn < NSUB; ++nn)
 #pragma unroll
-      for (int mg = 0; mg < 2; ++mg) {
-        const f32x4 m0 = acc[mg][0][nn], m1 = acc[mg][1][nn], m2 = acc[mg][2][nn], m3 = acc[mg][3][nn];
-        const int oy = y0 + mg * 2 + ((lane >> 3) & 1), co = cobase + nn * 16 + (lane >> 4) * 4;
-        emit(oy, oxe, co, (m0 + m1) + m2, sa, sb);
-        emit(oy, oxe + 1, co, (m1 - m2) - m3, sa, sb);
-      }
-      if constexpr (stats_on) park(nn, sa, sb);
+      for (int j = 0; j < 4; ++j) { sa[nn][j] = 0.f; sb[nn][j] = 0.f; }
+#pragma unroll
+    for (int mg = 0; mg < 2; ++mg) {
+      const int oy = y0 + mg * 2 + ((lane >> 3) & 1);
+#pragma unroll
+      for (int nn = 0; nn < NSUB; ++nn)
+        emit(oy, oxe, cobase + nn * 16 + (lane >> 4) * 4, (acc[mg][0][nn] + acc[mg][1][nn]) + acc[mg][2][nn], sa[nn], sb[nn]);
+#pragma unroll
+      for (int nn = 0; nn < NSUB; ++nn)
+        emit(oy, oxe + 1, cobase + nn * 16 + (lane >> 4) * 4, (acc[mg][1][nn] - acc[mg][2][nn]) - acc[mg][3][nn], sa[nn], sb[nn]);
+    }
+    if constexpr (stats_on) {
+#pragma unroll
+      for (int nn = 0; nn < NSUB; ++nn) park(nn, sa[nn], sb[nn]);
     }
   }
 }

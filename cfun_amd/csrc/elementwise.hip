@@ -267,6 +267,32 @@ k_stats_finalize_rows(const double* __restrict__ part, float* __restrict__ stats
   }
 }
 
+// out[c] = sum_v g[v][c] in ONE launch for the small tensors of the detector (bias gradients of the backbone / FPN / RPN
+// convs: <= a few MB): a block owns 16 channels (64 contiguous bytes per voxel row) x 64 voxel lanes, fp64 sums, fixed
+// order -- instead of k_channel_reduce + k_channel_finalize (two launches of ~5 us for ~2 us of work each)
+__global__ void __launch_bounds__(kBlock)
+k_channel_sum_direct(const float* __restrict__ g, float* __restrict__ out, int64_t V, int C) {
+  __shared__ double sm[kBlock * 4];
+  const int tid = threadIdx.x, q = tid & 3, vl = tid >> 2;      // 4 channel quads x 64 voxel lanes
+  const int c0 = blockIdx.x * 16 + q * 4;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  if (c0 < C) {
+    for (int64_t v = vl; v < V; v += kBlock / 4) {
+      const float4 a = *reinterpret_cast<const float4*>(g + v * C + c0);
+      acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) sm[tid * 4 + j] = acc[j];
+  __syncthreads();
+  if (tid < 16 && blockIdx.x * 16 + tid < C) {      // thread = channel: the 64 lanes' sums in lane order
+    const int qq = tid >> 2, j = tid & 3;
+    double s = 0.0;
+    for (int l = 0; l < kBlock / 4; ++l) s += sm[(l * 4 + qq) * 4 + j];
+    out[blockIdx.x * 16 + tid] = (float)s;
+  }
+}
+
 struct ReducePlan {
   int lanes, blocks;
 };
@@ -672,6 +698,11 @@ int cfun_channel_sum(const float* g, float* out, int64_t nvox, int32_t C, void* 
   if (nvox <= 0) return (int)hipMemsetAsync(out, 0, C * sizeof(float), cfun_st(stream));
   if (vec_of(C) == 4 && !cfun_aligned16(g)) return CFUN_EALIGN;
   if (ws_bytes < reduce_ws(1, nvox, C, 1)) return CFUN_EWORKSPACE;
+  if (vec_of(C) == 4 && nvox * (int64_t)C <= ((int64_t)1 << 22)) {      // <= 16 MB: one launch (see k_channel_sum_direct)
+    hipLaunchKernelGGL(k_channel_sum_direct, dim3((unsigned)((C + 15) / 16)), dim3(kBlock), 0, cfun_st(stream), g, out, nvox, C);
+    CFUN_LAUNCH_CHECK();
+    return CFUN_OK;
+  }
   const ReducePlan r = reduce_plan(1, nvox, C);
   if (vec_of(C) == 4) {
     auto kern = k_channel_reduce<StatSum<4>, 4>;
