@@ -431,6 +431,10 @@ def main():
                                       "`mfma_util_pmc` (SQ_VALU_MFMA_BUSY_CYCLES) -- read those as the utilisation figure",
                          "avg_launch_ms": t_k * 1e3, "launches_timed": len(durs)},
         }
+        for leg in ("dgrad", "wgrad"):      # the same conv's data / weight gradient calls inside the step (HIP events, incl. the
+            dl = timer.durations_ms("mfma_" + leg)      # weight-gradient chunk reduction; the mask head shares the GPU with the detector stream)
+            if dl:
+                result["roofline"]["in_step_%s_ms" % leg] = sum(dl) / len(dl)
         if args.workload == "cfg2" and not b3:
             r = result["roofline"]
             r["traffic"], r["traffic_source"] = pmc_record(PMC_TRAFFIC_JSON, "traffic_bytes_per_launch")

@@ -506,9 +506,10 @@ def _c(t):
 
 
 class LaunchTimer:
-    """Times forward conv launches with HIP events on the launch stream (bench.py roofline legs).
+    """Times conv launches with HIP events on the launch stream (bench.py roofline legs).
     ``match(p)`` returns a key (or None) for a launch's CfunConv3dParams; durations are read per key after a
-    synchronise with ``durations_ms(key)``."""
+    synchronise with ``durations_ms(key)`` -- the forward under ``key``, the data- and weight-gradient calls of the same
+    conv under ``key + "_dgrad"`` / ``key + "_wgrad"``."""
 
     def __init__(self, match):
         self.match = match
@@ -728,8 +729,15 @@ class _Conv3d(torch.autograd.Function):
                     wpT = _transpose_pack(wp if wp is not None else _pack(w_b3), p.Co)
                 nb = lib.cfun_conv3d_bwd_data_workspace_bytes(C.byref(p))
                 ws = workspace(nb, x)
+                tk = _TIMER.match(p) if (_TIMER is not None and x.is_cuda) else None
+                if tk:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 check(lib.cfun_conv3d_bwd_data(ptr(g), ptr(wpT), ptr(dx), C.byref(p), ptr(ws), ws.numel(), st),
                       "conv3d_bwd_data")
+                if tk:
+                    e1.record()
+                    _TIMER.add(tk + "_dgrad", e0, e1)
         if need_w:
             dwp = torch.empty_like(wp)
             nb = lib.cfun_conv3d_bwd_weight_workspace_bytes(C.byref(p))
@@ -753,8 +761,15 @@ class _Conv3d(torch.autograd.Function):
             else:
                 nb = lib.cfun_conv3d_bwd_weight_workspace_bytes(C.byref(p))
                 ws = workspace(nb, x)
+                tk = _TIMER.match(p) if (_TIMER is not None and x.is_cuda) else None
+                if tk:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 check(lib.cfun_conv3d_bwd_weight_oidhw(ptr(x), ptr(g), ptr(dw), C.byref(p), ptr(ws), ws.numel(), st),
                       "conv3d_bwd_weight_oidhw")
+                if tk:
+                    e1.record()
+                    _TIMER.add(tk + "_wgrad", e0, e1)
         if need_shift:      # (shift_scaled: db = sum(g) whichever way g was formed)
             dshift = channel_sum((g if ctx.shift_scaled and scale is not None else gp).view(-1, p.Co))
         if need_res:

@@ -1145,3 +1145,41 @@ def check_weight_scope_bit_identical(device, cfg, steps=3, seed=0):
     for st in later:
         assert sum(h for _, h, _ in st) > 0 and all(m == 0 for _, _, m in st), st
     return stats
+
+
+def check_two_models_alternating(device, seed=0, rounds=3):
+    """Per-step state kept between passes -- the recorded weight-preparation plans (ops.WeightScope, on the modules), the
+    batched bias folds (layers.begin_step), cached constants -- must not leak between networks: a heart net ('finetune',
+    Dropout3d) and a LiTS net (P3D35, 3 classes, no dropout) alternate steps in one process, and every step of each
+    equals that net's own first (recording) step bit for bit, as if it ran alone."""
+    from cfun_amd import step
+    nets = []
+    for cfg in (tiny_config("finetune"), tiny_lits_config()):
+        torch.manual_seed(seed)
+        net = step.CFUNHotPath(cfg).to(device)
+        s = step.synthetic_inputs(cfg, torch.device(device), seed)
+        keep = 1.0 - getattr(cfg, "UNET_DROPOUT", 0.6)
+        if keep < 1.0:
+            b = cfg.UNET_MASK_BRANCH_CHANNEL
+            gen = torch.Generator().manual_seed(1)
+            net.mask.modified_u_net.dropout_masks = [torch.empty(s["p_rois"].shape[0], ch).bernoulli_(keep, generator=gen) / keep
+                                                     for ch in (b, 2 * b, 4 * b, 8 * b, 16 * b)]
+        nets.append((net, s, None))
+
+    def run(net, s):
+        net.zero_grad(set_to_none=True)
+        _, losses, _ = step.training_step(net, s)
+        return [l.detach().clone() for l in losses] + [p.grad.detach().clone() for k, p in net.named_parameters()
+                                                       if p.grad is not None and not k.startswith("fpn.")]
+    for rnd in range(rounds):
+        for i, (net, s, ref) in enumerate(nets):
+            cur = run(net, s)
+            if ref is None:
+                nets[i] = (net, s, cur)
+            else:
+                assert len(cur) == len(ref)
+                for j, (a, c) in enumerate(zip(ref, cur)):
+                    assert torch.equal(a, c), "net %d, round %d: tensor %d differs from the net's own first step" % (i, rnd, j)
+    for net, _, _ in nets:      # each kept a plan of its own (the LiTS net's detector phase never runs its U-Net)
+        assert getattr(net, "_cfun_wplan", None)
+    assert getattr(nets[0][0].mask.modified_u_net, "_cfun_wplan", None)

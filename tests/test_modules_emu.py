@@ -76,6 +76,10 @@ def test_weight_scope_step_bit_identical(emu_direct):
     mc.check_weight_scope_bit_identical(emu_direct, mc.tiny_config("beginning"), steps=2)
 
 
+def test_two_models_alternating(emu_direct):
+    mc.check_two_models_alternating(emu_direct, rounds=2)
+
+
 def test_training_step_lits_shapes(emu_direct):
     """LiTS fork shapes: P3D35, (5,7,7) stem, 3 classes (C % 4 != 0 heads on the direct kernels), no dropout."""
     mc.check_training_step_vs_oracle(emu_direct, mc.tiny_lits_config(), n_pos=1, fp64_bound=False)

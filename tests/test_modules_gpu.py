@@ -75,6 +75,10 @@ def test_weight_scope_step_bit_identical(gpu, which):
     mc.check_weight_scope_bit_identical(gpu, cfg, steps=3)
 
 
+def test_two_models_alternating(gpu):
+    mc.check_two_models_alternating(gpu)
+
+
 def test_cfg2_full_size_step_properties(gpu, monkeypatch):
     """BASELINE.json configs[2] at FULL size (256x256x128, 'finetune', b = 20, 4 + 8 injected RoIs, 96^3 -> 192^3) --
     the step bench.py times: the heads are not skipped, all six losses and the gradients of all 95 trainable tensors are
