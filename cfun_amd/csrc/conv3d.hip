@@ -119,7 +119,7 @@ const Shape* mfma_shape(const CfunConv3dParams* p) {
   if (p->d2s) {   // a lane's float4 must stay inside one parity group; tap skipping needs tile | parity group
     const int cqp = p->Co >> 3, cq = p->d2s_cq > 0 ? p->d2s_cq : cqp;
     if ((cqp & 3) || (cq & 3)) return nullptr;
-    if (p->tap_skip && cqp != 20 && cqp != 40 && cqp != 8 && pick_nsub_parity(cqp, 5) == 0) return nullptr;
+    if (p->tap_skip && pick_nsub_parity(cqp, 5) == 0) return nullptr;      // every 16-column subtile inside one parity group
   }
   const Shape* s = find_shape(p->kd, p->kh, p->kw, p->stride);
   if (!s) return nullptr;
@@ -387,7 +387,12 @@ static int pick_tile(const Shape* s, int co, bool per_parity) {
 static void fwd_mode(const CfunConv3dParams* p, const Shape* s, ConvMode* md, int* nsub) {
   *md = kPlain;
   *nsub = pick_tile(s, p->Co, false);
-  if (p->d2s && p->tap_skip) { md->tap_skip = 1; *nsub = pick_tile(s, p->Co >> 3, true); }
+  if (p->d2s && p->tap_skip) {
+    md->tap_skip = 1;
+    // (several parity groups per workgroup -- tiles of 6 / 8 subtiles sharing one staged halo chunk -- measured no faster
+    // at 32 channels per parity and 14 % slower at 48: profiles/round4_upconv_forward.log; one group per workgroup stays)
+    *nsub = pick_tile(s, p->Co >> 3, true);
+  }
 }
 
 size_t cfun_conv3d_fwd_workspace_bytes(const CfunConv3dParams* p) {

@@ -73,7 +73,8 @@ struct ConvMode {
   int in_s2d;    // the logical input [N,Di,Hi,Wi,8*in_cq] is gathered from a hi-res tensor [N,2Di,2Hi,2Wi,in_cq]
                  // (the output gradient of a depth-to-space conv); weight rows of parity q start at q*in_cqp
   int in_cq, in_cqp;
-  int tap_skip;  // 0 none | 1 by the output-channel tile's parity | 2 by the input chunk's parity (flipped taps)
+  int tap_skip;  // 0 none | 1 by the output-channel subtile's parity (every 16-column subtile lies inside one parity group)
+                 // | 2 by the input chunk's parity (flipped taps)
   // ---- InstanceNorm / LeakyReLU folded into the conv (CfunConvFusion, include/cfun_hip.h)
   const float* in_stats;  // [N][Ci][2] {mean, rstd} or null: the staged input is in_act((x - mean) * rstd)
   int in_act;             // CFUN_ACT_* applied to the (normalised) input at commit time; zero padding stays zero
@@ -187,12 +188,18 @@ struct FwdTile {
 // Co = 20 / 40 / 8 tiles carry no channel padding (a 16-wide MFMA subtile would be 75 % / 50 % / 50 % idle).
 // STATS: the epilogue also produces the per-tile sums of y and y*y per channel (md.out_part) -- an instantiation of its
 // own, so that the plain kernels keep their register budget (the sums cost the 64-channel tile a resident wave)
-template <int KD, int KH, int KW, int S, int NSUB, bool SPECIAL, int REM, bool STATS = false>
+// MODE 0: plain; 1: s2d gather of the input without tap skipping (data gradient of the folded 5^3 conv); 2: the parity-folded
+// up-conv's forward (md.tap_skip == 1): live taps slot-major, (subtile, slot) MFMA loop; 3: its data gradient (s2d gather,
+// md.tap_skip == 2: the 8 live taps of the input chunk's parity, mirrored), slot-major as well.
+template <int KD, int KH, int KW, int S, int NSUB, int MODE, int REM, bool STATS = false>
 __global__ void __launch_bounds__(256)
 k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale,
             const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
             CfunConv3dParams p, ConvMode md, int ntz, int nty, int ntx, int ncot, float* __restrict__ partial,
             int chunks_per_split) {
+  constexpr bool SPECIAL = MODE != 0, UPF = MODE == 2, UPD = MODE == 3;
+  static_assert(!UPD || (KD == 3 && KH == 3 && KW == 3 && S == 1 && NSUB > 0 && REM == 0), "up-conv data-gradient tiles");
+  static_assert(!UPF || (KD == 3 && KH == 3 && KW == 3 && S == 1 && NSUB > 0 && REM == 0), "up-conv forward tiles");
   using T = FwdTile<KD, KH, KW, S>;
   constexpr int TAPS = T::TAPS, NT = 16 * NSUB + 4 * REM, NTP = row_stride(NT), NS1 = NSUB > 0 ? NSUB : 1;
   constexpr int W_ITEMS = TAPS * NT;  // float4 items per weight chunk: TAPS*4 rows x NT/4
@@ -245,9 +252,11 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
     return q * md.in_cqp + o4 * 4;
   };
   float4 xin[T::IN_LOADS], win[W_LOADS];
-  // tap skipping: only the 8 live taps {p, p+1}^3 of the tile's (tap_skip 1) / the chunk's (tap_skip 2) parity are staged
-  // -- slot j of the weight stage holds live tap j (8 * NT float4 items per chunk instead of 27 * NT)
-  const int w_items = (SPECIAL && TAPS == 27 && md.tap_skip) ? 8 * NT : W_ITEMS;
+  // tap skipping: only the 8 live taps {p, p+1}^3 of the column's (tap_skip 1) / the chunk's (tap_skip 2) parity are staged
+  // -- slot j of the weight stage holds live tap j (8 * NT float4 items per chunk instead of 27 * NT).  tap_skip 1 keeps
+  // them slot-major in LDS ([8 slots][4 ch][NTP]: the MFMA loop walks (subtile, slot)), tap_skip 2 at their tap's row.
+  const int w_items = (UPF || (SPECIAL && TAPS == 27 && md.tap_skip)) ? 8 * NT : W_ITEMS;
+  const int CqPw = p.Co >> 3;      // d2s: padded channels per parity (column -> parity for tap_skip 1)
   int q_staged = 0;
   auto live_tap_of = [](int q, int j) {      // unflipped weight tap of live slot j = (a,b,c) for parity q = (pz,py,px)
     return (((q >> 2) + (j >> 2)) * 3 + (((q >> 1) & 1) + ((j >> 1) & 1))) * 3 + ((q & 1) + (j & 1));
@@ -265,7 +274,7 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
 #pragma unroll
     for (int i = 0; i < T::IN_LOADS; ++i)
       xin[i] = in_off[i] >= 0 ? *reinterpret_cast<const float4*>(x + in_off[i] + xo) : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (SPECIAL && TAPS == 27 && md.tap_skip) q_staged = md.tap_skip == 1 ? cobase / (p.Co >> 3) : c / cpq;
+    if (SPECIAL && TAPS == 27 && md.tap_skip == 2) q_staged = c / cpq;
 #pragma unroll
     for (int i = 0; i < W_LOADS; ++i) {
       const int it = tid + i * 256;
@@ -274,7 +283,8 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
         const int row = it / (NT / 4), col = (it % (NT / 4)) * 4;
         int tapw = row >> 2;
         const int cc = row & 3;
-        if (SPECIAL && TAPS == 27 && md.tap_skip) tapw = live_tap_of(q_staged, tapw);      // weight tap of live slot j
+        if (UPF) tapw = live_tap_of((cobase + col) / CqPw, tapw);   // the column's parity
+        else if (SPECIAL && TAPS == 27 && md.tap_skip) tapw = live_tap_of(q_staged, tapw);      // weight tap of live slot j
         else if (md.flip) tapw = TAPS - 1 - tapw;
         if (cobase + col < p.CoP)
           win[i] = *reinterpret_cast<const float4*>(wp + ((int64_t)tapw * p.Ci + wrow + cc) * p.CoP + cobase + col);
@@ -301,7 +311,7 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
       if (it < w_items) {
         int row = it / (NT / 4);
         const int col = (it % (NT / 4)) * 4;
-        if (SPECIAL && TAPS == 27 && md.tap_skip) {      // live slot -> the row of its tap in the MFMA loop's (possibly mirrored) order
+        if (!UPD && SPECIAL && TAPS == 27 && md.tap_skip == 2) {      // live slot -> the row of its tap in the MFMA loop's mirrored order
           const int t = live_tap_of(q_staged, row >> 2);
           row = (md.flip ? TAPS - 1 - t : t) * 4 + (row & 3);
         }
@@ -328,7 +338,6 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
   const int nchunks = (SPECIAL && md.in_s2d) ? 8 * cpq : (p.Ci >> 2);
   const int CqP = p.Co >> 3;   // d2s: padded channels per parity
   unsigned tapmask = 0xffffffffu;
-  if (SPECIAL && TAPS == 27 && md.tap_skip == 1) tapmask = parity_tapmask(cobase / CqP, false);
   // split-K (small volumes: too few tiles to fill 256 CUs): blockIdx.y owns a range of channel chunks and
   // stores raw accumulators to partial[blockIdx.y]; cfun_splitk_finish sums them in order and runs the epilogue
   const int c_begin = blockIdx.y * chunks_per_split;
@@ -340,6 +349,48 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
     __syncthreads();
     if (c + 1 < c_end) prefetch(c + 1);
     if (SPECIAL && TAPS == 27 && md.tap_skip == 2) tapmask = parity_tapmask(c / cpq, true);
+    if constexpr (UPF) {
+      // parity-folded up-conv: subtile nn belongs to parity q = (pz,py,px) and reads the 2x2x2 taps {q, q+1} -- a loop over
+      // (subtile, live slot) with wave-uniform LDS offsets instead of 27 unrolled taps each behind a mask test (round 4:
+      // -7 ... -17 % on the four up-conv forwards, profiles/round4_upconv_forward.log)
+#pragma unroll
+      for (int nn = 0; nn < NSUB; ++nn) {
+        const int q = (cobase + nn * 16) / CqP;      // wave-uniform
+        const float* xq = Xw + (((q >> 2) * T::IY + ((q >> 1) & 1)) * T::IX + (q & 1));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float a = Ww[j * 4 * NTP + nn * 16];
+          const float* xt = xq + (((j >> 2) * T::IY + ((j >> 1) & 1)) * T::IX + (j & 1));
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+            acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xt[m * T::RS * T::IX], acc[m][nn], 0, 0, 0);
+        }
+#ifndef CFUN_HIP_EMULATION
+        __builtin_amdgcn_sched_barrier(0);      // one subtile's 40 LDS reads at a time: hoisted across subtiles they cost 200+ registers
+#endif
+      }
+    } else if constexpr (UPD) {
+      // data gradient of the parity-folded up-conv: the chunk's 4 channels belong to output parity q of the forward conv and
+      // meet only its 8 live taps, mirrored (tap 26 - t): the same (slot) loop with wave-uniform LDS offsets
+      const int q = c / cpq;
+      const float* xq = Xw + (((2 - (q >> 2)) * T::IY + (2 - ((q >> 1) & 1))) * T::IX + (2 - (q & 1)));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float a[NS1];
+#pragma unroll
+        for (int nn = 0; nn < NSUB; ++nn) a[nn] = Ww[j * 4 * NTP + nn * 16];
+        const float* xt = xq - (((j >> 2) * T::IY + ((j >> 1) & 1)) * T::IX + (j & 1));
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const float b = xt[m * T::RS * T::IX];
+#pragma unroll
+          for (int nn = 0; nn < NSUB; ++nn) acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nn], b, acc[m][nn], 0, 0, 0);
+        }
+#ifndef CFUN_HIP_EMULATION
+        if (j & 1) __builtin_amdgcn_sched_barrier(0);      // two slots' reads in flight: hoisting all 8 costs a resident wave
+#endif
+      }
+    } else {
 #pragma unroll
     for (int dz = 0; dz < KD; ++dz)
 #pragma unroll
@@ -371,6 +422,7 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
                 accr[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(Wr[(tap * 4 + cc) * NTP + 4 * q], xb[cc], accr[q], 0, 0, 0);
           }
         }
+    }
   }
 
   // ---- epilogue.  16-wide subtiles: lane owns voxel (z0+wv, y0+m, x0+(lane&15)), channels nn*16 + (lane>>4)*4..+3;
@@ -476,16 +528,25 @@ int launch_conv_mfma(const float* x, const float* wp, const float* scale, const 
   const int64_t nblk = (int64_t)p.N * ntz * nty * ntx * ncot;
   if (nblk == 0) return CFUN_OK;
   if (nblk > 0x7fffffffLL) return CFUN_EINVAL;
-  const size_t lds = (size_t)(4 * T::PLANEP + T::TAPS * 4 * NTP) * sizeof(float);
   constexpr bool kHasSpecial = (KD == 3 && KH == 3 && KW == 3 && S == 1);
   const bool special = md.in_s2d || md.tap_skip;
   if (special && !kHasSpecial) return CFUN_EINVAL;
+  // (tap_skip 1 keeps only the 8 live taps of each column in LDS)
+  const bool upd = kHasSpecial && NSUB > 0 && REM == 0 && md.in_s2d && md.tap_skip == 2;      // MODE 3
+  const size_t lds = (size_t)(4 * T::PLANEP + ((md.tap_skip == 1 || upd) ? 8 : T::TAPS) * 4 * NTP) * sizeof(float);
   const int nchunks = md.in_s2d ? 8 * (md.in_cq >> 2) : (p.Ci >> 2);
   const int ksplit = splitk_factor(nblk, nchunks, p, ws_bytes);
   const bool stats = md.out_part != nullptr && ksplit == 1;      // (split-K: the finish pass takes the statistics)
-  auto kern = stats ? k_conv_mfma<KD, KH, KW, S, NSUB, false, REM, true> : k_conv_mfma<KD, KH, KW, S, NSUB, false, REM, false>;
+  auto kern = stats ? k_conv_mfma<KD, KH, KW, S, NSUB, 0, REM, true> : k_conv_mfma<KD, KH, KW, S, NSUB, 0, REM, false>;
   if constexpr (kHasSpecial) {
-    if (special) kern = stats ? k_conv_mfma<KD, KH, KW, S, NSUB, true, REM, true> : k_conv_mfma<KD, KH, KW, S, NSUB, true, REM, false>;
+    if (special && md.tap_skip != 1)
+      kern = stats ? k_conv_mfma<KD, KH, KW, S, NSUB, 1, REM, true> : k_conv_mfma<KD, KH, KW, S, NSUB, 1, REM, false>;
+    if constexpr (NSUB > 0 && REM == 0) {
+      if (md.tap_skip == 1) kern = stats ? k_conv_mfma<KD, KH, KW, S, NSUB, 2, 0, true> : k_conv_mfma<KD, KH, KW, S, NSUB, 2, 0, false>;
+      if (upd) kern = k_conv_mfma<KD, KH, KW, S, NSUB, 3, 0, false>;      // (a data gradient: no statistics epilogue)
+    } else {
+      if (md.tap_skip == 1) return CFUN_EINVAL;
+    }
   }
   size_t lds_k = lds;
   if (stats && lds_k < stat_lds_floats(NT) * sizeof(float)) lds_k = stat_lds_floats(NT) * sizeof(float);
@@ -504,10 +565,13 @@ int launch_conv_mfma(const float* x, const float* wp, const float* scale, const 
   return CFUN_OK;
 }
 
+// tile code -> output channels per workgroup: NSUB + 8*REM (16*NSUB + 4*REM channels)
+inline int tile_channels(int code) { return 16 * (code & 7) + 4 * (code >> 3); }
+
 // statistics slots per sample that launch_conv_mfma fills for (p, tile code nsub) given ws_bytes of split-K workspace:
 // > 0 by the conv's tiles (slot-minor layout), < 0 by the split-K finish (-(blocks), k_channel_finalize's layout)
 inline int fwd_stat_slots(int nsub, const CfunConv3dParams& p, const ConvMode& md, size_t ws_bytes) {
-  const int nt = 16 * (nsub & 7) + 4 * (nsub >> 3);
+  const int nt = tile_channels(nsub);
   const int tiles = cdiv(p.Do, 4) * cdiv(p.Ho, 4) * cdiv(p.Wo, 16);
   const int64_t nblk = (int64_t)p.N * tiles * cdiv(p.Co, nt);
   const int nchunks = md.in_s2d ? 8 * (md.in_cq >> 2) : (p.Ci >> 2);
@@ -517,7 +581,7 @@ inline int fwd_stat_slots(int nsub, const CfunConv3dParams& p, const ConvMode& m
 template <int KD, int KH, int KW, int S>
 size_t fwd_workspace(int nsub, const CfunConv3dParams& p, const ConvMode& md) {
   using T = FwdTile<KD, KH, KW, S>;
-  const int nt = 16 * (nsub & 7) + 4 * (nsub >> 3);
+  const int nt = tile_channels(nsub);
   const int64_t nblk = (int64_t)p.N * cdiv(p.Do, T::TD) * cdiv(p.Ho, T::TH) * cdiv(p.Wo, T::TW) * cdiv(p.Co, nt);
   const int nchunks = md.in_s2d ? 8 * (md.in_cq >> 2) : (p.Ci >> 2);
   return splitk_workspace(nblk, nchunks, p);
