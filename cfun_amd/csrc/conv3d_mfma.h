@@ -663,7 +663,14 @@ wgrad_body(float* smem, const float* __restrict__ x, const float* __restrict__ g
   constexpr int TAPS = T::TAPS, NT = 16 * NSUB, GS = pad_row16(NT);
   constexpr int NLIVE = TSKIP ? 8 : TAPS;                         // taps this block accumulates
   constexpr int R = 16 / PACK;                                    // channels per packed tap
-  constexpr int TPW = cdiv(cdiv(NLIVE, PACK), T::TSPLIT);         // tap groups per wave
+  // taps over the waves (TSPLIT) or voxel groups over the waves (KSPLIT partial sums per chunk).  TSKIP: all 8 live taps in
+  // EVERY wave and the voxel groups dealt over the waves -- with 2 taps per wave a group's 2 + NSUB fragment reads fed only
+  // 2 * NSUB MFMAs (counters, round 4: 4 VALU + 4 SALU + 0.8 LDS instructions per MFMA, the pipe 0.49 busy); 8 + NSUB reads
+  // now feed 8 * NSUB
+  // (tiles of <= 32 columns only: at 48 / 80 columns the 8 * NSUB accumulators cost the second resident wave and the small
+  // volumes pay for 4 x the partials -- 80 -> 40 @ 24^3 0.45 -> 0.57 ms, measured; 40 -> 20 @ 48^3 1.14 -> 1.02)
+  constexpr int TSPLIT = (TSKIP && NSUB <= 2) ? 1 : T::TSPLIT, KSPLIT = 4 / TSPLIT;
+  constexpr int TPW = cdiv(cdiv(NLIVE, PACK), TSPLIT);            // tap groups per wave
   constexpr int G_ITEMS = T::TVOX * (NT / 4);
   constexpr int G_LOADS = cdiv(G_ITEMS, 256);
   float* Xl = smem;                       // [IVOX][16]
@@ -683,7 +690,7 @@ wgrad_body(float* smem, const float* __restrict__ x, const float* __restrict__ g
   }
   const int sh = p.up2 ? 1 : 0;
   const int Dv = p.Di << sh, Hv = p.Hi << sh, Wv = p.Wi << sh;
-  const int tslot = wv % T::TSPLIT, kslot = wv / T::TSPLIT;
+  const int tslot = wv % TSPLIT, kslot = wv / TSPLIT;
 
   f32x4 acc[TPW][NSUB];
 #pragma unroll
@@ -795,7 +802,7 @@ wgrad_body(float* smem, const float* __restrict__ x, const float* __restrict__ g
   int toff[TPW];
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
-    int j = (t * T::TSPLIT + tslot) * PACK + (PACK == 1 ? 0 : (lane & 15) / R), tap;
+    int j = (t * TSPLIT + tslot) * PACK + (PACK == 1 ? 0 : (lane & 15) / R), tap;
     if (j >= NLIVE) j = NLIVE - 1;
     live_tap(j, tap, toff[t]);
     if (PACK > 1) toff[t] += (lane & 15) % R;
@@ -811,8 +818,8 @@ wgrad_body(float* smem, const float* __restrict__ x, const float* __restrict__ g
     // the fragment reads of the following groups overlap the MFMAs (hand-placed sched_barrier pipelining measured
     // slower: it pins hipcc's own interleave, tools/bench_layers.py)
 #pragma unroll 4
-    for (int it = 0; it < T::TVOX / 4 / T::KSPLIT; ++it) {   // constant trip count: MFMA loops only unroll evenly
-      const int grp = it * T::KSPLIT + kslot;
+    for (int it = 0; it < T::TVOX / 4 / KSPLIT; ++it) {   // constant trip count: MFMA loops only unroll evenly
+      const int grp = it * KSPLIT + kslot;
       const int xq = grp & 3, ly = (grp >> 2) & 3, lz = grp >> 4;
       float b[NSUB], a[TPW];
 #pragma unroll
@@ -829,13 +836,13 @@ wgrad_body(float* smem, const float* __restrict__ x, const float* __restrict__ g
   }
 
   // partial[(chunk*KSPLIT + kslot)][tap][ci][CoP]; D[i][j=co]: lane -> co = lane&15, row i = (lane>>4)*4 + r
-  float* out = partial + (int64_t)(chunk * T::KSPLIT + kslot) * TAPS * p.Ci * p.CoP;
+  float* out = partial + (int64_t)(chunk * KSPLIT + kslot) * TAPS * p.Ci * p.CoP;
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = (lane >> 4) * 4 + r;
-      const int j = (t * T::TSPLIT + tslot) * PACK + i / R, ci = ci0 + i % R;
+      const int j = (t * TSPLIT + tslot) * PACK + i / R, ci = ci0 + i % R;
       if (j >= NLIVE || ci >= p.Ci) continue;
       int tap, off;
       live_tap(j, tap, off);
@@ -846,11 +853,11 @@ wgrad_body(float* smem, const float* __restrict__ x, const float* __restrict__ g
       }
     }
   }
-  if (TSKIP) {   // the folded-zero taps of this (ci subtile, co tile) region
+  if (TSKIP) {   // the folded-zero taps of this (ci subtile, co tile) region -- in every wave's own partial (`out` is per kslot)
     const unsigned live = parity_tapmask(qpar, false);
     for (int tap = 0; tap < TAPS; ++tap) {
       if ((live >> tap) & 1u) continue;
-      for (int e = tid; e < 16 * NT; e += 256) {
+      for (int e = (KSPLIT == 1 ? tid : lane); e < 16 * NT; e += (KSPLIT == 1 ? 256 : 64)) {
         const int ci = ci0 + e / NT, col = e % NT, co = cobase + col;
         if (ci < p.Ci && col < colimit && co < p.CoP) out[((int64_t)tap * p.Ci + ci) * p.CoP + co] = 0.f;
       }
@@ -1110,7 +1117,7 @@ WgPlan wgrad_plan(const CfunConv3dParams& p, int nsub) {
   if (w.tiles_per_chunk < 1) w.tiles_per_chunk = 1;
   w.nchunks = cdiv(w.ntiles, w.tiles_per_chunk);
   if (w.nchunks < 1) w.nchunks = 1;
-  w.kslots = T::KSPLIT;
+  w.kslots = (p.d2s && p.tap_skip && T::TAPS == 27 && nsub <= 2) ? 4 : T::KSPLIT;      // (TSKIP: voxel groups over the waves, wgrad_body)
   w.in_stats = nullptr; w.in_act = 0; w.in_slope = 0.f;
   return w;
 }
