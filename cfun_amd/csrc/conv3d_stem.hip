@@ -337,6 +337,134 @@ k_conv_pointwise(const float* __restrict__ x, const float* __restrict__ wp, cons
   }
 }
 
+// The same conv with the rows staged through LDS (round 4).  One thread per voxel reading ITS row as float4s makes every
+// load instruction of a wave touch 64 different cache lines, each of which the following chunks of the row touch again:
+// with 8+ waves per CU the rows in flight (10 KB per wave at C_in = 40) overflow the 32 KB L1 and the kernel ran at
+// 3.1 TB/s.  Here a workgroup's 256 voxels x CH channels are ONE contiguous span (CH = C_in) or 128 / 160-byte row
+// segments (C_in = k * CH) that the waves read with consecutive lanes on consecutive float4s; rows land in LDS with a
+// stride of CH + 4 floats ((CH + 4) / 4 odd: the 8 lanes of one ds_read_b128 phase hit 8 different 4-bank groups) and
+// every thread then reads its own row from there.  The next segment's loads are in flight under the FMAs.
+template <int CO, int CH, bool IN>
+__global__ void __launch_bounds__(256)
+k_conv_pointwise_t(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale,
+                   const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
+                   CfunConv3dParams p, int64_t total, const float* __restrict__ in_stats, int in_act, float in_slope) {
+  constexpr int Q = CH / 4, S = CH + 4;                 // float4s per row segment, LDS row stride
+  static_assert((S / 4) % 2 == 1, "row stride must be an odd number of float4s");
+  CFUN_DYN_LDS(float4, smem4);
+  float* Xl = reinterpret_cast<float*>(smem4);          // [256][S]
+  float4* stab = smem4 + 256 * S / 4;                   // IN: [N * Ci / 4][2] (mean, rstd) rows, as in k_conv_pointwise
+  const int tid = threadIdx.x;
+  if constexpr (IN) {
+    const int rows = p.N * (p.Ci >> 2) * 2;
+    for (int i = tid; i < rows; i += 256)
+      stab[i] = in_stats ? reinterpret_cast<const float4*>(in_stats)[i] : make_float4(0.f, 1.f, 0.f, 1.f);
+  }
+  const int64_t per_n = (int64_t)p.Do * p.Ho * p.Wo;
+  const int npass = p.Ci / CH;
+  const int64_t ngroups = (total + 255) >> 8;
+  const int64_t nseg = ngroups * npass;                 // segment = (group of 256 voxels, channel pass)
+  float4 xin[Q];
+  auto prefetch = [&](int64_t seg) __attribute__((always_inline)) {
+    const int64_t v0 = (seg / npass) << 8;
+    const int c0 = (int)(seg % npass) * CH;
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+      const int it = tid + i * 256;
+      const int64_t v = v0 + it / Q;
+      const int64_t off = v * p.Ci + c0 + (it % Q) * 4;
+      xin[i] = *reinterpret_cast<const float4*>(x + (v < total ? off : 0));
+    }
+  };
+  int64_t seg = (int64_t)blockIdx.x * npass;
+  const int64_t seg_step = (int64_t)gridDim.x * npass;
+  if (seg < nseg) prefetch(seg);
+  for (; seg < nseg; seg += seg_step) {                 // this block's groups; the passes of a group run back to back
+    const int64_t v = ((seg / npass) << 8) + tid;
+    float acc[CO];
+#pragma unroll
+    for (int j = 0; j < CO; ++j) acc[j] = 0.f;
+    for (int ps = 0; ps < npass; ++ps) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < Q; ++i) {
+        const int it = tid + i * 256;
+        *reinterpret_cast<float4*>(Xl + (it / Q) * S + (it % Q) * 4) = make_float4(xin[i].x, xin[i].y, xin[i].z, xin[i].w);
+      }
+      __syncthreads();
+      const int64_t nxt = ps + 1 < npass ? seg + ps + 1 : seg + seg_step;
+      if (nxt < nseg) prefetch(nxt);
+      const int c0 = ps * CH;
+      const float4* srow = stab + (IN ? ((v < total ? v : 0) / per_n) * (p.Ci >> 2) * 2 + (c0 >> 2) * 2 : 0);
+      const float* xr = Xl + tid * S;
+#pragma unroll
+      for (int c = 0; c < CH; c += 4) {
+        float4 xv = *reinterpret_cast<const float4*>(xr + c);
+        if constexpr (IN) xv = cfun_mfma::norm_act_in4(xv, srow[(c >> 2) * 2], srow[(c >> 2) * 2 + 1], in_act, in_slope);
+        const float* w = wp + (int64_t)(c0 + c) * p.CoP;          // wave-uniform: scalar loads
+#pragma unroll
+        for (int j = 0; j < CO; ++j) {
+          acc[j] = fmaf(xv.x, w[j], acc[j]);
+          acc[j] = fmaf(xv.y, w[p.CoP + j], acc[j]);
+          acc[j] = fmaf(xv.z, w[2 * p.CoP + j], acc[j]);
+          acc[j] = fmaf(xv.w, w[3 * p.CoP + j], acc[j]);
+        }
+      }
+    }
+    if (v >= total) continue;
+    const int n = (int)(v / per_n);
+    int64_t ridx = v;
+    if (p.res_mode && p.res_up2) {
+      int64_t t = v - n * per_n;
+      const int xo = (int)(t % p.Wo); t /= p.Wo;
+      const int yo = (int)(t % p.Ho);
+      const int zo = (int)(t / p.Ho);
+      ridx = (((int64_t)n * (p.Do >> 1) + (zo >> 1)) * (p.Ho >> 1) + (yo >> 1)) * (p.Wo >> 1) + (xo >> 1);
+    }
+#pragma unroll
+    for (int j = 0; j < CO; j += 4) {
+      float r[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float a = acc[j + k];
+        if (p.scale_mode == 1) a *= scale[j + k];
+        else if (p.scale_mode == 2) a *= scale[n * CO + j + k];
+        if (p.has_shift) a += shift[j + k];
+        if (p.res_mode) a += res[ridx * CO + j + k];
+        r[k] = cfun_apply_act(a, p.act, p.slope);
+      }
+      *reinterpret_cast<float4*>(y + v * CO + j) = make_float4(r[0], r[1], r[2], r[3]);
+    }
+  }
+}
+
+template <int CH>
+void launch_pointwise_t(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
+                        const CfunConv3dParams* p, int64_t total, const float* in_stats, int in_act, float in_slope,
+                        hipStream_t st) {
+  const bool in = in_stats || in_act != CFUN_ACT_NONE;
+  const size_t lds = (size_t)256 * (CH + 4) * sizeof(float) + (in ? (size_t)p->N * p->Ci * 2 * sizeof(float) : 0);
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 12) blocks = 256 * 12;
+  if (in)
+    hipLaunchKernelGGL((k_conv_pointwise_t<8, CH, true>), dim3((unsigned)blocks), dim3(256), lds, st, x, wp, scale, shift, res, y,
+                       *p, total, in_stats, in_act, in_slope);
+  else
+    hipLaunchKernelGGL((k_conv_pointwise_t<8, CH, false>), dim3((unsigned)blocks), dim3(256), lds, st, x, wp, scale, shift, res, y,
+                       *p, total, nullptr, 0, 0.f);
+}
+
+// CFUN_POINTWISE_LDS = 0: the one-thread-per-row kernel for every shape (A/B)
+int pointwise_staged_ch(const CfunConv3dParams* p) {
+  static int knob = -2;
+  if (knob == -2) {
+    const char* e = getenv("CFUN_POINTWISE_LDS");
+    knob = e ? atoi(e) : -1;
+  }
+  if (knob == 0) return 0;
+  return p->Ci % 40 == 0 ? 40 : p->Ci % 32 == 0 ? 32 : 0;
+}
+
 }  // namespace
 
 int cfun_conv_pointwise_supported(const CfunConv3dParams* p) {
@@ -357,8 +485,14 @@ int cfun_conv_pointwise_fwd(const float* x, const float* wp, const float* scale,
   if (total <= 0) return CFUN_OK;
   int64_t blocks = (total + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;
+  if ((in_stats || in_act != CFUN_ACT_NONE) && !cfun_conv_pointwise_in_supported(p)) return CFUN_EINVAL;
+  if (const int ch = pointwise_staged_ch(p)) {
+    if (ch == 40) launch_pointwise_t<40>(x, wp, scale, shift, res, y, p, total, in_stats, in_act, in_slope, st);
+    else launch_pointwise_t<32>(x, wp, scale, shift, res, y, p, total, in_stats, in_act, in_slope, st);
+    CFUN_LAUNCH_CHECK();
+    return CFUN_OK;
+  }
   if (in_stats || in_act != CFUN_ACT_NONE) {
-    if (!cfun_conv_pointwise_in_supported(p)) return CFUN_EINVAL;
     const size_t lds = (size_t)p->N * p->Ci * 2 * sizeof(float);
     hipLaunchKernelGGL((k_conv_pointwise<8, true>), dim3((unsigned)blocks), dim3(256), lds, st, x, wp, scale, shift, res, y, *p,
                        total, in_stats, in_act, in_slope);

@@ -1,6 +1,7 @@
 // HBM-bound passes of the hot path: activation derivatives, InstanceNorm3d(+LeakyReLU) forward/backward,
 // per-channel reductions, nearest-x2 upsample backward, MaxPool3d(2,2), halo pack/unpack.
 // All NDHWC fp32, float4 (16 B/lane) accesses along the channel axis, grid-stride loops.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -267,8 +268,8 @@ k_stats_finalize_rows(const double* __restrict__ part, float* __restrict__ stats
   }
 }
 
-// out[c] = sum_v g[v][c] in ONE launch for the small tensors of the detector (bias gradients of the backbone / FPN / RPN
-// convs: <= a few MB): a block owns 16 channels (64 contiguous bytes per voxel row) x 64 voxel lanes, fp64 sums, fixed
+// out[c] = sum_v g[v][c] in ONE launch for the short tensors of the detector (bias gradients of the FPN / RPN / classifier
+// convs: <= 4 096 rows): a block owns 16 channels (64 contiguous bytes per voxel row) x 64 voxel lanes, fp64 sums, fixed
 // order -- instead of k_channel_reduce + k_channel_finalize (two launches of ~5 us for ~2 us of work each)
 __global__ void __launch_bounds__(kBlock)
 k_channel_sum_direct(const float* __restrict__ g, float* __restrict__ out, int64_t V, int C) {
@@ -291,6 +292,18 @@ k_channel_sum_direct(const float* __restrict__ g, float* __restrict__ out, int64
     for (int l = 0; l < kBlock / 4; ++l) s += sm[(l * 4 + qq) * 4 + j];
     out[blockIdx.x * 16 + tid] = (float)s;
   }
+}
+
+// most rows for the one-launch sum; CFUN_SUM_DIRECT_LOG2 overrides.  Its C / 16 workgroups walk all rows with 64 lanes
+// each: measured (tools/bench_channel_sum.py, profiles/round4_channel_sum.txt) it matches reduce + finalize up to 4 096
+// rows and loses beyond (16 384 rows: 34 vs 14 us, 65 536: 134 - 330 vs 14 - 19 us), whatever the channel count.
+inline int64_t sum_direct_max() {
+  static int64_t lim = -1;
+  if (lim < 0) {
+    const char* e = getenv("CFUN_SUM_DIRECT_LOG2");
+    lim = (int64_t)1 << (e ? atoi(e) : 12);
+  }
+  return lim;
 }
 
 struct ReducePlan {
@@ -698,7 +711,7 @@ int cfun_channel_sum(const float* g, float* out, int64_t nvox, int32_t C, void* 
   if (nvox <= 0) return (int)hipMemsetAsync(out, 0, C * sizeof(float), cfun_st(stream));
   if (vec_of(C) == 4 && !cfun_aligned16(g)) return CFUN_EALIGN;
   if (ws_bytes < reduce_ws(1, nvox, C, 1)) return CFUN_EWORKSPACE;
-  if (vec_of(C) == 4 && nvox * (int64_t)C <= ((int64_t)1 << 22)) {      // <= 16 MB: one launch (see k_channel_sum_direct)
+  if (vec_of(C) == 4 && nvox <= sum_direct_max()) {      // few rows: one launch (see k_channel_sum_direct)
     hipLaunchKernelGGL(k_channel_sum_direct, dim3((unsigned)((C + 15) / 16)), dim3(kBlock), 0, cfun_st(stream), g, out, nvox, C);
     CFUN_LAUNCH_CHECK();
     return CFUN_OK;
