@@ -127,6 +127,36 @@ def stem_back_to_back(cfg, net, n_roi, dev, launches=64):
     return e0.elapsed_time(e1) * 1e-3 / launches, launches, name
 
 
+def pointwise_back_to_back(cfg, net, n_roi, dev, launches=64):
+    """conv3d_l4 (1x1x1, 2b -> n_classes on the 96^3 crops: the other HBM-bound conv of the U-Net, pure streaming) through the
+    same C-ABI entry point, timed like stem_back_to_back.  Returns (seconds per launch, algorithmic bytes per launch)."""
+    import ctypes as C
+    from cfun_amd import _lib, ops
+    conv = net.mask.modified_u_net.conv3d_l4
+    side = tuple(cfg.MASK_POOL_SIZE)
+    ci, co = conv.in_channels, conv.out_channels
+    x = torch.randn((n_roi,) + side + (ci,), device=dev)
+    spec = ops.ConvSpec(k=(1, 1, 1), co=co, pad=(0, 0, 0))
+    p = ops._params(spec, x.shape, False, False, False)
+    lib = _lib.load()
+    with torch.no_grad():
+        wp = ops.pack_weight(conv.weight)
+        y = torch.empty((n_roi,) + side + (co,), device=dev)
+        ws = _lib.workspace(lib.cfun_conv3d_fwd_workspace_bytes(C.byref(p)), x)
+        args = (_lib.ptr(x), _lib.ptr(wp), None, None, None, _lib.ptr(y), C.byref(p), _lib.ptr(ws), ws.numel(), _lib.stream(x))
+        for _ in range(4):
+            _lib.check(lib.cfun_conv3d_fwd(*args), "conv3d_fwd")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(launches):
+            lib.cfun_conv3d_fwd(*args)
+        e1.record()
+        torch.cuda.synchronize()
+    vox = n_roi * side[0] * side[1] * side[2]
+    return e0.elapsed_time(e1) * 1e-3 / launches, 4.0 * (vox * ci + vox * co + ci * co)
+
+
 def git_blob_sha1(path):
     """= `git hash-object path` (works without a .git directory, as on the GPU box)."""
     import hashlib
@@ -460,7 +490,19 @@ def main():
                 "timing": "%d back-to-back launches of the step's own C-ABI call between ONE pair of HIP events on the "
                           "launch stream (launch-to-launch rate; rocprofv3's kernel time for the same launch is ~15 %% "
                           "shorter: profiles/)" % nb2b,
-                "avg_launch_ms_in_step": t_step * 1e3, "launches_timed_in_step": len(durs_h)}
+                "avg_launch_ms_in_step": t_step * 1e3, "launches_timed_in_step": len(durs_h),
+                "frac_in_step": nbytes / t_step / 1e9 / PEAK_HBM_GBS,
+                "methodology": "since round 3 `frac` is the back-to-back launch rate above; rounds 1-2 reported the in-step "
+                               "per-launch event timing, which this line keeps as `frac_in_step` / `avg_launch_ms_in_step` "
+                               "(one event pair per launch: ~10 us of event overhead on an ~80 us kernel) -- compare like "
+                               "with like across rounds"}
+            if not args.no_hbm_loop:
+                t_p, pbytes = pointwise_back_to_back(cfg, net, n_roi_launch, dev)
+                result["roofline_hbm"]["second_leg"] = {
+                    "kernel": "k_conv_pointwise_t<8, 40> (conv3d_l4: 1x1x1 %d->%d @ %dx%d^3, rows staged through LDS)"
+                              % (2 * b, cfg.NUM_CLASSES, n_roi_launch, side[0]),
+                    "achieved": pbytes / t_p / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": pbytes / t_p / 1e9 / PEAK_HBM_GBS,
+                    "bytes_per_launch": pbytes, "avg_launch_ms": t_p * 1e3, "launches_timed": 64}
         parity_fail = None
         if world == 1 and not args.no_cpu_baseline:
             # full-size parity check: ONE more (untimed) GPU step with the Dropout3d masks the oracle leg uses, so that the

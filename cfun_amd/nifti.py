@@ -62,9 +62,13 @@ def _qform_affine(h):
 def load(path):
     """-> Nifti1Image (data in file index order [X, Y, Z(, T...)], scaled by scl_slope / scl_inter when set)."""
     with _open(path, "rb") as f:
-        raw = f.read()
-    if len(raw) < 348:
-        raise ValueError("%s: shorter than a NIfTI-1 header" % path)
+        raw = f.read(352)
+        if len(raw) >= 348:
+            return _load_body(path, f, raw)
+    raise ValueError("%s: shorter than a NIfTI-1 header" % path)
+
+
+def _load_body(path, f, raw):
     end = "<" if struct.unpack("<i", raw[:4])[0] == 348 else ">"
     if struct.unpack(end + "i", raw[:4])[0] != 348:
         raise ValueError("%s: sizeof_hdr is not 348 (NIfTI-2 / not NIfTI)" % path)
@@ -89,8 +93,25 @@ def load(path):
     dt = np.dtype(_DTYPES[datatype]).newbyteorder(end)
     off = int(vox_offset) if vox_offset >= 352 else 352
     n = int(np.prod(shape))
-    data = np.frombuffer(raw, dtype=dt, count=n, offset=off).reshape(shape, order="F")
-    data = data.astype(dt.newbyteorder("="))
+    # the voxels are read straight into the array that is returned (one buffer, writable like nibabel's get_data());
+    # only a foreign byte order costs a second pass
+    skip = off - len(raw)
+    while skip > 0:
+        got = f.read(min(skip, 1 << 20))
+        if not got:
+            break
+        skip -= len(got)
+    data = np.empty(n, dtype=dt)
+    view = memoryview(data).cast("B")
+    filled = 0
+    while filled < len(view):
+        got = f.readinto(view[filled:])
+        if not got:
+            raise ValueError("%s: %d bytes of voxel data, header promises %d" % (path, filled, len(view)))
+        filled += got
+    data = data.reshape(shape, order="F")
+    if not dt.isnative:
+        data = data.astype(dt.newbyteorder("="))
     if slope not in (0.0, 1.0) or (slope != 0.0 and inter != 0.0):
         if np.isfinite(slope) and np.isfinite(inter) and slope != 0.0:
             data = data.astype(np.float64) * slope + inter
@@ -106,9 +127,40 @@ def load(path):
     return Nifti1Image(data, aff, hdr)
 
 
+def _affine_to_quaternion(aff):
+    """(quatern_b, c, d, qfac, zooms) of the rotation closest to the affine's 3 x 3 part -- what nibabel's ``set_qform`` stores:
+    column norms as zooms, a negative determinant folded into qfac (third column flipped), the polar factor of the rest
+    (SVD) as the rotation, and its unit quaternion with a >= 0 from the dominant eigenvector of the symmetric 4 x 4 matrix
+    built from the rotation's entries (Bar-Itzhack's formulation, as nibabel.quaternions.mat2quat)."""
+    rzs = aff[:3, :3]
+    zooms = np.sqrt((rzs ** 2).sum(axis=0))
+    zooms[zooms == 0] = 1.0
+    r = rzs / zooms
+    qfac = 1.0
+    if np.linalg.det(r) < 0:
+        qfac = -1.0
+        r = r.copy()
+        r[:, 2] *= -1.0
+    u, _, vt = np.linalg.svd(r)
+    m = u @ vt
+    (xx, yx, zx), (xy, yy, zy), (xz, yz, zz) = m
+    k = np.array([[xx - yy - zz, 0, 0, 0],
+                  [yx + xy, yy - xx - zz, 0, 0],
+                  [zx + xz, zy + yz, zz - xx - yy, 0],
+                  [yz - zy, zx - xz, xy - yx, xx + yy + zz]]) / 3.0
+    vals, vecs = np.linalg.eigh(k)
+    x, y, z, w = vecs[:, np.argmax(vals)]
+    if w < 0:
+        x, y, z = -x, -y, -z
+    return float(x), float(y), float(z), qfac, zooms
+
+
 def save(img, path):
     """Write ``img`` (Nifti1Image, or any object with ``get_data()`` and ``affine``) as a single-file little-endian
-    NIfTI-1; the affine goes into the sform (code 2, 'aligned') and the pixdims are its column norms."""
+    NIfTI-1 the way ``nib.Nifti1Image(array, affine)`` + ``nib.save`` does (heart_main.py:349-352): the affine goes into the
+    sform with code 2 ('aligned'); the qform fields (quaternion of the closest rotation, offsets, qfac in pixdim[0]) are
+    filled from the same affine and its code is left 0 ('unknown'), so a reader that honours the codes takes the sform and
+    one that reads the quaternion regardless still finds the orientation; the pixdims are the affine's column norms."""
     data = np.asarray(img.get_data())
     if data.dtype == np.bool_:
         data = data.astype(np.uint8)
@@ -118,8 +170,8 @@ def save(img, path):
         raise ValueError("NIfTI-1 stores 1 to 7 dimensions")
     aff = np.asarray(img.affine, dtype=np.float64).reshape(4, 4)
     dim = [data.ndim] + list(data.shape) + [1] * (7 - data.ndim)
-    vox = np.sqrt((aff[:3, :3] ** 2).sum(axis=0))
-    pixdim = [1.0] + [float(v) if v > 0 else 1.0 for v in vox] + [1.0] * 4
+    qb, qc, qd, qfac, vox = _affine_to_quaternion(aff)
+    pixdim = [qfac] + [float(v) for v in vox] + [1.0] * 4
     h = bytearray(348)
     struct.pack_into("<i", h, 0, 348)
     struct.pack_into("<8h", h, 40, *dim)
@@ -127,7 +179,8 @@ def save(img, path):
     struct.pack_into("<8f", h, 76, *pixdim)
     struct.pack_into("<3f", h, 108, 352.0, 1.0, 0.0)
     h[123] = 2                                  # xyzt_units: millimetres
-    struct.pack_into("<2h", h, 252, 0, 2)       # qform unknown, sform 'aligned'
+    struct.pack_into("<2h", h, 252, 0, 2)       # qform 'unknown' (fields filled, as nibabel), sform 'aligned'
+    struct.pack_into("<6f", h, 256, qb, qc, qd, *[float(v) for v in aff[:3, 3]])
     struct.pack_into("<12f", h, 280, *aff[:3].reshape(-1))
     h[344:348] = b"n+1\0"
     with _open(path, "wb") as f:

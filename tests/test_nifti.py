@@ -81,3 +81,37 @@ def test_reference_call_pattern(tmp_path):
     assert image.shape == (8, 8, 4) and back.get_data().dtype == np.int32
     np.testing.assert_array_equal(back.get_data(), mask.astype(np.int32))
     np.testing.assert_allclose(back.affine, aff, atol=1e-6)
+
+
+@pytest.mark.parametrize("flip", [False, True])
+def test_saved_qform_fields_carry_the_affine(tmp_path, flip):
+    """save() fills the quaternion / offsets / qfac from the affine as nibabel's Nifti1Image(array, affine) does (sform code 2,
+    qform code 0): flipping the codes in the written header (qform 1, sform 0) must give the same affine back for a
+    rotation + anisotropic scale, with and without a reflection (qfac = -1)."""
+    ang = 0.3
+    rz = np.array([[np.cos(ang), -np.sin(ang), 0.0], [np.sin(ang), np.cos(ang), 0.0], [0.0, 0.0, 1.0]])
+    rx = np.array([[1.0, 0.0, 0.0], [0.0, np.cos(0.7), -np.sin(0.7)], [0.0, np.sin(0.7), np.cos(0.7)]])
+    aff = np.eye(4)
+    aff[:3, :3] = (rz @ rx) * np.array([0.8, 1.25, -2.5 if flip else 2.5])
+    aff[:3, 3] = [-12.5, 40.0, 7.25]
+    p = str(tmp_path / "q.nii")
+    nifti.save(nifti.Nifti1Image(np.zeros((3, 4, 5), np.int16), aff), p)
+    img = nifti.load(p)
+    assert (img.header["qform_code"], img.header["sform_code"]) == (0, 2)
+    np.testing.assert_allclose(img.affine, aff, atol=1e-5)
+    assert img.header["pixdim"][0] == (-1.0 if flip else 1.0)
+    raw = bytearray(open(p, "rb").read())
+    struct.pack_into("<2h", raw, 252, 1, 0)
+    open(p, "wb").write(bytes(raw))
+    np.testing.assert_allclose(nifti.load(p).affine, aff, atol=1e-5)
+
+
+def test_load_returns_a_writable_array_for_gz(tmp_path):
+    a = np.arange(60, dtype=np.float32).reshape(3, 4, 5)
+    p = str(tmp_path / "w.nii.gz")
+    nifti.save(nifti.Nifti1Image(a, np.eye(4)), p)
+    d = nifti.load(p).get_data()
+    np.testing.assert_array_equal(d, a)
+    d[0, 0, 0] = 5.0            # nibabel's get_data() hands out a writable array
+    with open(str(tmp_path / "short.nii"), "wb") as f:
+        f.write(open(p, "rb").read()[:100])
