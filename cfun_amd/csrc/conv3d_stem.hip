@@ -12,6 +12,8 @@
 #include "conv3d_mfma.h"
 #include <stdlib.h>
 
+#include <utility>
+
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -117,6 +119,47 @@ k_conv_stem(const float* __restrict__ x, const float* __restrict__ wp, const flo
   }
 }
 
+// The 3 x 20 weights of one (dz, dy) tap row of the 1 -> 20 conv: three 20-float groups, 32 floats apart in the packed
+// [tap][1][CoP = 32] weights, in 60 SGPRs at once.  Written by hand because hipcc reuses ONE 20-register window for the three
+// dx groups: load -> s_waitcnt -> 20 FMAs -> load -> ... exposes the scalar-cache latency three times per row (counters,
+// profiles/round4_pmc_stem.txt: 1 007 VALU instructions per wave keep the SIMDs 59 % busy, the waves wait 41 % of their
+// time); with distinct destination registers the six loads go out together and one wait covers the row.
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+typedef float f32x16s __attribute__((ext_vector_type(16)));
+struct StemRow60 {
+  f32x16s a[3];
+  f32x4s b[3];
+};
+__device__ __forceinline__ void stem_load_row60(StemRow60& w, const float* wrow) {      // wrow: wave-uniform, CoP = 32
+#ifdef CFUN_HIP_EMULATION
+  for (int dx = 0; dx < 3; ++dx) {
+    for (int i = 0; i < 16; ++i) w.a[dx][i] = wrow[dx * 32 + i];
+    for (int i = 0; i < 4; ++i) w.b[dx][i] = wrow[dx * 32 + 16 + i];
+  }
+#else
+  asm volatile(
+      "s_load_dwordx16 %0, %6, 0x0\n\t"
+      "s_load_dwordx4 %1, %6, 0x40\n\t"
+      "s_load_dwordx16 %2, %6, 0x80\n\t"
+      "s_load_dwordx4 %3, %6, 0xc0\n\t"
+      "s_load_dwordx16 %4, %6, 0x100\n\t"
+      "s_load_dwordx4 %5, %6, 0x140\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&s"(w.a[0]), "=&s"(w.b[0]), "=&s"(w.a[1]), "=&s"(w.b[1]), "=&s"(w.a[2]), "=&s"(w.b[2])
+      : "s"(wrow)
+      : "memory");
+#endif
+}
+template <int DX, int F>      // floats F, F + 1 of group DX (F even)
+__device__ __forceinline__ f32x2 stem_row_pair(const StemRow60& w) {
+  if constexpr (F < 16) return f32x2{w.a[DX][F], w.a[DX][F + 1]};
+  else return f32x2{w.b[DX][F - 16], w.b[DX][F - 15]};
+}
+template <int... I, class Fn>
+__device__ __forceinline__ void stem_static_for(std::integer_sequence<int, I...>, Fn&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+
 // ---- 3x3x3 stride-1 variant with ZPT output voxels (a z-column) per thread.  Each (dz, dy) tap row costs a wave one
 // scalar-memory round trip for its 3 x CO weights; with one voxel per thread the 9 dependent round trips are the
 // kernel's floor (measured: 0.050 ms of 0.100 with the FMAs and the stores removed).  A thread that owns ZPT voxels
@@ -166,15 +209,37 @@ k_conv_stem333z(const float* __restrict__ x, const float* __restrict__ wp, const
     const int dz = r / 3, dy = r - dz * 3;
     const float* trow = t0 + (dz * IY + dy) * IX;
     const float* wrow = wp + (int64_t)r * 3 * p.CoP;               // wave-uniform: scalar loads
+#ifndef CFUN_STEM_NO_ROW60      /* build-time A/B only */
+    if constexpr (CO == 20) {
+      float xs[3][ZPT];                                            // the row's LDS reads are in flight under the weight loads
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      const f32x2* w = reinterpret_cast<const f32x2*>(wrow + dx * p.CoP);
+      for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-      for (int zi = 0; zi < ZPT; ++zi) {
-        const float xs = trow[zi * IY * IX + dx];
-        const f32x2 xv = {xs, xs};
+        for (int zi = 0; zi < ZPT; ++zi) xs[dx][zi] = trow[zi * IY * IX + dx];
+      StemRow60 w;
+      stem_load_row60(w, wrow);
+      stem_static_for(std::make_integer_sequence<int, 30>{}, [&](auto jj) {
+        constexpr int J = decltype(jj)::value, dx = J / 10, j = J % 10;
+        const f32x2 wv = stem_row_pair<dx, 2 * j>(w);
 #pragma unroll
-        for (int j = 0; j < CO / 2; ++j) acc[zi][j] = __builtin_elementwise_fma(xv, w[j], acc[zi][j]);
+        for (int zi = 0; zi < ZPT; ++zi) {
+          const f32x2 xv = {xs[dx][zi], xs[dx][zi]};
+          acc[zi][j] = __builtin_elementwise_fma(xv, wv, acc[zi][j]);
+        }
+      });
+    } else
+#endif
+    {
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const f32x2* w = reinterpret_cast<const f32x2*>(wrow + dx * p.CoP);
+#pragma unroll
+        for (int zi = 0; zi < ZPT; ++zi) {
+          const float xs = trow[zi * IY * IX + dx];
+          const f32x2 xv = {xs, xs};
+#pragma unroll
+          for (int j = 0; j < CO / 2; ++j) acc[zi][j] = __builtin_elementwise_fma(xv, w[j], acc[zi][j]);
+        }
       }
     }
   }
@@ -262,8 +327,9 @@ int cfun_conv_stem_supported(const CfunConv3dParams* p) {
 int cfun_conv_stem_fwd(const float* x, const float* wp, const float* scale, const float* shift, float* y,
                        const CfunConv3dParams* p, hipStream_t st) {
   const int k = p->kd * 100 + p->kh * 10 + p->kw;
-  if (k == 333 && stem_zpt() == 4) return launch_stem333z<20, 4>(x, wp, scale, shift, y, *p, st);
-  if (k == 333 && stem_zpt() == 2) return launch_stem333z<20, 2>(x, wp, scale, shift, y, *p, st);
+  // (the z-column kernels read their weight rows with hand-written loads that assume CoP = 32: stem_load_row60)
+  if (k == 333 && stem_zpt() == 4 && p->CoP == 32) return launch_stem333z<20, 4>(x, wp, scale, shift, y, *p, st);
+  if (k == 333 && stem_zpt() == 2 && p->CoP == 32) return launch_stem333z<20, 2>(x, wp, scale, shift, y, *p, st);
   if (k == 333) return launch_stem<3, 3, 3, 1, 20>(x, wp, scale, shift, y, *p, st);
   if (k == 377) return launch_stem<3, 7, 7, 2, 16>(x, wp, scale, shift, y, *p, st);
   return launch_stem<5, 7, 7, 2, 24>(x, wp, scale, shift, y, *p, st);
