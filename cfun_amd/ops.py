@@ -4,6 +4,10 @@ All activations are fp32 tensors shaped [N, D, H, W, C] and contiguous (NDHWC). 
 (OIDHW -> [tap][ci][CoP]) is a differentiable one-launch op (cfun_weight_pack / cfun_weight_unpack), so parameter
 gradients arrive in the reference's OIDHW layout and shared weights (mask_branch.py:141/143 ...) are summed by
 autograd.
+
+This module holds the convolution / normalisation / buffer / RoI / resize bindings; the weight operands (pack, folds,
+``WeightScope``) live in ``weights.py``, the mask-head losses in ``loss_ops.py``, the non-blocking host plumbing in
+``hostio.py`` -- all re-exported here, so callers keep writing ``ops.<name>``.
 """
 import ctypes as C
 import os
@@ -17,441 +21,14 @@ from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ALGO_AUTO, ALGO_B3, ConvParams,
 LRELU_SLOPE = 0.01  # nn.LeakyReLU() default, mask_branch.py:18
 
 
-def _round16(v):
-    return (v + 15) // 16 * 16
-
-
-class _PackWeight(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, w):
-        co, ci = w.shape[0], w.shape[1]
-        t = w.shape[2] * w.shape[3] * w.shape[4]
-        ctx.wshape = tuple(w.shape)
-        return _pack(w)
-
-    @staticmethod
-    def backward(ctx, dwp):
-        co, ci = ctx.wshape[0], ctx.wshape[1]
-        dwp = dwp.contiguous()
-        dw = torch.empty(ctx.wshape, dtype=torch.float32, device=dwp.device)
-        check(_lib.load().cfun_weight_unpack(ptr(dwp), ptr(dw), co, ci, dwp.shape[0], stream(dwp)), "weight_unpack")
-        return dw
-
-
-def _pack(w, both=False):
-    """OIDHW -> packed wp [T,Ci,CoP]; with ``both`` also the data-gradient layout wpT [T,Co,CiP], same launch."""
-    co, ci = w.shape[0], w.shape[1]
-    t = w.shape[2] * w.shape[3] * w.shape[4]
-    w = w.detach().contiguous()
-    wp = torch.empty((t, ci, _round16(co)), dtype=torch.float32, device=w.device)
-    if not both:
-        check(_lib.load().cfun_weight_pack(ptr(w), ptr(wp), co, ci, t, stream(w)), "weight_pack")
-        return wp
-    wpT = torch.empty((t, co, _round16(ci)), dtype=torch.float32, device=w.device)
-    check(_lib.load().cfun_weight_pack_both(ptr(w), ptr(wp), ptr(wpT), co, ci, t, stream(w)), "weight_pack_both")
-    return wp, wpT
-
-
-def pack_weight(w):
-    """OIDHW [Co,Ci,kd,kh,kw] -> wp [taps, Ci, CoP] (differentiable; one kernel each way)."""
-    return _PackWeight.apply(w)
-
-
-_FOLD_MATRICES = {}
-
-
-def _fold_matrix(k, dtype, device):
-    """f[parity p][low-res offset a + 1][hi-res tap t] = 1 where tap t of output parity p reads low-res offset a -- a
-    constant per kernel size, built on the host once (element writes on a device tensor are one launch each)."""
-    key = (k, dtype, str(device))
-    f = _FOLD_MATRICES.get(key)
-    if f is None:
-        f = torch.zeros(2, 3, k, dtype=dtype)
-        for p in range(2):
-            for t in range(k):
-                f[p, (p + t - k // 2) // 2 + 1, t] = 1.0
-        f = _FOLD_MATRICES[key] = f.to(device)
-    return f
-
-
-class _FoldBias(torch.autograd.Function):
-    """t + b * s for a trainable conv bias b under a frozen BatchNorm's constant fold (s, t): the epilogue shift of
-    bn(conv + b) = conv * s + (b * s + t).  One launch each way (db = g * s) instead of addcmul's generic backward.
-    ``pre``: the consumer is a conv called with ``shift_scaled=True`` and scale = s -- it hands back db itself (the sum of
-    ITS scaled gradient, see _Conv3d.backward), so the backward here is the identity."""
-
-    @staticmethod
-    def forward(ctx, bias, s, t, pre):
-        ctx.pre = pre
-        ctx.save_for_backward(s)
-        return torch.addcmul(t, bias, s)
-
-    @staticmethod
-    def backward(ctx, g):
-        if ctx.pre:
-            return g, None, None, None
-        (s,) = ctx.saved_tensors
-        return g * s, None, None, None
-
-
-def fold_bias(bias, s, t, pre=False):
-    return _FoldBias.apply(bias, s, t, pre)
-
-
-class _FoldBiasMany(torch.autograd.Function):
-    """[t_i + b_i * s_i for i]: the bias folds of ALL conv + frozen-BatchNorm pairs of a step as one multi-tensor launch
-    each way (torch._foreach_*), instead of one tiny launch per pair and direction."""
-
-    @staticmethod
-    def forward(ctx, n, pre, *args):
-        biases, ss, ts = args[:n], args[n:2 * n], args[2 * n:]
-        ctx.ss, ctx.pre = ss, pre
-        ctx.set_materialize_grads(False)      # a fold no conv consumed this step: its bias gets NO gradient, not zeros
-        return tuple(torch._foreach_addcmul([t for t in ts], [b.detach() for b in biases], list(ss)))
-
-    @staticmethod
-    def backward(ctx, *grads):
-        ss = ctx.ss
-        out = list(grads)            # pre: the consumer convs deliver db themselves (see _FoldBias)
-        if not ctx.pre:
-            idx = [i for i, g in enumerate(grads) if g is not None]
-            if idx:
-                prods = torch._foreach_mul([grads[i] for i in idx], [ss[i] for i in idx])
-                for i, p in zip(idx, prods):
-                    out[i] = p
-        return (None, None) + tuple(out) + (None,) * (2 * len(grads))
-
-
-def fold_bias_many(biases, ss, ts, pre=False):
-    return _FoldBiasMany.apply(len(biases), pre, *biases, *ss, *ts)
-
-
-def _fold_tensor(k, dtype, device):
-    """F [8 parities (p,q,r)][k^3 hi-res taps (t,u,v)][27 low-res taps (a,b,c)] = f[p,a,t] f[q,b,u] f[r,c,v]: 0 / 1, constant
-    per kernel size (cached)."""
-    key = ("F", k, dtype, str(device))
-    big = _FOLD_MATRICES.get(key)
-    if big is None:
-        f = _fold_matrix(k, dtype, "cpu")
-        big = torch.einsum("pat,qbu,rcv->pqrtuvabc", f, f, f).reshape(8, k * k * k, 27).contiguous()
-        big = _FOLD_MATRICES[key] = big.to(device)
-    return big
-
-
-class _FoldUp2(torch.autograd.Function):
-    """fold_up2_weight as ONE batched matmul each way: wf[pqr][o][i][abc] = sum_tuv w[o][i][tuv] F[pqr][tuv][abc] (the
-    eight parities are the batch, w is broadcast); an einsum over the three axes costs ~10 launches per weight and
-    direction, four folded weights per step."""
-
-    @staticmethod
-    def forward(ctx, w, cqp):
-        o, i, k = w.shape[0], w.shape[1], w.shape[-1]
-        big = _fold_tensor(k, w.dtype, w.device)
-        a = w.detach().reshape(o, i * k ** 3)
-        if cqp != o:      # pad every parity group to cqp output channels (tile-aligned tap skipping): zero rows
-            a = torch.nn.functional.pad(a, (0, 0, 0, cqp - o))
-        wf = torch.matmul(a.reshape(1, cqp * i, k ** 3), big)              # [8, cqp*i, 27]
-        ctx.save_for_backward(big)
-        ctx.dims = (o, i, k, cqp)
-        return wf.reshape(8 * cqp, i, 3, 3, 3)
-
-    @staticmethod
-    def backward(ctx, g):
-        (big,) = ctx.saved_tensors
-        o, i, k, cqp = ctx.dims
-        g = g.reshape(8, cqp * i, 27)
-        dw = torch.matmul(g, big.transpose(1, 2)).sum(dim=0)               # [cqp*i, k^3]
-        return dw.reshape(cqp, i, k, k, k)[:o], None
-
-
-def fold_up2_weight(w, cqp=None):
-    """Fold "nearest x2 upsample -> conv k^3 (pad k//2)" into a 3x3x3 conv (pad 1) on the LOW-resolution input
-    that produces the 8 output parities as channels: [O,I,k,k,k] -> [8*O, I, 3,3,3], channel ((pz*2+py)*2+px)*O + o.
-    Hi-res tap t of output parity p reads low-res offset floor((p + t - k//2) / 2) in {-1,0,1}; taps that hit the
-    same low-res voxel are summed (differentiable, so the gradient reaches the original 5x5x5 weight).  The
-    hi-res zero padding of k//2 <= 2 maps exactly onto a low-res zero padding of 1."""
-    k = w.shape[-1]
-    if k not in (3, 5):
-        raise ValueError("fold_up2_weight: kernel size %d" % k)
-    cqp = w.shape[0] if cqp is None else cqp
-    scope = WeightScope.current()
-    if scope is not None:          # folded at the start of the pass, its operands are part of the batched preparation
-        wf = scope.folds.get((id(w), cqp))
-        if wf is not None:
-            return wf
-    wf = _FoldUp2.apply(w, cqp)
-    wf._cfun_src = ("f", w, cqp)
-    return wf
-
-
-class _SplitChannels(torch.autograd.Function):
-    """y [..., C] -> (y[..., :c0], y[..., c0:]) as dense tensors; the gradient is ONE concatenation instead of two
-    zero-filled tensors, two copies and their sum (the fused RPN head: class and box outputs of one conv)."""
-
-    @staticmethod
-    def forward(ctx, y, c0):
-        ctx.set_materialize_grads(False)
-        ctx.lead, ctx.widths = tuple(y.shape[:-1]), (c0, y.shape[-1] - c0)
-        return y[..., :c0].contiguous(), y[..., c0:].contiguous()
-
-    @staticmethod
-    def backward(ctx, ga, gb):
-        if ga is None and gb is None:
-            return None, None
-        like = gb if ga is None else ga
-        ga = like.new_zeros(ctx.lead + (ctx.widths[0],)) if ga is None else ga
-        gb = like.new_zeros(ctx.lead + (ctx.widths[1],)) if gb is None else gb
-        return torch.cat([ga, gb], dim=-1), None
-
-
-def split_channels(y, c0):
-    return _SplitChannels.apply(y, c0)
-
-
-class _GatherSlices(torch.autograd.Function):
-    """w -> tuple(w.index_select(dim, idx) for idx in idxs) with ONE gradient: zeros + one index_add_ per slice.
-    n separate index_select nodes each build a full-size zero-filled gradient and autograd then adds the n of them
-    (per-RoI Dropout3d weight slices: 3n - 1 launches per weight instead of n + 1).
-    ``lazy``: the slices are returned as UNWRITTEN tensors of the right shape -- their only consumers are convs whose
-    operands the batched weight preparation (WeightScope) has already gathered straight from ``w``; a consumer that
-    needs the values calls ``materialize_weight`` first."""
-
-    @staticmethod
-    def forward(ctx, w, dim, lazy, *idxs):
-        ctx.dim, ctx.wshape = dim, tuple(w.shape)
-        ctx.save_for_backward(*idxs)
-        if not lazy:
-            return tuple(w.index_select(dim, idx) for idx in idxs)
-        shp = list(w.shape)
-        outs = []
-        for idx in idxs:
-            shp[dim] = idx.numel()
-            outs.append(torch.empty(shp, dtype=w.dtype, device=w.device))
-        return tuple(outs)
-
-    @staticmethod
-    def backward(ctx, *grads):
-        idxs = ctx.saved_tensors
-        dw = None
-        for idx, g in zip(idxs, grads):
-            if g is None:
-                continue
-            if dw is None:
-                dw = torch.zeros(ctx.wshape, dtype=g.dtype, device=g.device)
-            dw.index_add_(ctx.dim, idx, g)
-        return (dw, None, None) + (None,) * len(idxs)
-
-
-def gather_slices(w, dim, idxs, key=None):
-    """[w.index_select(dim, idx) for idx in idxs], differentiable w.r.t. w with a single accumulated gradient.  ``key``
-    names the index lists inside the active ``WeightScope`` (its ``dyn`` table): where the scope has prepared the operands
-    of every slice the slices themselves are never gathered (see _GatherSlices)."""
-    scope = WeightScope.current()
-    lazy = bool(scope is not None and key is not None and scope.has_gather(w, dim, key, len(idxs)))
-    outs = _GatherSlices.apply(w, dim, lazy, *idxs)
-    if key is not None:
-        for i, (t, idx) in enumerate(zip(outs, idxs)):
-            t._cfun_src = ("g", w, dim, key, i)
-            t._cfun_lazy = (w, dim, idx) if lazy else None
-    return outs
-
-
-def materialize_weight(w):
-    """The values of a lazily gathered weight slice (gather_slices inside a WeightScope), written on first demand."""
-    lz = getattr(w, "_cfun_lazy", None)
-    if lz is not None:
-        base, dim, idx = lz
-        with torch.no_grad():
-            w.detach().copy_(base.detach().index_select(dim, idx))
-        w._cfun_lazy = None
-    return w
-
-
-class WeightScope:
-    """The weight operands of every conv a module runs in one pass, prepared by ONE launch (cfun_weight_prepare) instead of
-    2 - 3 small launches per conv (pack, Winograd transform, stride-2 fold) and one index_select per gathered slice.
-
-    Which convs run, with which parameters, is only known at the call sites: the first pass inside ``with
-    WeightScope(owner)`` records (weight source, conv parameters, needs a data gradient) per ``conv3d_w`` call and stores
-    the list on ``owner``; later passes replay it up front -- fold the up-conv weights, build the job table (one
-    host-to-device copy), launch -- and the convs pick their operands up by (source, operand kinds).  A conv the table
-    does not cover (first pass, another shape, a changed graph) packs its own weight as before and is recorded for the
-    next pass, so the scope never changes results, only the number of launches.  Sources: an ``nn.Parameter``; slice i of
-    ``gather_slices(param, dim, idxs, key=k)`` with this pass's index lists given as ``dyn[k]``; ``fold_up2_weight(param,
-    cqp)``."""
-
-    _stack = []
-
-    def __init__(self, owner, dyn=None, enabled=True):
-        self.owner, self.dyn = owner, dyn or {}
-        self.enabled = bool(enabled) and os.environ.get("CFUN_WEIGHT_SCOPE", "1") != "0"
-        self.table, self.folds, self.seen, self.seen_keys = {}, {}, [], {}
-        self.hits = self.misses = 0
-
-    @classmethod
-    def current(cls):
-        return cls._stack[-1] if cls._stack else None
-
-    def __enter__(self):
-        if self.enabled:
-            WeightScope._stack.append(self)
-            plan = getattr(self.owner, "_cfun_wplan", None)
-            if plan:
-                try:
-                    self._prepare(plan)
-                except Exception:
-                    WeightScope._stack.pop()
-                    raise
-        return self
-
-    def __exit__(self, *exc):
-        if self.enabled:
-            WeightScope._stack.pop()
-            if exc[0] is None:
-                self.owner._cfun_wplan = self.seen
-        return False
-
-    # -- keys ---------------------------------------------------------------------------------------------------------
-    @staticmethod
-    def _desc(w):
-        src = getattr(w, "_cfun_src", None)
-        if src is not None:
-            return src
-        if isinstance(w, torch.nn.Parameter):
-            return ("p", w)
-        return None
-
-    @staticmethod
-    def _desc_key(desc):
-        return (desc[0], id(desc[1])) + tuple(desc[2:])
-
-    @staticmethod
-    def _kinds(p):
-        kinds, nbytes = (C.c_int32 * 2)(), (C.c_size_t * 2)()
-        check(_lib.load().cfun_weight_prepare_kinds(C.byref(p), kinds, nbytes), "weight_prepare_kinds")
-        return int(kinds[0]), int(kinds[1]), int(nbytes[0]), int(nbytes[1])
-
-    def has_gather(self, w, dim, key, n):
-        have = [k for k in self.table if k[0] == "g" and k[1] == id(w) and k[2] == dim and k[3] == key]
-        return len({k[4] for k in have}) == n and n > 0
-
-    # -- the batched preparation ---------------------------------------------------------------------------------------
-    def _prepare(self, plan):
-        lib = _lib.load()
-        jobs, outs, keep = [], [], []
-        total = 0
-        for desc, pbytes, need_dgrad in plan:
-            p = ConvParams.from_buffer_copy(pbytes)
-            base = desc[1]
-            co_idx = ci_idx = None
-            if desc[0] == "p":
-                src = base
-            elif desc[0] == "f":
-                wf = self.folds.get((id(base), desc[2]))
-                if wf is None:
-                    wf = self.folds[(id(base), desc[2])] = fold_up2_weight_eager(base, desc[2])
-                src = wf
-            else:
-                _, _, dim, key, i = desc
-                idxs = self.dyn.get(key)
-                if idxs is None or i >= len(idxs):
-                    continue
-                n = int(idxs[i].numel())
-                if dim == 0:
-                    p.Co, p.CoP, co_idx = n, _round16(n), idxs[i]
-                    if p.d2s or p.d2s_cq:
-                        continue
-                else:
-                    p.Ci, p.CiP, ci_idx = n, _round16(n), idxs[i]
-                src = base
-            if not src.is_contiguous() or src.dtype != torch.float32:
-                continue
-            try:
-                fk, dk, fb, db = self._kinds(p)
-            except RuntimeError:
-                continue
-            if fk == _lib.WOP_NONE:
-                continue
-            if not need_dgrad:
-                dk, db = _lib.WOP_NONE, 0
-            key = self._desc_key(desc) + (fk, dk)
-            if key in self.table:
-                continue
-            offs = []
-            for nb in (fb, db):
-                offs.append(total)
-                total += (nb + 255) // 256 * 256
-            t = p.kd * p.kh * p.kw
-            jobs.append((src, co_idx, ci_idx, int(p.Co), int(p.Ci), t, int(src.shape[1]), fk, dk))
-            outs.append((key, offs, fb, db))
-            self.table[key] = None
-        if not jobs:
-            return
-        dev = jobs[0][0].device
-        arena = torch.empty(max(total, 256), dtype=torch.uint8, device=dev)
-        base_ptr = arena.data_ptr()
-        arr = (_lib.WeightJob * len(jobs))()
-        for j, ((src, co_idx, ci_idx, co, ci, t, src_ci, fk, dk), (key, offs, fb, db)) in enumerate(zip(jobs, outs)):
-            a = arr[j]
-            a.w = ptr(src.detach())
-            a.fwd = base_ptr + offs[0]
-            a.dgrad = (base_ptr + offs[1]) if dk != _lib.WOP_NONE else None
-            a.co_idx = None if co_idx is None else ptr(co_idx)
-            a.ci_idx = None if ci_idx is None else ptr(ci_idx)
-            a.Co, a.Ci, a.T, a.src_ci, a.fwd_kind, a.dgrad_kind = co, ci, t, src_ci, fk, dk
-            self.table[key] = (arena[offs[0]:offs[0] + fb].view(torch.float32),
-                               arena[offs[1]:offs[1] + db].view(torch.float32) if dk != _lib.WOP_NONE else None)
-        nblocks = C.c_int64(0)
-        check(lib.cfun_weight_prepare_plan(arr, len(jobs), C.byref(nblocks)), "weight_prepare_plan")
-        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-        tab = upload(host, dev)
-        check(lib.cfun_weight_prepare(ptr(tab), len(jobs), nblocks.value, stream(arena)), "weight_prepare")
-        self._keep = (tab, [j[0] for j in jobs])      # (held until the launch has been enqueued; the arena lives in the views)
-
-    # -- the conv call site ---------------------------------------------------------------------------------------------
-    def lookup(self, w, p, need_dgrad):
-        """(forward operand, data-gradient operand or None, w_prepared bits) for conv p on weight w, or None."""
-        desc = self._desc(w)
-        if desc is None:
-            return None
-        try:
-            fk, dk, _, _ = self._kinds(p)
-        except RuntimeError:
-            return None
-        if fk == _lib.WOP_NONE:
-            return None
-        dkey = self._desc_key(desc)
-        rec = self.seen_keys.get(dkey + (fk,))
-        if rec is None:
-            p0 = ConvParams.from_buffer_copy(bytes(p))
-            p0.w_prepared = 0
-            self.seen_keys[dkey + (fk,)] = len(self.seen)
-            self.seen.append((desc, bytes(p0), bool(need_dgrad)))
-        elif need_dgrad and not self.seen[rec][2]:
-            self.seen[rec] = self.seen[rec][:2] + (True,)
-        ops_ = self.table.get(dkey + (fk, dk if need_dgrad else _lib.WOP_NONE))
-        if ops_ is None and not need_dgrad:      # prepared with the data-gradient operand although this pass needs none
-            ops_ = self.table.get(dkey + (fk, dk))
-        if ops_ is None:
-            self.misses += 1
-            return None
-        self.hits += 1
-        fwd, dg = ops_
-        return fwd, (dg if need_dgrad else None), (1 | (2 if (need_dgrad and dg is not None) else 0))
-
-
-def fold_up2_weight_eager(w, cqp):
-    wf = _FoldUp2.apply(w, cqp)
-    wf._cfun_src = ("f", w, cqp)
-    return wf
-
-
-def _transpose_pack(wp, co):
-    """wp [T,Ci,CoP] -> wpT [T,Co,CiP] (no grad; used by bwd_data)."""
-    t, ci, _ = wp.shape
-    out = torch.empty((t, co, _round16(ci)), dtype=wp.dtype, device=wp.device)
-    check(_lib.load().cfun_weight_pack_transpose(ptr(wp), ptr(out), co, ci, t, stream(wp)), "weight_pack_transpose")
-    return out
+from .weights import (  # noqa: E402,F401  (the weight operands live in weights.py; re-exported)
+    _round16, _PackWeight, _pack, pack_weight, _fold_matrix, _FoldBias, fold_bias, _FoldBiasMany, fold_bias_many,
+    _fold_tensor, _FoldUp2, fold_up2_weight, _SplitChannels, split_channels, _GatherSlices, gather_slices,
+    materialize_weight, WeightScope, fold_up2_weight_eager, _transpose_pack, _FOLD_MATRICES)
+from .hostio import _UploadRing, AsyncScalar, upload, side_stream, side_streams, _UPLOADERS, _SIDE_STREAMS  # noqa: E402,F401
+from .loss_ops import (  # noqa: E402,F401
+    _Softmax, softmax_channels, _MaskCE, _MaskCEWeighted, mask_cross_entropy, _EdgeRaw, edge_loss_raw, _EdgeLoss,
+    edge_loss, _MaskLosses, mask_losses)
 
 
 @dataclass(frozen=True)
@@ -1500,217 +1077,6 @@ def nms3d(boxes, scores, threshold, max_num):
     return keep, count
 
 
-class _Softmax(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, logits):
-        lib = _lib.load()
-        logits = _c(logits)
-        c = logits.shape[-1]
-        probs = torch.empty_like(logits)
-        check(lib.cfun_softmax_fwd(ptr(logits), ptr(probs), logits.numel() // c, c, stream(logits)), "softmax_fwd")
-        ctx.save_for_backward(probs)
-        return probs
-
-    @staticmethod
-    def backward(ctx, dp):
-        lib = _lib.load()
-        (probs,) = ctx.saved_tensors
-        dp = _c(dp)
-        c = probs.shape[-1]
-        dl = torch.empty_like(probs)
-        check(lib.cfun_softmax_bwd(ptr(probs), ptr(dp), ptr(dl), probs.numel() // c, c, stream(probs)), "softmax_bwd")
-        return dl
-
-
-def softmax_channels(logits):
-    """softmax over the last (channel) axis of an NDHWC tensor (model.py:799)."""
-    return _Softmax.apply(logits)
-
-
-class _MaskCE(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, logits, labels):
-        lib = _lib.load()
-        logits = _c(logits)
-        labels = _c(labels)
-        c = logits.shape[-1]
-        nvox = logits.numel() // c
-        if labels.dtype != torch.uint8 or labels.numel() != nvox:
-            raise RuntimeError("mask_cross_entropy: labels must be uint8 [n,D,H,W]")
-        loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
-        ws = workspace(lib.cfun_loss_workspace_bytes(nvox), logits)
-        check(lib.cfun_softmax_ce_fwd(ptr(logits), ptr(labels), ptr(loss), nvox, c, ptr(ws), ws.numel(),
-                                      stream(logits)), "softmax_ce_fwd")
-        ctx.save_for_backward(logits, labels)
-        return loss[0]
-
-    @staticmethod
-    def backward(ctx, g):
-        lib = _lib.load()
-        logits, labels = ctx.saved_tensors
-        c = logits.shape[-1]
-        gs = _c(g.reshape(1).float())
-        dl = torch.empty_like(logits)
-        check(lib.cfun_softmax_ce_bwd(ptr(logits), ptr(labels), ptr(gs), ptr(dl), logits.numel() // c, c,
-                                      stream(logits)), "softmax_ce_bwd")
-        return dl, None
-
-
-class _MaskCEWeighted(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, logits, labels, weight):
-        lib = _lib.load()
-        logits, labels = _c(logits), _c(labels)
-        weight = _c(weight.detach().to(device=logits.device, dtype=torch.float32))
-        c = logits.shape[-1]
-        nvox = logits.numel() // c
-        if labels.dtype != torch.uint8 or labels.numel() != nvox or weight.numel() != c:
-            raise RuntimeError("mask_cross_entropy: labels must be uint8 [n,D,H,W], weight [C]")
-        loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
-        wsum = torch.empty((1,), dtype=torch.float32, device=logits.device)
-        ws = workspace(lib.cfun_ce_weighted_workspace_bytes(), logits)
-        check(lib.cfun_softmax_ce_weighted_fwd(ptr(logits), ptr(labels), ptr(weight), ptr(loss), ptr(wsum), nvox, c, ptr(ws),
-                                               ws.numel(), stream(logits)), "softmax_ce_weighted_fwd")
-        ctx.save_for_backward(logits, labels, weight, wsum)
-        return loss[0]
-
-    @staticmethod
-    def backward(ctx, g):
-        lib = _lib.load()
-        logits, labels, weight, wsum = ctx.saved_tensors
-        c = logits.shape[-1]
-        gs = _c(g.reshape(1).float())
-        dl = torch.empty_like(logits)
-        check(lib.cfun_softmax_ce_weighted_bwd(ptr(logits), ptr(labels), ptr(weight), ptr(gs), ptr(wsum), ptr(dl),
-                                               logits.numel() // c, c, stream(logits)), "softmax_ce_weighted_bwd")
-        return dl, None, None
-
-
-def mask_cross_entropy(logits, labels, weight=None):
-    """CrossEntropyLoss(logits [n,D,H,W,C], labels uint8 [n,D,H,W]) -- model.py:909-935; ``weight`` [C]: the LiTS
-    fork's class weights (LiTS_2017/model.py:926)."""
-    if weight is None:
-        return _MaskCE.apply(logits, labels)
-    return _MaskCEWeighted.apply(logits, labels, torch.as_tensor(weight, dtype=torch.float32))
-
-
-class _EdgeRaw(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, probs, labels):
-        lib = _lib.load()
-        probs, labels = _c(probs), _c(labels)
-        n, d, h, w, c = probs.shape
-        loss = torch.empty((1,), dtype=torch.float32, device=probs.device)
-        keep = ctx.needs_input_grad[0]
-        dc = torch.empty(lib.cfun_edge_raw_dc_bytes(n, d, h, w, c) // 4, dtype=torch.float32, device=probs.device) \
-            if keep else None
-        ws = workspace(lib.cfun_loss_workspace_bytes(n * d * h * w), probs)
-        check(lib.cfun_edge_raw_fwd(ptr(probs), ptr(labels), ptr(loss), ptr(dc), n, d, h, w, c, ptr(ws), ws.numel(),
-                                    stream(probs)), "edge_raw_fwd")
-        ctx.shape = tuple(probs.shape)
-        ctx.save_for_backward(dc)
-        return loss[0]
-
-    @staticmethod
-    def backward(ctx, g):
-        lib = _lib.load()
-        (dc,) = ctx.saved_tensors
-        n, d, h, w, c = ctx.shape
-        gs = _c(g.reshape(1).float())
-        dp = torch.empty(ctx.shape, dtype=torch.float32, device=dc.device)
-        check(lib.cfun_edge_raw_bwd(ptr(dc), ptr(gs), ptr(dp), n, d, h, w, c, stream(dc)), "edge_raw_bwd")
-        return dp, None
-
-
-def edge_loss_raw(probs, labels):
-    """The LiTS fork's edge loss (LiTS_2017/model.py:936-979): MSE on the raw three Sobel responses of NDHWC probabilities
-    vs uint8 labels, foreground classes only; differentiable w.r.t. ``probs``."""
-    return _EdgeRaw.apply(probs, labels)
-
-
-class _EdgeLoss(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, probs, labels):
-        lib = _lib.load()
-        probs = _c(probs)
-        labels = _c(labels)
-        n, d, h, w, c = probs.shape
-        loss = torch.empty((1,), dtype=torch.float32, device=probs.device)
-        ws = workspace(lib.cfun_loss_workspace_bytes(n * d * h * w), probs)
-        check(lib.cfun_edge_loss_fwd(ptr(probs), ptr(labels), ptr(loss), n, d, h, w, c, ptr(ws), ws.numel(),
-                                     stream(probs)), "edge_loss_fwd")
-        ctx.save_for_backward(probs, labels)
-        return loss[0]
-
-    @staticmethod
-    def backward(ctx, g):
-        lib = _lib.load()
-        probs, labels = ctx.saved_tensors
-        n, d, h, w, c = probs.shape
-        gs = _c(g.reshape(1).float())
-        dp = torch.empty_like(probs)
-        ws = workspace(lib.cfun_edge_loss_bwd_workspace_bytes(n, d, h, w, c), probs)
-        check(lib.cfun_edge_loss_bwd(ptr(probs), ptr(labels), ptr(gs), ptr(dp), n, d, h, w, c, ptr(ws), ws.numel(),
-                                     stream(probs)), "edge_loss_bwd")
-        return dp, None
-
-
-def edge_loss(probs, labels):
-    """3-D Sobel edge-agreement loss (model.py:938-981) on NDHWC probabilities and uint8 labels."""
-    return _EdgeLoss.apply(probs, labels)
-
-
-class _MaskLosses(torch.autograd.Function):
-    """(CE(logits, labels), edge(probs, labels)) with ONE fused backward pass; probs = softmax(logits) comes from
-    the Mask module (model.py:799) and is taken as a constant here -- its dependence on logits is folded into the
-    backward (softmax_bwd inside cfun_mask_losses_bwd), so no gradient flows through the softmax node."""
-
-    @staticmethod
-    def forward(ctx, logits, probs, labels):
-        lib = _lib.load()
-        logits, probs, labels = _c(logits), _c(probs), _c(labels)
-        n, d, h, w, c = logits.shape
-        nvox = n * d * h * w
-        if labels.dtype != torch.uint8 or labels.numel() != nvox:
-            raise RuntimeError("mask_losses: labels must be uint8 [n,D,H,W]")
-        out = torch.empty((2,), dtype=torch.float32, device=logits.device)
-        ws = workspace(lib.cfun_loss_workspace_bytes(nvox), logits)
-        st = stream(logits)
-        check(lib.cfun_softmax_ce_fwd(ptr(logits), ptr(labels), ptr(out), nvox, c, ptr(ws), ws.numel(), st),
-              "softmax_ce_fwd")
-        dc = None
-        if ctx.needs_input_grad[0] and min(d, h, w) >= 3:   # training: keep the edge coefficients, one-pass backward
-            dc = torch.empty(lib.cfun_edge_loss_bwd_workspace_bytes(n, d, h, w, c) // 4, dtype=torch.float32,
-                             device=logits.device)
-            check(lib.cfun_edge_loss_fwd_save(ptr(probs), ptr(labels), ptr(out[1:]), ptr(dc), n, d, h, w, c, ptr(ws),
-                                              ws.numel(), st), "edge_loss_fwd_save")
-        else:
-            check(lib.cfun_edge_loss_fwd(ptr(probs), ptr(labels), ptr(out[1:]), n, d, h, w, c, ptr(ws), ws.numel(), st),
-                  "edge_loss_fwd")
-        ctx.save_for_backward(probs, labels, dc)
-        return out[0], out[1]
-
-    @staticmethod
-    def backward(ctx, g_ce, g_edge):
-        lib = _lib.load()
-        probs, labels, dc = ctx.saved_tensors
-        n, d, h, w, c = probs.shape
-        g = torch.stack([g_ce.reshape(()).float(), g_edge.reshape(()).float()])
-        dl = torch.empty_like(probs)
-        if dc is not None:
-            check(lib.cfun_mask_losses_bwd_saved(ptr(probs), ptr(labels), ptr(g), ptr(g[1:]), ptr(dc), ptr(dl), n, d, h,
-                                                 w, c, stream(probs)), "mask_losses_bwd_saved")
-        else:
-            ws = workspace(lib.cfun_edge_loss_bwd_workspace_bytes(n, d, h, w, c), probs)
-            check(lib.cfun_mask_losses_bwd(ptr(probs), ptr(labels), ptr(g), ptr(g[1:]), ptr(dl), n, d, h, w, c, ptr(ws),
-                                           ws.numel(), stream(probs)), "mask_losses_bwd")
-        return dl, None, None
-
-
-def mask_losses(logits, probs, labels):
-    """Both 'finetune' mask losses (model.py:909-981) of logits [n,D,H,W,C] with probs = softmax(logits):
-    returns (cross entropy, Sobel edge loss); the backward is one fused pass (cfun_mask_losses_bwd)."""
-    return _MaskLosses.apply(logits, probs.detach(), labels)
 
 
 def resize3d(vol, out_dims, order=1, frame=None, offset=None, clip=False):
@@ -1753,107 +1119,6 @@ def halo_unpack(buf, x, z0):
     return x
 
 
-# ---- host -> device uploads that never block the host -----------------------------------------------------------------
-class _UploadRing:
-    """Small per-step host tensors (Dropout3d masks and kept-channel lists, weight-preparation tables) go to the device
-    through a ring of PERSISTENT pinned staging buffers with an asynchronous copy.  A pageable ``tensor.to(device)`` is a
-    blocking copy in stream order: the host stops until the GPU has drained everything queued before it -- the previous
-    step's backward -- and the GPU then idles until the host has caught up (tools/gap_report.py: ~2.7 ms of gaps per step
-    before).  A slot is reused only after the copy that read it has completed (its event; by then long done)."""
-
-    SLOTS = 8
-
-    def __init__(self, device):
-        self.device, self.slots, self.i = device, [[None, None] for _ in range(self.SLOTS)], 0
-
-    def upload(self, host):
-        host = host.contiguous()
-        nbytes = host.numel() * host.element_size()
-        out = torch.empty(host.shape, dtype=host.dtype, device=self.device)
-        if nbytes == 0:
-            return out
-        slot = self.slots[self.i]
-        self.i = (self.i + 1) % self.SLOTS
-        if slot[1] is not None:
-            slot[1].synchronize()
-        if slot[0] is None or slot[0].numel() < nbytes:
-            slot[0] = torch.empty(max(2 * nbytes, 1 << 16), dtype=torch.uint8).pin_memory()
-        stage = slot[0][:nbytes].view(host.dtype).view(host.shape)
-        stage.copy_(host)
-        out.copy_(stage, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
-        slot[1] = ev
-        return out
-
-
-class AsyncScalar:
-    """A small device tensor on its way to the host: the copy into a persistent pinned buffer is enqueued now, ``get()``
-    waits only for THAT copy (an event), not for whatever was enqueued after it."""
-
-    _ring, _i = [], 0
-
-    def __init__(self, t):
-        cls = AsyncScalar
-        if t.is_cuda:
-            if len(cls._ring) < 16:
-                cls._ring.append([torch.empty(64, dtype=torch.int64).pin_memory(), None])
-            slot = cls._ring[cls._i % len(cls._ring)]
-            cls._i += 1
-            if slot[1] is not None:
-                slot[1].synchronize()
-            n = t.numel() * t.element_size()
-            if n > slot[0].numel() * 8:
-                raise RuntimeError("AsyncScalar: tensor of %d bytes" % n)
-            self.host = slot[0].view(torch.uint8)[:n].view(t.dtype).view(t.shape)
-            self.host.copy_(t, non_blocking=True)
-            self.event = torch.cuda.Event()
-            self.event.record(torch.cuda.current_stream(t.device))
-            slot[1] = self.event
-        else:
-            self.host, self.event = t.detach().clone(), None
-
-    def get(self):
-        if self.event is not None:
-            self.event.synchronize()
-            self.host, self.event = self.host.clone(), None      # (the ring slot may be reused)
-        return self.host
-
-
-_UPLOADERS = {}
-
-
-def upload(host, device):
-    """``host`` (a CPU tensor) on ``device`` without blocking the host (see _UploadRing); plain copy on a CPU device."""
-    device = torch.device(device)
-    if device.type != "cuda":
-        return host.to(device)
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    ring = _UPLOADERS.get(idx)
-    if ring is None:
-        ring = _UPLOADERS[idx] = _UploadRing(torch.device("cuda", idx))
-    return ring.upload(host)
-
-
-# ---- layout helpers (module boundary only; NCDHW <-> NDHWC) -------------------------------------------
-# ---- side streams (independent branches of one step on concurrent HIP streams) ---------------------------------------
-_SIDE_STREAMS = {}
-
-
-def side_stream(device, name, priority=0):
-    """The process-wide side HIP stream ``name`` of ``device`` (created on first use; ``priority`` < 0: high)."""
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    key = (idx, name)
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=idx, priority=priority)
-    return _SIDE_STREAMS[key]
-
-
-def side_streams(device):
-    """Every side stream handed out for ``device`` -- whoever consumes results off-stream (the gradient reducer's
-    communication stream) has to wait for all of them, not only for the current stream."""
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    return [s for (d, _), s in _SIDE_STREAMS.items() if d == idx]
 
 
 def to_ndhwc(x):

@@ -1,0 +1,449 @@
+"""Weight operands of the HIP convolutions: the differentiable pack (OIDHW -> [tap][ci][CoP]), the folds (conv bias under a
+frozen BatchNorm, nearest-x2 up-sampling into the conv's weights), the lazily gathered Dropout3d slices and ``WeightScope`` --
+one ``k_weight_prepare`` launch per pass for all convs of a module.  Split out of ops.py in round 4;
+``cfun_amd.ops`` re-exports every name, so ``ops.pack_weight`` etc. keep working."""
+import ctypes as C
+import os
+
+import torch
+
+from . import _lib
+from ._lib import ConvParams, check, ptr, stream, workspace
+from .hostio import upload
+
+
+def _round16(v):
+    return (v + 15) // 16 * 16
+
+
+class _PackWeight(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w):
+        co, ci = w.shape[0], w.shape[1]
+        t = w.shape[2] * w.shape[3] * w.shape[4]
+        ctx.wshape = tuple(w.shape)
+        return _pack(w)
+
+    @staticmethod
+    def backward(ctx, dwp):
+        co, ci = ctx.wshape[0], ctx.wshape[1]
+        dwp = dwp.contiguous()
+        dw = torch.empty(ctx.wshape, dtype=torch.float32, device=dwp.device)
+        check(_lib.load().cfun_weight_unpack(ptr(dwp), ptr(dw), co, ci, dwp.shape[0], stream(dwp)), "weight_unpack")
+        return dw
+
+
+def _pack(w, both=False):
+    """OIDHW -> packed wp [T,Ci,CoP]; with ``both`` also the data-gradient layout wpT [T,Co,CiP], same launch."""
+    co, ci = w.shape[0], w.shape[1]
+    t = w.shape[2] * w.shape[3] * w.shape[4]
+    w = w.detach().contiguous()
+    wp = torch.empty((t, ci, _round16(co)), dtype=torch.float32, device=w.device)
+    if not both:
+        check(_lib.load().cfun_weight_pack(ptr(w), ptr(wp), co, ci, t, stream(w)), "weight_pack")
+        return wp
+    wpT = torch.empty((t, co, _round16(ci)), dtype=torch.float32, device=w.device)
+    check(_lib.load().cfun_weight_pack_both(ptr(w), ptr(wp), ptr(wpT), co, ci, t, stream(w)), "weight_pack_both")
+    return wp, wpT
+
+
+def pack_weight(w):
+    """OIDHW [Co,Ci,kd,kh,kw] -> wp [taps, Ci, CoP] (differentiable; one kernel each way)."""
+    return _PackWeight.apply(w)
+
+
+_FOLD_MATRICES = {}
+
+
+def _fold_matrix(k, dtype, device):
+    """f[parity p][low-res offset a + 1][hi-res tap t] = 1 where tap t of output parity p reads low-res offset a -- a
+    constant per kernel size, built on the host once (element writes on a device tensor are one launch each)."""
+    key = (k, dtype, str(device))
+    f = _FOLD_MATRICES.get(key)
+    if f is None:
+        f = torch.zeros(2, 3, k, dtype=dtype)
+        for p in range(2):
+            for t in range(k):
+                f[p, (p + t - k // 2) // 2 + 1, t] = 1.0
+        f = _FOLD_MATRICES[key] = f.to(device)
+    return f
+
+
+class _FoldBias(torch.autograd.Function):
+    """t + b * s for a trainable conv bias b under a frozen BatchNorm's constant fold (s, t): the epilogue shift of
+    bn(conv + b) = conv * s + (b * s + t).  One launch each way (db = g * s) instead of addcmul's generic backward.
+    ``pre``: the consumer is a conv called with ``shift_scaled=True`` and scale = s -- it hands back db itself (the sum of
+    ITS scaled gradient, see _Conv3d.backward), so the backward here is the identity."""
+
+    @staticmethod
+    def forward(ctx, bias, s, t, pre):
+        ctx.pre = pre
+        ctx.save_for_backward(s)
+        return torch.addcmul(t, bias, s)
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.pre:
+            return g, None, None, None
+        (s,) = ctx.saved_tensors
+        return g * s, None, None, None
+
+
+def fold_bias(bias, s, t, pre=False):
+    return _FoldBias.apply(bias, s, t, pre)
+
+
+class _FoldBiasMany(torch.autograd.Function):
+    """[t_i + b_i * s_i for i]: the bias folds of ALL conv + frozen-BatchNorm pairs of a step as one multi-tensor launch
+    each way (torch._foreach_*), instead of one tiny launch per pair and direction."""
+
+    @staticmethod
+    def forward(ctx, n, pre, *args):
+        biases, ss, ts = args[:n], args[n:2 * n], args[2 * n:]
+        ctx.ss, ctx.pre = ss, pre
+        ctx.set_materialize_grads(False)      # a fold no conv consumed this step: its bias gets NO gradient, not zeros
+        return tuple(torch._foreach_addcmul([t for t in ts], [b.detach() for b in biases], list(ss)))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ss = ctx.ss
+        out = list(grads)            # pre: the consumer convs deliver db themselves (see _FoldBias)
+        if not ctx.pre:
+            idx = [i for i, g in enumerate(grads) if g is not None]
+            if idx:
+                prods = torch._foreach_mul([grads[i] for i in idx], [ss[i] for i in idx])
+                for i, p in zip(idx, prods):
+                    out[i] = p
+        return (None, None) + tuple(out) + (None,) * (2 * len(grads))
+
+
+def fold_bias_many(biases, ss, ts, pre=False):
+    return _FoldBiasMany.apply(len(biases), pre, *biases, *ss, *ts)
+
+
+def _fold_tensor(k, dtype, device):
+    """F [8 parities (p,q,r)][k^3 hi-res taps (t,u,v)][27 low-res taps (a,b,c)] = f[p,a,t] f[q,b,u] f[r,c,v]: 0 / 1, constant
+    per kernel size (cached)."""
+    key = ("F", k, dtype, str(device))
+    big = _FOLD_MATRICES.get(key)
+    if big is None:
+        f = _fold_matrix(k, dtype, "cpu")
+        big = torch.einsum("pat,qbu,rcv->pqrtuvabc", f, f, f).reshape(8, k * k * k, 27).contiguous()
+        big = _FOLD_MATRICES[key] = big.to(device)
+    return big
+
+
+class _FoldUp2(torch.autograd.Function):
+    """fold_up2_weight as ONE batched matmul each way: wf[pqr][o][i][abc] = sum_tuv w[o][i][tuv] F[pqr][tuv][abc] (the
+    eight parities are the batch, w is broadcast); an einsum over the three axes costs ~10 launches per weight and
+    direction, four folded weights per step."""
+
+    @staticmethod
+    def forward(ctx, w, cqp):
+        o, i, k = w.shape[0], w.shape[1], w.shape[-1]
+        big = _fold_tensor(k, w.dtype, w.device)
+        a = w.detach().reshape(o, i * k ** 3)
+        if cqp != o:      # pad every parity group to cqp output channels (tile-aligned tap skipping): zero rows
+            a = torch.nn.functional.pad(a, (0, 0, 0, cqp - o))
+        wf = torch.matmul(a.reshape(1, cqp * i, k ** 3), big)              # [8, cqp*i, 27]
+        ctx.save_for_backward(big)
+        ctx.dims = (o, i, k, cqp)
+        return wf.reshape(8 * cqp, i, 3, 3, 3)
+
+    @staticmethod
+    def backward(ctx, g):
+        (big,) = ctx.saved_tensors
+        o, i, k, cqp = ctx.dims
+        g = g.reshape(8, cqp * i, 27)
+        dw = torch.matmul(g, big.transpose(1, 2)).sum(dim=0)               # [cqp*i, k^3]
+        return dw.reshape(cqp, i, k, k, k)[:o], None
+
+
+def fold_up2_weight(w, cqp=None):
+    """Fold "nearest x2 upsample -> conv k^3 (pad k//2)" into a 3x3x3 conv (pad 1) on the LOW-resolution input
+    that produces the 8 output parities as channels: [O,I,k,k,k] -> [8*O, I, 3,3,3], channel ((pz*2+py)*2+px)*O + o.
+    Hi-res tap t of output parity p reads low-res offset floor((p + t - k//2) / 2) in {-1,0,1}; taps that hit the
+    same low-res voxel are summed (differentiable, so the gradient reaches the original 5x5x5 weight).  The
+    hi-res zero padding of k//2 <= 2 maps exactly onto a low-res zero padding of 1."""
+    k = w.shape[-1]
+    if k not in (3, 5):
+        raise ValueError("fold_up2_weight: kernel size %d" % k)
+    cqp = w.shape[0] if cqp is None else cqp
+    scope = WeightScope.current()
+    if scope is not None:          # folded at the start of the pass, its operands are part of the batched preparation
+        wf = scope.folds.get((id(w), cqp))
+        if wf is not None:
+            return wf
+    wf = _FoldUp2.apply(w, cqp)
+    wf._cfun_src = ("f", w, cqp)
+    return wf
+
+
+class _SplitChannels(torch.autograd.Function):
+    """y [..., C] -> (y[..., :c0], y[..., c0:]) as dense tensors; the gradient is ONE concatenation instead of two
+    zero-filled tensors, two copies and their sum (the fused RPN head: class and box outputs of one conv)."""
+
+    @staticmethod
+    def forward(ctx, y, c0):
+        ctx.set_materialize_grads(False)
+        ctx.lead, ctx.widths = tuple(y.shape[:-1]), (c0, y.shape[-1] - c0)
+        return y[..., :c0].contiguous(), y[..., c0:].contiguous()
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None and gb is None:
+            return None, None
+        like = gb if ga is None else ga
+        ga = like.new_zeros(ctx.lead + (ctx.widths[0],)) if ga is None else ga
+        gb = like.new_zeros(ctx.lead + (ctx.widths[1],)) if gb is None else gb
+        return torch.cat([ga, gb], dim=-1), None
+
+
+def split_channels(y, c0):
+    return _SplitChannels.apply(y, c0)
+
+
+class _GatherSlices(torch.autograd.Function):
+    """w -> tuple(w.index_select(dim, idx) for idx in idxs) with ONE gradient: zeros + one index_add_ per slice.
+    n separate index_select nodes each build a full-size zero-filled gradient and autograd then adds the n of them
+    (per-RoI Dropout3d weight slices: 3n - 1 launches per weight instead of n + 1).
+    ``lazy``: the slices are returned as UNWRITTEN tensors of the right shape -- their only consumers are convs whose
+    operands the batched weight preparation (WeightScope) has already gathered straight from ``w``; a consumer that
+    needs the values calls ``materialize_weight`` first."""
+
+    @staticmethod
+    def forward(ctx, w, dim, lazy, *idxs):
+        ctx.dim, ctx.wshape = dim, tuple(w.shape)
+        ctx.save_for_backward(*idxs)
+        if not lazy:
+            return tuple(w.index_select(dim, idx) for idx in idxs)
+        shp = list(w.shape)
+        outs = []
+        for idx in idxs:
+            shp[dim] = idx.numel()
+            outs.append(torch.empty(shp, dtype=w.dtype, device=w.device))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        idxs = ctx.saved_tensors
+        dw = None
+        for idx, g in zip(idxs, grads):
+            if g is None:
+                continue
+            if dw is None:
+                dw = torch.zeros(ctx.wshape, dtype=g.dtype, device=g.device)
+            dw.index_add_(ctx.dim, idx, g)
+        return (dw, None, None) + (None,) * len(idxs)
+
+
+def gather_slices(w, dim, idxs, key=None):
+    """[w.index_select(dim, idx) for idx in idxs], differentiable w.r.t. w with a single accumulated gradient.  ``key``
+    names the index lists inside the active ``WeightScope`` (its ``dyn`` table): where the scope has prepared the operands
+    of every slice the slices themselves are never gathered (see _GatherSlices)."""
+    scope = WeightScope.current()
+    lazy = bool(scope is not None and key is not None and scope.has_gather(w, dim, key, len(idxs)))
+    outs = _GatherSlices.apply(w, dim, lazy, *idxs)
+    if key is not None:
+        for i, (t, idx) in enumerate(zip(outs, idxs)):
+            t._cfun_src = ("g", w, dim, key, i)
+            t._cfun_lazy = (w, dim, idx) if lazy else None
+    return outs
+
+
+def materialize_weight(w):
+    """The values of a lazily gathered weight slice (gather_slices inside a WeightScope), written on first demand."""
+    lz = getattr(w, "_cfun_lazy", None)
+    if lz is not None:
+        base, dim, idx = lz
+        with torch.no_grad():
+            w.detach().copy_(base.detach().index_select(dim, idx))
+        w._cfun_lazy = None
+    return w
+
+
+class WeightScope:
+    """The weight operands of every conv a module runs in one pass, prepared by ONE launch (cfun_weight_prepare) instead of
+    2 - 3 small launches per conv (pack, Winograd transform, stride-2 fold) and one index_select per gathered slice.
+
+    Which convs run, with which parameters, is only known at the call sites: the first pass inside ``with
+    WeightScope(owner)`` records (weight source, conv parameters, needs a data gradient) per ``conv3d_w`` call and stores
+    the list on ``owner``; later passes replay it up front -- fold the up-conv weights, build the job table (one
+    host-to-device copy), launch -- and the convs pick their operands up by (source, operand kinds).  A conv the table
+    does not cover (first pass, another shape, a changed graph) packs its own weight as before and is recorded for the
+    next pass, so the scope never changes results, only the number of launches.  Sources: an ``nn.Parameter``; slice i of
+    ``gather_slices(param, dim, idxs, key=k)`` with this pass's index lists given as ``dyn[k]``; ``fold_up2_weight(param,
+    cqp)``."""
+
+    _stack = []
+
+    def __init__(self, owner, dyn=None, enabled=True):
+        self.owner, self.dyn = owner, dyn or {}
+        self.enabled = bool(enabled) and os.environ.get("CFUN_WEIGHT_SCOPE", "1") != "0"
+        self.table, self.folds, self.seen, self.seen_keys = {}, {}, [], {}
+        self.hits = self.misses = 0
+
+    @classmethod
+    def current(cls):
+        return cls._stack[-1] if cls._stack else None
+
+    def __enter__(self):
+        if self.enabled:
+            WeightScope._stack.append(self)
+            plan = getattr(self.owner, "_cfun_wplan", None)
+            if plan:
+                try:
+                    self._prepare(plan)
+                except Exception:
+                    WeightScope._stack.pop()
+                    raise
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            WeightScope._stack.pop()
+            if exc[0] is None:
+                self.owner._cfun_wplan = self.seen
+        return False
+
+    # -- keys ---------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _desc(w):
+        src = getattr(w, "_cfun_src", None)
+        if src is not None:
+            return src
+        if isinstance(w, torch.nn.Parameter):
+            return ("p", w)
+        return None
+
+    @staticmethod
+    def _desc_key(desc):
+        return (desc[0], id(desc[1])) + tuple(desc[2:])
+
+    @staticmethod
+    def _kinds(p):
+        kinds, nbytes = (C.c_int32 * 2)(), (C.c_size_t * 2)()
+        check(_lib.load().cfun_weight_prepare_kinds(C.byref(p), kinds, nbytes), "weight_prepare_kinds")
+        return int(kinds[0]), int(kinds[1]), int(nbytes[0]), int(nbytes[1])
+
+    def has_gather(self, w, dim, key, n):
+        have = [k for k in self.table if k[0] == "g" and k[1] == id(w) and k[2] == dim and k[3] == key]
+        return len({k[4] for k in have}) == n and n > 0
+
+    # -- the batched preparation ---------------------------------------------------------------------------------------
+    def _prepare(self, plan):
+        lib = _lib.load()
+        jobs, outs, keep = [], [], []
+        total = 0
+        for desc, pbytes, need_dgrad in plan:
+            p = ConvParams.from_buffer_copy(pbytes)
+            base = desc[1]
+            co_idx = ci_idx = None
+            if desc[0] == "p":
+                src = base
+            elif desc[0] == "f":
+                wf = self.folds.get((id(base), desc[2]))
+                if wf is None:
+                    wf = self.folds[(id(base), desc[2])] = fold_up2_weight_eager(base, desc[2])
+                src = wf
+            else:
+                _, _, dim, key, i = desc
+                idxs = self.dyn.get(key)
+                if idxs is None or i >= len(idxs):
+                    continue
+                n = int(idxs[i].numel())
+                if dim == 0:
+                    p.Co, p.CoP, co_idx = n, _round16(n), idxs[i]
+                    if p.d2s or p.d2s_cq:
+                        continue
+                else:
+                    p.Ci, p.CiP, ci_idx = n, _round16(n), idxs[i]
+                src = base
+            if not src.is_contiguous() or src.dtype != torch.float32:
+                continue
+            try:
+                fk, dk, fb, db = self._kinds(p)
+            except RuntimeError:
+                continue
+            if fk == _lib.WOP_NONE:
+                continue
+            if not need_dgrad:
+                dk, db = _lib.WOP_NONE, 0
+            key = self._desc_key(desc) + (fk, dk)
+            if key in self.table:
+                continue
+            offs = []
+            for nb in (fb, db):
+                offs.append(total)
+                total += (nb + 255) // 256 * 256
+            t = p.kd * p.kh * p.kw
+            jobs.append((src, co_idx, ci_idx, int(p.Co), int(p.Ci), t, int(src.shape[1]), fk, dk))
+            outs.append((key, offs, fb, db))
+            self.table[key] = None
+        if not jobs:
+            return
+        dev = jobs[0][0].device
+        arena = torch.empty(max(total, 256), dtype=torch.uint8, device=dev)
+        base_ptr = arena.data_ptr()
+        arr = (_lib.WeightJob * len(jobs))()
+        for j, ((src, co_idx, ci_idx, co, ci, t, src_ci, fk, dk), (key, offs, fb, db)) in enumerate(zip(jobs, outs)):
+            a = arr[j]
+            a.w = ptr(src.detach())
+            a.fwd = base_ptr + offs[0]
+            a.dgrad = (base_ptr + offs[1]) if dk != _lib.WOP_NONE else None
+            a.co_idx = None if co_idx is None else ptr(co_idx)
+            a.ci_idx = None if ci_idx is None else ptr(ci_idx)
+            a.Co, a.Ci, a.T, a.src_ci, a.fwd_kind, a.dgrad_kind = co, ci, t, src_ci, fk, dk
+            self.table[key] = (arena[offs[0]:offs[0] + fb].view(torch.float32),
+                               arena[offs[1]:offs[1] + db].view(torch.float32) if dk != _lib.WOP_NONE else None)
+        nblocks = C.c_int64(0)
+        check(lib.cfun_weight_prepare_plan(arr, len(jobs), C.byref(nblocks)), "weight_prepare_plan")
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        tab = upload(host, dev)
+        check(lib.cfun_weight_prepare(ptr(tab), len(jobs), nblocks.value, stream(arena)), "weight_prepare")
+        self._keep = (tab, [j[0] for j in jobs])      # (held until the launch has been enqueued; the arena lives in the views)
+
+    # -- the conv call site ---------------------------------------------------------------------------------------------
+    def lookup(self, w, p, need_dgrad):
+        """(forward operand, data-gradient operand or None, w_prepared bits) for conv p on weight w, or None."""
+        desc = self._desc(w)
+        if desc is None:
+            return None
+        try:
+            fk, dk, _, _ = self._kinds(p)
+        except RuntimeError:
+            return None
+        if fk == _lib.WOP_NONE:
+            return None
+        dkey = self._desc_key(desc)
+        rec = self.seen_keys.get(dkey + (fk,))
+        if rec is None:
+            p0 = ConvParams.from_buffer_copy(bytes(p))
+            p0.w_prepared = 0
+            self.seen_keys[dkey + (fk,)] = len(self.seen)
+            self.seen.append((desc, bytes(p0), bool(need_dgrad)))
+        elif need_dgrad and not self.seen[rec][2]:
+            self.seen[rec] = self.seen[rec][:2] + (True,)
+        ops_ = self.table.get(dkey + (fk, dk if need_dgrad else _lib.WOP_NONE))
+        if ops_ is None and not need_dgrad:      # prepared with the data-gradient operand although this pass needs none
+            ops_ = self.table.get(dkey + (fk, dk))
+        if ops_ is None:
+            self.misses += 1
+            return None
+        self.hits += 1
+        fwd, dg = ops_
+        return fwd, (dg if need_dgrad else None), (1 | (2 if (need_dgrad and dg is not None) else 0))
+
+
+def fold_up2_weight_eager(w, cqp):
+    wf = _FoldUp2.apply(w, cqp)
+    wf._cfun_src = ("f", w, cqp)
+    return wf
+
+
+def _transpose_pack(wp, co):
+    """wp [T,Ci,CoP] -> wpT [T,Co,CiP] (no grad; used by bwd_data)."""
+    t, ci, _ = wp.shape
+    out = torch.empty((t, co, _round16(ci)), dtype=wp.dtype, device=wp.device)
+    check(_lib.load().cfun_weight_pack_transpose(ptr(wp), ptr(out), co, ci, t, stream(wp)), "weight_pack_transpose")
+    return out
