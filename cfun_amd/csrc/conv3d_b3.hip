@@ -280,9 +280,11 @@ int launch_b3(const float* x, const void* wb3, const float* scale, const float* 
   const int64_t nblk = (int64_t)p.N * ntz * nty * ntx * ncot;
   if (nblk == 0) return CFUN_OK;
   if (nblk > 0x7fffffffLL) return CFUN_EINVAL;
-  if constexpr (NSUB == 5 && !GROUPED && MODE == 0) {
-    if (nblk >= 256) return launch_b3<NSUB, true>(x, wb3, scale, shift, res, y, p, nsub_total, cq, st);
-  }
+  // (The GROUPED form of the NSUB = 5 kernel -- two workgroups per CU inside 256 registers -- is not dispatched any more: it
+  // spills 112 bytes per lane to SCRATCH, and a scratch-using kernel on the mask head's side stream corrupted 64-byte pieces of
+  // tensors the main stream was writing whenever torch's allocator had just returned memory to the driver and asked for new
+  // blocks (round 4, tools/probe_repro.py: 14 of 23 steps not bit-reproducible; 0 of 23 with every kernel of the library at
+  // scratch size 0).  No kernel of libcfun_hip.so may use scratch: tests/test_abi.py checks the code objects.)
   const int nchunks = (p.Ci + 7) >> 3;
   int ksplit = 1;
   if (MODE == 0) ksplit = b3_splitk(nblk, nchunks, p, ws && cfun_aligned16(ws) ? ws_bytes : 0);

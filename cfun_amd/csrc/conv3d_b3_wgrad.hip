@@ -225,6 +225,7 @@ inline W3Plan w3_plan(const CfunConv3dParams& p) {
   // column sub-tiles per workgroup: 3 unless that pads the columns by more than 20 % (NCO = 5 would need more than the
   // 170 registers a 9-wave workgroup leaves each wave)
   w.nco = nsub == 1 ? 1 : ((nsub + 2) / 3 * 3 - nsub) * 5 <= nsub ? 3 : (nsub % 2 == 0 ? 2 : 3);
+  if (w.nco == 2) w.nco = 1;      // k_wgrad_b3<2> spills to scratch under its 168-register cap (9 waves): see launch_b3 on scratch
   w.ncot = (nsub + w.nco - 1) / w.nco;
   // ~3 workgroups per CU in total (one resident per CU: 81 KB of LDS), at least 4 tiles each where the volume allows
   int want = (768 + w.ncisub * w.ncot - 1) / (w.ncisub * w.ncot);
@@ -293,7 +294,6 @@ int cfun_conv3d_b3_wgrad_oidhw(const float* x, const float* g, float* dw, const 
   int rc;
   switch (w.nco) {
     case 3: rc = launch_w3<3>(x, g, (float*)ws, *p, w, st); break;
-    case 2: rc = launch_w3<2>(x, g, (float*)ws, *p, w, st); break;
     default: rc = launch_w3<1>(x, g, (float*)ws, *p, w, st); break;
   }
   if (rc) return rc;
