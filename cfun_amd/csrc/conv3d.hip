@@ -151,12 +151,6 @@ bool use_folded_s2_dgrad(const CfunConv3dParams* p) {
          p->Di == 2 * p->Do && p->Hi == 2 * p->Ho && p->Wi == 2 * p->Wo;
 }
 
-static int s2_dgrad_skip() {      // CFUN_S2_DGRAD_SKIP = 0: the dense 2x2x2 conv (A/B)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("CFUN_S2_DGRAD_SKIP"); v = e ? atoi(e) : 1; }
-  return v;
-}
-
 __global__ void __launch_bounds__(256)
 k_fold_s2_dgrad_weights(const float* __restrict__ wpT, float* __restrict__ wd, int Ci, int Co, int CiP, int CoPd) {
   // one thread per element of wd [8][Co][CoPd]
@@ -589,9 +583,7 @@ int cfun_conv3d_bwd_data(const float* g, const float* wpT, float* dx, const Cfun
       wd = (const float*)ws;
     }
     const Shape* s2 = find_shape(2, 2, 2, 1);
-    ConvMode md = kPlain;
-    md.tap_skip = s2_dgrad_skip() ? 3 : 0;      // the folded-zero (parity, tap) pairs issue no MFMAs (k_conv_mfma MODE 4)
-    return s2->fwd(pick_nsub(q.Co, s2->max_nsub), g, wd, nullptr, nullptr, nullptr, dx, q, md, nullptr, 0, cfun_st(stream));
+    return s2->fwd(pick_nsub(q.Co, s2->max_nsub), g, wd, nullptr, nullptr, nullptr, dx, q, kPlain, nullptr, 0, cfun_st(stream));
   }
   if (use_mfma_dgrad(p, &q, &s)) {
     if (!cfun_aligned16(g) || !cfun_aligned16(wpT) || !cfun_aligned16(dx)) return CFUN_EALIGN;

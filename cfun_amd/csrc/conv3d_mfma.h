@@ -74,7 +74,7 @@ struct ConvMode {
                  // (the output gradient of a depth-to-space conv); weight rows of parity q start at q*in_cqp
   int in_cq, in_cqp;
   int tap_skip;  // 0 none | 1 by the output-channel subtile's parity (every 16-column subtile lies inside one parity group)
-                 // | 2 by the input chunk's parity (flipped taps) | 3 the stride-2 data gradient's 2x2x2 conv: by (tap, subtile)
+                 // | 2 by the input chunk's parity (flipped taps)
   // ---- InstanceNorm / LeakyReLU folded into the conv (CfunConvFusion, include/cfun_hip.h)
   const float* in_stats;  // [N][Ci][2] {mean, rstd} or null: the staged input is in_act((x - mean) * rstd)
   int in_act;             // CFUN_ACT_* applied to the (normalised) input at commit time; zero padding stays zero
@@ -190,18 +190,14 @@ struct FwdTile {
 // own, so that the plain kernels keep their register budget (the sums cost the 64-channel tile a resident wave)
 // MODE 0: plain; 1: s2d gather of the input without tap skipping (data gradient of the folded 5^3 conv); 2: the parity-folded
 // up-conv's forward (md.tap_skip == 1): live taps slot-major, (subtile, slot) MFMA loop; 3: its data gradient (s2d gather,
-// md.tap_skip == 2: the 8 live taps of the input chunk's parity, mirrored), slot-major as well; 4: the 2x2x2 conv that is the
-// data gradient of a stride-2 3x3x3 conv (md.tap_skip == 3: columns = (output parity q, channel); per axis parity 0 meets
-// offset 0 only, so 37 of the 64 (parity, tap) pairs are folded zeros -- MFMAs issued per (tap, 16-column subtile) only where
-// a parity of the subtile has a live tap).
+// md.tap_skip == 2: the 8 live taps of the input chunk's parity, mirrored), slot-major as well.
 template <int KD, int KH, int KW, int S, int NSUB, int MODE, int REM, bool STATS = false>
 __global__ void __launch_bounds__(256)
 k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale,
             const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
             CfunConv3dParams p, ConvMode md, int ntz, int nty, int ntx, int ncot, float* __restrict__ partial,
             int chunks_per_split) {
-  constexpr bool SPECIAL = MODE != 0 && MODE != 4, UPF = MODE == 2, UPD = MODE == 3, S2G = MODE == 4;
-  static_assert(!S2G || (KD == 2 && KH == 2 && KW == 2 && S == 1 && NSUB > 0 && REM == 0), "stride-2 data-gradient tiles");
+  constexpr bool SPECIAL = MODE != 0, UPF = MODE == 2, UPD = MODE == 3;
   static_assert(!UPD || (KD == 3 && KH == 3 && KW == 3 && S == 1 && NSUB > 0 && REM == 0), "up-conv data-gradient tiles");
   static_assert(!UPF || (KD == 3 && KH == 3 && KW == 3 && S == 1 && NSUB > 0 && REM == 0), "up-conv forward tiles");
   using T = FwdTile<KD, KH, KW, S>;
@@ -346,21 +342,6 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
   // stores raw accumulators to partial[blockIdx.y]; cfun_splitk_finish sums them in order and runs the epilogue
   const int c_begin = blockIdx.y * chunks_per_split;
   const int c_end = (c_begin + chunks_per_split < nchunks) ? c_begin + chunks_per_split : nchunks;
-  // S2G: bit tap * 8 + nn of `live` = some parity q among subtile nn's 16 columns meets tap (a, b, c): per axis the offset is
-  // 0 or the parity bit is 1, i.e. (tap & ~q) == 0
-  uint64_t live = 0;
-  if constexpr (S2G) {
-#pragma unroll
-    for (int nn = 0; nn < NSUB; ++nn) {
-      const int c0 = cobase + nn * 16;
-      int q_lo = c0 / CqP, q_hi = (c0 + 15) / CqP;
-      if (q_hi > 7) q_hi = 7;
-      for (int q = q_lo; q <= q_hi; ++q)
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-          if ((t & ~q & 7) == 0) live |= (uint64_t)1 << (t * 8 + nn);
-    }
-  }
   if (c_begin < c_end) prefetch(c_begin);
   for (int c = c_begin; c < c_end; ++c) {
     __syncthreads();           // every wave is done reading the previous chunk
@@ -408,23 +389,6 @@ k_conv_mfma(const float* __restrict__ x, const float* __restrict__ wp, const flo
 #ifndef CFUN_HIP_EMULATION
         if (j & 1) __builtin_amdgcn_sched_barrier(0);      // two slots' reads in flight: hoisting all 8 costs a resident wave
 #endif
-      }
-    } else if constexpr (S2G) {
-#pragma unroll
-      for (int tap = 0; tap < 8; ++tap) {
-        const unsigned lm = (unsigned)(live >> (tap * 8)) & 0xffu;      // wave-uniform
-        if (!lm) continue;
-        const int dz = tap >> 2, dy = (tap >> 1) & 1, dx = tap & 1;
-        float b[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) b[m] = Xw[(dz * T::IY + (m * T::RS + dy)) * T::IX + dx];
-#pragma unroll
-        for (int nn = 0; nn < NSUB; ++nn) {
-          if (!((lm >> nn) & 1u)) continue;
-          const float a = Ww[tap * 4 * NTP + nn * 16];
-#pragma unroll
-          for (int m = 0; m < 4; ++m) acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[m], acc[m][nn], 0, 0, 0);
-        }
       }
     } else {
 #pragma unroll
@@ -565,10 +529,7 @@ int launch_conv_mfma(const float* x, const float* wp, const float* scale, const 
   if (nblk == 0) return CFUN_OK;
   if (nblk > 0x7fffffffLL) return CFUN_EINVAL;
   constexpr bool kHasSpecial = (KD == 3 && KH == 3 && KW == 3 && S == 1);
-  constexpr bool kHasS2G = (KD == 2 && KH == 2 && KW == 2 && S == 1 && NSUB > 0 && REM == 0);
-  const bool s2g = md.tap_skip == 3;
-  if (s2g && (!kHasS2G || md.in_s2d || !p.d2s)) return CFUN_EINVAL;
-  const bool special = !s2g && (md.in_s2d || md.tap_skip);
+  const bool special = md.in_s2d || md.tap_skip;
   if (special && !kHasSpecial) return CFUN_EINVAL;
   // (tap_skip 1 keeps only the 8 live taps of each column in LDS)
   const bool upd = kHasSpecial && NSUB > 0 && REM == 0 && md.in_s2d && md.tap_skip == 2;      // MODE 3
@@ -586,9 +547,6 @@ int launch_conv_mfma(const float* x, const float* wp, const float* scale, const 
     } else {
       if (md.tap_skip == 1) return CFUN_EINVAL;
     }
-  }
-  if constexpr (kHasS2G) {
-    if (s2g) kern = k_conv_mfma<KD, KH, KW, S, NSUB, 4, 0, false>;      // (a data gradient: no statistics epilogue)
   }
   size_t lds_k = lds;
   if (stats && lds_k < stat_lds_floats(NT) * sizeof(float)) lds_k = stat_lds_floats(NT) * sizeof(float);
