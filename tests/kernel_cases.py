@@ -93,6 +93,9 @@ CONV_CASES = {
     "mfma_333_s2_rem_20_40": (1, (8, 8, 10), 20, 40, (3, 3, 3), dict(algo=ALGO_MFMA, stride=2)),
     "mfma_333_d2s_res": (2, (3, 4, 5), 8, 64, (3, 3, 3), dict(algo=ALGO_MFMA, d2s=True, res=True)),
     "auto_111_8_8_pointwise": (1, (16, 32, 64), 8, 8, (1, 1, 1), dict(algo=ALGO_AUTO, res=True, res_up2=True, shift=True, act=ACT_RELU, scale=True)),
+    # k_conv_pointwise_t (rows staged through LDS): 40 = one segment, 64 = two segments of 32; 33 in x: a ragged last group
+    "auto_111_40_8_pointwise_t": (1, (32, 32, 33), 40, 8, (1, 1, 1), dict(algo=ALGO_AUTO, shift=True, act=ACT_LRELU)),
+    "auto_111_64_8_pointwise_t": (2, (16, 32, 33), 64, 8, (1, 1, 1), dict(algo=ALGO_AUTO, res=True, scale=True, per_n=True)),
     "direct_333_d2s_res_cq3": (1, (3, 4, 5), 3, 24, (3, 3, 3), dict(algo=ALGO_DIRECT, d2s=True, res=True, act=ACT_LRELU)),
     # Winograd F(2,3) along x (conv3d_wino.hip): forward and data gradient; ragged tiles, odd widths, epilogue, split-K
     "wino_333_8_48_ragged": (1, (5, 6, 18), 8, 48, (3, 3, 3), dict(algo=ALGO_WINO)),
@@ -127,6 +130,8 @@ CONV_CASES_LARGE = {
     "direct_stem_96": (2, (48, 48, 48), 1, 20, (3, 3, 3), dict(algo=ALGO_DIRECT)),
     "auto_111_40_8_pointwise_res_up2": (2, (24, 32, 34), 40, 8, (1, 1, 1), dict(algo=ALGO_AUTO, res=True, res_up2=True, shift=True)),
     "auto_111_256_8_pointwise": (1, (16, 32, 64), 256, 8, (1, 1, 1), dict(algo=ALGO_AUTO, shift=True, act=ACT_LRELU)),
+    # 80 = 2 row segments of 40 channels through k_conv_pointwise_t (the ds3 conv); 33 x 31 x 33 voxels: a ragged last group
+    "auto_111_80_8_pointwise_ragged": (1, (33, 31, 33), 80, 8, (1, 1, 1), dict(algo=ALGO_AUTO, shift=True, scale=True)),
     "auto_stem_c1_48cube": (2, (48, 48, 50), 1, 20, (3, 3, 3), dict(algo=ALGO_AUTO, scale=True, per_n=True)),
     "auto_p3d_stem_64": (1, (32, 64, 66), 1, 16, (3, 7, 7), dict(stride=2, pad=(1, 3, 3), act=ACT_RELU, scale=True, shift=True, algo=ALGO_AUTO)),
     "auto_333_20_20_48cube": (2, (48, 48, 48), 20, 20, (3, 3, 3), dict(algo=ALGO_AUTO, scale=True, per_n=True)),

@@ -1183,3 +1183,41 @@ def check_two_models_alternating(device, seed=0, rounds=3):
     for net, _, _ in nets:      # each kept a plan of its own (the LiTS net's detector phase never runs its U-Net)
         assert getattr(net, "_cfun_wplan", None)
     assert getattr(nets[0][0].mask.modified_u_net, "_cfun_wplan", None)
+
+
+def check_step_bit_reproducible_under_churn(device, runs=6):
+    """The cfg0 reference-golden step `runs` times in one process -- a fresh network each time, NaN-filled allocator churn and
+    ``torch.cuda.empty_cache()`` in between -- must give bit-identical forward outputs: with the mask head on its own stream, a
+    kernel that wrote where it should not (round 4: scratch memory of a kernel on the side stream, profiles/round4_scratch_hazard.txt)
+    shows up as a few 64-byte pieces of some main-stream tensor, and only in some allocator states."""
+    from cfun_amd import config, step
+    g = load_golden("predict_cfg0")
+    dev = torch.device(device)
+    keys = ("mrcnn_class_logits", "mrcnn_bbox", "rpn_class_logits", "rpn_bbox", "rois", "mrcnn_mask_logits")
+    ref = None
+    for it in range(runs):
+        cfg = config.heart_config("beginning", 64, 64, 32)
+        net = step.CFUNHotPath(cfg)
+        net.load_state_dict(golden_state_dict(g), strict=True)
+        net = net.to(dev)
+        net.mask.modified_u_net.dropout_masks = [torch.from_numpy(g["drop%d" % i]) for i in range(5)]
+        image = torch.from_numpy(g["image"])[None, None].to(dev)
+        out, losses, total = step.training_step_full(
+            net, image, torch.from_numpy(g["gt_class_ids"][0].astype(np.int64)).to(dev),
+            torch.from_numpy(g["gt_boxes"][0]).to(dev), torch.from_numpy(g["gt_masks_labels"]).to(dev),
+            torch.from_numpy(g["rpn_match"]).to(dev), torch.from_numpy(g["rpn_bbox_t"]).to(dev),
+            perms=(torch.from_numpy(g["randperm0"]), torch.from_numpy(g["randperm1"])))
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        got = {k: out[k].detach().cpu().numpy().copy() for k in keys}
+        junk = [torch.full((1000000 * (1 + (it * 7) % 5),), float("nan"), device=dev) for _ in range(3)]
+        del junk, net, out, losses, total
+        if dev.type == "cuda" and it % 2:
+            torch.cuda.empty_cache()
+        if ref is None:
+            ref = got
+            continue
+        for k in keys:
+            assert np.array_equal(got[k], ref[k]), "run %d: %s differs from run 0 (max |diff| %.3e)" % (
+                it, k, np.abs(got[k] - ref[k]).max())
+

@@ -79,6 +79,14 @@ def test_two_models_alternating(gpu):
     mc.check_two_models_alternating(gpu)
 
 
+@pytest.mark.parametrize("algo", ["auto", "b3!"])
+def test_step_bit_reproducible_under_allocator_churn(gpu, monkeypatch, algo):
+    """Product kernels and the opt-in 3xBF16 ones: the two-stream step repeated under allocator churn, bit for bit."""
+    if algo != "auto":
+        monkeypatch.setenv("CFUN_CONV_ALGO", algo)
+    mc.check_step_bit_reproducible_under_churn(gpu, runs=8)
+
+
 def test_cfg2_full_size_step_properties(gpu, monkeypatch):
     """BASELINE.json configs[2] at FULL size (256x256x128, 'finetune', b = 20, 4 + 8 injected RoIs, 96^3 -> 192^3) --
     the step bench.py times: the heads are not skipped, all six losses and the gradients of all 95 trainable tensors are
