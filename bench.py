@@ -423,6 +423,32 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    sharded_parity = None
+    if sharded:
+        # the ranks hold additive SHARES of the one volume's losses: report their sum; and check the layout against the
+        # single-GPU step in this very run -- one more (untimed) sharded step and, on rank 0, the single-process step of the
+        # same sample with the same Dropout3d masks: the summed loss shares must be the single-GPU losses
+        lt = torch.stack([l.detach().float() for l in losses])
+        dist.all_reduce(lt)
+        losses = list(lt)
+        unet = net.mask.modified_u_net
+        pm = parity_dropout_masks(cfg, 4)
+        unet.dropout_masks = cdist.rank_dropout_masks(pm, 4, cdist.ShardContext())
+        lp = torch.stack([l.detach().float() for l in one_step()])
+        dist.all_reduce(lp)
+        if rank == 0:
+            unet.dropout_masks = pm
+            reducer.zero_grad()
+            reducer.arm(sync=False)                 # single-process step: accumulate into the buckets, no collective
+            _, ls, _ = step.training_step(net, sample)
+            ls = [float(l.detach()) for l in ls]
+            rel = [abs(a - b) / max(abs(b), 1e-12) for a, b in zip(lp.tolist(), ls)]
+            sharded_parity = {"what": "sum over the %d ranks' loss shares of one extra, untimed sharded step vs the "
+                                      "single-process step on rank 0 (same weights, sample, Dropout3d masks)" % world,
+                              "sharded_sum": lp.tolist(), "single": ls, "rel_diff": rel, "tolerance_rel": 5e-4,
+                              "ok": bool(max(rel) <= 5e-4)}
+        unet.dropout_masks = None
+        fence()
     lv = [float(l.detach()) for l in losses]
     assert all(v == v and abs(v) != float("inf") for v in lv), "non-finite loss: %s" % lv
 
@@ -453,7 +479,7 @@ def main():
                        "parallelism": ("ONE volume over %d GPUs: depth-sharded FPN/RPN with xGMI halo exchange overlapped "
                                        "with the interior planes, RPN all-gather, classifier RoIs round-robin, every "
                                        "positive RoI's U-Net z-sharded over world/4 ranks when world > 4 (else one RoI per "
-                                       "rank), gradient all-reduce; losses = rank 0's shares" % world) if sharded else
+                                       "rank), gradient all-reduce; losses = the sum of the ranks' shares" % world) if sharded else
                                       ("1 volume per GPU x %d, bucketed gradient all-reduce (RCCL) overlapped with backward"
                                        % world) if world > 1 else "single GPU"},
             "losses": lv,
@@ -488,6 +514,8 @@ def main():
                                              % (2 * b, 2 * b, n_roi_launch, side[0], PEAK_BF16_MFMA_TFLOPS, B3_PRODUCTS))
         if alt is not None:
             result["alt_3xbf16"] = alt
+        if sharded_parity is not None:
+            result["sharded_parity"] = sharded_parity
         if durs_h:   # north_star's "HBM roofline on the 3x3x3 conv kernel": the C_in = 1 stem, algorithmic bytes / time
             t_step = sum(durs_h) / len(durs_h) * 1e-3       # one event pair per launch inside the step (~10 us of overhead)
             t_h, nb2b, hname = stem_back_to_back(cfg, net, n_roi_launch, dev, launches=1 if args.no_hbm_loop else 64)
@@ -556,6 +584,8 @@ def main():
                                              "oracle's CPU backward at the benchmarked size", "tensors": gp, "ok": ok}
             if not ok and parity_fail is None:
                 parity_fail = "gradient parity FAILED at full size: %s" % {k: v["rel_l2"] for k, v in gp.items()}
+        if sharded_parity is not None and not sharded_parity["ok"]:
+            parity_fail = "sharded step does not reproduce the single-GPU losses: rel diff %s" % sharded_parity["rel_diff"]
         print(json.dumps(result), flush=True)
         if parity_fail:
             sys.stderr.write(parity_fail + "\n")

@@ -520,15 +520,21 @@ void launch_pointwise_t(const float* x, const float* wp, const float* scale, con
                        *p, total, nullptr, 0, 0.f);
 }
 
-// CFUN_POINTWISE_LDS = 0: the one-thread-per-row kernel for every shape (A/B)
-int pointwise_staged_ch(const CfunConv3dParams* p) {
+// CFUN_POINTWISE_LDS = 0: the one-thread-per-row kernel for every shape (A/B).  `in`: the launch carries the input prologue,
+// whose (mean, rstd) table shares the workgroup's LDS with the staged rows -- the staged kernel only while both fit the 64 KB
+// a launch gets without raising hipFuncAttributeMaxDynamicSharedMemorySize (N * Ci <= 2 560 at CH = 40); beyond that the
+// per-row kernel, which holds the table alone (the launch failed there with an invalid-value error).
+int pointwise_staged_ch(const CfunConv3dParams* p, bool in) {
   static int knob = -2;
   if (knob == -2) {
     const char* e = getenv("CFUN_POINTWISE_LDS");
     knob = e ? atoi(e) : -1;
   }
   if (knob == 0) return 0;
-  return p->Ci % 40 == 0 ? 40 : p->Ci % 32 == 0 ? 32 : 0;
+  const int ch = p->Ci % 40 == 0 ? 40 : p->Ci % 32 == 0 ? 32 : 0;
+  if (ch == 0) return 0;
+  const size_t lds = (size_t)256 * (ch + 4) * sizeof(float) + (in ? (size_t)p->N * p->Ci * 2 * sizeof(float) : 0);
+  return lds <= 64 * 1024 ? ch : 0;
 }
 
 }  // namespace
@@ -552,7 +558,7 @@ int cfun_conv_pointwise_fwd(const float* x, const float* wp, const float* scale,
   int64_t blocks = (total + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;
   if ((in_stats || in_act != CFUN_ACT_NONE) && !cfun_conv_pointwise_in_supported(p)) return CFUN_EINVAL;
-  if (const int ch = pointwise_staged_ch(p)) {
+  if (const int ch = pointwise_staged_ch(p, in_stats || in_act != CFUN_ACT_NONE)) {
     if (ch == 40) launch_pointwise_t<40>(x, wp, scale, shift, res, y, p, total, in_stats, in_act, in_slope, st);
     else launch_pointwise_t<32>(x, wp, scale, shift, res, y, p, total, in_stats, in_act, in_slope, st);
     CFUN_LAUNCH_CHECK();

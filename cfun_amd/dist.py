@@ -526,6 +526,19 @@ def zshard_plan(shard, n_pos):
     return _ZPLANS[key].get(n_pos)
 
 
+def rank_dropout_masks(masks, n_pos, shard=None, zshard_unet=True):
+    """This rank's rows of preset Dropout3d masks (five [n_pos, C] tensors, one row per positive RoI) for
+    ``sharded_training_step``: the row of the RoI its z-shard sub-group shares, or the rows of its round-robin RoIs."""
+    shard = shard or _CTX or ShardContext()
+    if masks is None:
+        return None
+    plan = zshard_plan(shard, n_pos) if zshard_unet else None
+    if plan is not None:
+        roi = shard.rank // plan[0]
+        return [m[roi:roi + 1] for m in masks]
+    return [m[:n_pos][shard.rank::shard.world] for m in masks]
+
+
 def sharded_training_step(net, s, shard=None, zshard_unet=True, dropout_seed=0):
     """ONE volume on R ranks: forward + the 6 losses + backward of ``cfun_amd.step.training_step`` with
 
@@ -576,7 +589,7 @@ def sharded_training_step(net, s, shard=None, zshard_unet=True, dropout_seed=0):
     # 512x512x256), and the backward all-reduces the crops' gradients the same way before each rank scatters into its slabs.
     rois = torch.cat([s["p_rois"], s["n_rois"]], dim=0)
     n_all, n_pos = rois.shape[0], s["p_rois"].shape[0]
-    mine = torch.arange(r, n_all, R, device=rois.device)
+    mine = torch.arange(n_all, device=rois.device)[r::R]         # (empty on a rank beyond the RoI count: world-4 test)
     slabs = tuple((r * t.shape[1], R * t.shape[1]) for t in (p2s, p3s))
     crops = all_reduce_sum(M.pyramid_roi_align_ndhwc(rois.detach(), [p2s[0], p3s[0]], net.classifier.pool_size, slabs), shard)
     # Every rank must run the crops' backward (an all-reduce): a rank that holds no RoI at all when R > number of RoIs
@@ -591,7 +604,7 @@ def sharded_training_step(net, s, shard=None, zshard_unet=True, dropout_seed=0):
         npos_all = int((s["target_class_ids"] > 0).sum())
         if pos.numel():
             l_box = F.smooth_l1_loss(cls_bbox[pos, 1, :], s["target_deltas"][mine][pos], reduction="sum") / (npos_all * 6)
-    pmine = torch.arange(r, n_pos, R, device=rois.device)
+    pmine = torch.arange(n_pos, device=rois.device)[r::R]
     l_mask = l_edge = zero
     plan = zshard_plan(shard, n_pos) if (zshard_unet and not net.detector_phase_only) else None
     unet = net.mask.modified_u_net
@@ -702,6 +715,7 @@ class GradientReducer:
             for i, p in enumerate(bucket["params"]):
                 self._where[id(p)] = (b, i)
         self.comm_stream = None
+        self._main_stream = None    # the stream the step is enqueued on (zero_grad / arm record it)
         if self.params and self.params[0].is_cuda:
             self.comm_stream = torch.cuda.Stream(device=self.params[0].device)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if self.active else []
@@ -734,6 +748,7 @@ class GradientReducer:
         """Zero the buckets and (re)attach ``p.grad`` to its bucket view; call instead of ``net.zero_grad()``."""
         self._next = 0
         self.hold = False
+        self._record_main()
         for bucket in self.buckets:
             bucket["flat"].zero_()
             bucket["pending"], bucket["work"], bucket["launched"] = len(bucket["params"]), None, False
@@ -749,8 +764,13 @@ class GradientReducer:
             raise RuntimeError("GradientReducer.arm: a reduction is in flight (finish() the previous batch first)")
         self.hold = not sync
         self._next = 0
+        self._record_main()
         for bucket in self.buckets:
             bucket["pending"], bucket["work"], bucket["launched"] = len(bucket["params"]), None, False
+
+    def _record_main(self):
+        if self.comm_stream is not None:
+            self._main_stream = torch.cuda.current_stream(self.params[0].device)
 
     def in_flight(self):
         """Has any bucket's all-reduce been launched since the last zero_grad() / arm() (and not been finished)?"""
@@ -762,9 +782,16 @@ class GradientReducer:
             return
         flat = bucket["flat"]
         if self.comm_stream is not None:
-            self.comm_stream.wait_stream(torch.cuda.current_stream(flat.device))   # the gradients are complete
-            for s in ops.side_streams(flat.device):      # ... including those a branch produced on its own stream
-                self.comm_stream.wait_stream(s)
+            # The gradients are complete once EVERY stream that produced one of the bucket's slices has got this far: the
+            # hook of the bucket's last gradient may fire under a side stream (autograd replays the mask head's nodes on
+            # the stream of their forward pass) while other slices of the same bucket came from the step's main stream --
+            # so wait for the current stream, for the stream the step runs on (recorded by zero_grad / arm) and for every
+            # side stream (without the main stream only timing ordered the all-reduce behind those kernels)
+            cur = torch.cuda.current_stream(flat.device)
+            self.comm_stream.wait_stream(cur)
+            for s in [self._main_stream] + list(ops.side_streams(flat.device)):
+                if s is not None and s != cur:
+                    self.comm_stream.wait_stream(s)
             with torch.cuda.stream(self.comm_stream):
                 bucket["work"] = dist.all_reduce(flat, group=self.group, async_op=True)
         else:

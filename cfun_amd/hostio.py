@@ -39,19 +39,24 @@ class _UploadRing:
 
 class AsyncScalar:
     """A small device tensor on its way to the host: the copy into a persistent pinned buffer is enqueued now, ``get()``
-    waits only for THAT copy (an event), not for whatever was enqueued after it."""
+    waits only for THAT copy (an event), not for whatever was enqueued after it.  The 16 pinned buffers form a ring; an
+    instance whose buffer is about to be handed to a newer one first moves its value into private memory (``_evict``), so a
+    caller may defer any number of scalars (per-step loss logging) and still read each one's own value."""
 
     _ring, _i = [], 0
 
     def __init__(self, t):
         cls = AsyncScalar
         if t.is_cuda:
+            import weakref
             if len(cls._ring) < 16:
                 cls._ring.append([torch.empty(64, dtype=torch.int64).pin_memory(), None])
             slot = cls._ring[cls._i % len(cls._ring)]
             cls._i += 1
             if slot[1] is not None:
-                slot[1].synchronize()
+                owner = slot[1]()
+                if owner is not None:
+                    owner._evict()
             n = t.numel() * t.element_size()
             if n > slot[0].numel() * 8:
                 raise RuntimeError("AsyncScalar: tensor of %d bytes" % n)
@@ -59,15 +64,26 @@ class AsyncScalar:
             self.host.copy_(t, non_blocking=True)
             self.event = torch.cuda.Event()
             self.event.record(torch.cuda.current_stream(t.device))
-            slot[1] = self.event
+            slot[1] = weakref.ref(self)
         else:
             self.host, self.event = t.detach().clone(), None
 
-    def get(self):
+    def _evict(self):
+        """The ring slot is needed by a newer instance: finish the copy and keep the value privately."""
         if self.event is not None:
             self.event.synchronize()
-            self.host, self.event = self.host.clone(), None      # (the ring slot may be reused)
+            self.host, self.event = self.host.clone(), None
+
+    def get(self):
+        self._evict()
         return self.host
+
+    def __del__(self):          # a dropped instance's copy may still be in flight into the slot the ring hands out next
+        try:
+            if self.event is not None:
+                self.event.synchronize()
+        except Exception:
+            pass
 
 
 _UPLOADERS = {}

@@ -150,7 +150,7 @@ def end_step(net, ok=True):
     if scope is not None:
         scope.__exit__(None if ok else RuntimeError, None, None)
     rec = _STEP["record"]
-    if rec is not None and getattr(net, "_cfun_fold_pairs", None) is None:
+    if rec is not None and ok and getattr(net, "_cfun_fold_pairs", None) is None:
         seen, pairs = set(), []
         for c, bn, eps in rec:
             if id(c) not in seen:

@@ -449,9 +449,14 @@ def compute_mrcnn_mask_edge_loss(target_masks, target_class_ids, pred_masks):
 def compute_rpn_class_loss(rpn_match, rpn_class_logits):
     """model.py:808-832 (<= a few hundred anchors: left to torch)."""
     # mean over the non-neutral anchors as a masked sum: torch.nonzero would make the host wait for its result size
+    # (rows the reference never gathers -- neutral anchors -- are SELECTED away before any arithmetic, torch.where on the
+    # inputs: a NaN / Inf there must neither reach the loss nor, as 0 * NaN, the gradient; ADVICE round 4)
     m = rpn_match.squeeze(2).reshape(-1)
-    ce = F.cross_entropy(rpn_class_logits.reshape(-1, rpn_class_logits.shape[-1]), (m == 1).long(), reduction="none")
-    used = (m != 0).to(ce.dtype)
+    usedb = m != 0
+    logits = rpn_class_logits.reshape(-1, rpn_class_logits.shape[-1])
+    logits = torch.where(usedb.unsqueeze(1), logits, torch.zeros_like(logits))
+    ce = F.cross_entropy(logits, (m == 1).long(), reduction="none")
+    used = usedb.to(ce.dtype)
     return (ce * used).sum() / used.sum()
 
 
@@ -461,9 +466,11 @@ def compute_rpn_bbox_loss(target_bbox, rpn_match, rpn_bbox):
     # per anchor and masked -- no nonzero(), no host wait
     pos = (rpn_match.squeeze(2).reshape(-1) == 1)
     row = (torch.cumsum(pos.long(), 0) - 1).clamp(min=0, max=target_bbox.shape[1] - 1)
-    l1 = F.smooth_l1_loss(rpn_bbox.reshape(-1, 6), target_bbox[0][row], reduction="none")
-    posf = pos.to(l1.dtype)
-    return (l1 * posf.unsqueeze(1)).sum() / (posf.sum() * 6)
+    pred, tgt = rpn_bbox.reshape(-1, 6), target_bbox[0][row]
+    sel = pos.unsqueeze(1)                  # non-positive rows: both operands selected to 0 (no 0 * NaN, see above)
+    l1 = F.smooth_l1_loss(torch.where(sel, pred, torch.zeros_like(pred)), torch.where(sel, tgt, torch.zeros_like(tgt)),
+                          reduction="none")
+    return l1.sum() / (pos.to(l1.dtype).sum() * 6)
 
 
 def compute_mrcnn_class_loss(target_class_ids, pred_class_logits):
@@ -477,7 +484,10 @@ def compute_mrcnn_bbox_loss(target_bbox, target_class_ids, pred_bbox):
     """model.py:881-906 with the binarised ids (class column 1)."""
     if target_class_ids.numel() == 0:
         return torch.zeros((), device=pred_bbox.device)
-    pos = (target_class_ids > 0).to(pred_bbox.dtype)          # masked mean: no nonzero(), no host wait
-    l1 = F.smooth_l1_loss(pred_bbox[:, 1, :], target_bbox, reduction="none")
-    cnt = pos.sum() * 6
-    return torch.where(cnt > 0, (l1 * pos.unsqueeze(1)).sum() / cnt.clamp(min=1), torch.zeros_like(cnt))
+    posb = target_class_ids > 0                               # masked mean: no nonzero(), no host wait
+    sel = posb.unsqueeze(1)                 # negative RoIs' rows (padded / uninitialised targets) are selected to 0 first
+    pred = pred_bbox[:, 1, :]
+    l1 = F.smooth_l1_loss(torch.where(sel, pred, torch.zeros_like(pred)),
+                          torch.where(sel, target_bbox, torch.zeros_like(target_bbox)), reduction="none")
+    cnt = posb.to(pred_bbox.dtype).sum() * 6
+    return torch.where(cnt > 0, l1.sum() / cnt.clamp(min=1), torch.zeros_like(cnt))

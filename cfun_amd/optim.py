@@ -108,23 +108,34 @@ class FlatSGD:
                       "sumsq_partials")
             check(lib.cfun_norm_finalize(ptr(self._partials), self._partials.numel(), ptr(self.grad_norm),
                                          stream(self.grad_norm)), "norm_finalize")
-        keep = []            # parameters no backward pass reached since zero_grad(): torch.optim.SGD leaves them alone
-        touched = self._touched
-        if self.reducer.active and self._slots:      # ... on ANY rank: a parameter is left alone only if no rank reached it
+        # Parameters no backward pass reached since zero_grad(): torch.optim.SGD leaves them (and their momentum) alone.  With
+        # data-parallel ranks a parameter is left alone only if NO rank reached it -- which implies this rank did not, so the
+        # candidates are known on the host; whether a candidate was reached elsewhere stays on the DEVICE (flags all-reduced
+        # with MAX, then torch.where): no host read between the bucket reductions and the update.
+        cand = [i for i, hit in enumerate(self._touched) if not hit]
+        flags = None
+        if self.reducer.active and self._slots:
             import torch.distributed as tdist
-            flags = torch.tensor([1 if t else 0 for t in touched], dtype=torch.int32, device=self.param_arenas[0].device)
+            from . import hostio
+            flags = hostio.upload(torch.tensor([1 if t else 0 for t in self._touched], dtype=torch.int32),
+                                  self.param_arenas[0].device)
             tdist.all_reduce(flags, op=tdist.ReduceOp.MAX, group=self.reducer.group)
-            touched = [bool(v) for v in flags.tolist()]
-        for (p, a, off), hit in zip(self._slots, touched):
-            if not hit:
-                m = self.momentum_arenas[a][off:off + p.numel()]
-                keep.append((p, m, p.data.clone(), m.clone()))
+        keep = []
+        for i in cand:
+            p, a, off = self._slots[i]
+            m = self.momentum_arenas[a][off:off + p.numel()]
+            keep.append((i, p, m, p.data.clone(), m.clone()))
         for bucket, p, m in zip(self.reducer.buckets, self.param_arenas, self.momentum_arenas):
             g = bucket["flat"]
             check(lib.cfun_sgd_momentum_step(ptr(p), ptr(g), ptr(m), p.numel(), self.lr, self.momentum,
                                              self.weight_decay, clip, ptr(self.grad_norm) if clip > 0.0 else None,
                                              1 if self.steps == 0 else 0, stream(p)), "sgd_momentum_step")
-        for p, m, p0, m0 in keep:
-            p.data.copy_(p0)
-            m.copy_(m0)
+        for i, p, m, p0, m0 in keep:
+            if flags is None:
+                p.data.copy_(p0)
+                m.copy_(m0)
+            else:                   # reached on another rank: keep the update
+                hit = flags[i] > 0
+                p.data.copy_(torch.where(hit, p.data, p0))
+                m.copy_(torch.where(hit, m, m0.view_as(m)))
         self.steps += 1

@@ -132,6 +132,7 @@ class CFUNHotPath(nn.Module):
         mask_logits = mask_probs = cls_logits = cls_probs = cls_bbox = None
         join = lambda: None
         layers.begin_step(self)         # the step's conv-bias folds under frozen BatchNorm: one multi-tensor launch
+        ok = False
         try:
             if not self.detector_phase_only:
                 mask_logits, mask_probs, join = self._mask_head(image, p_rois)  # enqueued first, on its own stream
@@ -140,8 +141,9 @@ class CFUNHotPath(nn.Module):
             if not self.mask_phase_only:
                 rois = torch.cat([p_rois, n_rois], dim=0)
                 cls_logits, cls_probs, cls_bbox = self.classifier.forward_ndhwc([p2[0], p3[0]], rois)
+            ok = True
         finally:
-            layers.end_step(self)
+            layers.end_step(self, ok)   # (a pass that raised must not leave its partial record as the net's weight plan)
         join()
         return dict(rpn_class_logits=rpn_logits, rpn_probs=rpn_probs, rpn_bbox=rpn_bbox, rpn_rois=rpn_rois,
                     mrcnn_class_logits=cls_logits, mrcnn_class=cls_probs, mrcnn_bbox=cls_bbox,

@@ -96,6 +96,9 @@ CONV_CASES = {
     # k_conv_pointwise_t (rows staged through LDS): 40 = one segment, 64 = two segments of 32; 33 in x: a ragged last group
     "auto_111_40_8_pointwise_t": (1, (32, 32, 33), 40, 8, (1, 1, 1), dict(algo=ALGO_AUTO, shift=True, act=ACT_LRELU)),
     "auto_111_64_8_pointwise_t": (2, (16, 32, 33), 64, 8, (1, 1, 1), dict(algo=ALGO_AUTO, res=True, scale=True, per_n=True)),
+    # the input prologue's (mean, rstd) table next to the staged rows: N * C_in = 3 200 > 2 560 does not fit 64 KB of LDS with
+    # them -> the per-row kernel must take the prologue launches (the staged launch failed with invalid value)
+    "auto_111_40_8_pointwise_prologue_big_n": (80, (8, 8, 8), 40, 8, (1, 1, 1), dict(algo=ALGO_AUTO, shift=True)),
     "direct_333_d2s_res_cq3": (1, (3, 4, 5), 3, 24, (3, 3, 3), dict(algo=ALGO_DIRECT, d2s=True, res=True, act=ACT_LRELU)),
     # Winograd F(2,3) along x (conv3d_wino.hip): forward and data gradient; ragged tiles, odd widths, epilogue, split-K
     "wino_333_8_48_ragged": (1, (5, 6, 18), 8, 48, (3, 3, 3), dict(algo=ALGO_WINO)),

@@ -75,3 +75,31 @@ def test_two_ranks_cfg1_volume_sharded_step(gpu, tmp_path):
     np.testing.assert_allclose(r[0]["c0z_losses"], ref["c0z_ref_losses"], rtol=5e-4, atol=1e-6)
     w = _grads_close(ref["c0_names"], ref["c0_sizes"], r[0]["c0z_grads"], ref["c0z_ref_grads"], 2e-3, 2e-2)
     print("128x128x64 z-sharded U-Net step, worst gradient rel-L2 vs single process:", w)
+
+
+def test_four_ranks_on_real_kernels(gpu, tmp_path):
+    """FOUR ranks on the real kernels (4 processes on cuda:0, gloo) -- interior ranks with a
+    previous and a next neighbour, slabs of 1 - 2 p3 planes, 2 RoIs x 2 ranks and 1 RoI x 4 ranks z-sharded, round-robin
+    with idle ranks through the ordered GradientReducer (tiny channel counts), and BASELINE configs[1]'s volume with the
+    real channel counts: 4 + 8 RoIs one positive RoI per rank, then 2 positive RoIs z-sharded over 2 ranks each."""
+    from test_dist_gloo import check_worldn, run_world
+    env = {k: v for k, v in os.environ.items() if k not in ("CFUN_LIB_PATH", "CFUN_CONV_ALGO")}
+    env["PYTHONPATH"] = ROOT
+    sections = "halo,conv,rpn,step,rr,dp,unet,cfg1"
+    r = run_world(tmp_path, env, 4, "dist_worker_n.py", ("cuda:0", sections), timeout=1800)
+    print("4 ranks on one GPU, worst gradient rel-L2 vs single process:", check_worldn(r, sections))
+
+
+def test_rccl_two_gpus(tmp_path):
+    """The `nccl` (= RCCL) branch of ``dist._exchange`` -- device buffers straight into batch_isend_irecv on the side
+    stream -- and the reducer's RCCL all-reduces, with a real peer: 2 processes on 2 GPUs.  Skips cleanly on the 1-GPU test
+    box; the first multi-GPU lease runs it before bench.py does."""
+    import torch
+    from test_dist_gloo import check_worldn, run_world
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (RCCL refuses two ranks on one device)")
+    env = {k: v for k, v in os.environ.items() if k not in ("CFUN_LIB_PATH", "CFUN_CONV_ALGO")}
+    env.update(PYTHONPATH=ROOT, CFUN_DIST_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sections = "halo,conv,rpn,step,rr,dp,unet"
+    r = run_world(tmp_path, env, 2, "dist_worker_n.py", ("cuda", sections), timeout=1800)
+    print("2 ranks over RCCL, worst gradient rel-L2 vs single process:", check_worldn(r, sections))

@@ -173,3 +173,50 @@ def test_predict_lits_golden(emu_direct, stage):
 
 def test_input_pipeline(emu):
     mc.check_input_pipeline(emu)
+
+
+def test_masked_losses_ignore_rows_the_reference_never_gathers():
+    """the nonzero()-free losses mask instead of gathering -- a NaN / Inf in a row the reference would never
+    have gathered (a neutral anchor's logits, a negative RoI's padded target row) must reach neither the loss nor, as
+    0 * NaN, the gradients; with finite inputs the masked form equals the gather form of model.py:808-906."""
+    import torch
+    import torch.nn.functional as F
+    from cfun_amd import model as M
+    g = torch.Generator().manual_seed(0)
+    A = 40
+    match = torch.zeros(1, A, 1, dtype=torch.int32)
+    match[0, [3, 9, 20], 0] = 1
+    match[0, [1, 2, 30, 31], 0] = -1
+    logits = torch.randn(1, A, 2, generator=g)
+    bbox = torch.randn(1, A, 6, generator=g)
+    tgt = torch.zeros(1, 8, 6)
+    tgt[0, :3] = torch.randn(3, 6, generator=g)
+    tgt[0, 3:] = float("nan")                     # padded rows of the RPN target
+    neutral = (match[0, :, 0] == 0).nonzero()[:, 0]
+    nonpos = (match[0, :, 0] != 1).nonzero()[:, 0]
+    lg, bb = logits.clone(), bbox.clone()
+    lg[0, neutral[0]] = float("nan")
+    lg[0, neutral[1]] = float("inf")
+    bb[0, nonpos[0]] = float("nan")
+    lg.requires_grad_(True)
+    bb.requires_grad_(True)
+    l1, l2 = M.compute_rpn_class_loss(match, lg), M.compute_rpn_bbox_loss(tgt, match, bb)
+    (l1 + l2).backward()
+    m = match[0, :, 0]
+    ref1 = F.cross_entropy(logits[0][m != 0], (m[m != 0] == 1).long())
+    ref2 = F.smooth_l1_loss(bbox[0][m == 1], tgt[0, :3])
+    assert torch.allclose(l1, ref1, rtol=1e-6, atol=1e-7) and torch.allclose(l2, ref2, rtol=1e-6, atol=1e-7)
+    assert torch.isfinite(lg.grad).all() and torch.isfinite(bb.grad).all()
+    assert float(lg.grad[0, neutral].abs().max()) == 0.0 and float(bb.grad[0, nonpos].abs().max()) == 0.0
+    # head box loss: negative RoIs' target rows are uninitialised in the reference's buffers
+    ids = torch.tensor([2, 1, 0, 0, 0])
+    tb = torch.randn(5, 6, generator=g)
+    pb = torch.randn(5, 2, 6, generator=g)
+    tb2, pb2 = tb.clone(), pb.clone()
+    tb2[3] = float("nan")
+    pb2[4, 1] = float("inf")
+    pb2.requires_grad_(True)
+    l3 = M.compute_mrcnn_bbox_loss(tb2, ids, pb2)
+    l3.backward()
+    assert torch.allclose(l3, F.smooth_l1_loss(pb[:2, 1], tb[:2]), rtol=1e-6, atol=1e-7)
+    assert torch.isfinite(pb2.grad).all() and float(pb2.grad[2:].abs().max()) == 0.0

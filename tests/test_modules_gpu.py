@@ -521,3 +521,14 @@ def test_predict_lits_golden(gpu, stage):
 
 def test_input_pipeline(gpu):
     mc.check_input_pipeline(gpu)
+
+
+def test_async_scalar_ring_keeps_every_deferred_value(gpu):
+    """AsyncScalar's 16 pinned buffers are a ring -- an instance whose buffer is handed to a newer one must
+    keep ITS value (40 scalars deferred, read back afterwards in creation order and in reverse)."""
+    import torch
+    from cfun_amd import hostio
+    vals = [torch.full((3,), float(i), device=gpu) + torch.arange(3, device=gpu) for i in range(40)]
+    pend = [hostio.AsyncScalar(v) for v in vals]
+    for i in list(range(0, 40, 2)) + list(range(39, 0, -2)):
+        assert pend[i].get().tolist() == [float(i), float(i) + 1, float(i) + 2], i
