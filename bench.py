@@ -81,12 +81,44 @@ def dominant_kernel_info(cfg, n_roi):
     twod, nsub, sb, cols = [int(v) for v in plan]
     executed = 2.0 * tiles * 256 * 27 * ((4.0 / 9.0) if twod else (2.0 / 3.0)) * (2 * b) * cols
     if twod:
-        label = ("k_conv_wino<%d, 2-D%s> (x and y in the Winograd F(2x2,3x3) domain: 4/9 of the direct MACs on the MFMA pipe, "
-                 "incl. its k_wino2_weights transform launch)" % (nsub, ", two waves per SIMD" if sb else ""))
+        label = ("k_conv_wino<%d, 2-D%s> (x and y in the Winograd F(2x2,3x3) domain: 4/9 of the direct MACs on the MFMA pipe; "
+                 "weights transformed by the step's batched cfun_weight_prepare launch)" % (nsub, ", two waves per SIMD" if sb else ""))
     else:
-        label = ("k_conv_wino<%d> (x axis in the Winograd F(2,3) domain: 2/3 of the direct MACs on the MFMA pipe, incl. its "
-                 "k_wino_weights transform launch)" % nsub)
+        label = ("k_conv_wino<%d> (x axis in the Winograd F(2,3) domain: 2/3 of the direct MACs on the MFMA pipe; weights "
+                 "transformed by the step's batched cfun_weight_prepare launch, outside the timed call)" % nsub)
     return kern, executed, label
+
+
+def dominant_back_to_back(cfg, n_roi, dev, launches=8):
+    """conv_norm_lrelu_l4.0's forward through the C ABI, `launches` times back to back between one pair of HIP events, two
+    ways: (a) KERNEL ONLY -- the operand the step's batched weight preparation hands it (w_prepared; for timing any values
+    of the right size do), plain epilogue: one launch per call, the figure rocprofv3's per-kernel average reproduces;
+    (b) from the plain packed weight: the call first launches its own weight transform (what a caller outside a
+    WeightScope pays).  Returns (seconds per call (a), seconds per call (b))."""
+    import ctypes as C
+    from cfun_amd import _lib, ops
+    b, side = cfg.UNET_MASK_BRANCH_CHANNEL, tuple(cfg.MASK_POOL_SIZE)
+    lib = _lib.load()
+    spec = ops.ConvSpec(k=(3, 3, 3), co=2 * b, pad=(1, 1, 1))
+    with torch.no_grad():
+        x = torch.randn((n_roi,) + side + (2 * b,), device=dev)
+        y = torch.empty((n_roi,) + side + (2 * b,), device=dev)
+        out = []
+        for prepared in (True, False):
+            p = ops._params(spec, x.shape, False, False, False)
+            if prepared:
+                kinds, nbytes = (C.c_int32 * 2)(), (C.c_size_t * 2)()
+                _lib.check(lib.cfun_weight_prepare_kinds(C.byref(p), kinds, nbytes), "weight_prepare_kinds")
+                wp = torch.randn(max(1, int(nbytes[0]) // 4), device=dev) * 0.05
+                p.w_prepared = 1
+            else:
+                wp = ops.pack_weight(torch.randn(2 * b, 2 * b, 3, 3, 3, device=dev) * 0.05)
+            ws = _lib.workspace(lib.cfun_conv3d_fwd_workspace_bytes(C.byref(p)), x)
+            args = (_lib.ptr(x), _lib.ptr(wp), None, None, None, _lib.ptr(y), C.byref(p), _lib.ptr(ws), ws.numel(), _lib.stream(x))
+            for _ in range(2):
+                _lib.check(lib.cfun_conv3d_fwd(*args), "conv3d_fwd")
+            out.append(back_to_back(lambda: lib.cfun_conv3d_fwd(*args), launches))
+    return out[0], out[1]
 
 
 B2B_REPS = []      # every repetition of the last back_to_back() call, ms per launch (reported next to the figure used)
@@ -289,9 +321,12 @@ def cpu_baseline(cfg, net, sample, threads, iters=1, small_iters=3):
         small = {"workload": "BASELINE configs[0]: 64x64x32 volume, stage 'beginning', 1 positive + 2 negative RoIs, forward + backward",
                  "value": 1.0 / st[len(st) // 2], "unit": "volumes/s", "iters": len(st), "median_s": st[len(st) // 2]}
     times, losses, grads = [], None, None
-    for _ in range(max(1, iters)):
+    want = iters if iters > 0 else 3
+    for i in range(want):
         t, losses, grads = one(cfg, net, sample, 4)
         times.append(t)
+        if iters <= 0 and i == 0 and t >= 60.0:      # auto: a slow host times one iteration only
+            break
     med = sorted(times)[len(times) // 2]
     d, h, w = cfg.image_dhw
     phys, logical = physical_cores()
@@ -313,8 +348,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-iters", type=int, default=1,
-                    help="timed full iterations of the oracle's CPU step (median reported); each takes ~1 min at cfg2")
+    ap.add_argument("--cpu-baseline-iters", type=int, default=0,
+                    help="timed full iterations of the oracle's CPU step (median reported).  0 (default): 3 -- the median of 3 "
+                         "warm iterations SURVEY.md section 8(d) asks for -- when the first one takes < 60 s on this host, "
+                         "else that one only (the whole run has to finish within a few minutes)")
     ap.add_argument("--no-alt", action="store_true",
                     help="skip the extra, separately reported leg on the opt-in 3xBF16 conv kernels (CFUN_CONV_ALGO=b3)")
     ap.add_argument("--no-hbm-loop", action="store_true",
@@ -498,6 +535,19 @@ def main():
                                       "`mfma_util_pmc` (SQ_VALU_MFMA_BUSY_CYCLES) -- read those as the utilisation figure",
                          "avg_launch_ms": t_k * 1e3, "launches_timed": len(durs)},
         }
+        if args.workload == "cfg2" and not b3 and not args.no_hbm_loop and kern == 2:
+            # the same conv back to back outside the step: kernel only (comparable to rocprofv3's per-kernel average under
+            # profiles/) and with the per-call weight transform a caller outside a WeightScope pays
+            t_ko, t_wt = dominant_back_to_back(cfg, n_roi_launch, dev)
+            result["roofline"].update(
+                avg_launch_ms_note="`avg_launch_ms` (behind `frac`): one HIP-event pair per call INSIDE the step -- the conv "
+                                   "kernel plus the finalize of its epilogue's InstanceNorm statistics, the mask head sharing the "
+                                   "GPU with the detector stream; the weight transform is NOT in it (hoisted into the step's one "
+                                   "cfun_weight_prepare launch)",
+                avg_launch_ms_kernel_only=t_ko * 1e3, frac_kernel_only=flops / t_ko / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                avg_launch_ms_with_weight_transform=t_wt * 1e3,
+                frac_with_weight_transform=flops / t_wt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                back_to_back="8 calls between one HIP-event pair, 4 repetitions, first dropped, median of 3 (as roofline_hbm)")
         for leg in ("dgrad", "wgrad"):      # the same conv's data / weight gradient calls inside the step (HIP events, incl. the
             dl = timer.durations_ms("mfma_" + leg)      # weight-gradient chunk reduction; the mask head shares the GPU with the detector stream)
             if dl:
