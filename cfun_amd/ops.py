@@ -100,6 +100,50 @@ class LaunchTimer:
 
 
 _TIMER = None
+# The weight gradient of a conv is off the backward chain's critical path -- dx feeds the next layer, dw only the optimizer --
+# so conv3d_w's backward enqueues it on a HIP stream of its own BEFORE the data gradient: it runs beside the chain's HBM- and
+# latency-bound stretches (norm / activation gradients, the small launches of the deep levels): 42.9 -> 40.0 ms per step at
+# cfg2 (round 5, same box A/B).  CFUN_WGRAD_STREAM=0: everything on the chain's stream.
+WGRAD_STREAM = os.environ.get("CFUN_WGRAD_STREAM", "1") == "1"
+
+
+def wgrad_stream(device, chain_stream):
+    """The weight-gradient stream that belongs to the stream a conv runs on (one per chain: the mask head's and the
+    detector's weight gradients do not queue behind each other)."""
+    return side_stream(device, "wgrad%d" % chain_stream.cuda_stream)
+
+
+class _OnWgradStream(torch.autograd.Function):
+    """Identity on a weight whose autograd NODE lives on the weight-gradient stream.  conv3d_w's backward produces dw on that
+    stream; the engine attributes a gradient to the stream of the node that returned it (the conv's forward stream) and orders
+    consumers only against that.  Routed through this node -- created under the weight-gradient stream, so the engine runs its
+    backward there and records ITS event there -- dw reaches every consumer (AccumulateGrad, the gather / fold backward of a
+    sliced or folded weight, a reducer hook) ordered behind the kernels that write it, with no hand-placed waits; the leaf's
+    accumulation runs on the same stream and ``backward()`` joins it with the caller's stream at its end."""
+
+    @staticmethod
+    def forward(ctx, w):
+        return w.view_as(w)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def _tag_wgrad_stream(w, x):
+    if not (WGRAD_STREAM and x.is_cuda and w.requires_grad and torch.is_grad_enabled()):
+        return w
+    cur = torch.cuda.current_stream(x.device)
+    with torch.cuda.stream(wgrad_stream(x.device, cur)):
+        wj = _OnWgradStream.apply(w)
+    desc = WeightScope._desc(w)
+    if desc is not None:
+        wj._cfun_src = desc
+    lz = getattr(w, "_cfun_lazy", None)
+    if lz is not None:
+        wj._cfun_lazy = lz
+    wj._cfun_wstream = True
+    return wj
 
 
 def set_launch_timer(timer):
@@ -234,6 +278,7 @@ class _Conv3d(torch.autograd.Function):
         ctx.b3 = b3
         ctx.pro = None if pro is None else (int(pro[1]), float(pro[2]))
         ctx.shift_scaled = bool(shift_scaled)
+        ctx.w_on_stream = bool(w_src is not None and getattr(w_src, "_cfun_wstream", False))
         ctx.save_for_backward(x, wp if not (p.w_prepared & 1) else None, scale, y if spec.act != ACT_NONE else None, wpT,
                               w_src.detach() if b3 and ctx.needs_input_grad[0] else None,
                               None if pro is None or pro[0] is None else _c(pro[0]))
@@ -277,7 +322,41 @@ class _Conv3d(torch.autograd.Function):
                 g = torch.empty_like(dy)
                 check(lib.cfun_act_bwd(None, ptr(gp), ptr(scale), ptr(g), nvox, p.Co, p.Do * p.Ho * p.Wo, ACT_NONE,
                                        LRELU_SLOPE, p.scale_mode, st), "act_bwd(scale)")
+        def run_wgrad(st):
+            dw = torch.empty(ctx.wshape, dtype=torch.float32, device=dy.device)
+            if spec.algo == ALGO_B3 and _b3_wgrad_wanted(lib, p):      # opt-in 3xBF16 weight gradient
+                ws = workspace(lib.cfun_conv3d_b3_wgrad_workspace_bytes(C.byref(p)), x)
+                check(lib.cfun_conv3d_b3_wgrad_oidhw(ptr(x), ptr(g), ptr(dw), C.byref(p), ptr(ws), ws.numel(), st),
+                      "conv3d_b3_wgrad_oidhw")
+            elif fz is not None:
+                ws = workspace(lib.cfun_conv3d_bwd_weight_workspace_bytes(C.byref(p)), x)
+                check(lib.cfun_conv3d_bwd_weight_fused(ptr(x), ptr(g), ptr(dw), 1, C.byref(p), C.byref(fz), ptr(ws),
+                                                       ws.numel(), st), "conv3d_bwd_weight_fused(oidhw)")
+            else:
+                nb = lib.cfun_conv3d_bwd_weight_workspace_bytes(C.byref(p))
+                ws = workspace(nb, x)
+                tk = _TIMER.match(p) if (_TIMER is not None and x.is_cuda) else None
+                if tk:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                check(lib.cfun_conv3d_bwd_weight_oidhw(ptr(x), ptr(g), ptr(dw), C.byref(p), ptr(ws), ws.numel(), st),
+                      "conv3d_bwd_weight_oidhw")
+                if tk:
+                    e1.record()
+                    _TIMER.add(tk + "_wgrad", e0, e1)
+            return dw
         dx = dwp = dshift = dres = dw = None
+        # the weight gradient on its own stream, enqueued BEFORE the data gradient (see WGRAD_STREAM / _OnWgradStream)
+        side_w = None
+        if need_wsrc and ctx.w_on_stream:
+            cur_s = torch.cuda.current_stream(dy.device)
+            side_w = wgrad_stream(dy.device, cur_s)
+            side_w.wait_stream(cur_s)            # g (and x) are complete
+            with torch.cuda.stream(side_w):
+                dw = run_wgrad(side_w.cuda_stream)
+            for t in (x, g, pst):
+                if t is not None:
+                    t.record_stream(side_w)
         if need_x:
             # dx of a per-sample conv goes straight into its sample of the batch's gradient (zero-copy batch split)
             dx = torch.empty_like(x) if ctx.dx_slot is None else ctx.dx_slot[0].sample(ctx.dx_slot[1], x.shape, x)
@@ -325,28 +404,8 @@ class _Conv3d(torch.autograd.Function):
             else:
                 check(lib.cfun_conv3d_bwd_weight(ptr(x), ptr(g), ptr(dwp), C.byref(p), ptr(ws), ws.numel(), st),
                       "conv3d_bwd_weight")
-        if need_wsrc:
-            dw = torch.empty(ctx.wshape, dtype=torch.float32, device=dy.device)
-            if spec.algo == ALGO_B3 and _b3_wgrad_wanted(lib, p):      # opt-in 3xBF16 weight gradient
-                ws = workspace(lib.cfun_conv3d_b3_wgrad_workspace_bytes(C.byref(p)), x)
-                check(lib.cfun_conv3d_b3_wgrad_oidhw(ptr(x), ptr(g), ptr(dw), C.byref(p), ptr(ws), ws.numel(), st),
-                      "conv3d_b3_wgrad_oidhw")
-            elif fz is not None:
-                ws = workspace(lib.cfun_conv3d_bwd_weight_workspace_bytes(C.byref(p)), x)
-                check(lib.cfun_conv3d_bwd_weight_fused(ptr(x), ptr(g), ptr(dw), 1, C.byref(p), C.byref(fz), ptr(ws),
-                                                       ws.numel(), st), "conv3d_bwd_weight_fused(oidhw)")
-            else:
-                nb = lib.cfun_conv3d_bwd_weight_workspace_bytes(C.byref(p))
-                ws = workspace(nb, x)
-                tk = _TIMER.match(p) if (_TIMER is not None and x.is_cuda) else None
-                if tk:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                check(lib.cfun_conv3d_bwd_weight_oidhw(ptr(x), ptr(g), ptr(dw), C.byref(p), ptr(ws), ws.numel(), st),
-                      "conv3d_bwd_weight_oidhw")
-                if tk:
-                    e1.record()
-                    _TIMER.add(tk + "_wgrad", e0, e1)
+        if need_wsrc and side_w is None:
+            dw = run_wgrad(st)
         if need_shift:      # (shift_scaled: db = sum(g) whichever way g was formed)
             dshift = channel_sum((g if ctx.shift_scaled and scale is not None else gp).view(-1, p.Co))
         if need_res:
@@ -459,7 +518,7 @@ def conv3d_w(x, w, spec, scale=None, shift=None, res=None, out=None, dx_slot=Non
             x, pro = x.token, x.pro()
         else:
             x = x.materialize()
-    return _Conv3d.apply(x, None, scale, shift, res, spec, out, dx_slot, w, stats, pro, shift_scaled)
+    return _Conv3d.apply(x, None, scale, shift, res, spec, out, dx_slot, _tag_wgrad_stream(w, x), stats, pro, shift_scaled)
 
 
 # ---- EXPERIMENTAL: 3x3x3 conv with fp32 emulated on the bf16 matrix cores (conv3d_b3.hip; not used by the modules) ----

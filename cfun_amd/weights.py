@@ -174,9 +174,7 @@ def fold_up2_weight(w, cqp=None):
         wf = scope.folds.get((id(w), cqp))
         if wf is not None:
             return wf
-    wf = _FoldUp2.apply(w, cqp)
-    wf._cfun_src = ("f", w, cqp)
-    return wf
+    return fold_up2_weight_eager(w, cqp)
 
 
 class _SplitChannels(torch.autograd.Function):
@@ -237,13 +235,49 @@ class _GatherSlices(torch.autograd.Function):
         return (dw, None, None) + (None,) * len(idxs)
 
 
+class _weight_side:
+    """Weight-side autograd nodes (the gather of per-RoI Dropout3d slices, the up-conv fold) are created under the
+    weight-gradient stream of the chain they serve (ops.wgrad_stream): their backward -- index_add_ / matmul on the convs'
+    weight gradients, which ops._Conv3d produces on that stream -- then runs there too, and the chain's own stream never
+    waits for a weight gradient in the middle of the backward pass.  In forward the side stream first waits for the chain
+    (index lists, weights), and the chain for the side stream when the node computes values a conv is about to read
+    (``wait_after``; lazy gathers write nothing).  Yields the chain's stream (to ``record_stream`` the outputs on), or None
+    when nothing is switched (CPU tensors, no gradient, CFUN_WGRAD_STREAM=0)."""
+
+    def __init__(self, w, wait_after):
+        self.w, self.wait_after, self.ctx = w, wait_after, None
+
+    def __enter__(self):
+        from . import ops
+        w = self.w
+        if not (ops.WGRAD_STREAM and w.is_cuda and w.requires_grad and torch.is_grad_enabled()):
+            return None
+        self.cur = torch.cuda.current_stream(w.device)
+        self.side = ops.wgrad_stream(w.device, self.cur)
+        self.side.wait_stream(self.cur)
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self.cur
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+            if self.wait_after:
+                self.cur.wait_stream(self.side)
+        return False
+
+
 def gather_slices(w, dim, idxs, key=None):
     """[w.index_select(dim, idx) for idx in idxs], differentiable w.r.t. w with a single accumulated gradient.  ``key``
     names the index lists inside the active ``WeightScope`` (its ``dyn`` table): where the scope has prepared the operands
     of every slice the slices themselves are never gathered (see _GatherSlices)."""
     scope = WeightScope.current()
     lazy = bool(scope is not None and key is not None and scope.has_gather(w, dim, key, len(idxs)))
-    outs = _GatherSlices.apply(w, dim, lazy, *idxs)
+    with _weight_side(w, wait_after=not lazy) as on_side:
+        outs = _GatherSlices.apply(w, dim, lazy, *idxs)
+        if on_side is not None:
+            for t in outs:
+                t.record_stream(on_side)
     if key is not None:
         for i, (t, idx) in enumerate(zip(outs, idxs)):
             t._cfun_src = ("g", w, dim, key, i)
@@ -436,7 +470,10 @@ class WeightScope:
 
 
 def fold_up2_weight_eager(w, cqp):
-    wf = _FoldUp2.apply(w, cqp)
+    with _weight_side(w, wait_after=True) as on_side:
+        wf = _FoldUp2.apply(w, cqp)
+        if on_side is not None:
+            wf.record_stream(on_side)
     wf._cfun_src = ("f", w, cqp)
     return wf
 
