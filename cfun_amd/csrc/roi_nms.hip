@@ -82,30 +82,58 @@ k_roi_align_fwd(const float* __restrict__ fm, const int32_t* __restrict__ bounds
   }
 }
 
+// Backward of RoIAlign as a GATHER (round 5): one thread per (slab voxel, channel) walks the RoIs in index order and, per
+// RoI whose crop holds the voxel, the output samples whose trilinear footprint touches it -- the transpose of k_roi_align_fwd's
+// weights, evaluated with the same make_lerp -- and writes the sum once.  No atomics: the summation order is fixed, so the
+// gradients of the feature maps (and with them every FPN / RPN / classifier gradient) are run-to-run reproducible like the
+// reference's CPU path; the round 1-4 kernel scattered with fp32 atomicAdd (1e-5 relative run-to-run noise).
+__device__ __forceinline__ float lerp_weight_of(int o, int j, int n, int p) {       // d out[o] / d in[j] along one axis
+  const Lerp l = make_lerp(o, n, p);
+  return (l.i0 == j ? l.w0 : 0.f) + (l.i1 == j ? l.w1 : 0.f);      // (i1 == i0 on the last sample: both terms)
+}
+// [lo, hi): the outputs with a non-zero weight on input j -- contiguous, because the source index is monotone in o
+__device__ __forceinline__ void lerp_range_of(int j, int n, int p, int* lo, int* hi) {
+  int a = p, b = 0;
+  for (int o = 0; o < p; ++o) {
+    const Lerp l = make_lerp(o, n, p);
+    if (l.i0 == j || l.i1 == j) { a = o < a ? o : a; b = o + 1; }
+  }
+  *lo = a; *hi = b;
+}
+
 __global__ void __launch_bounds__(256)
 k_roi_align_bwd(const float* __restrict__ dout, const int32_t* __restrict__ bounds, float* __restrict__ dfm,
-                int64_t total, int D, int H, int W, int C, int pd, int ph, int pw, int sz0, int sdl) {
+                int64_t total, int R, int D, int H, int W, int C, int pd, int ph, int pw, int sz0, int sdl) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     int64_t t = i;
     const int c = (int)(t % C); t /= C;
-    const int ox = (int)(t % pw); t /= pw;
-    const int oy = (int)(t % ph); t /= ph;
-    const int oz = (int)(t % pd);
-    const int r = (int)(t / pd);
-    const int32_t* b = bounds + r * 6;
-    const int nz = b[3] - b[0], ny = b[4] - b[1], nx = b[5] - b[2];
-    if (nz <= 0 || ny <= 0 || nx <= 0) continue;
-    const Lerp lz = make_lerp(oz, nz, pd), ly = make_lerp(oy, ny, ph), lx = make_lerp(ox, nx, pw);
-    const float g = dout[i];
-    const int zi[2] = {b[0] + lz.i0, b[0] + lz.i1}, yi[2] = {b[1] + ly.i0, b[1] + ly.i1}, xi[2] = {b[2] + lx.i0, b[2] + lx.i1};
-    const float wz[2] = {lz.w0, lz.w1}, wy[2] = {ly.w0, ly.w1}, wx[2] = {lx.w0, lx.w1};
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int a = k >> 2, bb = (k >> 1) & 1, cc = k & 1;
-      const int zl = zi[a] - sz0;
-      if (zl < 0 || zl >= sdl) continue;       // another slab's plane
-      atomicAdd(&dfm[(((int64_t)zl * H + yi[bb]) * W + xi[cc]) * C + c], g * wz[a] * wy[bb] * wx[cc]);
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const int z = (int)(t / H) + sz0;
+    float acc = 0.f;
+    for (int r = 0; r < R; ++r) {
+      const int32_t* b = bounds + r * 6;
+      const int nz = b[3] - b[0], ny = b[4] - b[1], nx = b[5] - b[2];
+      if (nz <= 0 || ny <= 0 || nx <= 0) continue;
+      if (z < b[0] || z >= b[3] || y < b[1] || y >= b[4] || x < b[2] || x >= b[5]) continue;
+      const int jz = z - b[0], jy = y - b[1], jx = x - b[2];
+      int z0, z1, y0, y1, x0, x1;
+      lerp_range_of(jz, nz, pd, &z0, &z1);
+      lerp_range_of(jy, ny, ph, &y0, &y1);
+      lerp_range_of(jx, nx, pw, &x0, &x1);
+      const float* g = dout + (int64_t)r * pd * ph * pw * C + c;
+      for (int oz = z0; oz < z1; ++oz) {
+        const float wz = lerp_weight_of(oz, jz, nz, pd);
+        for (int oy = y0; oy < y1; ++oy) {
+          const float wy = lerp_weight_of(oy, jy, ny, ph);
+          for (int ox = x0; ox < x1; ++ox) {
+            const float wx = lerp_weight_of(ox, jx, nx, pw);
+            acc += g[(((int64_t)oz * ph + oy) * pw + ox) * C] * wz * wy * wx;
+          }
+        }
+      }
     }
+    dfm[i] = acc;
   }
 }
 
@@ -411,12 +439,12 @@ int cfun_roi_align3d_slab_fwd(const float* fm, const float* boxes, float* out, i
 int cfun_roi_align3d_slab_bwd(const float* dout, const int32_t* bounds, float* dfm, int32_t R, int32_t D, int32_t H,
                               int32_t W, int32_t C, int32_t z0, int32_t dl, int32_t pd, int32_t ph, int32_t pw,
                               cfun_stream_t stream) {
-  if (R <= 0) return CFUN_OK;
   if (z0 < 0 || dl <= 0 || z0 + dl > D) return CFUN_EINVAL;
-  const int64_t total = (int64_t)R * pd * ph * pw * C;
+  const int64_t total = (int64_t)dl * H * W * C;          // every element of the slab's gradient is WRITTEN (R = 0: zeros)
+  if (total <= 0) return CFUN_OK;
   int64_t blocks = (total + 255) / 256;
-  if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(k_roi_align_bwd, dim3((unsigned)blocks), dim3(256), 0, cfun_st(stream), dout, bounds, dfm, total, D, H, W, C, pd, ph, pw, z0, dl);
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(k_roi_align_bwd, dim3((unsigned)blocks), dim3(256), 0, cfun_st(stream), dout, bounds, dfm, total, R < 0 ? 0 : R, D, H, W, C, pd, ph, pw, z0, dl);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }

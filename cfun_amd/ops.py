@@ -1059,7 +1059,7 @@ class _RoIAlign(torch.autograd.Function):
         (bounds,) = ctx.saved_tensors
         r, d, h, w, c, pd, ph, pw, z0, dl = ctx.dims
         dout = _c(dout)
-        dfm = torch.zeros((dl, h, w, c), dtype=torch.float32, device=dout.device)
+        dfm = torch.empty((dl, h, w, c), dtype=torch.float32, device=dout.device)      # (every element is written)
         check(lib.cfun_roi_align3d_slab_bwd(ptr(dout), ptr(bounds), ptr(dfm), r, d, h, w, c, z0, dl, pd, ph, pw,
                                             stream(dout)), "roi_align3d_bwd")
         return dfm, None, None, None

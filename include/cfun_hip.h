@@ -293,7 +293,7 @@ int cfun_mask_target_labels(const uint8_t* labels, const int32_t* bounds, uint8_
  * ---------------------------------------------------------------------------------------------- */
 int cfun_roi_align3d_fwd(const float* fm, const float* boxes, float* out, int32_t* bounds, int32_t R, int32_t D,
                          int32_t H, int32_t W, int32_t C, int32_t pd, int32_t ph, int32_t pw, cfun_stream_t stream);
-/* dfm must be zero-initialised by the caller; gradients are accumulated with fp32 atomics. */
+/* Every element of dfm is written (a gather over the RoIs in index order: no atomics, run-to-run reproducible). */
 int cfun_roi_align3d_bwd(const float* dout, const int32_t* bounds, float* dfm, int32_t R, int32_t D, int32_t H,
                          int32_t W, int32_t C, int32_t pd, int32_t ph, int32_t pw, cfun_stream_t stream);
 /* The same on ONE depth slab of a depth-sharded map: fm / dfm hold planes [z0, z0 + dl) of the

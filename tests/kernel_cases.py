@@ -437,7 +437,7 @@ def check_roi_align(device, fm, boxes, pool, gy=None, expect=None, expect_grad=N
         (ref * g).sum().backward()
         (got * g.to(device)).sum().backward()
         gd = fd.grad.permute(3, 0, 1, 2).cpu()
-        # the backward accumulates overlapping boxes with fp32 atomics: tolerance relative to the gradient's scale
+        # (the backward is a gather in RoI order; the oracle sums in torch's order: tolerance relative to the gradient's scale)
         assert float((gd - fr.grad).abs().max()) < 1e-5 * max(1.0, float(fr.grad.abs().max()))
         if expect_grad is not None:
             assert float((gd - torch.from_numpy(expect_grad)).abs().max()) < 1e-5

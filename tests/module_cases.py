@@ -4,7 +4,9 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from conftest import golden_state_dict, load_golden
+import os
+
+from conftest import GOLDEN, golden_state_dict, load_golden
 from oracle import cfun_oracle as orc
 from oracle import formula
 
@@ -1221,3 +1223,51 @@ def check_step_bit_reproducible_under_churn(device, runs=6):
             assert np.array_equal(got[k], ref[k]), "run %d: %s differs from run 0 (max |diff| %.3e)" % (
                 it, k, np.abs(got[k] - ref[k]).max())
 
+
+
+def resize_kat_cases():
+    """tests/golden/resize_kat.json: hand-derived known answers of skimage.transform.resize as the reference calls it
+    (gen_resize_kat.py: exact rational arithmetic from the published algorithm, no scipy)."""
+    import json
+    with open(os.path.join(GOLDEN, "resize_kat.json")) as f:
+        return json.load(f)["cases"]
+
+
+def check_resize_kat_oracle():
+    """The oracle's scipy restatement (orc.skimage_resize; clip = what skimage's clip=True does) against the known answers."""
+    import scipy.ndimage as ndi
+    for c in resize_kat_cases():
+        img = np.array(c["image"], np.float64).reshape(c["in_shape"])
+        exp = np.array(c["expected"], np.float64).reshape(c["out_shape"])
+        if c["order"] == 0:
+            got = orc.skimage_resize(img.astype(np.int32), tuple(c["out_shape"]), 0)
+            np.testing.assert_array_equal(got, exp.astype(np.int32), err_msg=c["name"])
+        elif c["clip"]:
+            np.testing.assert_allclose(orc.skimage_resize(img, tuple(c["out_shape"]), 1), exp, rtol=0, atol=1e-12, err_msg=c["name"])
+        else:      # the restatement always clips: compare its un-clipped core
+            got = ndi.zoom(img, [o / float(i) for o, i in zip(c["out_shape"], c["in_shape"])], order=1, mode="grid-constant",
+                           cval=0.0, grid_mode=True)
+            np.testing.assert_allclose(got, exp, rtol=0, atol=1e-12, err_msg=c["name"])
+
+
+def check_resize_kat_device(device):
+    """cfun_resize3d (order 1 with and without the clip, order 0) against the same known answers."""
+    from cfun_amd import ops
+    for c in resize_kat_cases():
+        img = torch.tensor(c["image"], dtype=torch.float32).reshape(c["in_shape"]).to(device)
+        exp = np.array(c["expected"], np.float64).reshape(c["out_shape"])
+        got = ops.resize3d(img, tuple(c["out_shape"]), order=c["order"], clip=bool(c["clip"])).cpu().numpy()
+        if c["order"] == 0:
+            np.testing.assert_array_equal(got, exp.astype(np.float32), err_msg=c["name"])
+        else:
+            np.testing.assert_allclose(got, exp, rtol=2e-7, atol=2e-7 * float(np.abs(exp).max()), err_msg=c["name"])
+        # a permuted (strided) view of the same volume is read in place: resize of the transpose = transpose of the resize
+        gt = ops.resize3d(img.permute(2, 0, 1), tuple(c["out_shape"][k] for k in (2, 0, 1)), order=c["order"],
+                          clip=bool(c["clip"])).cpu().numpy()
+        # (held to the known answers like the dense call: the weight product is taken in the output's axis order, so the
+        # two differ in the last bit)
+        if c["order"] == 0:
+            np.testing.assert_array_equal(gt, got.transpose(2, 0, 1), err_msg=c["name"] + " (strided view)")
+        else:
+            np.testing.assert_allclose(gt, exp.transpose(2, 0, 1), rtol=2e-7, atol=2e-7 * float(np.abs(exp).max()),
+                                       err_msg=c["name"] + " (strided view)")

@@ -220,3 +220,7 @@ def test_masked_losses_ignore_rows_the_reference_never_gathers():
     l3.backward()
     assert torch.allclose(l3, F.smooth_l1_loss(pb[:2, 1], tb[:2]), rtol=1e-6, atol=1e-7)
     assert torch.isfinite(pb2.grad).all() and float(pb2.grad[2:].abs().max()) == 0.0
+
+
+def test_resize_known_answers_device(emu):
+    mc.check_resize_kat_device(emu)

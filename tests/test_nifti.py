@@ -115,3 +115,50 @@ def test_load_returns_a_writable_array_for_gz(tmp_path):
     d[0, 0, 0] = 5.0            # nibabel's get_data() hands out a writable array
     with open(str(tmp_path / "short.nii"), "wb") as f:
         f.write(open(p, "rb").read()[:100])
+
+
+def test_spec_fixture_sform_scaled():
+    """A file written byte by byte from the NIfTI-1 header layout (tests/golden/gen_nifti_fixture.py; not by cfun_amd.nifti):
+    int16 [3,2,2] stored x + 3y + 6z, scl_slope 2 / scl_inter -5, sform and qform both coded -- the sform wins."""
+    import os
+    from conftest import GOLDEN
+    img = nifti.load(os.path.join(GOLDEN, "nifti1_sform.nii"))
+    x, y, z = np.meshgrid(np.arange(3), np.arange(2), np.arange(2), indexing="ij")
+    expect = (x + 3 * y + 6 * z) * 2.0 - 5.0
+    assert img.shape == (3, 2, 2)
+    np.testing.assert_array_equal(img.get_data(), expect)
+    np.testing.assert_array_equal(img.affine, np.array([[2.0, 0.0, 0.5, -10.0], [0.0, 1.5, 0.0, 20.0], [-0.25, 0.0, 3.0, 30.0],
+                                                        [0.0, 0.0, 0.0, 1.0]]))
+    assert img.header["sform_code"] == 1 and img.header["qform_code"] == 1 and img.header["datatype"] == 4
+
+
+def test_spec_fixture_qform_big_endian_4d():
+    """Big-endian float32 [2,3,1,2], unscaled, qform only: quaternion (0, 0, sqrt(1/2)) = 90 degrees about z, pixdim (2,3,4),
+    qfac -1 -> affine columns (0,2,0), (-3,0,0), (0,0,-4), offsets (7,-8,9) -- the standard's METHOD 2, worked by hand."""
+    import os
+    from conftest import GOLDEN
+    img = nifti.load(os.path.join(GOLDEN, "nifti1_qform_be.nii"))
+    vals = (0.5 * np.arange(12) - 1.0).astype(np.float32)
+    assert img.shape == (2, 3, 1, 2) and img.get_data().dtype == np.float32
+    np.testing.assert_array_equal(img.get_data(), vals.reshape((2, 3, 1, 2), order="F"))
+    np.testing.assert_allclose(img.affine, np.array([[0.0, -3.0, 0.0, 7.0], [2.0, 0.0, 0.0, -8.0], [0.0, 0.0, -4.0, 9.0],
+                                                     [0.0, 0.0, 0.0, 1.0]]), rtol=0, atol=1e-6)
+
+
+def test_writer_matches_the_spec_layout(tmp_path):
+    """The writer's header read back with plain struct at the offsets of nifti1.h (not with the reader under test)."""
+    import struct
+    aff = np.array([[2.0, 0.0, 0.5, -10.0], [0.0, 1.5, 0.0, 20.0], [-0.25, 0.0, 3.0, 30.0], [0.0, 0.0, 0.0, 1.0]])
+    data = (np.arange(24, dtype=np.int16).reshape(2, 3, 4) - 7)
+    p = tmp_path / "w.nii"
+    nifti.save(nifti.Nifti1Image(data, aff), str(p))
+    raw = p.read_bytes()
+    assert struct.unpack("<i", raw[:4])[0] == 348 and raw[344:348] == b"n+1\0" and raw[348:352] == b"\0\0\0\0"
+    assert struct.unpack("<8h", raw[40:56])[:4] == (3, 2, 3, 4)
+    assert struct.unpack("<2h", raw[70:74]) == (4, 16)
+    assert struct.unpack("<3f", raw[108:120]) == (352.0, 1.0, 0.0)
+    assert struct.unpack("<2h", raw[252:256])[1] > 0
+    np.testing.assert_allclose(np.array(struct.unpack("<12f", raw[280:328])).reshape(3, 4), aff[:3], rtol=0, atol=1e-6)
+    stored = np.frombuffer(raw[352:], dtype="<i2")
+    np.testing.assert_array_equal(stored, data.reshape(-1, order="F"))       # first index fastest
+    assert len(raw) == 352 + 2 * 24

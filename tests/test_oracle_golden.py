@@ -456,3 +456,11 @@ def test_predict_lits_two_phase(stage):
         a, r = params[k].grad.numpy(), g["grad:" + k]
         e = np.linalg.norm((a - r).ravel()) / max(np.linalg.norm(r.ravel()), 1e-30)
         assert e < 2e-2, "%s: rel L2 %.3e" % (k, e)
+
+
+def test_resize_known_answers():
+    """f-4: the oracle's restatement of skimage.transform.resize (scipy.ndimage.zoom, grid-constant, grid_mode) against known
+    answers derived by hand from skimage's published algorithm (tests/golden/gen_resize_kat.py) -- scikit-image itself is not
+    in the image, so this is what pins the restatement."""
+    import module_cases as mc
+    mc.check_resize_kat_oracle()
