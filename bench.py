@@ -257,19 +257,42 @@ def parity_dropout_masks(cfg, n_pos):
 
 
 # parameter gradients compared between the extra GPU step and the oracle's CPU step at full size (`grad_parity`): the
-# first, the dominant and the last conv of the U-Net, its deepest level, and one tensor of each detector part; rel. L2
-# bounds: both legs are fp32 with different summation orders -- the U-Net tensors sit behind 25 InstanceNorms (fp32 noise
-# floor 2e-4 ... 7e-3 against fp64 at these shapes, tests/module_cases.py GRAD_FP64_FACTOR table), the others do not
+# first, the dominant and the last conv of the U-Net, its deepest level, and one tensor of each detector part.
+#   * U-Net tensors: held to a MEASURED bound since round 5 -- tests/golden/grad_fp64_cfg2.npz carries the fp64 gradients of
+#     exactly this step's mask head (same weights, volume, RoIs, Dropout3d masks; gen_grad_fp64_cfg2.py, computed on the GPU box's
+#     host) and, per tensor, the deviation of the reference's own fp32 arithmetic from them (floor: 4.2e-3 / 1.8e-4 / 9.8e-3 /
+#     2.1e-6 for the four below -- InstanceNorm over 6^3 voxels amplifies fp32 rounding in the deep levels):
+#     relL2(GPU, fp64) <= GRAD_FP64_FACTOR * floor + GRAD_FP64_FLOOR, the rule of tests/module_cases.py.  The second column is
+#     the fall-back bound on relL2(GPU, CPU fp32) when the fixture does not belong to the run's weights (another torch build).
+#   * detector tensors (no normalisation over tiny volumes on their path): relL2(GPU, CPU fp32) <= 1e-3 as before.
+GRAD_FP64_FACTOR, GRAD_FP64_FLOOR = 3.0, 2e-5
 GRAD_PARITY_KEYS = {
-    "mask.modified_u_net.conv3d_c1_1.weight": 1e-2,
-    "mask.modified_u_net.conv_norm_lrelu_l4.0.weight": 1e-2,
-    "mask.modified_u_net.norm_lrelu_conv_c5.2.weight": 2e-2,
-    "mask.modified_u_net.out_upscale_conv.1.weight": 1e-2,
+    "mask.modified_u_net.conv3d_c1_1.weight": 2e-2,
+    "mask.modified_u_net.conv_norm_lrelu_l4.0.weight": 1e-3,
+    "mask.modified_u_net.norm_lrelu_conv_c5.2.weight": 4e-2,
+    "mask.modified_u_net.out_upscale_conv.1.weight": 1e-4,
     "fpn.C1.0.weight": 1e-3,
     "fpn.P2_conv2.weight": 1e-3,
     "rpn.conv_shared.weight": 1e-3,
     "classifier.conv1.weight": 1e-3,
 }
+GRAD_FP64_FIXTURE = "tests/golden/grad_fp64_cfg2.npz"
+
+
+def load_grad_fp64(net, cfg, workload):
+    """The fp64 reference gradients of the cfg2 bench step's mask head, or None when they do not apply to this run (another
+    workload, or weights that are not the ones the fixture was generated from: checked through |weight| checksums)."""
+    import numpy as np
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), GRAD_FP64_FIXTURE)
+    if workload != "cfg2" or not os.path.exists(path):
+        return None
+    d = np.load(path)
+    names = sorted(k[4:] for k in d.files if k.startswith("g64_"))
+    sd = net.state_dict()
+    chk = np.array([float(sd[k].detach().double().abs().sum().cpu()) for k in names])
+    if chk.shape != d["w_check"].shape or np.abs(chk - d["w_check"]).max() > 1e-6 * np.abs(d["w_check"]).max():
+        return None
+    return {k: (d["g64_" + k].astype(np.float64), int(d["stride_" + k]), float(d["floor_" + k])) for k in names}
 
 
 def cpu_baseline(cfg, net, sample, threads, iters=1, small_iters=3):
@@ -623,17 +646,36 @@ def main():
             if max(rel) > tol:
                 parity_fail = "loss parity FAILED at full size: rel diff %s > %g" % (rel, tol)
             # ... and the parameter gradients of the same two steps (the oracle leg calls backward() anyway)
+            ref64 = load_grad_fp64(net, cfg, args.workload)
             gp = {}
             for k, bound in GRAD_PARITY_KEYS.items():
                 if k in gg and k in cg:
                     a, c = gg[k].double(), cg[k].double()
-                    gp[k] = {"rel_l2": float((a - c).norm() / c.norm().clamp(min=1e-300)), "bound": bound,
-                             "norm_cpu": float(c.norm())}
+                    e = {"rel_l2_vs_cpu_fp32": float((a - c).norm() / c.norm().clamp(min=1e-300)), "norm_cpu": float(c.norm())}
+                    if ref64 is not None and k in ref64:
+                        g64, stride, floor = ref64[k]
+                        g64 = torch.from_numpy(g64)
+                        den = g64.norm().clamp(min=1e-300)
+                        e.update(rel_l2_vs_fp64=float((a[::stride] - g64).norm() / den),
+                                 cpu_fp32_vs_fp64=float((c[::stride] - g64).norm() / den), reference_fp32_floor=floor)
+                        # the reference arithmetic's deviation from fp64: the larger of the fixture's two evaluations (torch CPU
+                        # fp32 with 8 and with 96 threads) and THIS run's CPU oracle leg -- it moves with the thread count where a
+                        # LeakyReLU kink flip reaches the tensor (l4.0: 1.8e-4 / 6.8e-4)
+                        floor = max(floor, e["cpu_fp32_vs_fp64"])
+                        e.update(bound=GRAD_FP64_FACTOR * floor + GRAD_FP64_FLOOR,
+                                 rule="relL2(GPU, fp64) <= %g * relL2(reference fp32, fp64) + %g" % (GRAD_FP64_FACTOR, GRAD_FP64_FLOOR))
+                        e["rel_l2"] = e["rel_l2_vs_fp64"]
+                    else:
+                        e.update(rel_l2=e["rel_l2_vs_cpu_fp32"], bound=bound, rule="relL2(GPU, CPU fp32) <= bound")
+                    gp[k] = e
             ok = bool(gp) and all(v["rel_l2"] <= v["bound"] for v in gp.values())
-            result["grad_parity"] = {"what": "rel. L2 difference of parameter gradients, the same extra GPU step vs the "
-                                             "oracle's CPU backward at the benchmarked size", "tensors": gp, "ok": ok}
+            result["grad_parity"] = {"what": "parameter gradients of the same extra GPU step at the benchmarked size: U-Net "
+                                             "tensors against the mask head's fp64 gradients (%s; bound = 3 x the deviation "
+                                             "of the reference's own fp32 arithmetic from them + 2e-5), detector tensors "
+                                             "against the oracle's CPU fp32 backward" % GRAD_FP64_FIXTURE,
+                                     "fp64_fixture_applies": ref64 is not None, "tensors": gp, "ok": ok}
             if not ok and parity_fail is None:
-                parity_fail = "gradient parity FAILED at full size: %s" % {k: v["rel_l2"] for k, v in gp.items()}
+                parity_fail = "gradient parity FAILED at full size: %s" % {k: (v["rel_l2"], v["bound"]) for k, v in gp.items()}
         if sharded_parity is not None and not sharded_parity["ok"]:
             parity_fail = "sharded step does not reproduce the single-GPU losses: rel diff %s" % sharded_parity["rel_diff"]
         print(json.dumps(result), flush=True)

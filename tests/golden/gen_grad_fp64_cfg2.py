@@ -15,7 +15,11 @@ positive RoIs -- same weights (torch.manual_seed(0) + initialize_weights), same 
 Dropout3d masks (bench.parity_dropout_masks: generator seed 1) -- through the oracle's U-Net in fp32 AND in fp64, one RoI at
 a time (the losses are means over the RoIs, so the four gradients add up).  Stored:
 
-  floor_<name>   relL2(oracle fp32, oracle fp64) of every U-Net parameter gradient: the reference arithmetic's own noise floor
+  floor_<name>   relL2(oracle fp32, oracle fp64) of every U-Net parameter gradient: the reference arithmetic's own noise floor.
+                 The committed file holds the LARGER of two evaluations -- floorA_ (8 threads, the build container: the run
+                 survived at 63 GB) and floorB_ (96 threads, the GPU box's host); the fp64 gradients of the two runs agree to
+                 3e-10, the fp32 floors to 1 - 5 % except where a LeakyReLU kink flip reaches a tensor (l4.0: 6.8e-4 / 1.8e-4,
+                 l3.3: 5.2e-4 / 2.7e-4: torch's fp32 result itself depends on the thread count there)
   g64_<name>     the fp64 gradient (stored as fp32; norm_<name> = its fp64 L2 norm) of the tensors bench.py checks -- whole for
                  the small ones, every 8th output channel of norm_lrelu_conv_c5.2.weight (2.76 M entries)
   w_check        |weights| checksums, so that a consumer can tell whether ITS weights are the ones these gradients belong to

@@ -418,17 +418,39 @@ def flip_fit(taps64, taps32, params64, got, ref32, max_basis=None, max_params=3_
                                     for g, p in zip(gr, plist)]))
     A = np.stack(cols, axis=1)
     g64 = np.concatenate([params64[k].grad.reshape(-1).numpy() for k in names])
-    out = []
+    out, stats = [], []
     for vec in (got, ref32):
         d = np.concatenate([np.asarray(vec[k], np.float64).reshape(-1) for k in names]) - g64
         coef = np.linalg.lstsq(A, d, rcond=None)[0]
-        r = d - A @ coef
+        fitted = A @ coef
+        r = d - fitted
         res, off = {}, 0
         for k, p in zip(names, plist):
             res[k] = r[off:off + p.numel()]
             off += p.numel()
         out.append(res)
+        # how much the fit took away: a genuine kink flip has coefficient ~ +-1 (the column IS the effect of one flip), so the
+        # number of coefficients that matter and their size bound what the escape hatch may explain
+        stats.append(dict(active=int((np.abs(coef) > 0.25).sum()), max_coef=float(np.abs(coef).max()),
+                          fitted_rel=float(np.linalg.norm(fitted) / (np.linalg.norm(g64) + 1e-300))))
+    check_flip_fit_limits(stats[0], len(cand))
+    FLIP_FIT_LOG.append(dict(basis=len(cand), hip=stats[0], ref32=stats[1]))
     return out[0], out[1], len(cand)
+
+
+# What flip_fit may subtract from HIP - fp64 before the measured bound is applied (limits chosen ~2x above the largest values
+# the tiers show, printed by the tests through FLIP_FIT_LOG): at most FLIP_MAX_ACTIVE basis voxels with a coefficient that
+# matters (observed: 10 of 192 in the 32^3 toy step), none beyond +-FLIP_MAX_COEF (one voxel flips at most once; least squares
+# over near-collinear columns reaches 2.4 there), and a fitted part of at most FLIP_MAX_FITTED_REL of the gradient's norm (6e-3
+# there; the reference's own fp32 run: 1e-2) -- a wrong kernel cannot hide behind "kink flips".
+FLIP_MAX_ACTIVE, FLIP_MAX_COEF, FLIP_MAX_FITTED_REL = 32, 4.0, 0.03
+FLIP_FIT_LOG = []
+
+
+def check_flip_fit_limits(st, n_basis):
+    assert st["active"] <= FLIP_MAX_ACTIVE, "flip_fit: %d of %d basis voxels carry a coefficient > 0.25" % (st["active"], n_basis)
+    assert st["max_coef"] <= FLIP_MAX_COEF, "flip_fit: coefficient %.2f (a voxel flips at most once)" % st["max_coef"]
+    assert st["fitted_rel"] <= FLIP_MAX_FITTED_REL, "flip_fit: the fitted part is %.3e of the gradient's norm" % st["fitted_rel"]
 
 
 def _oracle_step(cfg, net, cpu, masks, dtype, taps=None):
