@@ -56,8 +56,8 @@ def dominant_kernel_match(cfg):
     return match
 
 
-PMC_TRAFFIC_JSON = "profiles/round4_pmc_wino_l4_0.json"
-PMC_MFMA_JSON = "profiles/round4_pmc_mfma_wino_l4_0.json"
+PMC_TRAFFIC_JSON = "profiles/round5_pmc_wino_l4_0.json"
+PMC_MFMA_JSON = "profiles/round5_pmc_mfma_wino_l4_0.json"
 
 
 def dominant_kernel_info(cfg, n_roi):
@@ -575,6 +575,11 @@ def main():
             dl = timer.durations_ms("mfma_" + leg)      # weight-gradient chunk reduction; the mask head shares the GPU with the detector stream)
             if dl:
                 result["roofline"]["in_step_%s_ms" % leg] = sum(dl) / len(dl)
+        if ops.WGRAD_STREAM:
+            result["roofline"]["in_step_note"] = ("since round 5 the weight gradient runs on its own HIP stream BESIDE the data "
+                                                  "gradient (cfun_amd.ops.WGRAD_STREAM): the two in-step event pairs above time "
+                                                  "kernels that share the GPU -- each is slower than alone, their sum is not "
+                                                  "step time; the isolated figures are tools/bench_layers.py's (profiles/)")
         if args.workload == "cfg2" and not b3:
             r = result["roofline"]
             r["traffic"], r["traffic_source"] = pmc_record(PMC_TRAFFIC_JSON, "traffic_bytes_per_launch")
