@@ -273,11 +273,18 @@ def gather_slices(w, dim, idxs, key=None):
     of every slice the slices themselves are never gathered (see _GatherSlices)."""
     scope = WeightScope.current()
     lazy = bool(scope is not None and key is not None and scope.has_gather(w, dim, key, len(idxs)))
-    with _weight_side(w, wait_after=not lazy) as on_side:
+    ws = _weight_side(w, wait_after=not lazy)
+    with ws as on_side:
         outs = _GatherSlices.apply(w, dim, lazy, *idxs)
         if on_side is not None:
             for t in outs:
                 t.record_stream(on_side)
+            # the index lists were uploaded on the chain's stream and are read again by this node's BACKWARD on the side
+            # stream (index_add_), after which autograd frees them at once: without this the caching allocator may hand their
+            # memory to the chain while the index_add_ is still queued -- garbage indices, a memory fault (found by the 4-rank
+            # GPU test, where the side stream lags furthest)
+            for idx in idxs:
+                idx.record_stream(ws.side)
     if key is not None:
         for i, (t, idx) in enumerate(zip(outs, idxs)):
             t._cfun_src = ("g", w, dim, key, i)

@@ -57,6 +57,7 @@ def main():
     g = torch.Generator().manual_seed(0)
 
     if "halo" in sections:
+        print("[rank %d] section halo" % rank, flush=True)
         # 1) halo exchange, 2 planes per rank, forward + backward against plain padding of the full tensor
         full = torch.randn(1, 2 * world, 3, 4, 4, generator=g).to(dev)
         gy_full = torch.randn(1, 4 * world, 3, 4, 4, generator=g).to(dev)            # per-rank padded slabs, concatenated
@@ -67,6 +68,7 @@ def main():
         res["halo_y"], res["halo_gx"] = y.detach().cpu().numpy(), x.grad.cpu().numpy()
 
     if "conv" in sections:
+        print("[rank %d] section conv" % rank, flush=True)
         # 2) depth-coupled convs trained through the exchange at 1, 2 and 4 planes per rank: thinner than the kernel (padded
         #    slab), edges only, and interior + edges (the overlapped split) -- 3x3x3 stride 1 on the direct / MFMA kernel and
         #    on the Winograd kernels (16 -> 32), and the stride-2 down-conv (halo from the previous rank only)
@@ -107,6 +109,7 @@ def main():
         return cfg
 
     if "rpn" in sections:
+        print("[rank %d] section rpn" % rank, flush=True)
         # 3) depth-sharded FPN -> RPN -> proposals (ONE all-gather of candidates) == the single-process result, with 1 and
         #    with 2 p3 planes per rank (cfg3's 8-way split: 2)
         for planes3 in (1, 2):
@@ -145,6 +148,7 @@ def main():
         assert len(red.buckets) > 2
         for tag, n_pos, n_neg, zshard in cases:
             tag = prefix + tag
+            print("[rank %d] step case %s" % (rank, tag), flush=True)
             s = dict(s0)
             s["p_rois"], s["mask_labels"], s["n_rois"] = s0["p_rois"][:n_pos], s0["mask_labels"][:n_pos], s0["n_rois"][:n_neg]
             keep = list(range(n_pos)) + list(range(4, 4 + n_neg))
@@ -197,6 +201,7 @@ def main():
         step_cases(ccfg.heart_config("finetune", 128, 128, 64), "c1_", [("rr", 4, 8, False), ("z", 2, 4, True)], 64 << 20)
 
     if "dp" in sections:
+        print("[rank %d] section dp" % rank, flush=True)
         # 4b) data-parallel replicas of the WHOLE step (bench.py --gpus N): every rank its own volume (sample seed = rank),
         #     the mask head and its backward on their own HIP stream (step.OVERLAP_MASK_HEAD), 64 MB buckets that mix mask-head
         #     and detector gradients, the bucket all-reduces launched from the hooks under whichever stream produced a
@@ -242,6 +247,7 @@ def main():
             res["dp_names"] = np.array([k for k, _ in namedd])
 
     if "unet" in sections:
+        print("[rank %d] section unet" % rank, flush=True)
         # 5) ONE RoI's U-Net ('finetune', Dropout3d active) z-sharded over ALL ranks: logits slabs and summed gradients
         from cfun_amd.mask_branch import Modified3DUNet
         torch.manual_seed(7)

@@ -44,9 +44,9 @@ def run_world(tmp_path, env, world, worker="dist_worker.py", worker_args=(), tim
             f.close()
     logs = [open(str(tmp_path / ("rank%d.log" % r)), "rb").read().decode(errors="replace") for r in range(world)]
     bad = [r for r, p in enumerate(procs) if p.returncode != 0]
-    first = [r for r in bad if procs[r].returncode > 0] or bad          # (killed peers report a negative code)
+    first = [r for r in bad if procs[r].returncode != -9] or bad        # (the peers this harness stopped report -9)
     assert not bad, "rank %d of %d failed (exit codes %s):\n%s" % (
-        first[0], world, [p.returncode for p in procs], logs[first[0]][-3000:])
+        first[0], world, [p.returncode for p in procs], logs[first[0]][-4000:])
     return [dict(np.load(out % k)) for k in range(world)]
 
 
