@@ -529,3 +529,61 @@ def test_async_scalar_ring_keeps_every_deferred_value(gpu):
 def test_resize_known_answers_device(gpu):
     """cfun_resize3d against the hand-derived known answers of skimage.transform.resize (tests/golden/resize_kat.json)."""
     mc.check_resize_kat_device(gpu)
+
+
+@pytest.mark.parametrize("which", ["tiny", "cfg0_real_channels"])
+def test_wgrad_stream_lagging_far_behind_is_bit_identical(gpu, which):
+    """The weight-gradient stream (cfun_amd.ops.WGRAD_STREAM) reads tensors the backward chain allocated and
+    autograd frees the moment a node's backward returns.  Here the weight-gradient streams are put to sleep before
+    ``backward()`` so that the WHOLE chain -- and every free -- runs ahead of them, while the host keeps allocating and
+    freeing on the chain's streams: any tensor missing its ``record_stream`` is overwritten before the sleeping stream reads
+    it (the round-5 bug: the Dropout3d index lists -> a memory fault on an interior rank of the 4-rank test).  Every
+    gradient must equal the single-stream step bit for bit."""
+    from cfun_amd import config, ops, step
+    # tiny: 32^3 crops, b = 4 (direct kernels, per-RoI Dropout3d slices); cfg0_real_channels: 64x64x32 volume, b = 20, 96^3 -> 192^3
+    # (Winograd kernels, the fused norm prologue's statistics, folded up-convs, the 113 MB classifier weight)
+    cfg = mc.tiny_config("finetune") if which == "tiny" else config.heart_config("finetune", 64, 64, 32)
+    torch.manual_seed(0)
+    net = step.CFUNHotPath(cfg).to(gpu)
+    s = step.synthetic_inputs(cfg, gpu, 0)
+    dev = torch.device(gpu)
+
+    def run(lag):
+        torch.manual_seed(5)                      # the same host-drawn Dropout3d masks every time
+        net.zero_grad(set_to_none=True)
+        out = net.predict_training(s["image"], s["p_rois"], s["n_rois"], lazy_rois=True)
+        losses = net.compute_losses(out, s["rpn_match"], s["rpn_bbox_t"], s["target_class_ids"], s["target_deltas"], s["mask_labels"])
+        total = net.total_loss(losses)
+        if lag:
+            for (d, name), st in list(ops._SIDE_STREAMS.items()):
+                if name.startswith("wgrad"):
+                    with torch.cuda.stream(st):
+                        torch.cuda._sleep(int(3e8))          # ~0.15 s: the chain's backward takes a few ms
+        total.backward()
+        if lag:       # churn: the chain's allocator hands freed blocks out again while the weight-gradient streams sleep
+            junk = []
+            for (d, name), st in list(ops._SIDE_STREAMS.items()) + [((0, "main"), torch.cuda.current_stream(dev))]:
+                if name.startswith("wgrad"):
+                    continue
+                with torch.cuda.stream(st):
+                    for k in range(40):
+                        junk.append(torch.full((1 << (10 + k % 12),), float("nan"), device=dev))
+                    junk.clear()
+        torch.cuda.synchronize()
+        return [float(l) for l in losses], {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    old = ops.WGRAD_STREAM
+    try:
+        ops.WGRAD_STREAM = False
+        l0, g0 = run(False)
+        ops.WGRAD_STREAM = True
+        run(False)                                   # creates the weight-gradient streams
+        assert any(name.startswith("wgrad") for (_, name) in ops._SIDE_STREAMS)
+        for _ in range(3 if which == "tiny" else 2):
+            l1, g1 = run(True)
+            assert l1 == l0
+            assert g1.keys() == g0.keys()
+            for k in g0:
+                assert torch.equal(g1[k], g0[k]), k
+    finally:
+        ops.WGRAD_STREAM = old
