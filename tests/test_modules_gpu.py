@@ -267,16 +267,24 @@ def test_gradient_reducer_streams(gpu):
         ref = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
         red = cdist.GradientReducer(net.parameters(), bucket_bytes=16 << 10, always_reduce=True)
         assert len(red.buckets) > 3
-        for _ in range(2):
+        from cfun_amd import ops
+        for it in range(3):
             red.zero_grad()
+            if it == 2:
+                # third pass: the weight-gradient streams asleep while the step is enqueued -- the accumulation into the
+                # buckets and the hooks' all-reduces (RCCL, on the communication stream) must still come out in order
+                for (d, name), st in list(ops._SIDE_STREAMS.items()):
+                    if name.startswith("wgrad"):
+                        with torch.cuda.stream(st):
+                            torch.cuda._sleep(int(2e8))
             step.training_step(net, s)
             red.finish()
-        torch.cuda.synchronize()
-        for k, p in net.named_parameters():
-            if k in ref:
-                # bit-equal: the reducer (one rank) only routes the gradients through its buckets, and since round 5 no
-                # kernel on the path accumulates with atomics (RoIAlign's backward is a gather)
-                assert torch.equal(p.grad, ref[k]), k
+            torch.cuda.synchronize()
+            for k, p in net.named_parameters():
+                if k in ref:
+                    # bit-equal: the reducer (one rank) only routes the gradients through its buckets, and since round 5 no
+                    # kernel on the path accumulates with atomics (RoIAlign's backward is a gather)
+                    assert torch.equal(p.grad, ref[k]), (it, k)
         red.remove()
     finally:
         dist.destroy_process_group()
