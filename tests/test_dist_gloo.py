@@ -1,6 +1,8 @@
-"""CPU tier: the multi-GPU path (cfun_amd.dist) with world_size 2 over gloo -- halo exchange (forward and
-backward), depth-sharded FPN -> RPN -> proposal all-gather vs the single-rank result, and a depth-coupled conv
-trained through the exchange.  The kernels run through the HIP emulator build (CPU tensors)."""
+"""CPU tier: the multi-GPU path (cfun_amd.dist) over gloo with 2 ranks (tests/dist_worker.py: halo exchange forward and
+backward, depth-sharded FPN -> RPN -> proposal all-gather vs the single-rank result, depth-coupled convs trained through the
+exchange, the whole sharded step, the bucketed reducer, gradient accumulation) and with 4 and 8 ranks (tests/dist_worker_n.py,
+round 5: interior ranks, slabs of 1 - 2 p3 planes, the 4 RoIs x 2 ranks z-shard plan of an 8-GPU node, idle ranks).  The
+kernels run through the HIP emulator build (CPU tensors); tests/test_dist_gpu.py runs the same workers on the real library."""
 import os
 import socket
 import subprocess
