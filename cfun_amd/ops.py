@@ -102,8 +102,8 @@ class LaunchTimer:
 _TIMER = None
 # The weight gradient of a conv is off the backward chain's critical path -- dx feeds the next layer, dw only the optimizer --
 # so conv3d_w's backward enqueues it on a HIP stream of its own BEFORE the data gradient: it runs beside the chain's HBM- and
-# latency-bound stretches (norm / activation gradients, the small launches of the deep levels): 42.9 -> 40.0 ms per step at
-# cfg2 (round 5, same box A/B).  CFUN_WGRAD_STREAM=0: everything on the chain's stream.
+# latency-bound stretches (norm / activation gradients, the small launches of the deep levels): 42.7 -> 40.8 ms per step at
+# cfg2 (round 5, same-box A/B).  CFUN_WGRAD_STREAM=0: everything on the chain's stream.
 WGRAD_STREAM = os.environ.get("CFUN_WGRAD_STREAM", "1") == "1"
 
 
