@@ -184,10 +184,12 @@ def main():
             res[prefix + "grad_names"] = np.array([k for k, _ in named])
 
     cases = []
-    if "step" in sections:
-        # (a) world / 2 positive RoIs, each U-Net z-sharded over a sub-group of 2 ranks (8 GPUs: the 4 x 2 plan of cfg3);
-        # (b) ONE positive RoI over all `world` ranks: 32 / world planes per rank at level 1, one plane at the fold
-        cases += [("za", world // 2, world, True), ("zb", 1, 3, True)]
+    # (a) world / 2 positive RoIs, each U-Net z-sharded over a sub-group of 2 ranks (8 GPUs: the 4 x 2 plan of cfg3);
+    # (b) ONE positive RoI over all `world` ranks: 32 / world planes per rank at level 1, one plane at the fold
+    if "step" in sections or "stepa" in sections:
+        cases += [("za", world // 2, world, True)]
+    if "step" in sections or "stepb" in sections:
+        cases += [("zb", 1, 3, True)]
     if "rr" in sections:
         # (c) round-robin heads with more ranks than RoIs: 2 positive + 1 negative RoI, ranks >= 3 hold no RoI at all and
         #     ranks >= 2 no mask RoI (their U-Net buckets never complete through the hooks)

@@ -222,9 +222,9 @@ def check_worldn(r, sections="halo,conv,rpn,step,rr,dp,unet", tol_mask=2e-2, une
             assert r[0][key + "rois"].shape == ref["ref_" + key + "rois"].shape
             np.testing.assert_allclose(r[0][key + "rois"], ref["ref_" + key + "rois"], rtol=0, atol=1e-5)
     report = {}
-    for tag, sec, rs, pre in (("za", "step", 2, ""), ("zb", "step", world, ""), ("rr", "rr", 0, ""),
+    for tag, sec, rs, pre in (("za", "stepa", 2, ""), ("zb", "stepb", world, ""), ("rr", "rr", 0, ""),
                               ("c1_rr", "cfg1", 0, "c1_"), ("c1_z", "cfg1", world // 2, "c1_")):
-        if sec not in sections:
+        if sec not in sections and not (sec.startswith("step") and "step" in sections):
             continue
         assert int(ref[tag + "_zsharded"][0]) == rs, (tag, ref[tag + "_zsharded"])
         np.testing.assert_allclose(ref[tag + "_losses"], ref["ref_" + tag + "_losses"], rtol=2e-4, atol=1e-6, err_msg=tag)
@@ -259,12 +259,13 @@ def check_worldn(r, sections="halo,conv,rpn,step,rr,dp,unet", tol_mask=2e-2, une
 def test_depth_sharding_world4(emu_lib, tmp_path):
     """4 ranks: two interior ranks, 2 RoIs x 2 ranks and 1 RoI x 4 ranks z-sharded, round-robin with idle ranks."""
     env = dict(os.environ, CFUN_LIB_PATH=emu_lib, PYTHONPATH=ROOT)
-    print(check_worldn(run_world(tmp_path, env, 4, "dist_worker_n.py", ("cpu",), timeout=1500)))
+    sections = "halo,conv,rpn,stepa,stepb,dp"     # (round-robin with idle ranks and the U-Net over all ranks: at world 8)
+    print(check_worldn(run_world(tmp_path, env, 4, "dist_worker_n.py", ("cpu", sections), timeout=1500), sections))
 
 
 def test_depth_sharding_world8(emu_lib, tmp_path):
     """8 ranks -- the layout BASELINE configs[3] names: six interior ranks, slabs of 1 - 2 p3 planes, the 4 RoIs x 2 ranks
     z-shard plan, one RoI over all 8 ranks (4 / 2 / 1 planes per rank at the U-Net's sharded levels)."""
     env = dict(os.environ, CFUN_LIB_PATH=emu_lib, PYTHONPATH=ROOT)
-    sections = "halo,conv,rpn,step,rr,unet"       # (the data-parallel whole-step section runs at world 4)
+    sections = "halo,conv,rpn,stepa,rr,unet"      # (one RoI over all ranks inside a step and the data-parallel step: at world 4)
     print(check_worldn(run_world(tmp_path, env, 8, "dist_worker_n.py", ("cpu", sections), timeout=2400), sections))
