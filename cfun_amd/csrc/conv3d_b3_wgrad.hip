@@ -29,7 +29,7 @@ constexpr int kXRow = 48;      // bytes per halo row in LDS: 18 voxels + padding
 constexpr int kCHX = 1168;     // bytes per channel of the x halo (24 rows x 48 = 1152 used; 292 dwords: conflict-free b128 reads)
 constexpr int kPX = 16 * kCHX; // one bf16 plane of the 16-channel halo
 constexpr int kCHG = 272;      // bytes per channel of the g tile (256 used; 68 dwords: conflict-free)
-constexpr int kThreads = 576, kWaves = 9;      // wave w <-> tap row (dz, dy) = (w / 3, w % 3), its three dx taps
+constexpr int kThreads = 576;   // 9 waves: wave w <-> tap row (dz, dy) = (w / 3, w % 3), its three dx taps
 
 // Transposed staging writes whole dwords: a thread owns 2 (x halo) or 4 (g tile) CONSECUTIVE voxels of 4 channels, so
 // each (channel, plane) costs one ds_write_b32 / b64 instead of one ds_write_b16 per element (the 16-bit scatter made
