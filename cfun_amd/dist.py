@@ -608,6 +608,15 @@ def sharded_training_step(net, s, shard=None, zshard_unet=True, dropout_seed=0):
     l_mask = l_edge = zero
     plan = zshard_plan(shard, n_pos) if (zshard_unet and not net.detector_phase_only) else None
     unet = net.mask.modified_u_net
+    # the mask losses of the configuration (step.CFUNHotPath._mask_losses): heart -- CE, and in 'finetune' the Sobel-magnitude
+    # edge loss; LiTS fork -- class-weighted CE, raw-Sobel edge loss in every non-'beginning' stage (LiTS_2017/model.py:907-1001)
+    cw = getattr(cfg, "MASK_CE_CLASS_WEIGHTS", None)
+    raw = bool(getattr(cfg, "EDGE_LOSS_RAW_SOBEL", False))
+    edge_on = (cfg.STAGE != "beginning") if (getattr(cfg, "STAGE_SPLIT", False) or raw) else cfg.STAGE == "finetune"
+    edge_fn = ops.edge_loss_raw if raw else ops.edge_loss
+    if cw is not None:
+        cw_t = torch.tensor([float(v) for v in cw], dtype=torch.float32, device=image.device)
+        cw_den = cw_t[s["mask_labels"][:n_pos].long()].sum()       # the labels are replicated: no collective needed
     if plan is not None:        # this rank is one of `rs` ranks that share RoI `roi`
         rs, groups = plan
         roi = r // rs
@@ -634,15 +643,19 @@ def sharded_training_step(net, s, shard=None, zshard_unet=True, dropout_seed=0):
         z0 = zs.rank * dl
         lab_full = s["mask_labels"][roi]                                   # [D,H,W] uint8, replicated
         share = 1.0 / float(n_pos)
-        l_mask = ops.mask_cross_entropy(mslab, lab_full[z0:z0 + dl].unsqueeze(0).contiguous()) * (share * dl / Dm)
+        lab_slab = lab_full[z0:z0 + dl].unsqueeze(0).contiguous()
+        if cw is None:
+            l_mask = ops.mask_cross_entropy(mslab, lab_slab) * (share * dl / Dm)
+        else:       # class-weighted CE = sum(w * nll) / sum(w) over ALL RoIs' voxels: this slab's numerator over the global denominator
+            l_mask = ops.mask_cross_entropy(mslab, lab_slab, weight=cw) * (cw_t[lab_slab.long()].sum() / cw_den)
         pmine = torch.tensor([roi], device=rois.device)
-        if cfg.STAGE == "finetune":
+        if edge_on:
             mprob = ops.softmax_channels(mslab)
             ph = halo_exchange(mprob, 1, 1, zs)                            # [1, dl+2, ...]; zeros beyond the volume
             a, b = max(z0 - 1, 0), min(z0 + dl - 1, Dm - 2)                # output planes [a, b): inputs [a, b + 2)
             if b > a:
                 psl = ph[:, a - (z0 - 1):b + 2 - (z0 - 1)].contiguous()
-                l_edge = ops.edge_loss(psl, lab_full[a:b + 2].unsqueeze(0).contiguous()) * (share * (b - a) / (Dm - 2))
+                l_edge = edge_fn(psl, lab_full[a:b + 2].unsqueeze(0).contiguous()) * (share * (b - a) / (Dm - 2))
             else:
                 l_edge = ph.sum() * 0.0
     elif pmine.numel():
@@ -650,11 +663,16 @@ def sharded_training_step(net, s, shard=None, zshard_unet=True, dropout_seed=0):
             mlog, mprob = net.mask.forward_ndhwc(ops.to_ndhwc(image)[0], s["p_rois"][pmine])
         labels = s["mask_labels"][pmine].contiguous()
         share = pmine.numel() / float(n_pos)
-        if cfg.STAGE == "finetune":
+        if cw is None and not raw and edge_on:      # heart 'finetune': CE + edge share one fused backward pass
             ce, edge = ops.mask_losses(mlog, mprob, labels)
             l_mask, l_edge = ce * share, edge * share
         else:
-            l_mask = ops.mask_cross_entropy(mlog, labels) * share
+            if cw is None:
+                l_mask = ops.mask_cross_entropy(mlog, labels) * share
+            else:
+                l_mask = ops.mask_cross_entropy(mlog, labels, weight=cw) * (cw_t[labels.long()].sum() / cw_den)
+            if edge_on:
+                l_edge = edge_fn(mprob, labels) * share
     losses = [l_rpn_cls, l_rpn_box, l_cls, l_box, l_mask, l_edge]
     total = net.total_loss(losses) + zero
     total.backward()

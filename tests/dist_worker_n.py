@@ -196,6 +196,13 @@ def main():
         cases += [("rr", 2, 1, False)]
     if cases:                                   # tiny channel counts, 1 p3 plane per rank
         step_cases(tiny_cfg("finetune", 32, 16 * world), "", cases, 4096)
+    if "lits" in sections:
+        # the LiTS fork's shapes and mask losses (BASELINE configs[4]: "same pipeline", all heads in one step): P3D35 with the
+        # 5x7x7 stem (depth halo 2 / 1), 3 classes, non-cubic 32x48x32 crops, class-weighted CE (global weight sum) and the
+        # raw-Sobel edge loss on slabs -- z-sharded RoIs and round-robin heads
+        lcfg = mc.tiny_lits_config("finetune", 32, 16 * world)
+        lcfg.STAGE_SPLIT = False
+        step_cases(lcfg, "l_", [("z", max(world // 2, 1), 2, True), ("rr", 2, 1, False)], 4096)
     if "cfg1" in sections:
         # BASELINE configs[1]'s volume (128x128x64) with the REAL channel counts, 'finetune', 96^3 -> 192^3 masks: (a) the 4 + 8
         # RoIs of the benchmarked step, one positive RoI per rank when world == 4; (b) 2 positive RoIs, each U-Net z-sharded

@@ -223,7 +223,8 @@ def check_worldn(r, sections="halo,conv,rpn,step,rr,dp,unet", tol_mask=2e-2, une
             np.testing.assert_allclose(r[0][key + "rois"], ref["ref_" + key + "rois"], rtol=0, atol=1e-5)
     report = {}
     for tag, sec, rs, pre in (("za", "stepa", 2, ""), ("zb", "stepb", world, ""), ("rr", "rr", 0, ""),
-                              ("c1_rr", "cfg1", 0, "c1_"), ("c1_z", "cfg1", world // 2, "c1_")):
+                              ("c1_rr", "cfg1", 0, "c1_"), ("c1_z", "cfg1", world // 2, "c1_"),
+                              ("l_z", "lits", 2 if world > 2 else world, "l_"), ("l_rr", "lits", 0, "l_")):
         if sec not in sections and not (sec.startswith("step") and "step" in sections):
             continue
         assert int(ref[tag + "_zsharded"][0]) == rs, (tag, ref[tag + "_zsharded"])
@@ -259,7 +260,7 @@ def check_worldn(r, sections="halo,conv,rpn,step,rr,dp,unet", tol_mask=2e-2, une
 def test_depth_sharding_world4(emu_lib, tmp_path):
     """4 ranks: two interior ranks, 2 RoIs x 2 ranks and 1 RoI x 4 ranks z-sharded, round-robin with idle ranks."""
     env = dict(os.environ, CFUN_LIB_PATH=emu_lib, PYTHONPATH=ROOT)
-    sections = "halo,conv,rpn,stepa,stepb,dp"     # (round-robin with idle ranks and the U-Net over all ranks: at world 8)
+    sections = "halo,conv,rpn,stepa,stepb,dp,lits"    # (round-robin with idle ranks and the U-Net over all ranks: at world 8)
     print(check_worldn(run_world(tmp_path, env, 4, "dist_worker_n.py", ("cpu", sections), timeout=1500), sections))
 
 

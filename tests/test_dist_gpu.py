@@ -85,7 +85,7 @@ def test_four_ranks_on_real_kernels(gpu, tmp_path):
     from test_dist_gloo import check_worldn, run_world
     env = {k: v for k, v in os.environ.items() if k not in ("CFUN_LIB_PATH", "CFUN_CONV_ALGO")}
     env["PYTHONPATH"] = ROOT
-    sections = "halo,conv,rpn,step,rr,dp,unet,cfg1"
+    sections = "halo,conv,rpn,step,rr,dp,unet,lits,cfg1"
     r = run_world(tmp_path, env, 4, "dist_worker_n.py", ("cuda:0", sections), timeout=1800)
     print("4 ranks on one GPU, worst gradient rel-L2 vs single process:", check_worldn(r, sections))
 
