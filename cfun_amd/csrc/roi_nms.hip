@@ -1,6 +1,8 @@
 // 3-D RoIAlign (crop + trilinear align_corners resize) and greedy 3-D NMS.
 // Compiled with -ffp-contract=off: the integer crop bounds and the NMS keep list are bit-exact contracts
 // (SURVEY.md App. A-9/A-10), so the fp32 operation order of torch/numpy is reproduced without FMA contraction.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -253,6 +255,50 @@ k_nms_scan(const unsigned long long* __restrict__ mask, const int32_t* __restric
     }
 #pragma unroll
     for (int r = 0; r < CH; ++r) cur[r] = nxt[r];
+  }
+  if (lane == 0) count[0] = cnt;
+}
+
+// word `l` (wave-uniform) of a per-lane 64-bit value: two v_readlane_b32 (a few cycles) instead of two ds_bpermute round trips
+__device__ __forceinline__ unsigned long long lane_word(unsigned long long v, int l) {
+#ifdef CFUN_HIP_EMULATION
+  return __shfl(v, l, 64);
+#else
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+  return ((unsigned long long)hi << 32) | lo;
+#endif
+}
+
+// Round 5: the same greedy scan with the suppression rows in LDS and the loop over KEPT boxes only.  The row-by-row kernel
+// above walks all n <= 1000 candidates through one dependent shuffle each (0.38 ms per call); here 256 threads copy the n x W64
+// words into LDS (128 KB at n = 1000), then one wave takes the candidates 64 at a time: the block's word of the removed set is
+// wave-uniform, its zero bits are the survivors, and only a survivor costs an LDS row read + OR -- the time follows the number of
+// boxes kept (<= max_num), not n.  Same visiting order, same stop rule (utils.py:147-148), so the keep list is bit-identical.
+__global__ void __launch_bounds__(256)
+k_nms_scan_lds(const unsigned long long* __restrict__ mask, const int32_t* __restrict__ order, int n, int W64,
+               int max_num, int32_t* __restrict__ keep, int32_t* __restrict__ count) {
+  CFUN_DYN_LDS(unsigned long long, rows);      // [n][W64]
+  for (int i = threadIdx.x; i < n * W64; i += 256) rows[i] = mask[i];
+  __syncthreads();
+  if (threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
+  unsigned long long removed = 0ull;
+  int cnt = 0;
+  bool done = (max_num <= 0);
+  for (int blk = 0; blk < W64 && !done; ++blk) {
+    const int lim = n - blk * 64;
+    const unsigned long long valid = lim >= 64 ? ~0ull : ((1ull << lim) - 1ull);
+    unsigned long long alive = ~lane_word(removed, blk) & valid;          // wave-uniform
+    while (alive != 0ull && !done) {
+      const int b = __builtin_ctzll(alive);
+      const int i = blk * 64 + b;
+      if (lane == 0) keep[cnt] = order[i];
+      ++cnt;
+      if (cnt >= max_num) done = true;        // utils.py:147-148: break right after the append
+      if (lane < W64) removed |= rows[(int64_t)i * W64 + lane];
+      alive = ~lane_word(removed, blk) & valid & ~((2ull << b) - 1ull);   // candidates after i in this block that survive
+    }
   }
   if (lane == 0) count[0] = cnt;
 }
@@ -530,7 +576,18 @@ int cfun_nms3d(const float* boxes, const float* scores, int32_t n, float thresho
   const int np2 = next_pow2(n);
   hipLaunchKernelGGL(k_nms_sort, dim3(1), dim3(1024), (size_t)np2 * 8, cfun_st(stream), boxes, scores, n, np2, order, sboxes, svol);
   hipLaunchKernelGGL(k_nms_mask, dim3((n * W64 + 255) / 256), dim3(256), 0, cfun_st(stream), sboxes, svol, n, W64, threshold, mask);
-  hipLaunchKernelGGL(k_nms_scan, dim3(1), dim3(64), 0, cfun_st(stream), mask, order, n, W64, max_num, keep, count);
+  const size_t lds = (size_t)n * W64 * sizeof(unsigned long long);
+  static int scan_knob = -1;       // CFUN_NMS_SCAN_LDS = 0: the row-by-row kernel for every n (A/B, tests)
+  if (scan_knob < 0) { const char* e = getenv("CFUN_NMS_SCAN_LDS"); scan_knob = e ? atoi(e) : 1; }
+  if (scan_knob != 0 && lds <= 160 * 1024) {
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_nms_scan_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(k_nms_scan_lds, dim3(1), dim3(256), lds, cfun_st(stream), mask, order, n, W64, max_num, keep, count);
+  } else {       // more rows than LDS holds (n > ~1 130): row by row from memory
+    hipLaunchKernelGGL(k_nms_scan, dim3(1), dim3(64), 0, cfun_st(stream), mask, order, n, W64, max_num, keep, count);
+  }
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }
