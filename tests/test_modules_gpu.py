@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import module_cases as mc
-from conftest import load_golden
+from conftest import ROOT, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -124,6 +124,19 @@ def test_cfg2_full_size_step_properties(gpu, monkeypatch):
     for k in g1:
         assert torch.equal(g1[k], g2[k]), k
     del g2
+    # NOT a self-comparison: the product's gradients at the benchmarked size against the mask head's fp64
+    # gradients of exactly this step (tests/golden/grad_fp64_cfg2.npz: same seed-0 weights, volume, RoIs, seed-1 Dropout3d masks;
+    # generated through the oracle on the host) under the measured bound 3 x (the reference fp32 arithmetic's own deviation) + 2e-5
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    ref64 = bench.load_grad_fp64(net, cfg, "cfg2")
+    assert ref64 is not None, "tests/golden/grad_fp64_cfg2.npz does not belong to these weights (another torch build?)"
+    for k, (g64, stride, floor) in ref64.items():
+        g64 = torch.from_numpy(g64)
+        e = float((g1[k].cpu().double()[::stride] - g64).norm() / g64.norm())
+        bound = bench.GRAD_FP64_FACTOR * floor + bench.GRAD_FP64_FLOOR
+        assert e <= bound, "%s: relL2(GPU, fp64) %.3e > 3 x %.3e + 2e-5" % (k, e, floor)
     monkeypatch.setenv("CFUN_CONV_ALGO", "direct")
     _, l3, g3 = run()
     for a, r in zip(l1, l3):
