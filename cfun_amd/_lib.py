@@ -129,6 +129,8 @@ _SIGNATURES = {
     "cfun_weight_pack": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "cfun_weight_pack_transpose": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "cfun_weight_pack_both": (C.c_int, [_P, _P, _P, _I, _I, _I, _P]),
+    "cfun_fold_up2_fwd": (C.c_int, [_P, _P, _I, _I, _I, _I, _P]),
+    "cfun_fold_up2_bwd": (C.c_int, [_P, _P, _I, _I, _I, _I, _P]),
     "cfun_weight_prepare_kinds": (C.c_int, [_PP, C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]),
     "cfun_weight_prepare_plan": (C.c_int, [C.POINTER(WeightJob), _I, C.POINTER(C.c_int64)]),
     "cfun_weight_prepare": (C.c_int, [_P, _I, _L, _P]),

@@ -136,6 +136,59 @@ k_weight_prepare(const CfunWeightJob* __restrict__ jobs, int njobs) {
   }
 }
 
+
+// ---- fold of "nearest x2 up-sampling -> k^3 conv (pad k/2)" into a 3x3x3 conv on the LOW-resolution input whose 8 output
+// parities are channels (cfun_amd.weights.fold_up2_weight; mask_branch.py:108-116, 216-218).  Hi-res tap t of output parity p
+// reads the low-res offset a = floor((p + t - k/2) / 2) + 1 in {0, 1, 2} per axis; taps that land on the same low-res voxel are
+// summed.  wf [8 * cqp][Ci][27] from w [Co][Ci][k^3] (parity groups padded from Co to cqp channels with zero rows), and the
+// transpose for the weight's gradient.  One launch each way instead of pad + batched matmul (+ sum) of torch: the two Tensile
+// GEMMs and ~6 glue launches per folded weight and direction that rounds 3-4 had on the path (5 folded weights per step).
+__device__ __forceinline__ int fold_a(int p, int t, int k) { return ((p + t - (k >> 1)) >> 1) + 1; }      // (>>: floor)
+
+__global__ void __launch_bounds__(256)
+k_fold_up2_fwd(const float* __restrict__ w, float* __restrict__ wf, int Co, int Ci, int k, int cqp, int64_t total) {
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    int64_t r = idx;
+    const int abc = (int)(r % 27); r /= 27;
+    const int ci = (int)(r % Ci); r /= Ci;
+    const int oc = (int)(r % cqp);
+    const int q = (int)(r / cqp);
+    float acc = 0.f;
+    if (oc < Co) {
+      const int a = abc / 9, b = (abc / 3) % 3, c = abc % 3, pz = q >> 2, py = (q >> 1) & 1, px = q & 1;
+      const float* src = w + ((int64_t)oc * Ci + ci) * k * k * k;
+      for (int t = 0; t < k; ++t) {
+        if (fold_a(pz, t, k) != a) continue;
+        for (int u = 0; u < k; ++u) {
+          if (fold_a(py, u, k) != b) continue;
+          for (int v = 0; v < k; ++v)
+            if (fold_a(px, v, k) == c) acc += src[(t * k + u) * k + v];
+        }
+      }
+    }
+    wf[idx] = acc;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_fold_up2_bwd(const float* __restrict__ g, float* __restrict__ dw, int Co, int Ci, int k, int cqp, int64_t total) {
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    int64_t r = idx;
+    const int v = (int)(r % k); r /= k;
+    const int u = (int)(r % k); r /= k;
+    const int t = (int)(r % k); r /= k;
+    const int ci = (int)(r % Ci);
+    const int oc = (int)(r / Ci);
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {      // each parity reads this hi-res tap at exactly one low-res offset
+      const int abc = (fold_a(q >> 2, t, k) * 3 + fold_a((q >> 1) & 1, u, k)) * 3 + fold_a(q & 1, v, k);
+      acc += g[(((int64_t)q * cqp + oc) * Ci + ci) * 27 + abc];
+    }
+    dw[idx] = acc;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -160,6 +213,26 @@ int cfun_weight_prepare_plan(CfunWeightJob* jobs, int32_t njobs, int64_t* nblock
   }
   if (total > 0x7fffffffLL) return CFUN_EINVAL;
   *nblocks = total;
+  return CFUN_OK;
+}
+
+int cfun_fold_up2_fwd(const float* w, float* wf, int32_t Co, int32_t Ci, int32_t k, int32_t cqp, cfun_stream_t stream) {
+  if (!w || !wf || Co <= 0 || Ci <= 0 || (k != 3 && k != 5) || cqp < Co) return CFUN_EINVAL;
+  const int64_t total = (int64_t)8 * cqp * Ci * 27;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  hipLaunchKernelGGL(k_fold_up2_fwd, dim3((unsigned)blocks), dim3(256), 0, cfun_st(stream), w, wf, Co, Ci, k, cqp, total);
+  CFUN_LAUNCH_CHECK();
+  return CFUN_OK;
+}
+
+int cfun_fold_up2_bwd(const float* g, float* dw, int32_t Co, int32_t Ci, int32_t k, int32_t cqp, cfun_stream_t stream) {
+  if (!g || !dw || Co <= 0 || Ci <= 0 || (k != 3 && k != 5) || cqp < Co) return CFUN_EINVAL;
+  const int64_t total = (int64_t)Co * Ci * k * k * k;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  hipLaunchKernelGGL(k_fold_up2_bwd, dim3((unsigned)blocks), dim3(256), 0, cfun_st(stream), g, dw, Co, Ci, k, cqp, total);
+  CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }
 

@@ -22,9 +22,9 @@ LRELU_SLOPE = 0.01  # nn.LeakyReLU() default, mask_branch.py:18
 
 
 from .weights import (  # noqa: E402,F401  (the weight operands live in weights.py; re-exported)
-    _round16, _PackWeight, _pack, pack_weight, _fold_matrix, _FoldBias, fold_bias, _FoldBiasMany, fold_bias_many,
-    _fold_tensor, _FoldUp2, fold_up2_weight, _SplitChannels, split_channels, _GatherSlices, gather_slices,
-    materialize_weight, WeightScope, fold_up2_weight_eager, _transpose_pack, _FOLD_MATRICES)
+    _round16, _PackWeight, _pack, pack_weight, _FoldBias, fold_bias, _FoldBiasMany, fold_bias_many,
+    _FoldUp2, fold_up2_weight, _SplitChannels, split_channels, _GatherSlices, gather_slices,
+    materialize_weight, WeightScope, fold_up2_weight_eager, _transpose_pack)
 from .hostio import _UploadRing, AsyncScalar, upload, side_stream, side_streams, _UPLOADERS, _SIDE_STREAMS  # noqa: E402,F401
 from .loss_ops import (  # noqa: E402,F401
     _Softmax, softmax_channels, _MaskCE, _MaskCEWeighted, mask_cross_entropy, _EdgeRaw, edge_loss_raw, _EdgeLoss,

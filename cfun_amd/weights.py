@@ -52,23 +52,6 @@ def pack_weight(w):
     return _PackWeight.apply(w)
 
 
-_FOLD_MATRICES = {}
-
-
-def _fold_matrix(k, dtype, device):
-    """f[parity p][low-res offset a + 1][hi-res tap t] = 1 where tap t of output parity p reads low-res offset a -- a
-    constant per kernel size, built on the host once (element writes on a device tensor are one launch each)."""
-    key = (k, dtype, str(device))
-    f = _FOLD_MATRICES.get(key)
-    if f is None:
-        f = torch.zeros(2, 3, k, dtype=dtype)
-        for p in range(2):
-            for t in range(k):
-                f[p, (p + t - k // 2) // 2 + 1, t] = 1.0
-        f = _FOLD_MATRICES[key] = f.to(device)
-    return f
-
-
 class _FoldBias(torch.autograd.Function):
     """t + b * s for a trainable conv bias b under a frozen BatchNorm's constant fold (s, t): the epilogue shift of
     bn(conv + b) = conv * s + (b * s + t).  One launch each way (db = g * s) instead of addcmul's generic backward.
@@ -121,42 +104,28 @@ def fold_bias_many(biases, ss, ts, pre=False):
     return _FoldBiasMany.apply(len(biases), pre, *biases, *ss, *ts)
 
 
-def _fold_tensor(k, dtype, device):
-    """F [8 parities (p,q,r)][k^3 hi-res taps (t,u,v)][27 low-res taps (a,b,c)] = f[p,a,t] f[q,b,u] f[r,c,v]: 0 / 1, constant
-    per kernel size (cached)."""
-    key = ("F", k, dtype, str(device))
-    big = _FOLD_MATRICES.get(key)
-    if big is None:
-        f = _fold_matrix(k, dtype, "cpu")
-        big = torch.einsum("pat,qbu,rcv->pqrtuvabc", f, f, f).reshape(8, k * k * k, 27).contiguous()
-        big = _FOLD_MATRICES[key] = big.to(device)
-    return big
-
-
 class _FoldUp2(torch.autograd.Function):
-    """fold_up2_weight as ONE batched matmul each way: wf[pqr][o][i][abc] = sum_tuv w[o][i][tuv] F[pqr][tuv][abc] (the
-    eight parities are the batch, w is broadcast); an einsum over the three axes costs ~10 launches per weight and
-    direction, four folded weights per step."""
+    """fold_up2_weight: wf[pqr][o][i][abc] = sum_tuv w[o][i][tuv] F[pqr][tuv][abc], F[pqr][tuv][abc] = 1 where hi-res tap (t,u,v) of output parity
+    (p,q,r) reads the low-res offset (a,b,c) = floor((parity + tap - k/2) / 2) + 1 per axis --
+    one launch each way (cfun_fold_up2_fwd / _bwd, round 5).  Rounds 3-4 ran it as a batched torch.matmul against F: two
+    Tensile GEMMs plus pad / sum / fill glue, ~6 launches per folded weight and direction, five folded weights per step."""
 
     @staticmethod
     def forward(ctx, w, cqp):
         o, i, k = w.shape[0], w.shape[1], w.shape[-1]
-        big = _fold_tensor(k, w.dtype, w.device)
-        a = w.detach().reshape(o, i * k ** 3)
-        if cqp != o:      # pad every parity group to cqp output channels (tile-aligned tap skipping): zero rows
-            a = torch.nn.functional.pad(a, (0, 0, 0, cqp - o))
-        wf = torch.matmul(a.reshape(1, cqp * i, k ** 3), big)              # [8, cqp*i, 27]
-        ctx.save_for_backward(big)
         ctx.dims = (o, i, k, cqp)
-        return wf.reshape(8 * cqp, i, 3, 3, 3)
+        src = w.detach().contiguous()
+        wf = torch.empty((8 * cqp, i, 3, 3, 3), dtype=torch.float32, device=w.device)
+        check(_lib.load().cfun_fold_up2_fwd(ptr(src), ptr(wf), o, i, k, cqp, stream(src)), "fold_up2_fwd")
+        return wf
 
     @staticmethod
     def backward(ctx, g):
-        (big,) = ctx.saved_tensors
         o, i, k, cqp = ctx.dims
-        g = g.reshape(8, cqp * i, 27)
-        dw = torch.matmul(g, big.transpose(1, 2)).sum(dim=0)               # [cqp*i, k^3]
-        return dw.reshape(cqp, i, k, k, k)[:o], None
+        g = g.contiguous()
+        dw = torch.empty((o, i, k, k, k), dtype=torch.float32, device=g.device)
+        check(_lib.load().cfun_fold_up2_bwd(ptr(g), ptr(dw), o, i, k, cqp, stream(g)), "fold_up2_bwd")
+        return dw, None
 
 
 def fold_up2_weight(w, cqp=None):

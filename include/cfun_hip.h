@@ -429,6 +429,14 @@ int cfun_weight_prepare_kinds(const CfunConv3dParams* p, int32_t kinds[2], size_
 int cfun_weight_prepare_plan(CfunWeightJob* jobs_host, int32_t njobs, int64_t* nblocks);
 int cfun_weight_prepare(const CfunWeightJob* jobs_dev, int32_t njobs, int64_t nblocks, cfun_stream_t stream);
 
+/* The weight fold of "nn.Upsample(scale_factor=2) -> Conv3d(k, padding=k/2)" (mask_branch.py:108-116: k = 3; 216-218: k = 5) into
+ * a 3x3x3 conv on the low-resolution input that produces the 8 output parities as channels: hi-res tap t of parity p reads the
+ * low-res offset floor((p + t - k/2) / 2) per axis, taps sharing an offset are summed.  w [Co][Ci][k][k][k] -> wf [8 * cqp][Ci][27]
+ * (channel = parity * cqp + co; rows co >= Co are zero: cqp pads a parity group to the kernels' tile width); _bwd is the transpose,
+ * g [8 * cqp][Ci][27] -> dw [Co][Ci][k^3].  k in {3, 5}. */
+int cfun_fold_up2_fwd(const float* w, float* wf, int32_t Co, int32_t Ci, int32_t k, int32_t cqp, cfun_stream_t stream);
+int cfun_fold_up2_bwd(const float* g, float* dw, int32_t Co, int32_t Ci, int32_t k, int32_t cqp, cfun_stream_t stream);
+
 /* cfun_weight_pack and cfun_weight_pack_transpose of the same OIDHW weight in ONE launch (a training step needs both
  * layouts of every conv weight: wp for the forward / weight-gradient kernels, wpT for the data gradient). */
 int cfun_weight_pack_both(const float* w, float* wp, float* wpT, int32_t Co, int32_t Ci, int32_t T, cfun_stream_t stream);
