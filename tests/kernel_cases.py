@@ -703,3 +703,29 @@ def check_weight_scope(device, seed=41):
             else:
                 for a, c, nm in zip(ref, cur, ("y", "dx", "dw")):
                     assert torch.equal(a, c), "%s differs on the prepared pass %d of case %s" % (nm, it, (ci, co, k, stride, algo, gather))
+
+
+def check_fold_up2_kernels(device, seed=41):
+    """cfun_fold_up2_fwd / _bwd against the fold written out with torch: F[pqr][tuv][abc] = f[p,a,t] f[q,b,u] f[r,c,v],
+    f[p][a][t] = 1 where hi-res tap t of output parity p reads low-res offset a = floor((p + t - k//2) / 2) + 1; the forward is
+    w . F (parity groups padded to cqp rows), the backward its transpose (the formulation rounds 3-4 ran as a batched matmul)."""
+    gen = _gen(seed)
+    for k, o, i, cqp in ((3, 20, 40, 32), (3, 40, 8, 48), (3, 8, 4, 8), (5, 8, 8, 8), (5, 3, 4, 16)):
+        f = torch.zeros(2, 3, k)
+        for p in range(2):
+            for t in range(k):
+                f[p, (p + t - k // 2) // 2 + 1, t] = 1.0
+        big = torch.einsum("pat,qbu,rcv->pqrtuvabc", f, f, f).reshape(8, k ** 3, 27)
+        w = randn(gen, o, i, k, k, k)
+        g = randn(gen, 8 * cqp, i, 3, 3, 3)
+        a = torch.nn.functional.pad(w.reshape(o, i * k ** 3), (0, 0, 0, cqp - o))
+        wf_ref = torch.matmul(a.reshape(1, cqp * i, k ** 3).double(), big.double()).reshape(8 * cqp, i, 3, 3, 3)
+        dw_ref = torch.matmul(g.reshape(8, cqp * i, 27).double(), big.double().transpose(1, 2)).sum(0).reshape(cqp, i, k, k, k)[:o]
+        wd = w.clone().to(device).requires_grad_(True)
+        wf = ops.fold_up2_weight(wd, cqp)
+        assert tuple(wf.shape) == (8 * cqp, i, 3, 3, 3)
+        wf.backward(g.to(device))
+        assert_close(wf.detach(), wf_ref.float(), "folded weight (k=%d)" % k, 1e-6)
+        assert_close(wd.grad, dw_ref.float(), "fold backward (k=%d)" % k, 1e-6)
+        pad_rows = wf.detach().reshape(8, cqp, -1)[:, o:]
+        assert pad_rows.numel() == 0 or float(pad_rows.abs().max()) == 0.0          # the padding rows of a parity group are zeros

@@ -20,6 +20,11 @@ def test_instnorm_lrelu(emu, name):
     kc.check_instnorm_lrelu(emu, *kc.NORM_CASES[name])
 
 
+def test_fold_up2_kernels(emu):
+    """cfun_fold_up2_fwd / _bwd against the fold written out as a tensor contraction (k = 3 and 5, padded parity groups)."""
+    kc.check_fold_up2_kernels(emu)
+
+
 def test_fold_up2_conv5(emu):
     kc.check_fold_up2(emu)
 

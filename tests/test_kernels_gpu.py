@@ -30,6 +30,11 @@ def test_instnorm_lrelu_large(gpu):
     kc.check_instnorm_lrelu(gpu, 4, (48, 48, 48), 40)
 
 
+def test_fold_up2_kernels(gpu):
+    """cfun_fold_up2_fwd / _bwd against the fold written out as a tensor contraction (k = 3 and 5, padded parity groups)."""
+    kc.check_fold_up2_kernels(gpu)
+
+
 def test_fold_up2_conv5(gpu):
     kc.check_fold_up2(gpu)
 
