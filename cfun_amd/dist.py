@@ -489,21 +489,34 @@ def local_anchor_index(level_counts, shard=None):
 _ZPLANS = {}
 
 
-def prepare_zshard_groups(group=None):
+def prepare_zshard_groups(group=None, device=None):
     """Create, ONCE and for every possible number of positive RoIs, the sub-groups ``zshard_plan`` hands out: for each
     divisor n of the group's size R (n < R) the n groups of R / n consecutive ranks.  ``dist.new_group`` is collective
     over the DEFAULT process group -- every rank of the job must call this (same ``group`` argument), at set-up time;
     creating groups lazily inside a step, keyed on the data-dependent RoI count, stalls all ranks mid-step and hangs
     when ``group`` is a strict sub-group (hybrid data-parallel x depth-sharded layouts) because the outside ranks never
-    reach the call."""
+    reach the call.  ``device``: this rank's device -- every sub-group it belongs to then runs one tiny all-reduce
+    here, so that RCCL builds the communicators at set-up (with ALL members present) and not inside the first step, where
+    a sub-group's first operation would be the batched halo send/recv of whichever ranks get there first."""
     world = dist.get_world_size(group)
     base = dist.get_process_group_ranks(group) if group is not None else list(range(world))
+    me = dist.get_rank()
     plans = {}
     for n_pos in range(1, world):
         if world % n_pos:
             continue
         rs = world // n_pos
-        plans[n_pos] = (rs, [dist.new_group(ranks=base[i * rs:(i + 1) * rs]) for i in range(n_pos)])
+        groups = []
+        for i in range(n_pos):
+            ranks = base[i * rs:(i + 1) * rs]
+            g = dist.new_group(ranks=ranks)
+            groups.append(g)
+            if device is not None and me in ranks:
+                warm = torch.zeros(1, dtype=torch.float32, device=device)
+                dist.all_reduce(warm, group=g)
+        plans[n_pos] = (rs, groups)
+    if device is not None and torch.device(device).type == "cuda":
+        torch.cuda.current_stream(device).synchronize()
     _ZPLANS[(id(group), world)] = plans
     return plans
 
