@@ -17,7 +17,6 @@ ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = 0, 1, 2
 ALGO_WINO = 4    # every supported 3x3x3 stride-1 conv on the Winograd F(2,3)-along-x kernel (AUTO picks it per shape)
 ALGO_WINO2 = 5   # ... with y in the Winograd domain as well (forward / data gradient)
-ALGO_B3 = 3      # host-side only (opt-in): eligible 3x3x3 convs on the experimental 3xBF16 kernels, the rest as AUTO
 
 
 class ConvParams(C.Structure):
@@ -134,18 +133,6 @@ _SIGNATURES = {
     "cfun_weight_prepare_kinds": (C.c_int, [_PP, C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]),
     "cfun_weight_prepare_plan": (C.c_int, [C.POINTER(WeightJob), _I, C.POINTER(C.c_int64)]),
     "cfun_weight_prepare": (C.c_int, [_P, _I, _L, _P]),
-    "cfun_conv3d_b3_supported": (C.c_int, [_PP]),
-    "cfun_conv3d_b3_preferred": (C.c_int, [_PP]),
-    "cfun_weight_pack_b3_bytes": (_Z, [_I, _I]),
-    "cfun_weight_pack_b3": (C.c_int, [_P, _P, _I, _I, _I, _P]),
-    "cfun_conv3d_b3_fwd_workspace_bytes": (_Z, [_PP]),
-    "cfun_conv3d_b3_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _PP, _P, _Z, _P]),
-    "cfun_conv3d_b3_dgrad_d2s_supported": (C.c_int, [_PP]),
-    "cfun_conv3d_b3_dgrad_d2s": (C.c_int, [_P, _P, _P, _PP, _P]),
-    "cfun_conv3d_b3_wgrad_supported": (C.c_int, [_PP]),
-    "cfun_conv3d_b3_wgrad_preferred": (C.c_int, [_PP]),
-    "cfun_conv3d_b3_wgrad_workspace_bytes": (_Z, [_PP]),
-    "cfun_conv3d_b3_wgrad_oidhw": (C.c_int, [_P, _P, _P, _PP, _P, _Z, _P]),
     "cfun_weight_unpack": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "cfun_halo_pack": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "cfun_halo_unpack": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

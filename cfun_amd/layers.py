@@ -11,13 +11,12 @@ import torch
 import torch.nn as nn
 
 from . import dist, ops
-from ._lib import ALGO_AUTO, ALGO_B3, ALGO_DIRECT, ALGO_MFMA
+from ._lib import ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA
 
 
 def default_algo():
-    """CFUN_CONV_ALGO=auto|direct|mfma selects the HIP conv kernel family (tests; default auto); b3 = auto plus the
-    experimental 3xBF16 kernels (conv3d_b3.hip) for the forward / data-gradient of eligible 3x3x3 convs (opt-in)."""
-    return {"auto": ALGO_AUTO, "direct": ALGO_DIRECT, "mfma": ALGO_MFMA, "b3": ALGO_B3, "b3!": ALGO_B3}[
+    """CFUN_CONV_ALGO=auto|direct|mfma selects the HIP conv kernel family (tests; default auto)."""
+    return {"auto": ALGO_AUTO, "direct": ALGO_DIRECT, "mfma": ALGO_MFMA}[
         os.environ.get("CFUN_CONV_ALGO", "auto")]
 
 

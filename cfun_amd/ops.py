@@ -16,7 +16,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib
-from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ALGO_AUTO, ALGO_B3, ConvParams, check, ptr, stream, workspace
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ALGO_AUTO, ConvParams, check, ptr, stream, workspace
 
 LRELU_SLOPE = 0.01  # nn.LeakyReLU() default, mask_branch.py:18
 
@@ -74,7 +74,7 @@ def _params(spec, x_shape, has_scale, has_shift, has_res):
     p.d2s = int(spec.d2s)
     p.d2s_cq = int(spec.d2s_cq)
     p.tap_skip = int(spec.tap_skip)
-    p.algo = ALGO_AUTO if spec.algo == ALGO_B3 else spec.algo      # ALGO_B3 is resolved on the host (_Conv3d)
+    p.algo = spec.algo
     return p
 
 
@@ -151,20 +151,6 @@ def set_launch_timer(timer):
     _TIMER = timer
 
 
-def _b3_wanted(lib, p):
-    """CFUN_CONV_ALGO=b3: the 3xBF16 kernel for this conv?  ``b3!`` (tests) takes every supported shape, ``b3`` only those
-    large enough to beat the exact-fp32 kernel (cfun_conv3d_b3_preferred)."""
-    if os.environ.get("CFUN_CONV_ALGO") == "b3!":
-        return bool(lib.cfun_conv3d_b3_supported(C.byref(p)))
-    return bool(lib.cfun_conv3d_b3_preferred(C.byref(p)))
-
-
-def _b3_wgrad_wanted(lib, p):
-    if os.environ.get("CFUN_CONV_ALGO") == "b3!":
-        return bool(lib.cfun_conv3d_b3_wgrad_supported(C.byref(p)))
-    return bool(lib.cfun_conv3d_b3_wgrad_preferred(C.byref(p)))
-
-
 class StatsSlot:
     """Receives InstanceNorm statistics (mean, rstd) [N,C,2] of a conv's OUTPUT from the epilogue that writes it
     (cfun_conv3d_fwd_fused, CfunConvFusion.out_stats) -- ``conv3d_w(..., stats=slot)`` fills it, ``instnorm_lrelu(y,
@@ -201,11 +187,7 @@ class _Conv3d(torch.autograd.Function):
         shift = None if shift is None else _c(shift)
         res = None if res is None else _c(res)
         p = _params(spec, x.shape, scale is not None, shift is not None, res is not None)
-        # opt-in 3xBF16 kernels (CFUN_CONV_ALGO=b3): forward here, data gradient in backward; wgrad stays exact fp32
-        b3 = bool(spec.algo == ALGO_B3 and w_src is not None and _b3_wanted(lib, p))
-        if b3:
-            wp, wb3 = None, pack_weight_b3(materialize_weight(w_src))
-        elif w_src is not None:      # OIDHW weight: packed here, its gradient comes back in OIDHW (one fused pass)
+        if w_src is not None:      # OIDHW weight: packed here, its gradient comes back in OIDHW (one fused pass)
             scope = WeightScope.current()
             got = scope.lookup(w_src, p, ctx.needs_input_grad[0]) if scope is not None else None
             if got is not None:          # operands from the pass's batched preparation (the Winograd U etc., not plain packs)
@@ -216,10 +198,9 @@ class _Conv3d(torch.autograd.Function):
                     wp, wpT = _pack(w_src, both=True)
                 else:
                     wp = _pack(w_src)
-        if not b3:
-            wp = _c(wp)
-            if not (p.w_prepared & 1) and wp.shape != (p.kd * p.kh * p.kw, p.Ci, p.CoP):
-                raise RuntimeError("packed weight %s does not match conv %s" % (tuple(wp.shape), spec))
+        wp = _c(wp)
+        if not (p.w_prepared & 1) and wp.shape != (p.kd * p.kh * p.kw, p.Ci, p.CoP):
+            raise RuntimeError("packed weight %s does not match conv %s" % (tuple(wp.shape), spec))
         if spec.d2s:
             cq = spec.d2s_cq or p.Co // 8
             y = torch.empty((p.N, 2 * p.Do, 2 * p.Ho, 2 * p.Wo, cq), dtype=torch.float32, device=x.device)
@@ -236,11 +217,7 @@ class _Conv3d(torch.autograd.Function):
         if timed:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        if b3:
-            ws = workspace(lib.cfun_conv3d_b3_fwd_workspace_bytes(C.byref(p)), x)
-            check(lib.cfun_conv3d_b3_fwd(ptr(x), ptr(wb3), ptr(scale), ptr(shift), ptr(res), ptr(y), C.byref(p), ptr(ws),
-                                         ws.numel(), stream(x)), "conv3d_b3_fwd")
-        elif pro is not None or (stats is not None and (lib.cfun_conv3d_fused_support(C.byref(p)) & _lib.FUSE_OUT_STATS)):
+        if pro is not None or (stats is not None and (lib.cfun_conv3d_fused_support(C.byref(p)) & _lib.FUSE_OUT_STATS)):
             # InstanceNorm statistics of y from this epilogue (the norm that follows skips its pass over y) and / or the
             # norm + activation in front of this conv applied while x is staged
             dst = None
@@ -275,19 +252,17 @@ class _Conv3d(torch.autograd.Function):
         ctx.res_shape = None if res is None else res.shape
         ctx.dx_slot = dx_slot
         ctx.wshape = None if w_src is None else tuple(w_src.shape)
-        ctx.b3 = b3
         ctx.pro = None if pro is None else (int(pro[1]), float(pro[2]))
         ctx.shift_scaled = bool(shift_scaled)
         ctx.w_on_stream = bool(w_src is not None and getattr(w_src, "_cfun_wstream", False))
         ctx.save_for_backward(x, wp if not (p.w_prepared & 1) else None, scale, y if spec.act != ACT_NONE else None, wpT,
-                              w_src.detach() if b3 and ctx.needs_input_grad[0] else None,
                               None if pro is None or pro[0] is None else _c(pro[0]))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        x, wp, scale, y, wpT, w_b3, pst = ctx.saved_tensors
+        x, wp, scale, y, wpT, pst = ctx.saved_tensors
         spec, p = ctx.spec, ctx.p
         fz = None
         if ctx.pro is not None:      # the weight gradient stages x through the same prologue as the forward did
@@ -324,11 +299,7 @@ class _Conv3d(torch.autograd.Function):
                                        LRELU_SLOPE, p.scale_mode, st), "act_bwd(scale)")
         def run_wgrad(st):
             dw = torch.empty(ctx.wshape, dtype=torch.float32, device=dy.device)
-            if spec.algo == ALGO_B3 and _b3_wgrad_wanted(lib, p):      # opt-in 3xBF16 weight gradient
-                ws = workspace(lib.cfun_conv3d_b3_wgrad_workspace_bytes(C.byref(p)), x)
-                check(lib.cfun_conv3d_b3_wgrad_oidhw(ptr(x), ptr(g), ptr(dw), C.byref(p), ptr(ws), ws.numel(), st),
-                      "conv3d_b3_wgrad_oidhw")
-            elif fz is not None:
+            if fz is not None:
                 ws = workspace(lib.cfun_conv3d_bwd_weight_workspace_bytes(C.byref(p)), x)
                 check(lib.cfun_conv3d_bwd_weight_fused(ptr(x), ptr(g), ptr(dw), 1, C.byref(p), C.byref(fz), ptr(ws),
                                                        ws.numel(), st), "conv3d_bwd_weight_fused(oidhw)")
@@ -360,40 +331,21 @@ class _Conv3d(torch.autograd.Function):
         if need_x:
             # dx of a per-sample conv goes straight into its sample of the batch's gradient (zero-copy batch split)
             dx = torch.empty_like(x) if ctx.dx_slot is None else ctx.dx_slot[0].sample(ctx.dx_slot[1], x.shape, x)
-            pd = None
-            if ctx.b3 and spec.d2s:          # hi-res gradient gathered by parity inside the 3xBF16 kernel
-                if lib.cfun_conv3d_b3_dgrad_d2s_supported(C.byref(p)):
-                    wb3t = pack_weight_b3(w_b3, transpose_flip=True)
-                    check(lib.cfun_conv3d_b3_dgrad_d2s(ptr(g), ptr(wb3t), ptr(dx), C.byref(p), st),
-                          "conv3d_b3_dgrad_d2s")
-                    pd = "done"
-            elif ctx.b3:     # the data gradient is the same 3x3x3 conv on g with transposed, mirrored weights
-                pd = _params(ConvSpec(k=(3, 3, 3), co=p.Ci, pad=(1, 1, 1)), g.shape, False, False, False)
-                if not _b3_wanted(lib, pd):
-                    pd = None
-            if pd == "done":
-                pass
-            elif pd is not None:
-                wb3t = pack_weight_b3(w_b3, transpose_flip=True)     # (held until the launch is enqueued)
-                ws = workspace(lib.cfun_conv3d_b3_fwd_workspace_bytes(C.byref(pd)), x)
-                check(lib.cfun_conv3d_b3_fwd(ptr(g), ptr(wb3t), None, None, None, ptr(dx), C.byref(pd), ptr(ws), ws.numel(),
-                                             st), "conv3d_b3_fwd(dgrad)")
-            else:
-                if wpT is None:
-                    if wp is None and w_b3 is None:
-                        raise RuntimeError("conv3d backward: no weight operand was kept for the data gradient")
-                    wpT = _transpose_pack(wp if wp is not None else _pack(w_b3), p.Co)
-                nb = lib.cfun_conv3d_bwd_data_workspace_bytes(C.byref(p))
-                ws = workspace(nb, x)
-                tk = _TIMER.match(p) if (_TIMER is not None and x.is_cuda) else None
-                if tk:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                check(lib.cfun_conv3d_bwd_data(ptr(g), ptr(wpT), ptr(dx), C.byref(p), ptr(ws), ws.numel(), st),
-                      "conv3d_bwd_data")
-                if tk:
-                    e1.record()
-                    _TIMER.add(tk + "_dgrad", e0, e1)
+            if wpT is None:
+                if wp is None:
+                    raise RuntimeError("conv3d backward: no weight operand was kept for the data gradient")
+                wpT = _transpose_pack(wp, p.Co)
+            nb = lib.cfun_conv3d_bwd_data_workspace_bytes(C.byref(p))
+            ws = workspace(nb, x)
+            tk = _TIMER.match(p) if (_TIMER is not None and x.is_cuda) else None
+            if tk:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            check(lib.cfun_conv3d_bwd_data(ptr(g), ptr(wpT), ptr(dx), C.byref(p), ptr(ws), ws.numel(), st),
+                  "conv3d_bwd_data")
+            if tk:
+                e1.record()
+                _TIMER.add(tk + "_dgrad", e0, e1)
         if need_w:
             dwp = torch.empty_like(wp)
             nb = lib.cfun_conv3d_bwd_weight_workspace_bytes(C.byref(p))
@@ -484,7 +436,7 @@ class _Materialize(torch.autograd.Function):
 def _fusable_input(x, spec, scale, shift, res, need_wgrad):
     """Can the conv (spec) stage the NormedInput x through its prologue -- forward kernel and, when the weight needs a
     gradient, the weight-gradient kernel?"""
-    if spec.algo == ALGO_B3 or spec.up2:
+    if spec.up2:
         return False
     lib = _lib.load()
     p = _params(spec, x.shape, scale is not None, shift is not None, res is not None)
@@ -519,49 +471,6 @@ def conv3d_w(x, w, spec, scale=None, shift=None, res=None, out=None, dx_slot=Non
         else:
             x = x.materialize()
     return _Conv3d.apply(x, None, scale, shift, res, spec, out, dx_slot, _tag_wgrad_stream(w, x), stats, pro, shift_scaled)
-
-
-# ---- EXPERIMENTAL: 3x3x3 conv with fp32 emulated on the bf16 matrix cores (conv3d_b3.hip; not used by the modules) ----
-def pack_weight_b3(w, transpose_flip=False):
-    """OIDHW [Co,Ci,3,3,3] -> the 3xBF16 kernel's pre-split A-operand buffer (transpose_flip: the data gradient's)."""
-    lib = _lib.load()
-    w = _c(w.detach().float())
-    co, ci = w.shape[0], w.shape[1]
-    rows, kch = (ci, co) if transpose_flip else (co, ci)
-    nb = lib.cfun_weight_pack_b3_bytes(rows, kch)
-    wb3 = torch.empty(nb, dtype=torch.uint8, device=w.device)
-    check(lib.cfun_weight_pack_b3(ptr(w), ptr(wb3), co, ci, int(transpose_flip), stream(w)), "weight_pack_b3")
-    return wb3
-
-
-def conv3d_b3(x, wb3, co, scale=None, shift=None, res=None, act=ACT_NONE, scale_per_n=False):
-    """y = act(scale * conv3x3x3(x) + shift + res), stride 1, pad 1, NDHWC, forward only (no autograd)."""
-    lib = _lib.load()
-    x = _c(x.detach())
-    spec = ConvSpec(k=(3, 3, 3), co=co, pad=(1, 1, 1), act=act, scale_per_n=scale_per_n)
-    p = _params(spec, x.shape, scale is not None, shift is not None, res is not None)
-    if not lib.cfun_conv3d_b3_supported(C.byref(p)):
-        raise ValueError("conv3d_b3: unsupported shape (needs C_in % 4 == 0, C_in >= 8, C_out % 4 == 0)")
-    y = torch.empty((p.N, p.Do, p.Ho, p.Wo, p.Co), dtype=torch.float32, device=x.device)
-    scale, shift, res = [None if t is None else _c(t) for t in (scale, shift, res)]      # held across the launch
-    ws = workspace(lib.cfun_conv3d_b3_fwd_workspace_bytes(C.byref(p)), x)
-    check(lib.cfun_conv3d_b3_fwd(ptr(x), ptr(wb3), ptr(scale), ptr(shift), ptr(res), ptr(y), C.byref(p), ptr(ws), ws.numel(),
-                                 stream(x)), "conv3d_b3_fwd")
-    return y
-
-
-def conv3d_b3_wgrad(x, g, co):
-    """dW [Co,Ci,3,3,3] of y = conv3x3x3(x, W) (stride 1, pad 1) from x [N,D,H,W,Ci] and g = dL/dy [N,D,H,W,Co]."""
-    lib = _lib.load()
-    x, g = _c(x.detach()), _c(g.detach())
-    p = _params(ConvSpec(k=(3, 3, 3), co=co, pad=(1, 1, 1)), x.shape, False, False, False)
-    if not lib.cfun_conv3d_b3_wgrad_supported(C.byref(p)):
-        raise ValueError("conv3d_b3_wgrad: unsupported shape")
-    dw = torch.empty((co, x.shape[-1], 3, 3, 3), dtype=torch.float32, device=x.device)
-    ws = workspace(lib.cfun_conv3d_b3_wgrad_workspace_bytes(C.byref(p)), x)
-    check(lib.cfun_conv3d_b3_wgrad_oidhw(ptr(x), ptr(g), ptr(dw), C.byref(p), ptr(ws), ws.numel(), stream(x)),
-          "conv3d_b3_wgrad")
-    return dw
 
 
 # ---- zero-copy batch split / join (per-sample convs inside a batched graph) ------------------------------------

@@ -366,33 +366,6 @@ int cfun_mask_losses_bwd_saved(const float* probs, const uint8_t* labels, const 
  * ---------------------------------------------------------------------------------------------- */
 int cfun_weight_pack(const float* w, float* wp, int32_t Co, int32_t Ci, int32_t T, cfun_stream_t stream);
 int cfun_weight_pack_transpose(const float* wp, float* wpT, int32_t Co, int32_t Ci, int32_t T, cfun_stream_t stream);
-/* EXPERIMENTAL, opt-in (not used by the drop-in modules): 3x3x3 stride-1 pad-1 conv (backbone.py / mask_branch.py
- * 3x3x3 layers with C_in % 4 == 0, C_in >= 8, C_out % 4 == 0) with the fp32 operands emulated on the bf16 matrix cores: every
- * fp32 value is split exactly into three bf16 values and the six significant cross products are accumulated in fp32
- * ("3xBF16"; the neglected terms are below 2^-25 of each product).  cfun_weight_pack_b3 splits and swizzles an OIDHW
- * weight [Co,Ci,3,3,3] into the kernel's A-operand order (cfun_weight_pack_b3_bytes(rows, kch) bytes; rows = Co,
- * kch = Ci -- or, with transpose_flip = 1, the data-gradient's weights: rows = Ci, kch = Co).  Epilogue: scale_mode,
- * shift, plain residual and activation as cfun_conv3d_fwd; no up2 / d2s / tap_skip. */
-int cfun_conv3d_b3_supported(const CfunConv3dParams* p);
-int cfun_conv3d_b3_preferred(const CfunConv3dParams* p);   /* supported and large enough to beat the fp32 MFMA kernel */
-size_t cfun_weight_pack_b3_bytes(int32_t rows, int32_t kch);
-int cfun_weight_pack_b3(const float* w, void* wb3, int32_t Co, int32_t Ci, int32_t transpose_flip, cfun_stream_t stream);
-size_t cfun_conv3d_b3_fwd_workspace_bytes(const CfunConv3dParams* p);   /* split-K partials of small volumes (may be 0) */
-int cfun_conv3d_b3_fwd(const float* x, const void* wb3, const float* scale, const float* shift, const float* res,
-                       float* y, const CfunConv3dParams* p, void* ws, size_t ws_bytes, cfun_stream_t stream);
-/* ... also the parity-folded "nearest x2 -> 5x5x5" conv (p->d2s = 1, no tap_skip; mask_branch.py:216-218) with its
- * depth-to-space epilogue, and that conv's data gradient: g = dL/dy in y's hi-res layout [N,2D,2H,2W,cq] is gathered
- * by parity while staging (p = the FORWARD parameters, wb3t = cfun_weight_pack_b3(folded w, transpose_flip = 1)). */
-int cfun_conv3d_b3_dgrad_d2s_supported(const CfunConv3dParams* p);
-int cfun_conv3d_b3_dgrad_d2s(const float* g, const void* wb3t, float* dx, const CfunConv3dParams* p, cfun_stream_t stream);
-
-/* EXPERIMENTAL, opt-in: the weight gradient of the same convs on the bf16 matrix cores (conv3d_b3_wgrad.hip; same
- * operand split).  dw = torch OIDHW [Co,Ci,3,3,3] as cfun_conv3d_bwd_weight_oidhw; ws: _workspace_bytes(p). */
-int cfun_conv3d_b3_wgrad_supported(const CfunConv3dParams* p);
-int cfun_conv3d_b3_wgrad_preferred(const CfunConv3dParams* p);
-size_t cfun_conv3d_b3_wgrad_workspace_bytes(const CfunConv3dParams* p);
-int cfun_conv3d_b3_wgrad_oidhw(const float* x, const float* g, float* dw, const CfunConv3dParams* p, void* ws,
-                               size_t ws_bytes, cfun_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Weight operands of MANY convolutions in ONE launch, straight from their OIDHW tensors.

@@ -549,86 +549,6 @@ def check_weight_layouts(device, seed=13):
         assert torch.equal(wd.grad.cpu(), g[:, :, :co].reshape(*k, ci, co).permute(4, 3, 0, 1, 2)), (co, ci, k)
 
 
-def check_conv_b3(device, n, dhw, ci, co, seed=21, act=ACT_NONE, scale=False, shift=False, res=False):
-    """EXPERIMENTAL 3xBF16 conv (conv3d_b3.hip): forward and data gradient against an fp64 reference -- the error must be
-    at the level of an fp32 convolution (the exact-fp32 MFMA path's own error vs fp64 is the yardstick), not bf16's."""
-    gen = _gen(seed)
-    x = randn(gen, n, *dhw, ci)
-    w = randn(gen, co, ci, 3, 3, 3) / float(ci * 27) ** 0.5
-    sc = (torch.rand(co, generator=gen) + 0.5) if scale else None
-    sf = randn(gen, co) if shift else None
-    rs = randn(gen, n, *dhw, co) if res else None
-    spec = ops.ConvSpec(k=(3, 3, 3), co=co, pad=(1, 1, 1), act=act)
-
-    def ref64(xx, ww):
-        y = F.conv3d(xx.double().permute(0, 4, 1, 2, 3), ww.double(), padding=1).permute(0, 2, 3, 4, 1)
-        if sc is not None:
-            y = y * sc.double()
-        if sf is not None:
-            y = y + sf.double()
-        if rs is not None:
-            y = y + rs.double()
-        if act == ACT_LRELU:
-            y = F.leaky_relu(y, 0.01)
-        elif act == ACT_RELU:
-            y = F.relu(y)
-        return y
-
-    y64 = ref64(x, w)
-    dev = lambda t: None if t is None else t.to(device)
-    y_b3 = ops.conv3d_b3(dev(x), ops.pack_weight_b3(dev(w)), co, dev(sc), dev(sf), dev(rs), act).cpu()
-    y_f32 = ops.conv3d(dev(x), ops.pack_weight(dev(w)), spec, dev(sc), dev(sf), dev(rs)).detach().cpu()
-    scale64 = float(y64.abs().max())
-    e_b3 = float((y_b3.double() - y64).abs().max()) / scale64
-    e_f32 = float((y_f32.double() - y64).abs().max()) / scale64
-    assert e_b3 < 2e-6 and e_b3 < 4 * e_f32 + 5e-7, "3xBF16 forward error %.2e (exact fp32 MFMA: %.2e)" % (e_b3, e_f32)
-    # data gradient = the same kernel on the transposed, mirrored weights
-    g = randn(gen, n, *dhw, co)
-    dx64 = F.conv_transpose3d(g.double().permute(0, 4, 1, 2, 3), w.double(), padding=1).permute(0, 2, 3, 4, 1)
-    if ci % 4 == 0 and co % 4 == 0 and co >= 8:
-        dx_b3 = ops.conv3d_b3(dev(g), ops.pack_weight_b3(dev(w), transpose_flip=True), ci).cpu()
-        e_dx = float((dx_b3.double() - dx64).abs().max()) / float(dx64.abs().max())
-        assert e_dx < 2e-6, "3xBF16 data-gradient error %.2e" % e_dx
-    # weight gradient (conv3d_b3_wgrad.hip)
-    dw64 = torch.nn.grad.conv3d_weight(x.double().permute(0, 4, 1, 2, 3), (co, ci, 3, 3, 3),
-                                       g.double().permute(0, 4, 1, 2, 3), padding=1)
-    dw_b3 = ops.conv3d_b3_wgrad(dev(x), dev(g), co).cpu()
-    e_dw = float((dw_b3.double() - dw64).abs().max()) / float(dw64.abs().max())
-    assert e_dw < 3e-6, "3xBF16 weight-gradient error %.2e" % e_dw
-    return e_b3, e_f32
-
-
-def check_fold5_b3(device, seed=23):
-    """The parity-folded "nearest x2 -> 5x5x5" conv (d2s epilogue + low-res residual) and its data gradient (parity gather
-    of the hi-res gradient) on the 3xBF16 kernels against the exact-fp32 MFMA path: same module-level call
-    (ops.conv3d_w on the folded weight), CFUN_CONV_ALGO=b3! vs auto."""
-    import os
-    from cfun_amd._lib import ALGO_B3
-    gen = _gen(seed)
-    x = randn(gen, 2, 6, 8, 16, 8)
-    w5 = randn(gen, 8, 8, 5, 5, 5) / float(8 * 125) ** 0.5
-    gy = randn(gen, 2, 12, 16, 32, 8)
-    outs = []
-    old = os.environ.get("CFUN_CONV_ALGO")
-    try:
-        for algo, env in ((ALGO_AUTO, "auto"), (ALGO_B3, "b3!")):
-            os.environ["CFUN_CONV_ALGO"] = env
-            xd = x.clone().to(device).requires_grad_(True)
-            wd = w5.clone().to(device).requires_grad_(True)
-            spec = ops.ConvSpec(k=(3, 3, 3), co=64, pad=(1, 1, 1), d2s=True, res_up2=True, algo=algo)
-            y = ops.conv3d_w(xd, ops.fold_up2_weight(wd), spec, res=xd)
-            y.backward(gy.to(device))
-            outs.append((y.detach().cpu(), xd.grad.cpu(), wd.grad.cpu()))
-    finally:
-        if old is None:
-            os.environ.pop("CFUN_CONV_ALGO", None)
-        else:
-            os.environ["CFUN_CONV_ALGO"] = old
-    for a, b, what in zip(outs[0], outs[1], ("y", "dx", "dw")):
-        err = float((a - b).abs().max()) / float(a.abs().max())
-        assert err < 5e-6, "fold5 on 3xBF16: %s differs from the fp32 path by %.2e" % (what, err)
-
-
 def check_mask_losses_lits(device, g):
     """LiTS fork mask losses on the device (ops.mask_cross_entropy(weight=...), ops.edge_loss_raw through the
     differentiable softmax) vs the fork's own values and gradients (golden ``g`` = losses_lits.npz)."""

@@ -1036,41 +1036,6 @@ def check_unmold_lits_golden(device):
     assert int(empty.sum()) == 0
 
 
-def check_b3_module_path(device, seed=31):
-    """The opt-in 3xBF16 kernels through the module layer (layers.Conv3dParams -> ops.conv3d_w -> _Conv3d): forward,
-    data gradient and weight gradient of a two-conv chain with bias, LeakyReLU epilogue, Dropout-style per-sample scale
-    and a residual, CFUN_CONV_ALGO=b3! (every supported conv) against auto (exact fp32 kernels)."""
-    import os
-    from cfun_amd import ops
-    from cfun_amd.layers import Conv3dParams
-    torch.manual_seed(seed)
-    c1, c2 = Conv3dParams(16, 24, 3, padding=1).to(device), Conv3dParams(24, 16, 3, padding=1, bias=False).to(device)
-    gen = torch.Generator().manual_seed(seed)
-    x = torch.randn(2, 4, 5, 17, 16, generator=gen).to(device)
-    drop = (torch.rand(2, 24, generator=gen) + 0.5).to(device)
-    gy = torch.randn(2, 4, 5, 17, 16, generator=gen).to(device)
-    res = []
-    old = os.environ.get("CFUN_CONV_ALGO")
-    try:
-        for env in ("auto", "b3!"):
-            os.environ["CFUN_CONV_ALGO"] = env
-            xx = x.clone().requires_grad_(True)
-            for p in list(c1.parameters()) + list(c2.parameters()):
-                p.grad = None
-            h = c1(xx, act=ops.ACT_LRELU, scale=drop)          # per-sample channel scale (Dropout3d mask), bias, LeakyReLU
-            y = c2(h, res=xx)
-            (y * gy).sum().backward()
-            res.append([y.detach().cpu(), xx.grad.cpu()] + [p.grad.cpu() for p in list(c1.parameters()) + list(c2.parameters())])
-    finally:
-        if old is None:
-            os.environ.pop("CFUN_CONV_ALGO", None)
-        else:
-            os.environ["CFUN_CONV_ALGO"] = old
-    for a, b, what in zip(res[0], res[1], ("y", "dx", "dw1", "db1", "dw2")):
-        err = float((a - b).abs().max()) / max(float(a.abs().max()), 1e-12)
-        assert err < 2e-5, "3xBF16 module path: %s differs from the fp32 path by %.2e" % (what, err)
-
-
 def check_input_pipeline(device, seed=11):
     """f-4: utils.resize_image / resize_mask / mold_inputs (heart) and the LiTS pad-and-resize mold_inputs on the device
     (cfun_resize3d) against the oracle's scipy.ndimage.zoom restatement of skimage.transform.resize (the code path

@@ -90,17 +90,3 @@ def test_mask_losses_fuzz(gpu, seed):
     logits = (rng.normal(size=(shape[0], c) + shape[1:]) * 2).astype(np.float32)
     labels = rng.integers(0, c, shape).astype(np.uint8)
     kc.check_mask_losses(gpu, logits, labels)
-
-
-@pytest.mark.parametrize("seed", range(10))
-def test_conv_b3_fuzz(gpu, seed):
-    """The opt-in 3xBF16 kernels (forward, data gradient, weight gradient) on randomly drawn shapes -- ragged volumes
-    that leave partial tiles on every axis, channel counts that pad K (C % 8 == 4) and the 16-wide sub-tiles -- against
-    fp64 references at fp32-level tolerances."""
-    rng = np.random.default_rng(700 + seed)
-    n = int(rng.integers(1, 4))
-    dhw = (int(rng.integers(1, 11)), int(rng.integers(1, 13)), int(rng.integers(1, 40)))
-    ci = int(rng.choice([8, 12, 16, 20, 24, 40, 52, 80]))
-    co = int(rng.choice([4, 8, 12, 20, 36, 40, 64, 80, 100]))
-    kc.check_conv_b3(gpu, n, dhw, ci, co, seed=900 + seed, act=int(rng.choice([kc.ACT_NONE, kc.ACT_RELU, kc.ACT_LRELU])),
-                     scale=bool(rng.integers(0, 2)), shift=bool(rng.integers(0, 2)), res=bool(rng.integers(0, 2)))

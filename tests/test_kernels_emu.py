@@ -115,17 +115,5 @@ def test_weight_scope(emu):
     kc.check_weight_scope(emu)
 
 
-def test_conv_b3_experimental(emu):
-    """3xBF16 conv prototype on the emulator (the emulated bf16 MFMA sums in its own order: tolerances only)."""
-    kc.check_conv_b3(emu, 1, (5, 6, 17), 8, 20, act=kc.ACT_LRELU, shift=True)
-    kc.check_conv_b3(emu, 2, (4, 4, 16), 24, 40, scale=True, res=True)
-    kc.check_conv_b3(emu, 1, (4, 4, 8), 48, 16, shift=True, act=kc.ACT_RELU)   # 1 tile, 6 chunks: split-K over 3
-    kc.check_conv_b3(emu, 1, (4, 5, 9), 20, 12)                        # K padded 20 -> 24, data gradient K 12 -> 16
-
-
-def test_fold5_b3_experimental(emu):
-    kc.check_fold5_b3(emu)
-
-
 def test_mask_losses_lits_golden(emu):
     kc.check_mask_losses_lits(emu, load_golden("losses_lits"))

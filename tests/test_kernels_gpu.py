@@ -168,19 +168,5 @@ def test_weight_scope(gpu):
     kc.check_weight_scope(gpu)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("n,dhw,ci,co", [(1, (5, 6, 17), 8, 20), (2, (8, 12, 32), 40, 40), (1, (12, 12, 16), 80, 80),
-                                         (1, (6, 6, 16), 160, 160), (2, (9, 7, 21), 24, 32), (2, (8, 8, 16), 20, 20),
-                                         (1, (4, 9, 33), 12, 44), (1, (6, 6, 6), 160, 160), (2, (4, 4, 16), 64, 48)])
-def test_conv_b3_experimental(gpu, n, dhw, ci, co):
-    """3xBF16 conv prototype (conv3d_b3.hip): fp32-level accuracy against fp64, forward and data gradient."""
-    e_b3, e_f32 = kc.check_conv_b3(gpu, n, dhw, ci, co, act=kc.ACT_LRELU, shift=True, res=True)
-    print("3xBF16 max rel err %.2e, exact fp32 MFMA %.2e" % (e_b3, e_f32))
-
-
-def test_fold5_b3_experimental(gpu):
-    kc.check_fold5_b3(gpu)
-
-
 def test_mask_losses_lits_golden(gpu):
     kc.check_mask_losses_lits(gpu, load_golden("losses_lits"))

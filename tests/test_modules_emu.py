@@ -127,12 +127,6 @@ def test_unmold_lits_golden(emu):
     mc.check_unmold_lits_golden(emu)
 
 
-def test_b3_module_path(emu):
-    """Opt-in 3xBF16 conv kernels through the module layer on the emulator (the whole steps run on the GPU tier:
-    test_b3_* in test_modules_gpu.py; on the emulator one such step takes 90 s)."""
-    mc.check_b3_module_path(emu)
-
-
 def test_training_step_lits_finetune(emu_direct):
     """LiTS fork 'finetune': class-weighted mask CE + raw-Sobel edge loss through the whole step vs the oracle."""
     mc.check_training_step_vs_oracle(emu_direct, mc.tiny_lits_config("finetune"), n_pos=1, fp64_bound=False)

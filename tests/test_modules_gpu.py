@@ -79,11 +79,8 @@ def test_two_models_alternating(gpu):
     mc.check_two_models_alternating(gpu)
 
 
-@pytest.mark.parametrize("algo", ["auto", "b3!"])
-def test_step_bit_reproducible_under_allocator_churn(gpu, monkeypatch, algo):
-    """Product kernels and the opt-in 3xBF16 ones: the two-stream step repeated under allocator churn, bit for bit."""
-    if algo != "auto":
-        monkeypatch.setenv("CFUN_CONV_ALGO", algo)
+def test_step_bit_reproducible_under_allocator_churn(gpu):
+    """The two-stream step repeated under allocator churn, bit for bit."""
     mc.check_step_bit_reproducible_under_churn(gpu, runs=8)
 
 
@@ -480,39 +477,9 @@ def test_mask_head_side_stream(gpu):
             assert torch.equal(g, results[0][1][k]), k
 
 
-# ---- opt-in 3xBF16 conv kernels (CFUN_CONV_ALGO=b3): the same parity gates as the default fp32 MFMA path
-def test_b3_unet_golden(gpu, monkeypatch):
-    monkeypatch.setenv("CFUN_CONV_ALGO", "b3!")
-    for name in ("unet_beginning_train", "unet_finetune_train"):
-        mc.check_unet_golden(gpu, name)
-
-
-def test_b3_training_step_tiny_vs_oracle(gpu, monkeypatch):
-    monkeypatch.setenv("CFUN_CONV_ALGO", "b3!")
-    # (round 5: the opt-in path is held to the SAME measured fp64 bound as the exact-fp32 product, not the blanket tolerance)
-    mc.check_training_step_vs_oracle(gpu, mc.tiny_config("finetune"), fp64_bound=True)
-
-
-def test_b3_training_step_cfg0_vs_oracle(gpu, monkeypatch):
-    """Real channel counts (b = 20: the 40 / 80 / 160 / 320-channel 3x3x3 layers and FPN / RPN run on the 3xBF16
-    kernels, forward and data gradient) against the oracle on the host."""
-    from cfun_amd import config
-    monkeypatch.setenv("CFUN_CONV_ALGO", "b3!")
-    mc.check_training_step_vs_oracle(gpu, config.heart_config("beginning", 64, 64, 32), n_pos=2, fp64_bound=True)
-
-
-def test_b3_predict_cfg0_reference_golden(gpu, monkeypatch):
-    monkeypatch.setenv("CFUN_CONV_ALGO", "b3!")
-    mc.check_predict_cfg0_golden(gpu)
-
-
 def test_training_step_lits_finetune(gpu):
     """LiTS fork 'finetune': class-weighted mask CE + raw-Sobel edge loss through the whole step vs the oracle."""
     mc.check_training_step_vs_oracle(gpu, mc.tiny_lits_config("finetune"))
-
-
-def test_b3_module_path(gpu):
-    mc.check_b3_module_path(gpu)
 
 
 def test_fpn_rpn_lits_golden(gpu):

@@ -16,7 +16,7 @@ FAMILIES = [
     ("conv fwd / dgrad: Winograd (k_conv_wino)", r"k_conv_wino"),
     ("conv fwd / dgrad: direct MFMA (k_conv_mfma)", r"k_conv_mfma"),
     ("weight gradients (k_wgrad_*)", r"k_wgrad"),
-    ("stem / pointwise / direct VALU convs", r"k_conv_stem|k_conv_pointwise|k_conv_.*direct|k_conv_b3"),
+    ("stem / pointwise / direct VALU convs", r"k_conv_stem|k_conv_pointwise|k_conv_.*direct"),
     ("split-K finish, partial reductions, weight packs / transforms", r"splitk|reduce_partials|reduce_unpack|transpose_pad|k_wino_weights|weight_pack|k_fold|k_pack|k_unpack"),
     ("InstanceNorm / LeakyReLU / channel reductions", r"instnorm|channel_reduce|channel_finalize|lrelu|k_act_bwd|k_norm"),
     ("mask losses (softmax, CE, edge)", r"softmax|k_ce_|k_edge|loss"),
