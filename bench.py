@@ -285,25 +285,46 @@ GRAD_PARITY_KEYS = {
     "classifier.conv1.weight": 1e-3,
 }
 GRAD_FP64_FIXTURE = "tests/golden/grad_fp64_cfg2.npz"
+UNET_FALLBACK_BOUND = 4e-2      # U-Net tensors not named above, when the fp64 fixture does not belong to the run's weights
+
+
+def grad_parity_keys(net):
+    """The tensors of `grad_parity`: EVERY U-Net conv weight (27; the fp64 fixture covers them all since round 6) and one
+    tensor of each detector part.  {name: fall-back bound on relL2(GPU, CPU fp32)}."""
+    keys = dict(GRAD_PARITY_KEYS)
+    for k, p in net.named_parameters():
+        if k.startswith("mask.modified_u_net.") and k.endswith(".weight") and p.requires_grad:
+            keys.setdefault(k, UNET_FALLBACK_BOUND)
+    return keys
 
 
 def load_grad_fp64(net, cfg, workload):
-    """The fp64 reference gradients of the cfg2 bench step's mask head, or None when they do not apply to this run (another
-    workload, or weights that are not the ones the fixture was generated from: checked through |weight| checksums)."""
+    """The fp64 reference gradients of the cfg2 bench step's mask head -- every U-Net conv weight since round 6 -- or None when
+    they do not apply to this run (another workload, or weights that are not the ones the fixture was generated from: checked
+    through |weight| checksums).  {name: (g64 sample, flat stride, floor)}: the sample is tensor.reshape(-1)[::stride]."""
     import numpy as np
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), GRAD_FP64_FIXTURE)
     if workload != "cfg2" or not os.path.exists(path):
         return None
     d = np.load(path)
     names = sorted(k[4:] for k in d.files if k.startswith("g64_"))
+    chk_names = [str(k) for k in d["w_check_names"]]
     sd = net.state_dict()
-    chk = np.array([float(sd[k].detach().double().abs().sum().cpu()) for k in names])
+    chk = np.array([float(sd[k].detach().double().abs().sum().cpu()) for k in chk_names])
     if chk.shape != d["w_check"].shape or np.abs(chk - d["w_check"]).max() > 1e-6 * np.abs(d["w_check"]).max():
         return None
-    return {k: (d["g64_" + k].astype(np.float64), int(d["stride_" + k]), float(d["floor_" + k])) for k in names}
+    return {k: (d["g64_" + k].astype(np.float64), int(d["fstride_" + k]), float(d["floor_" + k])) for k in names}
 
 
-def cpu_baseline(cfg, net, sample, threads, iters=1, small_iters=3):
+def grad_fp64_error(grad, ref):
+    """relL2 of a parameter gradient (torch tensor) against its fixture entry (g64 sample, flat stride, floor)."""
+    g64, stride, _ = ref
+    g64 = torch.from_numpy(g64)
+    a = grad.detach().cpu().double().reshape(-1)[::stride]
+    return float((a - g64).norm() / g64.norm().clamp(min=1e-300))
+
+
+def cpu_baseline(cfg, net, sample, threads, iters=1, small_iters=3, grad_keys=GRAD_PARITY_KEYS):
     """The reference's CPU path timed beside the GPU run: the oracle (oracle/cfun_oracle.py -- the plain fp32 torch-CPU
     restatement of the reference, pinned to it by tests/golden) runs THE SAME training step -- this run's weights, image,
     4 + 8 injected RoIs, targets, all six losses incl. the 3-D Sobel edge loss, forward + backward -- on the host cores.
@@ -337,7 +358,7 @@ def cpu_baseline(cfg, net, sample, threads, iters=1, small_iters=3):
                                 loss_weights=[float(cfg_i.LOSS_WEIGHTS[k]) for k in keys])
         ref["total"].backward()
         dt = time.perf_counter() - t0
-        grads = {k: sd[k].grad.detach().clone() for k in GRAD_PARITY_KEYS if k in sd and sd[k].grad is not None}
+        grads = {k: sd[k].grad.detach().clone() for k in grad_keys if k in sd and sd[k].grad is not None}
         return dt, [float(l) for l in ref["losses"]], grads
 
     # warm-up: the same code path at the smallest configuration (BASELINE configs[0]'s 64x64x32 volume, 1 + 2 RoIs), then
@@ -690,10 +711,11 @@ def main():
                 unet.dropout_masks = prev_masks
             torch.cuda.synchronize()
             named = dict(net.named_parameters())
-            gg = {k: named[k].grad.detach().cpu().clone() for k in GRAD_PARITY_KEYS if k in named and named[k].grad is not None}
+            pkeys = grad_parity_keys(net)
+            gg = {k: named[k].grad.detach().cpu().clone() for k in pkeys if k in named and named[k].grad is not None}
             torch.cuda.empty_cache()
             phys, _ = physical_cores()
-            cb = cpu_baseline(cfg, net, sample, threads=max(1, min(phys, 64)), iters=args.cpu_baseline_iters)
+            cb = cpu_baseline(cfg, net, sample, threads=max(1, min(phys, 64)), iters=args.cpu_baseline_iters, grad_keys=pkeys)
             cg = cb.pop("_grads") or {}
             result["cpu_baseline"] = cb
             rel = [abs(g - c) / max(abs(c), 1e-12) for g, c in zip(gl, cb["losses"])]
@@ -707,16 +729,14 @@ def main():
             # ... and the parameter gradients of the same two steps (the oracle leg calls backward() anyway)
             ref64 = load_grad_fp64(net, cfg, args.workload)
             gp = {}
-            for k, bound in GRAD_PARITY_KEYS.items():
+            for k, bound in pkeys.items():
                 if k in gg and k in cg:
                     a, c = gg[k].double(), cg[k].double()
                     e = {"rel_l2_vs_cpu_fp32": float((a - c).norm() / c.norm().clamp(min=1e-300)), "norm_cpu": float(c.norm())}
                     if ref64 is not None and k in ref64:
-                        g64, stride, floor = ref64[k]
-                        g64 = torch.from_numpy(g64)
-                        den = g64.norm().clamp(min=1e-300)
-                        e.update(rel_l2_vs_fp64=float((a[::stride] - g64).norm() / den),
-                                 cpu_fp32_vs_fp64=float((c[::stride] - g64).norm() / den), reference_fp32_floor=floor)
+                        floor = ref64[k][2]
+                        e.update(rel_l2_vs_fp64=grad_fp64_error(a, ref64[k]), cpu_fp32_vs_fp64=grad_fp64_error(c, ref64[k]),
+                                 reference_fp32_floor=floor)
                         # the reference arithmetic's deviation from fp64: the larger of the fixture's two evaluations (torch CPU
                         # fp32 with 8 and with 96 threads) and THIS run's CPU oracle leg -- it moves with the thread count where a
                         # LeakyReLU kink flip reaches the tensor (l4.0: 1.8e-4 / 6.8e-4)
@@ -730,8 +750,8 @@ def main():
                         e.update(rel_l2=e["rel_l2_vs_cpu_fp32"], bound=bound, rule="relL2(GPU, CPU fp32) <= bound")
                     gp[k] = e
             ok = bool(gp) and all(v["rel_l2"] <= v["bound"] for v in gp.values())
-            result["grad_parity"] = {"what": "parameter gradients of the same extra GPU step at the benchmarked size: U-Net "
-                                             "tensors against the mask head's fp64 gradients (%s; bound = 3 x the deviation "
+            result["grad_parity"] = {"what": "parameter gradients of the same extra GPU step at the benchmarked size: all 27 U-Net "
+                                             "conv weights against the mask head's fp64 gradients (%s; bound = 3 x the deviation "
                                              "of the reference's own fp32 arithmetic from them + 2e-5), detector tensors "
                                              "against the oracle's CPU fp32 backward" % GRAD_FP64_FIXTURE,
                                      "fp64_fixture_applies": ref64 is not None, "tensors": gp, "ok": ok}

@@ -112,6 +112,11 @@ _SIGNATURES = {
     "cfun_mask_losses_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "cfun_edge_loss_fwd_save": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "cfun_mask_losses_bwd_saved": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "cfun_mask_fused_workspace_bytes": (_Z, []),
+    "cfun_mask_fused_supported": (C.c_int, [_I, _I, _I, _I, _I]),
+    "cfun_mask_fused_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "cfun_mask_fused_u_bytes": (_Z, [_I, _I, _I, _I, _I]),
+    "cfun_mask_fused_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cfun_mask_target_labels": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "cfun_ce_weighted_workspace_bytes": (_Z, []),
     "cfun_softmax_ce_weighted_fwd": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P, _Z, _P]),

@@ -580,46 +580,53 @@ def sharded_training_step(net, s, shard=None, zshard_unet=True, dropout_seed=0):
     with torch.no_grad():      # one 188 KB all-gather of the ranks' top candidates; identical proposals on every rank
         rpn_rois = gather_rpn_candidates(local, net, "training", shard)
 
-    # ---- RPN losses on the local anchors (model.py:808-860), global normalisation
-    counts = [lv[0].shape[1] * R for lv in local]
-    lidx = local_anchor_index(counts, shard).to(image.device)
-    m = s["rpn_match"].squeeze(2)[0]                                  # [A] global
-    logits_l = torch.cat([lv[0] for lv in local], dim=1)[0]           # [A/R, 2]
-    bbox_l = torch.cat([lv[2] for lv in local], dim=1)[0]             # [A/R, 6]
-    m_l = m[lidx]
-    nz, npos = int((m != 0).sum()), int((m == 1).sum())
-    sel = torch.nonzero(m_l != 0)[:, 0]
-    l_rpn_cls = F.cross_entropy(logits_l[sel], (m_l[sel] == 1).long(), reduction="sum") / max(nz, 1) if sel.numel() \
-        else logits_l.sum() * 0.0
-    pos_rank = torch.cumsum((m == 1).long(), 0) - 1                    # k-th positive <-> target row k
-    psel = torch.nonzero(m_l == 1)[:, 0]
-    l_rpn_box = F.smooth_l1_loss(bbox_l[psel], s["rpn_bbox_t"][0, pos_rank[lidx[psel]]], reduction="sum") / max(npos * 6, 1) \
-        if psel.numel() else bbox_l.sum() * 0.0
-
-    # ---- heads on this rank's share of the RoIs.  The classifier's RoIAlign crosses slabs: every rank aligns ALL RoIs on
-    # its own p2 / p3 slabs (planes it does not hold count as zeros -- RoIAlign is linear in the map), ONE all-reduce adds
-    # the shares up (12 crops: 10.6 MB, instead of all-gathering p2 + p3: 66 MB forward, 2 x 66 MB backward at
-    # 512x512x256), and the backward all-reduces the crops' gradients the same way before each rank scatters into its slabs.
+    # The LiTS fork trains in two phases (LiTSConfig.STAGE_SPLIT; LiTS_2017/model.py:985-1001, 1518-1548), as step.compute_losses
+    # does: 'beginning' = detector only (no mask head, both mask losses 0), any other stage = mask branch only (FPN / RPN frozen,
+    # no classifier head, the four detector losses 0).  ADVICE round 5: this function used to run every head in every phase.
+    det_on, mask_on = not net.mask_phase_only, not net.detector_phase_only
     rois = torch.cat([s["p_rois"], s["n_rois"]], dim=0)
     n_all, n_pos = rois.shape[0], s["p_rois"].shape[0]
-    mine = torch.arange(n_all, device=rois.device)[r::R]         # (empty on a rank beyond the RoI count: world-4 test)
-    slabs = tuple((r * t.shape[1], R * t.shape[1]) for t in (p2s, p3s))
-    crops = all_reduce_sum(M.pyramid_roi_align_ndhwc(rois.detach(), [p2s[0], p3s[0]], net.classifier.pool_size, slabs), shard)
-    # Every rank must run the crops' backward (an all-reduce): a rank that holds no RoI at all when R > number of RoIs
-    # would otherwise skip a collective its peers issue.  `zero` touches the crops and is added to the total unconditionally.
-    zero = crops.sum() * 0.0
-    l_cls = l_box = zero
-    if mine.numel():
-        cls_logits, _, cls_bbox = net.classifier.head_ndhwc(crops[mine])
-        tcls = s["target_class_ids"][mine]
-        l_cls = F.cross_entropy(cls_logits, (tcls > 0).long(), reduction="sum") / n_all
-        pos = torch.nonzero(tcls > 0)[:, 0]
-        npos_all = int((s["target_class_ids"] > 0).sum())
-        if pos.numel():
-            l_box = F.smooth_l1_loss(cls_bbox[pos, 1, :], s["target_deltas"][mine][pos], reduction="sum") / (npos_all * 6)
-    pmine = torch.arange(n_pos, device=rois.device)[r::R]
+    zero = torch.zeros((), dtype=torch.float32, device=image.device)
+    l_rpn_cls = l_rpn_box = l_cls = l_box = zero
+    if det_on:
+        # ---- RPN losses on the local anchors (model.py:808-860), global normalisation
+        counts = [lv[0].shape[1] * R for lv in local]
+        lidx = local_anchor_index(counts, shard).to(image.device)
+        m = s["rpn_match"].squeeze(2)[0]                                  # [A] global
+        logits_l = torch.cat([lv[0] for lv in local], dim=1)[0]           # [A/R, 2]
+        bbox_l = torch.cat([lv[2] for lv in local], dim=1)[0]             # [A/R, 6]
+        m_l = m[lidx]
+        nz, npos = int((m != 0).sum()), int((m == 1).sum())
+        sel = torch.nonzero(m_l != 0)[:, 0]
+        l_rpn_cls = F.cross_entropy(logits_l[sel], (m_l[sel] == 1).long(), reduction="sum") / max(nz, 1) if sel.numel() \
+            else logits_l.sum() * 0.0
+        pos_rank = torch.cumsum((m == 1).long(), 0) - 1                    # k-th positive <-> target row k
+        psel = torch.nonzero(m_l == 1)[:, 0]
+        l_rpn_box = F.smooth_l1_loss(bbox_l[psel], s["rpn_bbox_t"][0, pos_rank[lidx[psel]]], reduction="sum") / max(npos * 6, 1) \
+            if psel.numel() else bbox_l.sum() * 0.0
+
+        # ---- heads on this rank's share of the RoIs.  The classifier's RoIAlign crosses slabs: every rank aligns ALL RoIs on
+        # its own p2 / p3 slabs (planes it does not hold count as zeros -- RoIAlign is linear in the map), ONE all-reduce adds
+        # the shares up (12 crops: 10.6 MB, instead of all-gathering p2 + p3: 66 MB forward, 2 x 66 MB backward at
+        # 512x512x256), and the backward all-reduces the crops' gradients the same way before each rank scatters into its slabs.
+        mine = torch.arange(n_all, device=rois.device)[r::R]         # (empty on a rank beyond the RoI count: world-4 test)
+        slabs = tuple((r * t.shape[1], R * t.shape[1]) for t in (p2s, p3s))
+        crops = all_reduce_sum(M.pyramid_roi_align_ndhwc(rois.detach(), [p2s[0], p3s[0]], net.classifier.pool_size, slabs), shard)
+        # Every rank must run the crops' backward (an all-reduce): a rank that holds no RoI at all when R > number of RoIs
+        # would otherwise skip a collective its peers issue.  `zero` touches the crops and is added to the total unconditionally.
+        zero = crops.sum() * 0.0
+        l_cls = l_box = zero
+        if mine.numel():
+            cls_logits, _, cls_bbox = net.classifier.head_ndhwc(crops[mine])
+            tcls = s["target_class_ids"][mine]
+            l_cls = F.cross_entropy(cls_logits, (tcls > 0).long(), reduction="sum") / n_all
+            pos = torch.nonzero(tcls > 0)[:, 0]
+            npos_all = int((s["target_class_ids"] > 0).sum())
+            if pos.numel():
+                l_box = F.smooth_l1_loss(cls_bbox[pos, 1, :], s["target_deltas"][mine][pos], reduction="sum") / (npos_all * 6)
+    pmine = torch.arange(n_pos if mask_on else 0, device=rois.device)[r::R]
     l_mask = l_edge = zero
-    plan = zshard_plan(shard, n_pos) if (zshard_unet and not net.detector_phase_only) else None
+    plan = zshard_plan(shard, n_pos) if (zshard_unet and mask_on) else None
     unet = net.mask.modified_u_net
     # the mask losses of the configuration (step.CFUNHotPath._mask_losses): heart -- CE, and in 'finetune' the Sobel-magnitude
     # edge loss; LiTS fork -- class-weighted CE, raw-Sobel edge loss in every non-'beginning' stage (LiTS_2017/model.py:907-1001)
@@ -672,11 +679,15 @@ def sharded_training_step(net, s, shard=None, zshard_unet=True, dropout_seed=0):
             else:
                 l_edge = ph.sum() * 0.0
     elif pmine.numel():
+        fused = net.fused_mask_losses() and edge_on       # heart 'finetune': one loss pass each way (ops.mask_losses_fused)
         with slab_local():      # the U-Net's 3x3x3 convs see whole RoI crops, not depth slabs
-            mlog, mprob = net.mask.forward_ndhwc(ops.to_ndhwc(image)[0], s["p_rois"][pmine])
+            mlog, mprob = net.mask.forward_ndhwc(ops.to_ndhwc(image)[0], s["p_rois"][pmine], softmax=not fused)
         labels = s["mask_labels"][pmine].contiguous()
         share = pmine.numel() / float(n_pos)
-        if cw is None and not raw and edge_on:      # heart 'finetune': CE + edge share one fused backward pass
+        if fused:
+            ce, edge, mprob = ops.mask_losses_fused(mlog, labels)
+            l_mask, l_edge = ce * share, edge * share
+        elif cw is None and not raw and edge_on:    # ... or CE + edge with the separate forward kernels, one fused backward
             ce, edge = ops.mask_losses(mlog, mprob, labels)
             l_mask, l_edge = ce * share, edge * share
         else:
@@ -688,7 +699,8 @@ def sharded_training_step(net, s, shard=None, zshard_unet=True, dropout_seed=0):
                 l_edge = edge_fn(mprob, labels) * share
     losses = [l_rpn_cls, l_rpn_box, l_cls, l_box, l_mask, l_edge]
     total = net.total_loss(losses) + zero
-    total.backward()
+    if total.requires_grad:         # (mask phase on a rank that holds no positive RoI: nothing to back-propagate)
+        total.backward()
     return losses, total, rpn_rois
 
 

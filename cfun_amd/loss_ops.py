@@ -222,3 +222,56 @@ def mask_losses(logits, probs, labels):
     """Both 'finetune' mask losses (model.py:909-981) of logits [n,D,H,W,C] with probs = softmax(logits):
     returns (cross entropy, Sobel edge loss); the backward is one fused pass (cfun_mask_losses_bwd)."""
     return _MaskLosses.apply(logits, probs.detach(), labels)
+
+
+class _MaskLossesFused(torch.autograd.Function):
+    """(CE, edge, probs) from the logits in ONE forward pass (cfun_mask_fused_fwd: softmax + cross entropy + Sobel edge loss,
+    model.py:799 / 909-935 / 938-981) and ONE backward pass (cfun_mask_fused_bwd: a 2-D stencil per plane over the field the
+    training forward leaves behind + the softmax backward).  ``probs`` is returned as a constant (the reference's
+    Mask.forward output); the gradient of both losses through the softmax reaches ``logits`` in the backward."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        lib = _lib.load()
+        logits, labels = _c(logits), _c(labels)
+        n, d, h, w, c = logits.shape
+        if labels.dtype != torch.uint8 or labels.numel() != n * d * h * w:
+            raise RuntimeError("mask_losses_fused: labels must be uint8 [n,D,H,W]")
+        probs = torch.empty_like(logits)
+        out = torch.empty((2,), dtype=torch.float32, device=logits.device)
+        ws = workspace(lib.cfun_mask_fused_workspace_bytes(), logits)
+        u = None
+        if ctx.needs_input_grad[0]:
+            u = torch.empty(lib.cfun_mask_fused_u_bytes(n, d, h, w, c) // 4, dtype=torch.float32, device=logits.device)
+        check(lib.cfun_mask_fused_fwd(ptr(logits), ptr(labels), ptr(probs), ptr(out), ptr(u), n, d, h, w, c, ptr(ws),
+                                      ws.numel(), stream(logits)), "mask_fused_fwd")
+        ctx.save_for_backward(probs, labels, u)
+        ctx.mark_non_differentiable(probs)
+        return out[0], out[1], probs
+
+    @staticmethod
+    def backward(ctx, g_ce, g_edge, _g_probs):
+        lib = _lib.load()
+        probs, labels, u = ctx.saved_tensors
+        n, d, h, w, c = probs.shape
+        g = torch.stack([g_ce.reshape(()).float(), g_edge.reshape(()).float()])
+        dl = torch.empty_like(probs)
+        check(lib.cfun_mask_fused_bwd(ptr(u), ptr(probs), ptr(labels), ptr(g), ptr(dl), n, d, h, w, c, stream(probs)),
+              "mask_fused_bwd")
+        return dl, None
+
+
+def mask_losses_fused_supported(logits):
+    n, d, h, w, c = logits.shape
+    return bool(_lib.load().cfun_mask_fused_supported(n, d, h, w, c))
+
+
+def mask_losses_fused(logits, labels):
+    """Both 'finetune' mask losses AND the mask probabilities from the logits [n,D,H,W,C] in one pass each way: returns
+    (cross entropy, Sobel edge loss, probs = softmax(logits)).  Shapes the fused kernels do not take (C not 8 / 3, an axis
+    shorter than 3) go through the separate kernels."""
+    if not mask_losses_fused_supported(logits):
+        probs = softmax_channels(logits.detach())
+        ce, edge = mask_losses(logits, probs, labels)
+        return ce, edge, probs
+    return _MaskLossesFused.apply(logits, labels)

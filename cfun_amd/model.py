@@ -401,11 +401,12 @@ class Mask(nn.Module):
         self.pool_size, self.test_flag = pool_size, test_flag
         self.modified_u_net = mask_branch.Modified3DUNet(channel, num_classes, stage, conv_channel, dropout_p)
 
-    def forward_ndhwc(self, image, rois):
-        """image [D,H,W,C]; rois [R,6] -> (logits, probs) both [R,d,h,w,classes]."""
+    def forward_ndhwc(self, image, rois, softmax=True):
+        """image [D,H,W,C]; rois [R,6] -> (logits, probs) both [R,d,h,w,classes].  ``softmax=False``: (logits, None) -- the
+        training step's fused loss pass (ops.mask_losses_fused) produces the probabilities together with both mask losses."""
         x = ops.roi_align(image, rois.detach(), self.pool_size)[0]
         logits = self.modified_u_net.forward_ndhwc(x)
-        return logits, ops.softmax_channels(logits)
+        return logits, (ops.softmax_channels(logits) if softmax else None)
 
     def forward(self, x, rois):
         rois = rois.squeeze(0) if rois.dim() == 3 else rois

@@ -28,7 +28,7 @@ from .weights import (  # noqa: E402,F401  (the weight operands live in weights.
 from .hostio import _UploadRing, AsyncScalar, upload, side_stream, side_streams, _UPLOADERS, _SIDE_STREAMS  # noqa: E402,F401
 from .loss_ops import (  # noqa: E402,F401
     _Softmax, softmax_channels, _MaskCE, _MaskCEWeighted, mask_cross_entropy, _EdgeRaw, edge_loss_raw, _EdgeLoss,
-    edge_loss, _MaskLosses, mask_losses)
+    edge_loss, _MaskLosses, mask_losses, _MaskLossesFused, mask_losses_fused, mask_losses_fused_supported)
 
 
 @dataclass(frozen=True)

@@ -21,6 +21,11 @@ from . import backbone, layers, model, ops, utils
 # small, latency-bound launches of the detector hide beside the U-Net's chip-filling convs: 44.9 -> 42.9 ms per step at
 # cfg2 (profiles/round4_*), same bits (test_mask_head_side_stream).
 OVERLAP_MASK_HEAD = os.environ.get("CFUN_OVERLAP_MASK_HEAD", "1") == "1"
+# Round 6: in the heart 'finetune' step the softmax of Mask.forward (model.py:799), the cross entropy (model.py:909-935) and the
+# Sobel edge loss (model.py:938-981) are ONE pass over the logits, their backward ONE pass over the probabilities
+# (ops.mask_losses_fused, csrc/loss_fused.hip) instead of three forward passes + a gather over a 1.5 GB coefficient field.
+# CFUN_FUSED_MASK_LOSS=0: the separate kernels of rounds 1-5 (A/B runs; same values to fp32 summation order).
+FUSED_MASK_LOSS = os.environ.get("CFUN_FUSED_MASK_LOSS", "1") == "1"
 
 
 class CFUNHotPath(nn.Module):
@@ -102,7 +107,14 @@ class CFUNHotPath(nn.Module):
         return model.proposal_layer([rpn_probs, rpn_bbox], proposal_count=count, nms_threshold=cfg.RPN_NMS_THRESHOLD,
                                     anchors=self.anchors, config=cfg, lazy=lazy)
 
-    def _mask_head(self, image, p_rois):
+    def fused_mask_losses(self):
+        """Does this configuration's step take the one-pass mask losses (heart 'finetune': CE + Sobel-magnitude edge loss)?"""
+        cfg = self.config
+        return bool(FUSED_MASK_LOSS and cfg.STAGE == "finetune" and getattr(cfg, "MASK_CE_CLASS_WEIGHTS", None) is None
+                    and not getattr(cfg, "EDGE_LOSS_RAW_SOBEL", False) and int(cfg.NUM_CLASSES) in (8, 3)
+                    and min(int(v) for v in cfg.MASK_SHAPE) >= 3)
+
+    def _mask_head(self, image, p_rois, softmax=True):
         """The mask head (RoIAlign of the raw image + U-Net + softmax) on its own HIP stream: it reads only the image
         and the positive RoIs, so FPN / RPN / proposals / classifier -- a few hundred small, low-occupancy launches --
         run beside the U-Net's chip-filling convs instead of in front of them; autograd replays every node on its
@@ -110,24 +122,27 @@ class CFUNHotPath(nn.Module):
         makes the current stream wait for the head (call it before the outputs are consumed)."""
         img = ops.to_ndhwc(image)[0]
         if not (image.is_cuda and OVERLAP_MASK_HEAD):
-            logits, probs = self.mask.forward_ndhwc(img, p_rois)
+            logits, probs = self.mask.forward_ndhwc(img, p_rois, softmax)
             return logits, probs, (lambda: None)
         main = torch.cuda.current_stream(image.device)
         side = ops.side_stream(image.device, "mask_head", priority=int(os.environ.get("CFUN_MASK_STREAM_PRIORITY", "0")))
         side.wait_stream(main)                  # image / RoIs / this step's weights are ready
         with torch.cuda.stream(side):
-            logits, probs = self.mask.forward_ndhwc(img, p_rois)
+            logits, probs = self.mask.forward_ndhwc(img, p_rois, softmax)
 
         def join():
             main.wait_stream(side)
             for t in (logits, probs):           # allocated on `side`, consumed (and possibly freed) on `main`
-                t.record_stream(main)
+                if t is not None:
+                    t.record_stream(main)
         return logits, probs, join
 
-    def predict_training(self, image, p_rois, n_rois, lazy_rois=False):
+    def predict_training(self, image, p_rois, n_rois, lazy_rois=False, defer_mask_probs=False):
         """BatchNorm stays in eval mode while the rest trains (model.py:1397-1406): folded BN needs no switch.
         p_rois [n_pos,6] / n_rois [n_neg,6] normalised.  Returns a dict of the path's outputs.  ``lazy_rois``:
-        ``rpn_rois`` comes back as a ``model.LazyProposals`` (the NMS keep count is not read yet: no host wait here)."""
+        ``rpn_rois`` comes back as a ``model.LazyProposals`` (the NMS keep count is not read yet: no host wait here).
+        ``defer_mask_probs`` (training_step): where the configuration takes the one-pass mask losses, ``mrcnn_mask`` is left None
+        here and filled in by ``compute_losses`` (the fused loss pass produces the probabilities)."""
         self.train()
         mask_logits = mask_probs = cls_logits = cls_probs = cls_bbox = None
         join = lambda: None
@@ -135,7 +150,8 @@ class CFUNHotPath(nn.Module):
         ok = False
         try:
             if not self.detector_phase_only:
-                mask_logits, mask_probs, join = self._mask_head(image, p_rois)  # enqueued first, on its own stream
+                mask_logits, mask_probs, join = self._mask_head(        # enqueued first, on its own stream
+                    image, p_rois, softmax=not (defer_mask_probs and self.fused_mask_losses()))
             p2, p3, rpn_logits, rpn_probs, rpn_bbox = self.backbone_rpn(image)
             rpn_rois = self.proposals(rpn_probs, rpn_bbox, "training", lazy=lazy_rois)
             if not self.mask_phase_only:
@@ -260,6 +276,10 @@ class CFUNHotPath(nn.Module):
             else:
                 edge = torch.zeros((), device=mask_labels.device)
             losses += [ce, edge]
+        elif self.config.STAGE == "finetune" and out["mrcnn_mask"] is None:
+            # one pass forward (softmax + CE + Sobel edge loss), one pass backward; the probabilities come out of it
+            ce, edge, out["mrcnn_mask"] = ops.mask_losses_fused(out["mrcnn_mask_logits"], mask_labels)
+            losses += [ce, edge]
         elif self.config.STAGE == "finetune":   # CE + Sobel edge loss share one fused backward pass
             losses += list(ops.mask_losses(out["mrcnn_mask_logits"], out["mrcnn_mask"], mask_labels))
         else:
@@ -358,7 +378,7 @@ def training_step(net, s):
     """One forward + 6 losses + backward of the hot path on the sample ``s`` (no optimizer step).  The head RoI sets are
     inputs here, so nothing consumes the proposals inside the step: their NMS keep count is read only after the backward
     pass has been enqueued (model.LazyProposals) and the host never waits for the GPU mid-step."""
-    out = net.predict_training(s["image"], s["p_rois"], s["n_rois"], lazy_rois=True)
+    out = net.predict_training(s["image"], s["p_rois"], s["n_rois"], lazy_rois=True, defer_mask_probs=True)
     losses = net.compute_losses(out, s["rpn_match"], s["rpn_bbox_t"], s["target_class_ids"], s["target_deltas"],
                                 s["mask_labels"])
     total = net.total_loss(losses)

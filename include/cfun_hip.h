@@ -367,6 +367,25 @@ int cfun_mask_losses_bwd_saved(const float* probs, const uint8_t* labels, const 
 int cfun_weight_pack(const float* w, float* wp, int32_t Co, int32_t Ci, int32_t T, cfun_stream_t stream);
 int cfun_weight_pack_transpose(const float* wp, float* wpT, int32_t Co, int32_t Ci, int32_t T, cfun_stream_t stream);
 
+/* Round 6: the 'finetune' mask losses as ONE forward and ONE backward pass (loss_fused.hip).  Replaces, for the reference's
+ * Mask.forward softmax (model.py:799) + compute_mrcnn_mask_loss (model.py:909-935) + compute_mrcnn_mask_edge_loss
+ * (model.py:938-981), the three forward passes cfun_softmax_fwd / cfun_softmax_ce_fwd / cfun_edge_loss_fwd_save and the
+ * 27-neighbour gather cfun_mask_losses_bwd_saved:
+ *   fwd: logits [n,D,H,W,C], labels uint8 [n,D,H,W] -> probs [n,D,H,W,C] = softmax(logits), losses[0] = cross entropy,
+ *        losses[1] = Sobel edge loss.  u: NULL (forward only), or a cfun_mask_fused_u_bytes buffer that receives the
+ *        backward's operand: per output column (y,x) in [0,H-2) x [0,W-2) and input plane z in [0,D), 2(C-1) floats =
+ *        the z part of the transposed Sobel stencil applied to d(edge loss)/d(Sobel responses) for an upstream gradient of 1.
+ *        ws: cfun_mask_fused_workspace_bytes().
+ *   bwd: dlogits = g2[0] * dCE/dlogits + g2[1] * dEdge/dlogits: a 2-D stencil over u per plane + the softmax backward.
+ * C in {8, 3}, D, H, W >= 3 (cfun_mask_fused_supported); C % 4 == 0 needs 16-byte aligned tensors. */
+size_t cfun_mask_fused_workspace_bytes(void);
+int cfun_mask_fused_supported(int32_t n, int32_t D, int32_t H, int32_t W, int32_t C);
+size_t cfun_mask_fused_u_bytes(int32_t n, int32_t D, int32_t H, int32_t W, int32_t C);
+int cfun_mask_fused_fwd(const float* logits, const uint8_t* labels, float* probs, float* losses, float* u, int32_t n,
+                        int32_t D, int32_t H, int32_t W, int32_t C, void* ws, size_t ws_bytes, cfun_stream_t stream);
+int cfun_mask_fused_bwd(const float* u, const float* probs, const uint8_t* labels, const float* g2, float* dlogits, int32_t n,
+                        int32_t D, int32_t H, int32_t W, int32_t C, cfun_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Weight operands of MANY convolutions in ONE launch, straight from their OIDHW tensors.
  * cfun_weight_prepare_kinds(p): which operand the forward (kinds[0]) and the data gradient (kinds[1]) of conv p read

@@ -203,6 +203,14 @@ def main():
         lcfg = mc.tiny_lits_config("finetune", 32, 16 * world)
         lcfg.STAGE_SPLIT = False
         step_cases(lcfg, "l_", [("z", max(world // 2, 1), 2, True), ("rr", 2, 1, False)], 4096)
+    if "litsplit" in sections:
+        # the fork's DEFAULT: two training phases (LiTSConfig.STAGE_SPLIT = True; LiTS_2017/model.py:985-1001, 1518-1548) --
+        # 'beginning' = detector only (no mask head, mask losses 0), 'finetune' = mask branch only (FPN / RPN frozen, no
+        # classifier head, detector losses 0) -- through the sharded step, z-sharded and round-robin
+        for stg, pre in (("beginning", "sb_"), ("finetune", "sf_")):
+            scfg = mc.tiny_lits_config(stg, 32, 16 * world)
+            assert scfg.STAGE_SPLIT
+            step_cases(scfg, pre, [("z", max(world // 2, 1), 2, True), ("rr", 2, 1, False)], 4096)
     if "cfg1" in sections:
         # BASELINE configs[1]'s volume (128x128x64) with the REAL channel counts, 'finetune', 96^3 -> 192^3 masks: (a) the 4 + 8
         # RoIs of the benchmarked step, one positive RoI per rank when world == 4; (b) 2 positive RoIs, each U-Net z-sharded

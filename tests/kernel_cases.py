@@ -489,6 +489,19 @@ def check_mask_losses(device, logits_ncdhw, labels, expect=None):
     (0.7 * ce2 + 1.3 * el2).backward()
     assert_close(ld.grad, 0.7 * g_ce + 1.3 * g_el, "fused d(CE+Edge)/dlogits", 1e-5)
     assert_close(ld.grad.permute(0, 4, 1, 2, 3), 0.7 * g_ce_r + 1.3 * g_el_r, "fused vs oracle", 1e-3)
+    # round 6: ONE forward pass (softmax + CE + edge loss) and ONE backward pass that recomputes the edge coefficients
+    # (cfun_mask_fused_fwd / _bwd) against the separate kernels: identical probabilities, same losses, same gradient
+    if ops.mask_losses_fused_supported(ld):
+        sep_grad = ld.grad.clone()
+        ld.grad = None
+        ce3, el3, p3 = ops.mask_losses_fused(ld, labd)
+        # (same softmax up to the fused pass's v_exp_f32 and its one division per voxel: a few ulp)
+        assert float((p3 - probs.detach()).abs().max()) <= 2e-6, "fused forward: probabilities differ from cfun_softmax_fwd"
+        assert not p3.requires_grad
+        assert abs(float(ce3) - float(ce)) <= 2e-6 * abs(float(ce)) and abs(float(el3) - float(el)) <= 1e-5 * abs(float(el))
+        (0.7 * ce3 + 1.3 * el3).backward()
+        assert_close(ld.grad, sep_grad, "one-pass d(CE+Edge)/dlogits vs the separate kernels", 2e-5)
+        assert_close(ld.grad.permute(0, 4, 1, 2, 3), 0.7 * g_ce_r + 1.3 * g_el_r, "one-pass backward vs oracle", 1e-3)
     if expect is not None:
         assert abs(float(ce) - float(expect["ce"])) < 1e-5 * abs(float(expect["ce"]))
         assert abs(float(el) - float(expect["edge"].reshape(-1)[0])) < 1e-4 * abs(float(expect["edge"].reshape(-1)[0]))

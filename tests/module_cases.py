@@ -26,7 +26,8 @@ def rel_max(a, b):
 # entries by O(1) and parameter gradients by ~1e-2 (measured: the reference itself, fp32 vs fp64, flips one
 # mask in this very golden and moves conv_norm_lrelu_l4.0's gradient by 6e-3).  U-Net gradients are
 # therefore compared in relative L2 norm; forward values and every per-op gradient test stay tight.
-UNET_GRAD_L2_TOL = 6e-2
+UNET_GRAD_L2_TOL = 2e-2
+SMOKE_GRAD_L2_TOL = 1e-2      # __graft_entry__.smoke(): tensors over their measured fp64 bound (a kink flip) against the fp32 oracle
 
 
 def check_unet_golden(device, name, check_grads=True, logits_atol=1e-3):
@@ -491,11 +492,13 @@ def _oracle_forward(cfg, net, cpu, masks, sd, cast, onehot):
     return ref
 
 
-def check_training_step_vs_oracle(device, cfg, seed=0, n_pos=None, fp64_bound=True, report=None):
+def check_training_step_vs_oracle(device, cfg, seed=0, n_pos=None, fp64_bound=True, report=None, kink_fit=True):
     """One training step of cfun_amd.step (forward, 6 losses, backward) against oracle.training_step on the
     same weights, inputs and dropout masks.  ``fp64_bound``: gradients are held to the measured per-tensor bound (see
     GRAD_FP64_FACTOR); False (the emulator tier's budget): the blanket UNET_GRAD_L2_TOL.  ``report``: a list that
-    receives (name, err HIP-vs-fp64, err fp32-vs-fp64) per tensor."""
+    receives (name, err HIP-vs-fp64, err fp32-vs-fp64) per tensor.  ``kink_fit=False`` (smoke(): seconds, not minutes): a
+    tensor over its fp64 bound is not put through the LeakyReLU kink-flip fit but must then agree with the oracle's fp32
+    gradient to SMOKE_GRAD_L2_TOL."""
     from cfun_amd import step
     torch.manual_seed(seed)
     net = step.CFUNHotPath(cfg).to(device)
@@ -564,7 +567,12 @@ def check_training_step_vs_oracle(device, cfg, seed=0, n_pos=None, fp64_bound=Tr
             bad[k] = "%s: relL2(HIP,fp64) %.3e > %.1f * relL2(fp32,fp64) %.3e + %.0e" % (k, e_hip, GRAD_FP64_FACTOR, e_ref,
                                                                                         GRAD_FP64_FLOOR)
     n_kink = None
-    if bad:
+    if bad and not kink_fit:
+        named = dict(net.named_parameters())
+        for k in list(bad):
+            if rel_l2(named[k].grad.cpu().numpy(), sd[k].grad.numpy()) < SMOKE_GRAD_L2_TOL:
+                bad.pop(k)
+    elif bad:
         # Are the excesses LeakyReLU kink flips (a pre-activation within rounding of 0 landing on the other side)?  Fit
         # HIP - fp64 and oracle-fp32 - fp64 on the kink-flip basis of the fp64 graph; what the fit does not explain has
         # to meet the same bound, now with both sides flip-free.

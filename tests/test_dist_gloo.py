@@ -224,7 +224,9 @@ def check_worldn(r, sections="halo,conv,rpn,step,rr,dp,unet", tol_mask=2e-2, une
     report = {}
     for tag, sec, rs, pre in (("za", "stepa", 2, ""), ("zb", "stepb", world, ""), ("rr", "rr", 0, ""),
                               ("c1_rr", "cfg1", 0, "c1_"), ("c1_z", "cfg1", world // 2, "c1_"),
-                              ("l_z", "lits", 2 if world > 2 else world, "l_"), ("l_rr", "lits", 0, "l_")):
+                              ("l_z", "lits", 2 if world > 2 else world, "l_"), ("l_rr", "lits", 0, "l_"),
+                              ("sb_z", "litsplit", 2 if world > 2 else world, "sb_"), ("sb_rr", "litsplit", 0, "sb_"),
+                              ("sf_z", "litsplit", 2 if world > 2 else world, "sf_"), ("sf_rr", "litsplit", 0, "sf_")):
         if sec not in sections and not (sec.startswith("step") and "step" in sections):
             continue
         assert int(ref[tag + "_zsharded"][0]) == rs, (tag, ref[tag + "_zsharded"])
@@ -235,6 +237,11 @@ def check_worldn(r, sections="halo,conv,rpn,step,rr,dp,unet", tol_mask=2e-2, une
             np.testing.assert_array_equal(r[k][tag + "_grads"], ref[tag + "_grads"])
             np.testing.assert_array_equal(r[k][tag + "_losses"], ref[tag + "_losses"])
         assert np.abs(ref["ref_" + tag + "_grads"]).max() > 0
+        if sec == "litsplit":           # the phase's other losses are exactly zero, in the sharded step as in the reference's
+            dead = slice(4, 6) if pre == "sb_" else slice(0, 4)
+            assert not np.any(ref[tag + "_losses"][dead]) and not np.any(ref["ref_" + tag + "_losses"][dead]), tag
+            live = [i for i in range(6) if not (dead.start <= i < dead.stop)]
+            assert all(ref[tag + "_losses"][i] > 0 for i in live), tag
         # U-Net tensors of the 32^3 toy configuration carry a 1e-2 fp32 noise floor of their own (InstanceNorm over 2^3..4^3
         # voxels; check_training_step_vs_oracle measures it against fp64): slab sums combined across ranks move them by a
         # few 1e-3 when the RoI is z-sharded; everything else 2e-3
@@ -255,6 +262,13 @@ def check_worldn(r, sections="halo,conv,rpn,step,rr,dp,unet", tol_mask=2e-2, une
             np.testing.assert_array_equal(r[k]["zu_g"], ref["zu_g"])
         report["unet"] = _grad_table(ref["zu_names"], ref["zu_sizes"], ref["zu_g"], ref["ref_zu_g"], unet_tol, unet_tol)
     return report
+
+
+def test_lits_stage_split_world2(emu_lib, tmp_path):
+    """The LiTS fork's two training phases (STAGE_SPLIT, its default) through the sharded step on 2 ranks: the detector phase
+    runs no mask head, the mask phase no classifier / RPN losses -- losses and summed gradients equal step.training_step's."""
+    env = dict(os.environ, CFUN_LIB_PATH=emu_lib, PYTHONPATH=ROOT)
+    print(check_worldn(run_world(tmp_path, env, 2, "dist_worker_n.py", ("cpu", "litsplit"), timeout=1500), "litsplit"))
 
 
 def test_depth_sharding_world4(emu_lib, tmp_path):

@@ -90,6 +90,45 @@ def test_four_ranks_on_real_kernels(gpu, tmp_path):
     print("4 ranks on one GPU, worst gradient rel-L2 vs single process:", check_worldn(r, sections))
 
 
+def _bench(args, env_extra, timeout):
+    """`python bench.py ...` as PLAIN python (no torchrun): the script launches its ranks itself.  Returns the JSON line."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("CFUN_LIB_PATH", "CFUN_CONV_ALGO", "WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(PYTHONPATH=ROOT, **env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=timeout)
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout.decode()[-1500:], r.stderr.decode()[-3000:])
+    return json.loads(lines[0])
+
+
+def test_bench_plain_python_gpus2_is_a_two_rank_job(gpu):
+    """`python bench.py --gpus 2` (no torchrun) on the real kernels -- two ranks on this box's one GPU,
+    collectives over gloo -- prints n_gpus = 2, has run the communication pre-flight, and the same invocation carries BOTH
+    curves: the data-parallel `value` and the one-volume `sharded_one_volume` with its parity against the single-process step."""
+    d = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "cfg1"], dict(CFUN_BENCH_BACKEND="gloo"), 1500)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["preflight"]["ok"] and d["preflight"]["ranks_seen"] == 2 and d["rccl_ranks_seen"] == 0 and "NOT RCCL" in d["backend"]
+    leg = d["sharded_one_volume"]
+    assert "error" not in leg and leg["scaling"] == "strong" and leg["value"] > 0
+    assert leg["sharded_parity"]["ok"] and max(leg["sharded_parity"]["rel_diff"]) <= 5e-4
+    assert d["sharded_parity"] == leg["sharded_parity"]
+
+
+def test_bench_cfg3_one_volume_over_eight_ranks(gpu):
+    """BASELINE configs[3] in its specified form inside the driver-run tier: ONE 512x512x256 volume
+    depth-sharded over 8 ranks (32 input planes = 2 p3 planes per rank, 4 RoIs x 2 ranks z-sharded U-Nets), 2 timed steps;
+    the summed loss shares reproduce the single-process step.  (8 processes on this box's one GPU, gloo.)"""
+    d = _bench(["--gpus", "8", "--sharded", "--workload", "cfg3", "--steps", "2", "--warmup", "1"],
+               dict(CFUN_BENCH_BACKEND="gloo"), 2400)
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["steps"] == 2
+    assert d["preflight"]["ok"] and d["preflight"]["ranks_seen"] == 8
+    assert d["sharded_parity"]["ok"], d["sharded_parity"]
+    assert all(np.isfinite(v) and v > 0 for v in d["losses"])
+
+
 def test_rccl_two_gpus(tmp_path):
     """The `nccl` (= RCCL) branch of ``dist._exchange`` -- device buffers straight into batch_isend_irecv on the side
     stream -- and the reducer's RCCL all-reduces, with a real peer: 2 processes on 2 GPUs.  Skips cleanly on the 1-GPU test

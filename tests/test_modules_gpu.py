@@ -129,9 +129,9 @@ def test_cfg2_full_size_step_properties(gpu, monkeypatch):
     import bench
     ref64 = bench.load_grad_fp64(net, cfg, "cfg2")
     assert ref64 is not None, "tests/golden/grad_fp64_cfg2.npz does not belong to these weights (another torch build?)"
-    for k, (g64, stride, floor) in ref64.items():
-        g64 = torch.from_numpy(g64)
-        e = float((g1[k].cpu().double()[::stride] - g64).norm() / g64.norm())
+    assert len(ref64) == 27                 # every U-Net conv weight (round 6; rounds 4-5: four of them)
+    for k, ref in ref64.items():
+        e, floor = bench.grad_fp64_error(g1[k], ref), ref[2]
         bound = bench.GRAD_FP64_FACTOR * floor + bench.GRAD_FP64_FLOOR
         assert e <= bound, "%s: relL2(GPU, fp64) %.3e > 3 x %.3e + 2e-5" % (k, e, floor)
     monkeypatch.setenv("CFUN_CONV_ALGO", "direct")
@@ -260,9 +260,11 @@ def test_gradient_reducer_streams(gpu):
     import torch.distributed as dist
     from cfun_amd import dist as cdist
     from cfun_amd import step
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29531")
-    dist.init_process_group("nccl", rank=0, world_size=1)
+    import socket
+    with socket.socket() as sock:               # a free port (a fixed one clashes on a shared box and fails the tier under -x)
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
     try:
         cfg = mc.tiny_config("finetune")
         torch.manual_seed(0)

@@ -53,6 +53,25 @@ def main():
     print("softmax            %.3f ms  %5.0f GB/s (%.2f of 8 TB/s)" % (t_sm, b_sm / t_sm / 1e6, b_sm / t_sm / 8e9))
     print("CE + edge forward  %.3f ms  %5.0f GB/s (%.2f)" % (t_f, b_f / t_f / 1e6, b_f / t_f / 8e9))
     print("fused backward     %.3f ms  %5.0f GB/s (%.2f)   (forward+backward %.3f ms)" % (t_b, b_b / t_b / 1e6, b_b / t_b / 8e9, t_fb))
+    # round 6: ONE pass each way (softmax + CE + edge -> probs + 2 losses; backward recomputes the coefficients)
+    st2 = {}
+
+    def fwd1():
+        st2["l"] = ops.mask_losses_fused(logits, labels)
+    t_f1 = timeit(fwd1)
+
+    def fb1():
+        fwd1()
+        logits.grad = None
+        (st2["l"][0] + st2["l"][1]).backward()
+    t_fb1 = timeit(fb1)
+    t_b1 = t_fb1 - t_f1
+    ub = 8.0 * n * s * (s - 2) * (s - 2) * (c - 1)
+    b_f1 = 4.0 * vox * c * 2 + vox + ub       # reads logits + labels, writes probs + the backward's operand field
+    b_b1 = 4.0 * vox * c * 2 + vox + ub       # reads the field, probs + labels, writes dlogits
+    print("one-pass forward   %.3f ms  %5.0f GB/s (%.2f)   (was softmax + CE + edge: %.3f ms)" % (t_f1, b_f1 / t_f1 / 1e6, b_f1 / t_f1 / 8e9, t_sm + t_f))
+    print("one-pass backward  %.3f ms  %5.0f GB/s (%.2f)   (was %.3f ms; forward+backward %.3f ms, was %.3f)"
+          % (t_b1, b_b1 / t_b1 / 1e6, b_b1 / t_b1 / 8e9, t_b, t_fb1, t_sm + t_fb))
 
 
 if __name__ == "__main__":
