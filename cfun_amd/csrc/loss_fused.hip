@@ -58,6 +58,13 @@ __device__ __forceinline__ double block_sum_f(double v, double* red) {
   return s;
 }
 
+// both kernels sit at ~250 VGPRs: two waves per SIMD (hipcc left to itself takes 257 / 280 and one)
+#ifdef CFUN_HIP_EMULATION
+#define CFUN_OCC2
+#else
+#define CFUN_OCC2 __attribute__((amdgpu_waves_per_eu(2)))
+#endif
+
 template <int CT>
 struct PlaneF {      // in-plane Sobel sums of one (y, x) column at one z: classes 1..CT-1 at index c-1; targets packed
   float dy[CT - 1], sm[CT - 1];
@@ -176,7 +183,7 @@ __device__ __forceinline__ void store_vox(float* __restrict__ dst, int64_t v, co
 // A segment that writes U starts its march two planes early (dc[z0-2], dc[z0-1] belong to the previous segment's loss but
 // to this segment's U).
 template <int CT, bool WRITE_U>
-__global__ void __launch_bounds__(kFB)
+__global__ void __launch_bounds__(kFB) CFUN_OCC2
 k_mask_fused_fwd(const float* __restrict__ logits, const uint8_t* __restrict__ labels, float* __restrict__ probs,
                  double* __restrict__ partial, float* __restrict__ U, int n, int D, int H, int W, int ZS) {
   static_assert(CT >= 2 && CT <= 8, "packed target sums: 8 classes");
@@ -222,40 +229,49 @@ k_mask_fused_fwd(const float* __restrict__ logits, const uint8_t* __restrict__ l
       const bool inz = zl >= 0 && zl < D;
       const bool ownz = zl >= z0 && zl < z1;
       // ---- phase 1: the plane's 34 x 18 voxels, each loaded once: softmax, probs out, cross entropy, fg probs + label -> LDS
+      // (three voxel slots per thread, branch-free: clamped addresses, so that all loads of the plane are in flight together)
       if (inz) {
-        for (int i = threadIdx.x; i < kIY * kIX; i += kFB) {
+        constexpr int NS = (kIY * kIX + kFB - 1) / kFB;
+        float xs[NS][CT];
+        unsigned labs[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          const int i = threadIdx.x + q * kFB;
           const int ly = i / kIX, lx = i - ly * kIX;
-          const int gy = y0 + ly, gx = x0 + lx;
-          float x[CT];
-          unsigned lab = 255u;
-          if (gy < H && gx < W) {
-            const int64_t v = nbase + ((int64_t)zl * H + gy) * W + gx;
-            load_vox<CT>(logits, v, x);
-            lab = labels[v];
-            float m = -INFINITY;
+          const bool in = i < kIY * kIX && y0 + ly < H && x0 + lx < W;
+          const int64_t v = in ? nbase + ((int64_t)zl * H + (y0 + ly)) * W + (x0 + lx) : nbase;
+          load_vox<CT>(logits, v, xs[q]);
+          labs[q] = in ? labels[v] : 255u;
+        }
 #pragma unroll
-            for (int c = 0; c < CT; ++c) m = fmaxf(m, x[c]);
-            float xl = 0.f;
+        for (int q = 0; q < NS; ++q) {
+          const int i = threadIdx.x + q * kFB;
+          const int ly = i / kIX, lx = i - ly * kIX;
+          const bool in = i < kIY * kIX && y0 + ly < H && x0 + lx < W;
+          float (&x)[CT] = xs[q];
+          const unsigned lab = labs[q];
+          float m = -INFINITY;
 #pragma unroll
-            for (int c = 0; c < CT; ++c)
-              if (c == (int)lab) xl = x[c];
-            float s = 0.f;
+          for (int c = 0; c < CT; ++c) m = fmaxf(m, x[c]);
+          float xl = 0.f;
 #pragma unroll
-            for (int c = 0; c < CT; ++c) { x[c] = cfun_softmax_exp(x[c] - m); s += x[c]; }
-            const float inv = 1.f / s;
+          for (int c = 0; c < CT; ++c)
+            if (c == (int)lab) xl = x[c];
+          float s = 0.f;
 #pragma unroll
-            for (int c = 0; c < CT; ++c) x[c] = x[c] * inv;
-            if (ownz && (ly < kTY || lasty) && (lx < kTX || lastx)) {     // every voxel has exactly one owner
-              store_vox<CT>(probs, v, x);
-              ce_acc += (double)((m + cfun_softmax_log(s)) - xl);
-            }
-          } else {
+          for (int c = 0; c < CT; ++c) { x[c] = cfun_softmax_exp(x[c] - m); s += x[c]; }
+          const float inv = 1.f / s;
 #pragma unroll
-            for (int c = 0; c < CT; ++c) x[c] = 0.f;
+          for (int c = 0; c < CT; ++c) x[c] = in ? x[c] * inv : 0.f;
+          if (in && ownz && (ly < kTY || lasty) && (lx < kTX || lastx)) {     // every voxel has exactly one owner
+            store_vox<CT>(probs, nbase + ((int64_t)zl * H + (y0 + ly)) * W + (x0 + lx), x);
+            ce_acc += (double)((m + cfun_softmax_log(s)) - xl);
           }
+          if (i < kIY * kIX) {
 #pragma unroll
-          for (int c = 1; c < CT; ++c) bp[(c - 1) * kPlane + ly * kIXP + lx] = x[c];
-          bl[ly * kIXP + lx] = (uint8_t)lab;
+            for (int c = 1; c < CT; ++c) bp[(c - 1) * kPlane + ly * kIXP + lx] = x[c];
+            bl[ly * kIXP + lx] = (uint8_t)lab;
+          }
         }
       }
       __syncthreads();
@@ -304,17 +320,24 @@ __global__ void k_finalize_sum2(const double* __restrict__ partial, int blocks, 
 // --------------------------------------------------------------------------------------------------------------- backward
 // One input plane per step, no coupling along z left:  g(y,x) = sum_{j,i} B[j]A[i] U0(y-j,x-i) + A[j]A[i] U1(y-j,x-i), then
 //   dlogits = softmax_bwd(probs, g_edge * g) + g_ce / nvox * (probs - onehot(label)).
-// A workgroup owns 32 x 16 input voxels of the plane; the 34 x 18 U columns they read ((y-2 .. y) x (x-2 .. x), zero outside
-// [0, Ho) x [0, Wo)) are staged in LDS once (class-major, the forward's padded rows); a thread finishes the voxel pair (y, y+1).
+// A workgroup owns 32 x 16 input voxels of kBZ consecutive planes; the 34 x 18 U columns a plane's voxels read ((y-2 .. y) x
+// (x-2 .. x), zero outside [0, Ho) x [0, Wo)) are staged in LDS once per plane (class-major, the forward's padded rows), the
+// NEXT plane's granules are already in flight in registers while the current one is finished; a thread finishes the voxel
+// pair (y, y+1).
+constexpr int kUSP = kPlane + 25;            // backward: LDS plane stride (841 = 9 mod 32: the staging writes of one lane group
+                                             // -- consecutive class pairs of the same column -- land 9 banks apart)
+constexpr int kBZ = 24;                      // backward: planes per workgroup (one (y, x) tile, consecutive z)
+
 template <int CT>
-__global__ void __launch_bounds__(kFB)
+__global__ void __launch_bounds__(kFB) CFUN_OCC2
 k_mask_fused_bwd(const float* __restrict__ U, const float* __restrict__ probs, const uint8_t* __restrict__ labels,
                  const float* __restrict__ g2, float* __restrict__ dlogits, int n, int D, int H, int W) {
-  CFUN_DYN_LDS(float, lds);                                            // [2 (CT-1)][kPlane]
-  constexpr int NU = 2 * (CT - 1);
+  CFUN_DYN_LDS(float, lds);                                            // [2 (CT-1)][kUSP]: U0 planes 0 .. CT-2, U1 planes CT-1 ..
+  constexpr int NP = CT - 1;                                           // class pairs (U0, U1)
+  constexpr int NLD = kIY / 2;                                         // tile rows (float2 granules) per thread
   const int Ho = H - 2, Wo = W - 2;
-  const int tY = (H + kTY - 1) / kTY, tX = (W + kTX - 1) / kTX;
-  const int64_t tiles = (int64_t)n * D * tY * tX;
+  const int tY = (H + kTY - 1) / kTY, tX = (W + kTX - 1) / kTX, nzc = (D + kBZ - 1) / kBZ;
+  const int64_t tiles = (int64_t)n * nzc * tY * tX;
   const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
   const float ge = g2[1];
   const float gce = g2[0] / (float)((int64_t)n * D * H * W);
@@ -322,57 +345,87 @@ k_mask_fused_bwd(const float* __restrict__ U, const float* __restrict__ probs, c
     int64_t t = tile;
     const int bx = (int)(t % tX); t /= tX;
     const int by = (int)(t % tY); t /= tY;
-    const int z = (int)(t % D);
-    const int64_t r = t / D;
+    const int zc = (int)(t % nzc);
+    const int64_t r = t / nzc;
     const int x0 = bx * kTX, y0 = by * kTY;                            // first owned voxel; U tile origin = (y0 - 2, x0 - 2)
-    // ---- stage the U tile: rows of 18 columns x NU floats are contiguous in memory (float2 granules)
-    const int64_t ubase = (r * D + z) * (int64_t)Ho * Wo;
-    for (int i = threadIdx.x; i < kIY * kIX * (NU / 2); i += kFB) {
-      const int ly = i / (kIX * (NU / 2)), e = i - ly * (kIX * (NU / 2));
-      const int lx = e / (NU / 2), k = e - lx * (NU / 2);
-      const int uy = y0 - 2 + ly, ux = x0 - 2 + lx;
-      float2 v = make_float2(0.f, 0.f);
-      if (uy >= 0 && uy < Ho && ux >= 0 && ux < Wo)
-        v = reinterpret_cast<const float2*>(U + (ubase + (int64_t)uy * Wo + ux) * NU)[k];
-      lds[(2 * k) * kPlane + ly * kIXP + lx] = v.x;
-      lds[(2 * k + 1) * kPlane + ly * kIXP + lx] = v.y;
+    const int zb = zc * kBZ, ze = zb + kBZ < D ? zb + kBZ : D;
+    // Staging map: a tile row is kIX * NP float2 granules, contiguous in memory.  Thread (h, e) = (tid / RG, tid % RG) takes
+    // granule e of rows h, h + 2, h + 4, ...: memory and LDS offsets are affine in the row index (one VGPR each, the row
+    // stride goes into scalar offsets) -- a flat tid + q * 256 map costs a 64-bit address per granule (355 VGPRs).
+    constexpr int RG = kIX * NP;                                       // granules per tile row (126 at 8 classes)
+    static_assert(2 * RG <= kFB && kIY % 2 == 0, "two rows of granules per pass");
+    const int h = threadIdx.x >= RG ? 1 : 0, e = threadIdx.x - h * RG;
+    const bool lane_on = threadIdx.x < 2 * RG;
+    const int lx = e / NP, k = e - lx * NP;
+    const int ux = x0 - 2 + lx;
+    const bool col_ok = lane_on && ux >= 0 && ux < Wo;
+    const int lds0 = lane_on ? k * kUSP + h * kIXP + lx : NP * kUSP - 1;      // (idle lanes: a dead slot in the last plane's padding)
+    const int lrow = lane_on ? 2 * kIXP : 0;
+    const int64_t grow = (int64_t)Wo * NP;                             // granules per memory row
+    const int64_t g0 = ((int64_t)(y0 - 2 + h) * Wo + (x0 - 2)) * NP + e;
+    float2 pre[NLD];
+#define CFUN_STAGE_LOAD(up)                                                         \
+  _Pragma("unroll") for (int q = 0; q < NLD; ++q) {                                 \
+    const int uy = y0 - 2 + h + 2 * q;                                              \
+    const bool ok = col_ok && uy >= 0 && uy < Ho;                                   \
+    const float2 v = (up)[ok ? g0 + (int64_t)(2 * q) * grow : 0];   /* branch-free: clamped address, selected value */ \
+    pre[q] = make_float2(ok ? v.x : 0.f, ok ? v.y : 0.f);                           \
+  }
+    {
+      const float2* up = reinterpret_cast<const float2*>(U) + (r * D + zb) * (int64_t)Ho * Wo * NP;
+      CFUN_STAGE_LOAD(up)
     }
-    __syncthreads();
-    const int ry = 2 + 2 * ty, rx = 2 + tx;                            // tile-local U position of the pair's first voxel
-    float g[2][CT - 1];
+    for (int z = zb; z < ze; ++z) {
 #pragma unroll
-    for (int c = 0; c < CT - 1; ++c) {
-      float s0[4], s1[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {                                    // x sums (A = 1,2,1 over x, x-1, x-2) of U rows ry-2 .. ry+1
-        const float* u0 = lds + (2 * c) * kPlane + (ry - 2 + j) * kIXP + rx;
-        const float* u1 = lds + (2 * c + 1) * kPlane + (ry - 2 + j) * kIXP + rx;
-        s0[j] = (u0[0] + 2.f * u0[-1]) + u0[-2];
-        s1[j] = (u1[0] + 2.f * u1[-1]) + u1[-2];
+      for (int q = 0; q < NLD; ++q) { lds[lds0 + q * lrow] = pre[q].x; lds[NP * kUSP + lds0 + q * lrow] = pre[q].y; }
+      __syncthreads();
+      if (z + 1 < ze) {        // the next plane's granules travel while this plane is finished
+        const float2* up = reinterpret_cast<const float2*>(U) + (r * D + z + 1) * (int64_t)Ho * Wo * NP;
+        CFUN_STAGE_LOAD(up)
       }
-      // voxel row y = ry + o receives from U rows y (B = 1, A = 1), y-1 (B = 0, A = 2), y-2 (B = -1, A = 1)
+      const int ry = 2 + 2 * ty, rx = 2 + tx;                          // tile-local U position of the pair's first voxel
+      const int gy = y0 + 2 * ty, gx = x0 + tx;
+      const int64_t v0 = ((r * D + z) * (int64_t)H + gy) * W + gx;
+      float pr[2][CT];
+      int lab[2];
 #pragma unroll
-      for (int o = 0; o < 2; ++o) g[o][c] = ge * ((s0[2 + o] - s0[o]) + ((s1[2 + o] + s1[o]) + 2.f * s1[1 + o]));
-    }
-#pragma unroll
-    for (int o = 0; o < 2; ++o) {
-      const int gy = y0 + 2 * ty + o, gx = x0 + tx;
-      if (gy < H && gx < W) {
-        const int64_t v = ((r * D + z) * (int64_t)H + gy) * W + gx;
-        float pr[CT];
-        load_vox<CT>(probs, v, pr);
-        const int lab = labels[v];
-        float dot = 0.f;
-#pragma unroll
-        for (int c = 0; c < CT - 1; ++c) dot += pr[c + 1] * g[o][c];
-        float out[CT];
-        out[0] = pr[0] * (0.f - dot) + gce * (pr[0] - (lab == 0 ? 1.f : 0.f));
-#pragma unroll
-        for (int c = 1; c < CT; ++c) out[c] = pr[c] * (g[o][c - 1] - dot) + gce * (pr[c] - (c == lab ? 1.f : 0.f));
-        store_vox<CT>(dlogits, v, out);
+      for (int o = 0; o < 2; ++o) {
+        const bool in = gy + o < H && gx < W;
+        const int64_t vv = in ? v0 + (int64_t)o * W : 0;               // (clamped: branch-free)
+        load_vox<CT>(probs, vv, pr[o]);
+        lab[o] = labels[vv];
       }
+      float g[2][CT - 1];
+#pragma unroll
+      for (int c = 0; c < CT - 1; ++c) {
+        float s0[4], s1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                                  // x sums (A = 1,2,1 over x, x-1, x-2) of U rows ry-2 .. ry+1
+          const float* u0 = lds + c * kUSP + (ry - 2 + j) * kIXP + rx;
+          const float* u1 = lds + (NP + c) * kUSP + (ry - 2 + j) * kIXP + rx;
+          s0[j] = (u0[0] + 2.f * u0[-1]) + u0[-2];
+          s1[j] = (u1[0] + 2.f * u1[-1]) + u1[-2];
+        }
+        // voxel row y = ry + o receives from U rows y (B = 1, A = 1), y-1 (B = 0, A = 2), y-2 (B = -1, A = 1)
+#pragma unroll
+        for (int o = 0; o < 2; ++o) g[o][c] = ge * ((s0[2 + o] - s0[o]) + ((s1[2 + o] + s1[o]) + 2.f * s1[1 + o]));
+      }
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        if (gy + o < H && gx < W) {
+          float dot = 0.f;
+#pragma unroll
+          for (int c = 0; c < CT - 1; ++c) dot += pr[o][c + 1] * g[o][c];
+          float out[CT];
+          out[0] = pr[o][0] * (0.f - dot) + gce * (pr[o][0] - (lab[o] == 0 ? 1.f : 0.f));
+#pragma unroll
+          for (int c = 1; c < CT; ++c) out[c] = pr[o][c] * (g[o][c - 1] - dot) + gce * (pr[o][c] - (c == lab[o] ? 1.f : 0.f));
+          store_vox<CT>(dlogits, v0 + (int64_t)o * W, out);
+        }
+      }
+      __syncthreads();        // the next plane restages the LDS tile
     }
-    __syncthreads();        // the next tile restages the LDS tile
+#undef CFUN_STAGE_LOAD
   }
 }
 
@@ -392,7 +445,7 @@ inline int pick_zs(int planes, int64_t tiles_per_plane_seg) {
 template <int CT>
 size_t fwd_lds() { return (size_t)2 * (CT - 1) * kPlane * sizeof(float) + 2 * kPlane; }
 template <int CT>
-size_t bwd_lds() { return (size_t)2 * (CT - 1) * kPlane * sizeof(float); }
+size_t bwd_lds() { return (size_t)2 * (CT - 1) * kUSP * sizeof(float); }
 
 }  // namespace
 
@@ -435,7 +488,7 @@ int cfun_mask_fused_bwd(const float* u, const float* probs, const uint8_t* label
                         int32_t D, int32_t H, int32_t W, int32_t C, cfun_stream_t stream) {
   if (!cfun_mask_fused_supported(n, D, H, W, C) || !u || !probs || !labels || !g2 || !dlogits) return CFUN_EINVAL;
   if (C % 4 == 0 && (!cfun_aligned16(probs) || !cfun_aligned16(dlogits))) return CFUN_EINVAL;
-  const int64_t tiles = (int64_t)n * D * ((H + kTY - 1) / kTY) * ((W + kTX - 1) / kTX);
+  const int64_t tiles = (int64_t)n * ((D + kBZ - 1) / kBZ) * ((H + kTY - 1) / kTY) * ((W + kTX - 1) / kTX);
   const unsigned blocks = fused_grid(tiles, 1 << 20);
   if (C == 8) hipLaunchKernelGGL(k_mask_fused_bwd<8>, dim3(blocks), dim3(kFB), bwd_lds<8>(), cfun_st(stream), u, probs, labels, g2, dlogits, n, D, H, W);
   else hipLaunchKernelGGL(k_mask_fused_bwd<3>, dim3(blocks), dim3(kFB), bwd_lds<3>(), cfun_st(stream), u, probs, labels, g2, dlogits, n, D, H, W);
