@@ -184,6 +184,26 @@ def stem_back_to_back(cfg, net, n_roi, dev, launches=64):
     return t_launch, launches, name
 
 
+def p3d_stem_back_to_back(cfg, net, dev, launches=16):
+    """The OTHER C_in = 1 conv of the path: the P3D stem C1 = Conv3d(1 -> 16, k(3,7,7), s2) + BN + ReLU + MaxPool3d(2,2)
+    (backbone.py:123-128) on the whole volume, through the drop-in module exactly as FPN calls it (the stem kernel with the
+    folded BN + ReLU epilogue, then the pool kernel).  Returns (seconds per call, algorithmic bytes = volume in + pooled map
+    out, each once, algorithmic flops of the conv)."""
+    d, h, w = cfg.image_dhw
+    stem = net.fpn.C1
+    conv = stem[0]
+    with torch.no_grad():
+        x = torch.randn((1, d, h, w, 1), device=dev)
+        y = stem.forward_ndhwc(x)
+        for _ in range(3):
+            stem.forward_ndhwc(x)
+        t = back_to_back(lambda: stem.forward_ndhwc(x), launches)
+    kd, kh, kw = conv.kernel_size
+    do, ho, wo = d // 2, h // 2, w // 2
+    flops = 2.0 * conv.out_channels * kd * kh * kw * do * ho * wo
+    return t, 4.0 * (x.numel() + y.numel()), flops
+
+
 def pointwise_back_to_back(cfg, net, n_roi, dev, launches=64):
     """conv3d_l4 (1x1x1, 2b -> n_classes on the 96^3 crops: the other HBM-bound conv of the U-Net, pure streaming) through the
     same C-ABI entry point, timed like stem_back_to_back.  Returns (seconds per launch, algorithmic bytes per launch)."""
@@ -698,6 +718,16 @@ def main():
                     "achieved": pbytes / t_p / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": pbytes / t_p / 1e9 / PEAK_HBM_GBS,
                     "bytes_per_launch": pbytes, "avg_launch_ms": t_p * 1e3, "launches_timed": 64,
                     "repetitions_ms": list(B2B_REPS)}
+                # both C_in = 1 convs of the path on the line: the P3D stem is NOT HBM-bound -- 147
+                # taps per output at 49 flop/B put it on the vector ALU; both fractions are reported, the binding one is `bound`
+                t_s, sbytes, sflops = p3d_stem_back_to_back(cfg, net, dev)
+                result["roofline_hbm"]["p3d_stem"] = {
+                    "kernel": "k_conv_stem<3,7,7,2,16> + folded BN + ReLU, then k_maxpool2 (fpn.C1: Conv3d 1->16 k(3,7,7) s2 + BN + "
+                              "ReLU + MaxPool3d(2,2) on the %dx%dx%d volume, backbone.py:123-128)" % (h, w, d),
+                    "bytes_per_call": sbytes, "flops_per_call": sflops, "avg_call_ms": t_s * 1e3,
+                    "hbm_frac": sbytes / t_s / 1e9 / PEAK_HBM_GBS, "valu_frac": sflops / t_s / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                    "bound": "valu (fp32 vector peak = %.1f TFLOP/s with packed FMAs)" % PEAK_FP32_MFMA_TFLOPS,
+                    "launches_timed": 16, "repetitions_ms": list(B2B_REPS)}
         parity_fail = None
         if world == 1 and not args.no_cpu_baseline:
             # full-size parity check: ONE more (untimed) GPU step with the Dropout3d masks the oracle leg uses, so that the

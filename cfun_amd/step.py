@@ -26,6 +26,7 @@ OVERLAP_MASK_HEAD = os.environ.get("CFUN_OVERLAP_MASK_HEAD", "1") == "1"
 # (ops.mask_losses_fused, csrc/loss_fused.hip) instead of three forward passes + a gather over a 1.5 GB coefficient field.
 # CFUN_FUSED_MASK_LOSS=0: the separate kernels of rounds 1-5 (A/B runs; same values to fp32 summation order).
 FUSED_MASK_LOSS = os.environ.get("CFUN_FUSED_MASK_LOSS", "1") == "1"
+MASK_HEAD_BEFORE_PROLOGUE = os.environ.get("CFUN_MASK_HEAD_FIRST", "1") == "1"
 
 
 class CFUNHotPath(nn.Module):
@@ -146,10 +147,18 @@ class CFUNHotPath(nn.Module):
         self.train()
         mask_logits = mask_probs = cls_logits = cls_probs = cls_bbox = None
         join = lambda: None
+        early = MASK_HEAD_BEFORE_PROLOGUE and not self.detector_phase_only
+        if early:
+            # Round 6: the mask head is enqueued BEFORE the detector's step prologue (the batched weight preparation of FPN /
+            # RPN / classifier, the folded-bias launch, their table uploads): its stream waits for the main stream as it stands
+            # HERE -- the previous step's joined backward -- not for prologue work the U-Net does not read (its own weight
+            # preparation runs inside Modified3DUNet.forward_ndhwc, on its own stream)
+            mask_logits, mask_probs, join = self._mask_head(
+                image, p_rois, softmax=not (defer_mask_probs and self.fused_mask_losses()))
         layers.begin_step(self)         # the step's conv-bias folds under frozen BatchNorm: one multi-tensor launch
         ok = False
         try:
-            if not self.detector_phase_only:
+            if not self.detector_phase_only and not early:
                 mask_logits, mask_probs, join = self._mask_head(        # enqueued first, on its own stream
                     image, p_rois, softmax=not (defer_mask_probs and self.fused_mask_losses()))
             p2, p3, rpn_logits, rpn_probs, rpn_bbox = self.backbone_rpn(image)

@@ -47,7 +47,7 @@ if args.shapes_of_step:
         return orig(g2d)
 
     ops.channel_sum = logged
-    sys.argv = ["bench.py", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-alt", "--no-hbm-loop"]
+    sys.argv = ["bench.py", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-hbm-loop"]
     bench.main()
     print("# channel_sum shapes over 2 steps (+ the parity step): rows x channels : calls")
     for (v, c), k in sorted(seen.items(), key=lambda kv: -kv[0][0] * kv[0][1]):

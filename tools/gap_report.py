@@ -10,7 +10,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("csv")
 ap.add_argument("--min-gap-us", type=float, default=15.0)
 ap.add_argument("--top", type=int, default=25)
-ap.add_argument("--marker", default="k_mask_losses|k_softmax_ce|k_ce_fwd", help="regex of a kernel that runs once per step")
+ap.add_argument("--marker", default="k_mask_fused_fwd|k_mask_losses|k_softmax_ce|k_ce_fwd", help="regex of a kernel that runs once per step")
 args = ap.parse_args()
 rows = []
 for r in csv.DictReader(open(args.csv)):

@@ -19,7 +19,7 @@ FAMILIES = [
     ("stem / pointwise / direct VALU convs", r"k_conv_stem|k_conv_pointwise|k_conv_.*direct"),
     ("split-K finish, partial reductions, weight packs / transforms", r"splitk|reduce_partials|reduce_unpack|transpose_pad|k_wino_weights|weight_pack|k_fold|k_pack|k_unpack"),
     ("InstanceNorm / LeakyReLU / channel reductions", r"instnorm|channel_reduce|channel_finalize|lrelu|k_act_bwd|k_norm"),
-    ("mask losses (softmax, CE, edge)", r"softmax|k_ce_|k_edge|loss"),
+    ("mask losses (softmax, CE, edge)", r"softmax|k_ce_|k_edge|loss|k_mask_fused|k_finalize_sum"),
     ("RoIAlign / NMS / classifier / targets / resize / pool / upsample", r"roi_align|nms|k_fc_|mask_target|resize|maxpool|upsample|k_add|halo"),
     ("torch glue (at::native, copies, fills)", r"at::native|rocclr|Memset|fill"),
 ]

@@ -12,7 +12,7 @@ cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmcs_$c
   timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmcs_$c -o p -- \
-      python "$REPO/bench.py" --no-cpu-baseline --no-alt --no-hbm-loop --steps 2 --warmup 1 > "$REPO/gpurun_out/pmc_${TAG}_$c.log" 2>&1
+      python "$REPO/bench.py" --no-cpu-baseline --no-hbm-loop --steps 2 --warmup 1 > "$REPO/gpurun_out/pmc_${TAG}_$c.log" 2>&1
   f=$(find /tmp/pmcs_$c -name '*counter_collection.csv' | head -1)
   python "$REPO/tools/pmc_step.py" --compact "$f" "$REPO/gpurun_out/pmc_${TAG}_$c.csv"
 done

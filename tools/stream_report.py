@@ -11,7 +11,7 @@ import re
 ap = argparse.ArgumentParser()
 ap.add_argument("csv")
 ap.add_argument("--top", type=int, default=25)
-ap.add_argument("--marker", default="k_mask_losses|k_softmax_ce|k_ce_fwd")
+ap.add_argument("--marker", default="k_mask_fused_fwd|k_mask_losses|k_softmax_ce|k_ce_fwd")
 ap.add_argument("--dump", default=None, help="write the analysed rows (queue, start, end, name) here")
 args = ap.parse_args()
 opener = gzip.open if args.csv.endswith(".gz") else open

@@ -23,8 +23,12 @@ def full():
 def mask_only():
     net.train()
     img = ops.to_ndhwc(s["image"])[0]
-    logits, probs = net.mask.forward_ndhwc(img, s["p_rois"])
-    ce, edge = ops.mask_losses(logits, probs, s["mask_labels"])
+    if S.FUSED_MASK_LOSS:
+        logits, _ = net.mask.forward_ndhwc(img, s["p_rois"], softmax=False)
+        ce, edge, probs = ops.mask_losses_fused(logits, s["mask_labels"])
+    else:
+        logits, probs = net.mask.forward_ndhwc(img, s["p_rois"])
+        ce, edge = ops.mask_losses(logits, probs, s["mask_labels"])
     (ce + edge).backward()
 
 
