@@ -579,11 +579,20 @@ int cfun_nms3d(const float* boxes, const float* scores, int32_t n, float thresho
   const size_t lds = (size_t)n * W64 * sizeof(unsigned long long);
   static int scan_knob = -1;       // CFUN_NMS_SCAN_LDS = 0: the row-by-row kernel for every n (A/B, tests)
   if (scan_knob < 0) { const char* e = getenv("CFUN_NMS_SCAN_LDS"); scan_knob = e ? atoi(e) : 1; }
-  if (scan_knob != 0 && lds <= 160 * 1024) {
-    if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_nms_scan_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return (int)e;
-    }
+  // The LDS-resident scan may use all of a CU's LDS.  The limit is asked of the device once and the kernel's dynamic-LDS
+  // ceiling raised to it once (it used to be set on every call, the 160 KB of gfx950 were hard-coded and a raw
+  // hipError_t came back as a CFUN status); if either fails the row-by-row kernel -- same keep list -- takes the call.
+  static const size_t lds_max = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0)
+      return (size_t)(64 * 1024);
+    if (v > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_nms_scan_lds), hipFuncAttributeMaxDynamicSharedMemorySize, v) != hipSuccess)
+      return (size_t)(64 * 1024);
+    return (size_t)v;
+  }();
+  if (scan_knob != 0 && lds <= lds_max) {
     hipLaunchKernelGGL(k_nms_scan_lds, dim3(1), dim3(256), lds, cfun_st(stream), mask, order, n, W64, max_num, keep, count);
   } else {       // more rows than LDS holds (n > ~1 130): row by row from memory
     hipLaunchKernelGGL(k_nms_scan, dim3(1), dim3(64), 0, cfun_st(stream), mask, order, n, W64, max_num, keep, count);

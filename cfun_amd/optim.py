@@ -24,7 +24,7 @@ ranks, a parameter is left alone only where no rank reached it.
 """
 import torch
 
-from . import _lib
+from . import _lib, ops
 from . import dist as cdist
 from ._lib import check, ptr, stream
 
@@ -99,6 +99,14 @@ class FlatSGD:
     def step(self):
         """Average over data-parallel ranks (if any), clip to ``clip_norm`` by the global L2 norm, SGD update."""
         self.reducer.finish()
+        # the gradients were produced on several streams (mask head, weight gradients): the update waits for all of them
+        # explicitly instead of relying on the autograd engine's join at the end of backward() (ADVICE round 5)
+        if self.param_arenas and self.param_arenas[0].is_cuda:
+            dev = self.param_arenas[0].device
+            cur = torch.cuda.current_stream(dev)
+            for st in ops.side_streams(dev):
+                if st != cur:
+                    cur.wait_stream(st)
         lib = _lib.load()
         clip = float(self.clip_norm) if self.clip_norm else 0.0
         if clip > 0.0:

@@ -84,6 +84,9 @@ def test_step_bit_reproducible_under_allocator_churn(gpu):
     mc.check_step_bit_reproducible_under_churn(gpu, runs=8)
 
 
+CFG2_PEAK_GB_MAX = 14.0      # measured on the round-6 tree: 9.2 GB (the step incl. the weight-gradient stream's record_stream holds)
+
+
 def test_cfg2_full_size_step_properties(gpu, monkeypatch):
     """BASELINE.json configs[2] at FULL size (256x256x128, 'finetune', b = 20, 4 + 8 injected RoIs, 96^3 -> 192^3) --
     the step bench.py times: the heads are not skipped, all six losses and the gradients of all 95 trainable tensors are
@@ -106,7 +109,13 @@ def test_cfg2_full_size_step_properties(gpu, monkeypatch):
         torch.cuda.synchronize()
         return out, [float(l.detach()) for l in losses], {k: p.grad.clone() for k, p in net.named_parameters()
                                                           if p.grad is not None}
+    torch.cuda.reset_peak_memory_stats()
     out, l1, g1 = run()
+    # (record_stream on the activations the weight-gradient stream reads delays their reuse; the step's peak is
+    # pinned so that a change which starts holding whole levels longer shows up here -- 288 GB per GPU is not a licence)
+    peak_gb = torch.cuda.max_memory_allocated() / 1e9
+    print("cfg2 step peak memory: %.1f GB" % peak_gb)
+    assert peak_gb < CFG2_PEAK_GB_MAX, peak_gb
     assert tuple(out["mrcnn_mask_logits"].shape) == (4, 192, 192, 192, 8) and tuple(out["mrcnn_class_logits"].shape) == (12, 2)
     assert all(np.isfinite(v) and v > 0 for v in l1), l1
     trainable = [k for k, p in net.named_parameters() if p.requires_grad]
@@ -475,6 +484,39 @@ def test_mask_head_side_stream(gpu):
     for losses, grads in results[1:]:
         assert losses == results[0][0]
         assert grads.keys() == results[0][1].keys()
+        for k, g in grads.items():
+            assert torch.equal(g, results[0][1][k]), k
+
+
+def test_wgrad_stream_bitwise(gpu):
+    """the weight gradients on their own HIP stream (ops.WGRAD_STREAM) depend on the autograd engine replaying
+    _OnWgradStream / AccumulateGrad on the right stream and joining the leaf streams at the end of backward() -- behaviour of the
+    torch build.  Same kernels, same data: every gradient with the stream on equals the single-stream step's bit for bit, on the
+    real channel counts (b = 20, 'finetune', 96^3 -> 192^3: every weight-gradient kernel family of the bench step)."""
+    from cfun_amd import config, ops, step
+    cfg = config.heart_config("finetune", 64, 64, 32)
+    torch.manual_seed(0)
+    net = step.CFUNHotPath(cfg).to(gpu)
+    s = step.synthetic_inputs(cfg, gpu, 0)
+    b = cfg.UNET_MASK_BRANCH_CHANNEL
+    gen = torch.Generator().manual_seed(3)
+    net.mask.modified_u_net.dropout_masks = [torch.empty(4, c).bernoulli_(0.4, generator=gen) / 0.4
+                                             for c in (b, 2 * b, 4 * b, 8 * b, 16 * b)]
+    results = []
+    old = ops.WGRAD_STREAM
+    try:
+        for flag in (False, True, True):
+            ops.WGRAD_STREAM = flag
+            net.zero_grad(set_to_none=True)
+            _, losses, _ = step.training_step(net, s)
+            torch.cuda.synchronize()
+            results.append(([float(l) for l in losses],
+                            {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))
+    finally:
+        ops.WGRAD_STREAM = old
+    assert len(results[0][1]) == 95
+    for losses, grads in results[1:]:
+        assert losses == results[0][0]
         for k, g in grads.items():
             assert torch.equal(g, results[0][1][k]), k
 
