@@ -47,13 +47,13 @@ __device__ __forceinline__ float cfun_softmax_log(float v) {
 #endif
 }
 
-__device__ __forceinline__ double block_sum_f(double v, double* red) {
+__device__ __forceinline__ double block_sum_f(double v, double* red, int nwaves) {
   v = cfun_wave_sum_d(v);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
   double s = 0.0;
   if (threadIdx.x == 0)
-    for (int w = 0; w < kFB / 64; ++w) s += red[w];
+    for (int w = 0; w < nwaves; ++w) s += red[w];
   __syncthreads();
   return s;
 }
@@ -61,8 +61,12 @@ __device__ __forceinline__ double block_sum_f(double v, double* red) {
 // both kernels sit at ~250 VGPRs: two waves per SIMD (hipcc left to itself takes 257 / 280 and one)
 #ifdef CFUN_HIP_EMULATION
 #define CFUN_OCC2
+#define CFUN_OCC_BWD(VPT)
+#define CFUN_OCC_FWD(VPT)
 #else
 #define CFUN_OCC2 __attribute__((amdgpu_waves_per_eu(2)))
+#define CFUN_OCC_BWD(VPT) __attribute__((amdgpu_waves_per_eu((VPT) == 2 ? 2 : 4)))
+#define CFUN_OCC_FWD(VPT) __attribute__((amdgpu_waves_per_eu((VPT) == 2 ? 2 : 4)))
 #endif
 
 template <int CT>
@@ -71,13 +75,14 @@ struct PlaneF {      // in-plane Sobel sums of one (y, x) column at one z: class
   uint32_t tdy[2], tsm[2];
 };
 
-// the in-plane sums of the thread's output pair (rows r0, r0+1 of the tile, column c0) from the LDS plane
-template <int CT, bool SEQ>
-__device__ __forceinline__ void plane_pair(const float* __restrict__ lp, const uint8_t* __restrict__ ll, int r0, int c0,
-                                           PlaneF<CT> (&P)[2]) {
-  uint32_t t[4][2];
+// the in-plane sums of the thread's VPT outputs (rows r0 .. r0 + VPT - 1 of the tile, column c0) from the LDS plane: the x sums
+// of rows r0 .. r0 + VPT + 1 serve all of them
+template <int CT, int VPT>
+__device__ __forceinline__ void plane_rows(const float* __restrict__ lp, const uint8_t* __restrict__ ll, int r0, int c0,
+                                           PlaneF<CT> (&P)[VPT]) {
+  uint32_t t[VPT + 2][2];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < VPT + 2; ++j) {
     const int base = (r0 + j) * kIXP + c0;
     const unsigned l0 = ll[base], l1 = ll[base + 1], l2 = ll[base + 2];
     // packed 8-bit fields (classes 0-3 | 4-7), weights 1, 2, 1 along x; labels >= CT contribute nothing (k_edge_march2)
@@ -88,30 +93,25 @@ __device__ __forceinline__ void plane_pair(const float* __restrict__ lp, const u
     t[j][1] = ((l0 & 4u) ? v0 : 0u) + ((l1 & 4u) ? v1 : 0u) + ((l2 & 4u) ? v2 : 0u);
   }
 #pragma unroll
-  for (int o = 0; o < 2; ++o)
+  for (int o = 0; o < VPT; ++o)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       P[o].tdy[h] = t[o][h] + 0x04040404u - t[o + 2][h];          // dy + 4 per field
       P[o].tsm[h] = t[o][h] + 2u * t[o + 1][h] + t[o + 2][h];
     }
-  // one class at a time: 12 LDS reads -> 4 row sums -> (dy, sm) of both outputs.  (SEQ: a scheduling barrier per class keeps
-  // hipcc from hoisting every class's reads at once -- the backward kernel needs its registers for three rings)
 #pragma unroll
   for (int c = 0; c < CT - 1; ++c) {
-    float a[4];
+    float a[VPT + 2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < VPT + 2; ++j) {
       const float* q = lp + c * kPlane + (r0 + j) * kIXP + c0;
       a[j] = (q[0] + 2.f * q[1]) + q[2];
     }
 #pragma unroll
-    for (int o = 0; o < 2; ++o) {
+    for (int o = 0; o < VPT; ++o) {
       P[o].dy[c] = a[o] - a[o + 2];
       P[o].sm[c] = (a[o] + a[o + 2]) + 2.f * a[o + 1];
     }
-#ifndef CFUN_HIP_EMULATION
-    if (SEQ) __builtin_amdgcn_sched_barrier(0);
-#endif
   }
 }
 
@@ -182,15 +182,16 @@ __device__ __forceinline__ void store_vox(float* __restrict__ dst, int64_t v, co
 // as 2 (CT-1) floats per (z, y, x): (U0, U1) of class 1, of class 2, ...  The backward is then a 2-D stencil per plane.
 // A segment that writes U starts its march two planes early (dc[z0-2], dc[z0-1] belong to the previous segment's loss but
 // to this segment's U).
-template <int CT, bool WRITE_U>
-__global__ void __launch_bounds__(kFB) CFUN_OCC2
+template <int CT, bool WRITE_U, int VPT>
+__global__ void __launch_bounds__(kFB * 2 / VPT) CFUN_OCC_FWD(VPT)
 k_mask_fused_fwd(const float* __restrict__ logits, const uint8_t* __restrict__ labels, float* __restrict__ probs,
                  double* __restrict__ partial, float* __restrict__ U, int n, int D, int H, int W, int ZS) {
   static_assert(CT >= 2 && CT <= 8, "packed target sums: 8 classes");
   CFUN_DYN_LDS(float, lds);
   float* lp = lds;                                                     // [2][CT-1][kPlane]
   uint8_t* ll = reinterpret_cast<uint8_t*>(lds + 2 * (CT - 1) * kPlane);   // [2][kPlane]
-  __shared__ double red[kFB / 64];
+  constexpr int NT = kFB * 2 / VPT;                                    // VPT outputs (tile rows) per thread: 2 = 256 threads, 1 = 512
+  __shared__ double red[NT / 64];
   const int Do = D - 2, Ho = H - 2, Wo = W - 2;
   const int nseg = (D + ZS - 1) / ZS, tY = (Ho + kTY - 1) / kTY, tX = (Wo + kTX - 1) / kTX;
   const int64_t tiles = (int64_t)n * nseg * tY * tX;
@@ -208,11 +209,11 @@ k_mask_fused_fwd(const float* __restrict__ logits, const uint8_t* __restrict__ l
     const int z1 = z0 + ZS < D ? z0 + ZS : D;                          // owned planes [z0, z1): probs, CE, U; outputs zq < Do
     const int zl0 = WRITE_U ? z0 - 2 : z0, zl1 = z1 + 2;               // step zl loads plane zl and emits output plane zl - 2
     const int64_t nbase = r * D * H * W;
-    const int oy = y0 + 2 * ty, ox = x0 + tx;                          // the thread's output pair (oy, oy + 1) x ox
-    PlaneF<CT> P[3][2];
-    float d1[2][WRITE_U ? 2 * (CT - 1) : 1], d2[2][WRITE_U ? 2 * (CT - 1) : 1];     // dc[zq-1], dc[zq-2]
+    const int oy = y0 + VPT * ty, ox = x0 + tx;                        // the thread's outputs (oy .. oy + VPT - 1) x ox
+    PlaneF<CT> P[3][VPT];
+    float d1[VPT][WRITE_U ? 2 * (CT - 1) : 1], d2[VPT][WRITE_U ? 2 * (CT - 1) : 1];     // dc[zq-1], dc[zq-2]
 #pragma unroll
-    for (int o = 0; o < 2; ++o) {
+    for (int o = 0; o < VPT; ++o) {
 #pragma unroll
       for (int c = 0; c < (WRITE_U ? 2 * (CT - 1) : 1); ++c) { d1[o][c] = 0.f; d2[o][c] = 0.f; }
 #pragma unroll
@@ -231,12 +232,12 @@ k_mask_fused_fwd(const float* __restrict__ logits, const uint8_t* __restrict__ l
       // ---- phase 1: the plane's 34 x 18 voxels, each loaded once: softmax, probs out, cross entropy, fg probs + label -> LDS
       // (three voxel slots per thread, branch-free: clamped addresses, so that all loads of the plane are in flight together)
       if (inz) {
-        constexpr int NS = (kIY * kIX + kFB - 1) / kFB;
+        constexpr int NS = (kIY * kIX + NT - 1) / NT;
         float xs[NS][CT];
         unsigned labs[NS];
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
-          const int i = threadIdx.x + q * kFB;
+          const int i = threadIdx.x + q * NT;
           const int ly = i / kIX, lx = i - ly * kIX;
           const bool in = i < kIY * kIX && y0 + ly < H && x0 + lx < W;
           const int64_t v = in ? nbase + ((int64_t)zl * H + (y0 + ly)) * W + (x0 + lx) : nbase;
@@ -245,7 +246,7 @@ k_mask_fused_fwd(const float* __restrict__ logits, const uint8_t* __restrict__ l
         }
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
-          const int i = threadIdx.x + q * kFB;
+          const int i = threadIdx.x + q * NT;
           const int ly = i / kIX, lx = i - ly * kIX;
           const bool in = i < kIY * kIX && y0 + ly < H && x0 + lx < W;
           float (&x)[CT] = xs[q];
@@ -276,12 +277,12 @@ k_mask_fused_fwd(const float* __restrict__ logits, const uint8_t* __restrict__ l
       }
       __syncthreads();
       // ---- phase 2: in-plane sums of the output pair -> ring; output plane zq = zl - 2 (valid once three planes are in)
-      if (inz) plane_pair<CT, false>(bp, bl, 2 * ty, tx, P[2]);
+      if (inz) plane_rows<CT, VPT>(bp, bl, VPT * ty, tx, P[2]);
       const int zq = zl - 2;
       const bool have = zq >= 0 && zq < Do && zl - zl0 >= 2;           // the ring holds planes zq, zq+1, zq+2
       const bool mine = zq >= z0 && zq < z1;                           // this segment's loss terms / U planes
 #pragma unroll
-      for (int o = 0; o < 2; ++o) {
+      for (int o = 0; o < VPT; ++o) {
         const bool live = have && oy + o < Ho && ox < Wo;
         float d0[2 * (CT - 1)];
         float term = 0.f;
@@ -299,13 +300,13 @@ k_mask_fused_fwd(const float* __restrict__ logits, const uint8_t* __restrict__ l
         }
       }
 #pragma unroll
-      for (int o = 0; o < 2; ++o) { P[0][o] = P[1][o]; P[1][o] = P[2][o]; }
+      for (int o = 0; o < VPT; ++o) { P[0][o] = P[1][o]; P[1][o] = P[2][o]; }
     }
     ed_acc += (double)accf;
     __syncthreads();        // the next tile's first plane reuses an LDS buffer this tile's last phase 2 may still read
   }
-  const double s0 = block_sum_f(ce_acc, red);
-  const double s1 = block_sum_f(ed_acc, red);
+  const double s0 = block_sum_f(ce_acc, red, NT / 64);
+  const double s1 = block_sum_f(ed_acc, red, NT / 64);
   if (threadIdx.x == 0) { partial[blockIdx.x] = s0; partial[kMaxBlocksF + blockIdx.x] = s1; }
 }
 
@@ -328,13 +329,19 @@ constexpr int kUSP = kPlane + 25;            // backward: LDS plane stride (841 
                                              // -- consecutive class pairs of the same column -- land 9 banks apart)
 constexpr int kBZ = 24;                      // backward: planes per workgroup (one (y, x) tile, consecutive z)
 
-template <int CT>
-__global__ void __launch_bounds__(kFB) CFUN_OCC2
+// VPT voxels of the tile column pair (y, y+1) per thread: 2 = 256 threads (a pair shares its four U rows: 84 LDS reads per
+// voxel, ~250 VGPRs, two waves per SIMD), 1 = 512 threads (126 reads per voxel, half the registers, more waves in flight)
+template <int CT, int VPT>
+__global__ void __launch_bounds__(kFB * 2 / VPT) CFUN_OCC_BWD(VPT)
 k_mask_fused_bwd(const float* __restrict__ U, const float* __restrict__ probs, const uint8_t* __restrict__ labels,
                  const float* __restrict__ g2, float* __restrict__ dlogits, int n, int D, int H, int W) {
   CFUN_DYN_LDS(float, lds);                                            // [2 (CT-1)][kUSP]: U0 planes 0 .. CT-2, U1 planes CT-1 ..
+  constexpr int NT = kFB * 2 / VPT;
   constexpr int NP = CT - 1;                                           // class pairs (U0, U1)
-  constexpr int NLD = kIY / 2;                                         // tile rows (float2 granules) per thread
+  constexpr int RG = kIX * NP;                                         // float2 granules per tile row (126 at 8 classes)
+  constexpr int RPP = NT / RG;                                         // tile rows staged per pass
+  constexpr int NLD = (kIY + RPP - 1) / RPP;                           // passes = granules per thread
+  static_assert(RPP >= 1, "a tile row per pass");
   const int Ho = H - 2, Wo = W - 2;
   const int tY = (H + kTY - 1) / kTY, tX = (W + kTX - 1) / kTX, nzc = (D + kBZ - 1) / kBZ;
   const int64_t tiles = (int64_t)n * nzc * tY * tX;
@@ -349,26 +356,24 @@ k_mask_fused_bwd(const float* __restrict__ U, const float* __restrict__ probs, c
     const int64_t r = t / nzc;
     const int x0 = bx * kTX, y0 = by * kTY;                            // first owned voxel; U tile origin = (y0 - 2, x0 - 2)
     const int zb = zc * kBZ, ze = zb + kBZ < D ? zb + kBZ : D;
-    // Staging map: a tile row is kIX * NP float2 granules, contiguous in memory.  Thread (h, e) = (tid / RG, tid % RG) takes
-    // granule e of rows h, h + 2, h + 4, ...: memory and LDS offsets are affine in the row index (one VGPR each, the row
-    // stride goes into scalar offsets) -- a flat tid + q * 256 map costs a 64-bit address per granule (355 VGPRs).
-    constexpr int RG = kIX * NP;                                       // granules per tile row (126 at 8 classes)
-    static_assert(2 * RG <= kFB && kIY % 2 == 0, "two rows of granules per pass");
-    const int h = threadIdx.x >= RG ? 1 : 0, e = threadIdx.x - h * RG;
-    const bool lane_on = threadIdx.x < 2 * RG;
+    // Staging map: a tile row is RG float2 granules, contiguous in memory.  Thread (h, e) = (tid / RG, tid % RG) takes
+    // granule e of rows h, h + RPP, h + 2 RPP, ...: memory and LDS offsets are affine in the pass index (one VGPR each, the
+    // row stride goes into scalar offsets) -- a flat tid + q * 256 map costs a 64-bit address per granule (355 VGPRs).
+    const int h = threadIdx.x / RG, e = threadIdx.x - h * RG;
+    const bool lane_on = threadIdx.x < RPP * RG;
     const int lx = e / NP, k = e - lx * NP;
     const int ux = x0 - 2 + lx;
     const bool col_ok = lane_on && ux >= 0 && ux < Wo;
     const int lds0 = lane_on ? k * kUSP + h * kIXP + lx : NP * kUSP - 1;      // (idle lanes: a dead slot in the last plane's padding)
-    const int lrow = lane_on ? 2 * kIXP : 0;
+    const int lrow = lane_on ? RPP * kIXP : 0;
     const int64_t grow = (int64_t)Wo * NP;                             // granules per memory row
     const int64_t g0 = ((int64_t)(y0 - 2 + h) * Wo + (x0 - 2)) * NP + e;
     float2 pre[NLD];
 #define CFUN_STAGE_LOAD(up)                                                         \
   _Pragma("unroll") for (int q = 0; q < NLD; ++q) {                                 \
-    const int uy = y0 - 2 + h + 2 * q;                                              \
-    const bool ok = col_ok && uy >= 0 && uy < Ho;                                   \
-    const float2 v = (up)[ok ? g0 + (int64_t)(2 * q) * grow : 0];   /* branch-free: clamped address, selected value */ \
+    const int uy = y0 - 2 + h + RPP * q;                                            \
+    const bool ok = col_ok && h + RPP * q < kIY && uy >= 0 && uy < Ho;              \
+    const float2 v = (up)[ok ? g0 + (int64_t)(RPP * q) * grow : 0];   /* branch-free: clamped address, selected value */ \
     pre[q] = make_float2(ok ? v.x : 0.f, ok ? v.y : 0.f);                           \
   }
     {
@@ -377,30 +382,33 @@ k_mask_fused_bwd(const float* __restrict__ U, const float* __restrict__ probs, c
     }
     for (int z = zb; z < ze; ++z) {
 #pragma unroll
-      for (int q = 0; q < NLD; ++q) { lds[lds0 + q * lrow] = pre[q].x; lds[NP * kUSP + lds0 + q * lrow] = pre[q].y; }
+      for (int q = 0; q < NLD; ++q) {
+        const int lo = (h + RPP * q < kIY) ? lds0 + q * lrow : NP * kUSP - 1;      // (rows beyond the tile: the dead slot)
+        lds[lo] = pre[q].x; lds[NP * kUSP + lo] = pre[q].y;
+      }
       __syncthreads();
       if (z + 1 < ze) {        // the next plane's granules travel while this plane is finished
         const float2* up = reinterpret_cast<const float2*>(U) + (r * D + z + 1) * (int64_t)Ho * Wo * NP;
         CFUN_STAGE_LOAD(up)
       }
-      const int ry = 2 + 2 * ty, rx = 2 + tx;                          // tile-local U position of the pair's first voxel
-      const int gy = y0 + 2 * ty, gx = x0 + tx;
+      const int ry = 2 + VPT * ty, rx = 2 + tx;                        // tile-local U position of the thread's first voxel
+      const int gy = y0 + VPT * ty, gx = x0 + tx;
       const int64_t v0 = ((r * D + z) * (int64_t)H + gy) * W + gx;
-      float pr[2][CT];
-      int lab[2];
+      float pr[VPT][CT];
+      int lab[VPT];
 #pragma unroll
-      for (int o = 0; o < 2; ++o) {
+      for (int o = 0; o < VPT; ++o) {
         const bool in = gy + o < H && gx < W;
         const int64_t vv = in ? v0 + (int64_t)o * W : 0;               // (clamped: branch-free)
         load_vox<CT>(probs, vv, pr[o]);
         lab[o] = labels[vv];
       }
-      float g[2][CT - 1];
+      float g[VPT][CT - 1];
 #pragma unroll
       for (int c = 0; c < CT - 1; ++c) {
-        float s0[4], s1[4];
+        float s0[VPT + 2], s1[VPT + 2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {                                  // x sums (A = 1,2,1 over x, x-1, x-2) of U rows ry-2 .. ry+1
+        for (int j = 0; j < VPT + 2; ++j) {                            // x sums (A = 1,2,1 over x, x-1, x-2) of U rows ry-2 .. ry+VPT-1
           const float* u0 = lds + c * kUSP + (ry - 2 + j) * kIXP + rx;
           const float* u1 = lds + (NP + c) * kUSP + (ry - 2 + j) * kIXP + rx;
           s0[j] = (u0[0] + 2.f * u0[-1]) + u0[-2];
@@ -408,10 +416,10 @@ k_mask_fused_bwd(const float* __restrict__ U, const float* __restrict__ probs, c
         }
         // voxel row y = ry + o receives from U rows y (B = 1, A = 1), y-1 (B = 0, A = 2), y-2 (B = -1, A = 1)
 #pragma unroll
-        for (int o = 0; o < 2; ++o) g[o][c] = ge * ((s0[2 + o] - s0[o]) + ((s1[2 + o] + s1[o]) + 2.f * s1[1 + o]));
+        for (int o = 0; o < VPT; ++o) g[o][c] = ge * ((s0[2 + o] - s0[o]) + ((s1[2 + o] + s1[o]) + 2.f * s1[1 + o]));
       }
 #pragma unroll
-      for (int o = 0; o < 2; ++o) {
+      for (int o = 0; o < VPT; ++o) {
         if (gy + o < H && gx < W) {
           float dot = 0.f;
 #pragma unroll
@@ -472,7 +480,9 @@ int cfun_mask_fused_fwd(const float* logits, const uint8_t* labels, float* probs
   const int ZS = pick_zs(D, per_seg);
   const int64_t tiles = per_seg * ((D + ZS - 1) / ZS);
   const unsigned blocks = fused_grid(tiles, kMaxBlocksF);
-#define LAUNCH(CT, WU) hipLaunchKernelGGL((k_mask_fused_fwd<CT, WU>), dim3(blocks), dim3(kFB), fwd_lds<CT>(), cfun_st(stream), \
+  // (VPT = 1 -- 512 threads, one output per thread, 128 VGPRs -- measured 1.33 - 1.43 ms against 1.09 for the pair form on the same
+  // box: the pair shares its row sums and the pass is VALU-bound; profiles/round6_losses_vpt.log)
+#define LAUNCH(CT, WU) hipLaunchKernelGGL((k_mask_fused_fwd<CT, WU, 2>), dim3(blocks), dim3(kFB), fwd_lds<CT>(), cfun_st(stream), \
                                           logits, labels, probs, (double*)ws, u, n, D, H, W, ZS)
   if (C == 8) { if (u) LAUNCH(8, true); else LAUNCH(8, false); }
   else { if (u) LAUNCH(3, true); else LAUNCH(3, false); }
@@ -490,8 +500,12 @@ int cfun_mask_fused_bwd(const float* u, const float* probs, const uint8_t* label
   if (C % 4 == 0 && (!cfun_aligned16(probs) || !cfun_aligned16(dlogits))) return CFUN_EINVAL;
   const int64_t tiles = (int64_t)n * ((D + kBZ - 1) / kBZ) * ((H + kTY - 1) / kTY) * ((W + kTX - 1) / kTX);
   const unsigned blocks = fused_grid(tiles, 1 << 20);
-  if (C == 8) hipLaunchKernelGGL(k_mask_fused_bwd<8>, dim3(blocks), dim3(kFB), bwd_lds<8>(), cfun_st(stream), u, probs, labels, g2, dlogits, n, D, H, W);
-  else hipLaunchKernelGGL(k_mask_fused_bwd<3>, dim3(blocks), dim3(kFB), bwd_lds<3>(), cfun_st(stream), u, probs, labels, g2, dlogits, n, D, H, W);
+  // one voxel per thread (512 threads, 115 VGPRs) is the default: HBM-bound, more waves in flight win 2 - 4 % over the pair form
+  // (CFUN_FUSED_BWD_VPT=2), profiles/round6_losses_vpt.log
+  static const int vpt = [] { const char* e = getenv("CFUN_FUSED_BWD_VPT"); return (e && e[0] == '2') ? 2 : 1; }();
+  if (C == 8 && vpt == 1) hipLaunchKernelGGL((k_mask_fused_bwd<8, 1>), dim3(blocks), dim3(2 * kFB), bwd_lds<8>(), cfun_st(stream), u, probs, labels, g2, dlogits, n, D, H, W);
+  else if (C == 8) hipLaunchKernelGGL((k_mask_fused_bwd<8, 2>), dim3(blocks), dim3(kFB), bwd_lds<8>(), cfun_st(stream), u, probs, labels, g2, dlogits, n, D, H, W);
+  else hipLaunchKernelGGL((k_mask_fused_bwd<3, 2>), dim3(blocks), dim3(kFB), bwd_lds<3>(), cfun_st(stream), u, probs, labels, g2, dlogits, n, D, H, W);
   CFUN_LAUNCH_CHECK();
   return CFUN_OK;
 }

@@ -499,6 +499,9 @@ def check_mask_losses(device, logits_ncdhw, labels, expect=None):
         assert float((p3 - probs.detach()).abs().max()) <= 2e-6, "fused forward: probabilities differ from cfun_softmax_fwd"
         assert not p3.requires_grad
         assert abs(float(ce3) - float(ce)) <= 2e-6 * abs(float(ce)) and abs(float(el3) - float(el)) <= 1e-5 * abs(float(el))
+        with torch.no_grad():       # forward-only build of the kernel (no backward operand written): the same sums in the same order
+            ce4, el4, p4 = ops.mask_losses_fused(ld.detach(), labd)
+        assert float(ce4) == float(ce3) and float(el4) == float(el3) and torch.equal(p4, p3)
         (0.7 * ce3 + 1.3 * el3).backward()
         assert_close(ld.grad, sep_grad, "one-pass d(CE+Edge)/dlogits vs the separate kernels", 2e-5)
         assert_close(ld.grad.permute(0, 4, 1, 2, 3), 0.7 * g_ce_r + 1.3 * g_el_r, "one-pass backward vs oracle", 1e-3)
