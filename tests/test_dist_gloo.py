@@ -274,7 +274,9 @@ def test_lits_stage_split_world2(emu_lib, tmp_path):
 def test_depth_sharding_world4(emu_lib, tmp_path):
     """4 ranks: two interior ranks, 2 RoIs x 2 ranks and 1 RoI x 4 ranks z-sharded, round-robin with idle ranks."""
     env = dict(os.environ, CFUN_LIB_PATH=emu_lib, PYTHONPATH=ROOT)
-    sections = "halo,conv,rpn,stepa,stepb,dp,lits"    # (round-robin with idle ranks and the U-Net over all ranks: at world 8)
+    # (round-robin with idle ranks and the U-Net over all ranks: at world 8; the LiTS fork's losses on 4 ranks: GPU tier,
+    #  test_four_ranks_on_real_kernels -- here test_lits_stage_split_world2 holds them, with the fork's phase split)
+    sections = "halo,conv,rpn,stepa,stepb,dp"
     print(check_worldn(run_world(tmp_path, env, 4, "dist_worker_n.py", ("cpu", sections), timeout=1500), sections))
 
 
