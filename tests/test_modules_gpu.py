@@ -488,6 +488,104 @@ def test_mask_head_side_stream(gpu):
             assert torch.equal(g, results[0][1][k]), k
 
 
+def test_rccl_self_exchange_on_side_stream(gpu):
+    """The `nccl` (= RCCL) branch of ``dist._exchange`` has never met a peer (the test boxes have one GPU and RCCL refuses two
+    ranks on a device: tools/probe_rccl_one_gpu.py).  What CAN run here: a one-rank RCCL group whose ring neighbours are the
+    rank itself -- ``dist._exchange_async`` then hands DEVICE buffers straight to ``batch_isend_irecv`` on the side HIP stream
+    (no host staging), RCCL pairs the two self-sends with the two self-receives in order, and the main stream picks the planes
+    up after ``wait()``: the stream hand-over, the record_stream bookkeeping and the RCCL point-to-point calls of the halo
+    exchange, with real data, minus the xGMI link."""
+    import socket
+    import torch.distributed as dist
+    from cfun_amd import dist as cdist
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        class SelfRing:                       # a ShardContext whose previous AND next rank are this rank
+            group, rank, world, prev, next = None, 0, 1, 0, 0
+        gen = torch.Generator().manual_seed(0)
+        for it in range(3):
+            a = torch.randn(1, 2, 24, 24, 16, generator=gen).to(gpu)
+            b = torch.randn(1, 1, 24, 24, 16, generator=gen).to(gpu)
+            busy = torch.randn(2048, 2048, device=gpu)
+            busy = busy @ busy                                  # the main stream is still working when the transfer starts
+            sa, sb = a * 2.0, b * 3.0                           # produced on the main stream right before the exchange
+            fp, fn, wait = cdist._exchange_async(SelfRing, sa, sb, tuple(sa.shape), tuple(sb.shape), sa)
+            wait()
+            got_p, got_n = fp + 0.0, fn + 0.0                   # consumed on the main stream
+            torch.cuda.synchronize()
+            assert torch.equal(got_p, a * 2.0) and torch.equal(got_n, b * 3.0), it
+    finally:
+        dist.destroy_process_group()
+
+
+def test_preflight_over_single_rank_rccl(gpu):
+    """bench.py's communication pre-flight (cfun_amd.dist_selftest) on a one-rank RCCL group: every collective call it makes --
+    int64 all-gather, fp64 MAX all-reduce, the reducer's own communicator and stream -- goes through RCCL with device tensors
+    (the exchanges degenerate to zero padding at world size 1; the two self-ring tests below cover the point-to-point path)."""
+    import socket
+    import torch.distributed as dist
+    from cfun_amd import dist_selftest
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        pf = dist_selftest.preflight(torch.device(gpu))
+        assert pf["ok"] and pf["backend"] == "nccl" and pf["rccl_ranks_seen"] == 1 and pf["devices_seen"] == 1, pf
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_self_ring_halo_conv(gpu):
+    """... and the whole depth-coupled conv of the sharded layout over RCCL: ``layers.sharded_conv`` -> ``dist.halo_conv``
+    (interior planes enqueued while the halo planes travel on the side stream, edge planes after ``_HaloFinish``, the gradient
+    planes travelling back in the backward) on a one-rank RCCL group whose neighbours are the rank itself.  A slab whose both
+    halos come from itself is a convolution with REPLICATE depth padding (RCCL pairs a rank's self-sends with its
+    self-receives in issue order: the planes sent "to the previous rank" -- the slab's first -- come back as the low halo) --
+    checked against exactly that, forward, input gradient and weight gradient; plus the thin-slab fall-back
+    (``_HaloExchange``) the same way."""
+    import socket
+    import torch.distributed as dist
+    import torch.nn.functional as F
+    from cfun_amd import dist as cdist
+    from cfun_amd.layers import Conv3dParams
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        class SelfRing:                       # claims two ranks so that the sharded code paths engage; both neighbours = self
+            group, rank, world, prev, next = None, 0, 2, 0, 0
+        gen = torch.Generator().manual_seed(1)
+        for planes, ci, co in ((8, 16, 32), (1, 8, 8)):            # interior / edge split; slab thinner than the kernel (padded slab)
+            torch.manual_seed(3)
+            conv = Conv3dParams(ci, co, 3, padding=1).to(gpu)
+            x = torch.randn(1, planes, 8, 16, ci, generator=gen).to(gpu)
+            gy = torch.randn(1, planes, 8, 16, co, generator=gen).to(gpu)
+            xs = x.clone().requires_grad_(True)
+            with cdist.depth_sharded_as(SelfRing):
+                y = conv(xs)
+                (y * gy).sum().backward()
+            torch.cuda.synchronize()
+            got = (y.detach(), xs.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone())
+            conv.weight.grad = conv.bias.grad = None
+            # reference: replicate padding along depth, zero padding in (y, x), torch fp32
+            xr = x.clone().requires_grad_(True)
+            xp = torch.cat([xr[:, :1], xr, xr[:, -1:]], dim=1).permute(0, 4, 1, 2, 3)
+            yr = F.conv3d(xp, conv.weight, conv.bias, padding=(0, 1, 1)).permute(0, 2, 3, 4, 1)
+            (yr * gy).sum().backward()
+            ref = (yr.detach(), xr.grad, conv.weight.grad, conv.bias.grad)
+            for a, b, nm in zip(got, ref, ("y", "dx", "dw", "db")):
+                err = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12)
+                assert err < 2e-5, (planes, nm, err)
+            conv.weight.grad = conv.bias.grad = None
+    finally:
+        dist.destroy_process_group()
+
+
 def test_wgrad_stream_bitwise(gpu):
     """the weight gradients on their own HIP stream (ops.WGRAD_STREAM) depend on the autograd engine replaying
     _OnWgradStream / AccumulateGrad on the right stream and joining the leaf streams at the end of backward() -- behaviour of the
