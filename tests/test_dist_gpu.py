@@ -129,6 +129,17 @@ def test_bench_cfg3_one_volume_over_eight_ranks(gpu):
     assert all(np.isfinite(v) and v > 0 for v in d["losses"])
 
 
+def test_bench_cfg4_one_volume_over_eight_ranks(gpu):
+    """BASELINE configs[4] ("LiTS_2017 config, same pipeline, 8x MI355X") the same way: the fork's 320x320x256 volume, P3D35 with
+    the 5x7x7 stem, 3 classes, 32x80x80 crops, class-weighted CE, as ONE volume over 8 ranks (gloo on this box's one GPU); the
+    summed loss shares reproduce the single-process step."""
+    d = _bench(["--gpus", "8", "--sharded", "--workload", "cfg4", "--steps", "2", "--warmup", "1"],
+               dict(CFUN_BENCH_BACKEND="gloo"), 2400)
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["preflight"]["ok"]
+    assert d["sharded_parity"]["ok"], d["sharded_parity"]
+    assert all(np.isfinite(v) for v in d["losses"]) and d["losses"][0] > 0 and d["losses"][4] > 0
+
+
 def test_rccl_two_gpus(tmp_path):
     """The `nccl` (= RCCL) branch of ``dist._exchange`` -- device buffers straight into batch_isend_irecv on the side
     stream -- and the reducer's RCCL all-reduces, with a real peer: 2 processes on 2 GPUs.  Skips cleanly on the 1-GPU test
