@@ -445,6 +445,8 @@ inline unsigned fused_grid(int64_t tiles, int cap) {
 // z planes per segment: enough segments to fill the chip a few times over, long enough to amortise the ring's 2 (4 with U)
 // extra planes
 inline int pick_zs(int planes, int64_t tiles_per_plane_seg) {
+  static const int knob = [] { const char* e = getenv("CFUN_FUSED_ZS"); return e ? atoi(e) : 0; }();      // tuning knob
+  if (knob > 0) return knob < planes ? knob : planes;
   int zs = 32;
   while (zs > 8 && tiles_per_plane_seg * ((planes + zs - 1) / zs) < 1536) zs /= 2;
   return zs < planes ? zs : (planes > 0 ? planes : 1);
