@@ -232,6 +232,9 @@ class _MaskLossesFused(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, logits, labels):
+        # (undefined output gradients arrive as None: without this the engine materialises a ZERO tensor of the probabilities'
+        # shape for the non-differentiable third output on every backward -- a 0.9 GB fill, 127 us on the step's critical path)
+        ctx.set_materialize_grads(False)
         lib = _lib.load()
         logits, labels = _c(logits), _c(labels)
         n, d, h, w, c = logits.shape
@@ -254,7 +257,11 @@ class _MaskLossesFused(torch.autograd.Function):
         lib = _lib.load()
         probs, labels, u = ctx.saved_tensors
         n, d, h, w, c = probs.shape
-        g = torch.stack([g_ce.reshape(()).float(), g_edge.reshape(()).float()])
+        if g_ce is None and g_edge is None:
+            return None, None
+        zero = torch.zeros((), dtype=torch.float32, device=probs.device)
+        g = torch.stack([(zero if g_ce is None else g_ce.reshape(()).float()),
+                         (zero if g_edge is None else g_edge.reshape(()).float())])
         dl = torch.empty_like(probs)
         check(lib.cfun_mask_fused_bwd(ptr(u), ptr(probs), ptr(labels), ptr(g), ptr(dl), n, d, h, w, c, stream(probs)),
               "mask_fused_bwd")
