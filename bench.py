@@ -204,6 +204,36 @@ def p3d_stem_back_to_back(cfg, net, dev, launches=16):
     return t, 4.0 * (x.numel() + y.numel()), flops
 
 
+def mask_losses_back_to_back(cfg, n_roi, dev, reps=5):
+    """The one-pass mask-loss kernels of the step (csrc/loss_fused.hip) at the benchmarked shape, alone: forward (softmax + cross
+    entropy + Sobel edge loss + the backward's operand field) and backward, each between its own HIP-event pair, median of
+    `reps`.  Algorithmic bytes: logits in, probabilities + field out / field, probabilities in, dlogits out (+ the labels)."""
+    from cfun_amd import ops
+    c = int(cfg.NUM_CLASSES)
+    dd, hh, ww = [int(v) for v in cfg.MASK_SHAPE]
+    logits = torch.randn((n_roi, dd, hh, ww, c), device=dev).requires_grad_(True)
+    labels = torch.randint(0, c, (n_roi, dd, hh, ww), device=dev, dtype=torch.uint8)
+    tf, tb = [], []
+    for it in range(reps + 2):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        logits.grad = None
+        e[0].record()
+        ce, edge, _ = ops.mask_losses_fused(logits, labels)
+        e[1].record()
+        tot = ce + edge
+        e[2].record()
+        tot.backward()
+        e[3].record()
+        torch.cuda.synchronize()
+        if it >= 2:
+            tf.append(e[0].elapsed_time(e[1]) * 1e-3)
+            tb.append(e[2].elapsed_time(e[3]) * 1e-3)
+    vox = float(n_roi * dd * hh * ww)
+    field = 8.0 * n_roi * dd * (hh - 2) * (ww - 2) * (c - 1)
+    nbytes = 4.0 * vox * c * 2 + vox + field
+    return sorted(tf)[len(tf) // 2], sorted(tb)[len(tb) // 2], nbytes
+
+
 def pointwise_back_to_back(cfg, net, n_roi, dev, launches=64):
     """conv3d_l4 (1x1x1, 2b -> n_classes on the 96^3 crops: the other HBM-bound conv of the U-Net, pure streaming) through the
     same C-ABI entry point, timed like stem_back_to_back.  Returns (seconds per launch, algorithmic bytes per launch)."""
@@ -718,6 +748,15 @@ def main():
                     "achieved": pbytes / t_p / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": pbytes / t_p / 1e9 / PEAK_HBM_GBS,
                     "bytes_per_launch": pbytes, "avg_launch_ms": t_p * 1e3, "launches_timed": 64,
                     "repetitions_ms": list(B2B_REPS)}
+                if net.fused_mask_losses():       # the step's unhidden HBM-bound pair, alone
+                    t_lf, t_lb, lbytes = mask_losses_back_to_back(cfg, n_roi_launch, dev)
+                    result["roofline_hbm"]["mask_losses"] = {
+                        "kernel": "k_mask_fused_fwd (softmax + CE + 3-D Sobel edge loss, one pass over the logits) / k_mask_fused_bwd "
+                                  "(2-D stencil per plane + softmax backward) @ %dx%s" % (n_roi_launch, "x".join(map(str, cfg.MASK_SHAPE))),
+                        "bytes_per_pass": lbytes, "fwd_ms": t_lf * 1e3, "bwd_ms": t_lb * 1e3,
+                        "fwd_frac": lbytes / t_lf / 1e9 / PEAK_HBM_GBS, "bwd_frac": lbytes / t_lb / 1e9 / PEAK_HBM_GBS,
+                        "timing": "each pass between its own HIP-event pair (the backward incl. autograd's two scalar launches), "
+                                  "median of 5 after 2 warm-up rounds"}
                 # both C_in = 1 convs of the path on the line: the P3D stem is NOT HBM-bound -- 147
                 # taps per output at 49 flop/B put it on the vector ALU; both fractions are reported, the binding one is `bound`
                 t_s, sbytes, sflops = p3d_stem_back_to_back(cfg, net, dev)
